@@ -1,0 +1,435 @@
+"""CPU ORACLE -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+ctypes front-end of oracle/liboracle.so (the plain-C restatement of the
+reference hot path, oracle/tdk_oracle.c) plus a NumPy mirror of the reference's
+Python DVO orchestration.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module; tadataka_amd never does.
+
+Reference lines followed by the Python parts:
+  * dvo_estimate_level  <- tadataka/vo/dvo/__init__.py:79-111 (_PoseChangeEstimator)
+  * dvo_estimate        <- tadataka/vo/dvo/__init__.py:114-150 (PoseChangeEstimator)
+  * exp_se3_t           <- tadataka/se3.py:15-29
+  * solve (lstsq)       <- tadataka/math.py:17-19,32-45
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+from scipy.spatial.transform import Rotation
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+W_NONE, W_HUBER, W_STUDENT_T, W_TUKEY, W_MAP = 0, 1, 2, 3, 4
+WEIGHT_MODES = {None: W_NONE, "huber": W_HUBER, "student-t": W_STUDENT_T,
+                "tukey": W_TUKEY}
+
+_dp = C.POINTER(C.c_double)
+_u64p = C.POINTER(C.c_uint64)
+_i64p = C.POINTER(C.c_int64)
+_u8p = C.POINTER(C.c_uint8)
+
+
+class Params(C.Structure):
+    _fields_ = [("inv_depth_min", C.c_double), ("inv_depth_max", C.c_double),
+                ("geo_coeff", C.c_double), ("photo_coeff", C.c_double),
+                ("ref_step_size", C.c_double), ("min_gradient", C.c_double)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "tdk_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_calc_depth0.restype = C.c_double
+        _LIB.orc_ba_block_reduce.restype = C.c_double
+        for name in ("orc_dvo_rows", "orc_dvo_normal_equations",
+                     "orc_photometric_error", "orc_estimate_debug"):
+            getattr(_LIB, name).restype = C.c_int64
+    return _LIB
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _cam(cam):
+    """cam = (fx, fy, ox, oy) as float64[4]."""
+    return _d(np.asarray(cam, dtype=np.float64).reshape(4))
+
+
+# ---- per-point geometry --------------------------------------------------
+def normalize(kp, cam):
+    kp, p = _d(kp); cam, pc = _cam(cam)
+    out = np.empty_like(kp)
+    lib().orc_normalize(p, C.c_int64(kp.shape[0]), pc, out.ctypes.data_as(_dp))
+    return out
+
+
+def unnormalize(kp, cam):
+    kp, p = _d(kp); cam, pc = _cam(cam)
+    out = np.empty_like(kp)
+    lib().orc_unnormalize(p, C.c_int64(kp.shape[0]), pc, out.ctypes.data_as(_dp))
+    return out
+
+
+def project_vecs(P):
+    P, p = _d(P)
+    out = np.empty((P.shape[0], 2))
+    lib().orc_project_vecs(p, C.c_int64(P.shape[0]), out.ctypes.data_as(_dp))
+    return out
+
+
+def inv_project_vecs(xs, depths):
+    xs, p = _d(xs); depths, pd = _d(depths)
+    out = np.empty((xs.shape[0], 3))
+    lib().orc_inv_project_vecs(p, pd, C.c_int64(xs.shape[0]), out.ctypes.data_as(_dp))
+    return out
+
+
+def transform(T, P):
+    T, pt = _d(T); P, p = _d(P)
+    out = np.empty_like(P)
+    lib().orc_transform(pt, p, C.c_int64(P.shape[0]), out.ctypes.data_as(_dp))
+    return out
+
+
+def warp_vecs(T10, xs, depths):
+    T10, pt = _d(T10); xs, p = _d(xs); depths, pd = _d(depths)
+    oxs = np.empty_like(xs); od = np.empty_like(depths)
+    lib().orc_warp_vecs(pt, p, pd, C.c_int64(xs.shape[0]),
+                        oxs.ctypes.data_as(_dp), od.ctypes.data_as(_dp))
+    return oxs, od
+
+
+def interpolation(image, coords):
+    image, pi_ = _d(image); coords, pc = _d(coords)
+    out = np.empty(coords.shape[0])
+    rc = lib().orc_interpolation(pi_, C.c_int(image.shape[0]), C.c_int(image.shape[1]),
+                                 pc, C.c_int64(coords.shape[0]), out.ctypes.data_as(_dp))
+    if rc != 0:
+        raise ValueError("Coordinates out of image range")
+    return out
+
+
+def calc_depth0(T10, x0, x1):
+    T10, pt = _d(T10); x0, p0 = _d(x0); x1, p1 = _d(x1)
+    return float(lib().orc_calc_depth0(pt, p0, p1))
+
+
+def is_in_image_range(kp, shape):
+    kp, p = _d(kp)
+    out = np.empty(kp.shape[0], dtype=np.uint8)
+    lib().orc_is_in_image_range(p, C.c_int64(kp.shape[0]), C.c_int(shape[0]),
+                                C.c_int(shape[1]), out.ctypes.data_as(_u8p))
+    return out.astype(bool)
+
+
+# ---- DVO -----------------------------------------------------------------
+def image_gradient(I):
+    I, p = _d(I)
+    GX = np.empty_like(I); GY = np.empty_like(I)
+    lib().orc_image_gradient(p, C.c_int(I.shape[0]), C.c_int(I.shape[1]),
+                             GX.ctypes.data_as(_dp), GY.ctypes.data_as(_dp))
+    return GX, GY
+
+
+def _weight_args(weights):
+    if isinstance(weights, np.ndarray):
+        w0, pw = _d(weights)
+        return W_MAP, w0, pw
+    if weights not in WEIGHT_MODES:
+        raise ValueError(f"No such weights '{weights}'")
+    return WEIGHT_MODES[weights], None, None
+
+
+def dvo_rows(I0, D0, I1, GX1, GY1, cam0, cam1, R, t, weights=None):
+    """Masked (J, r, w) of one calc_pose_update call."""
+    I0, p0 = _d(I0); D0, pd = _d(D0); I1, p1 = _d(I1)
+    GX1, pgx = _d(GX1); GY1, pgy = _d(GY1)
+    cam0, pc0 = _cam(cam0); cam1, pc1 = _cam(cam1)
+    R, pr = _d(R); t, pt = _d(t)
+    mode, w0, pw = _weight_args(weights)
+    H, W = I0.shape
+    N = H * W
+    J = np.empty((N, 6)); r = np.empty(N); w = np.empty(N)
+    M = lib().orc_dvo_rows(p0, pd, p1, pgx, pgy, pw, C.c_int(H), C.c_int(W), pc0, pc1,
+                           pr, pt, C.c_int(mode), J.ctypes.data_as(_dp),
+                           r.ctypes.data_as(_dp), w.ctypes.data_as(_dp))
+    return J[:M], r[:M], w[:M]
+
+
+def dvo_normal_equations(I0, D0, I1, GX1, GY1, cam0, cam1, R, t, weights=None):
+    I0, p0 = _d(I0); D0, pd = _d(D0); I1, p1 = _d(I1)
+    GX1, pgx = _d(GX1); GY1, pgy = _d(GY1)
+    cam0, pc0 = _cam(cam0); cam1, pc1 = _cam(cam1)
+    R, pr = _d(R); t, pt = _d(t)
+    mode, w0, pw = _weight_args(weights)
+    H, W = I0.shape
+    Hm = np.empty(21); b = np.empty(6)
+    M = lib().orc_dvo_normal_equations(p0, pd, p1, pgx, pgy, pw, C.c_int(H), C.c_int(W),
+                                       pc0, pc1, pr, pt, C.c_int(mode),
+                                       Hm.ctypes.data_as(_dp), b.ctypes.data_as(_dp))
+    return Hm, b, int(M)
+
+
+def photometric_error_sums(I0, D0, I1, cam0, cam1, T10):
+    I0, p0 = _d(I0); D0, pd = _d(D0); I1, p1 = _d(I1)
+    cam0, pc0 = _cam(cam0); cam1, pc1 = _cam(cam1)
+    T10, pt = _d(T10)
+    s = C.c_double(0.0)
+    n = lib().orc_photometric_error(p0, pd, p1, C.c_int(I0.shape[0]), C.c_int(I0.shape[1]),
+                                    pc0, pc1, pt, C.byref(s))
+    return float(s.value), int(n)
+
+
+def photometric_error(I0, D0, I1, cam0, cam1, T10):
+    s, n = photometric_error_sums(I0, D0, I1, cam0, cam1, T10)
+    return s / n if n > 0 else float("nan")
+
+
+def rescale_shape(shape, scale):
+    return (int(np.round(shape[0] * scale)), int(np.round(shape[1] * scale)))
+
+
+def rescale(image, scale):
+    image, p = _d(image)
+    Ho, Wo = rescale_shape(image.shape, scale)
+    out = np.empty((Ho, Wo))
+    lib().orc_rescale_bilinear(p, C.c_int(image.shape[0]), C.c_int(image.shape[1]),
+                               out.ctypes.data_as(_dp), C.c_int(Ho), C.c_int(Wo))
+    return out
+
+
+def tangent_so3(v):
+    return np.array([[0., -v[2], v[1]], [v[2], 0., -v[0]], [-v[1], v[0], 0.]])
+
+
+def exp_se3_t(xi):
+    """tadataka/se3.py:15-29 -- K is built from the *normalised* rotvec."""
+    v, rotvec = xi[:3], xi[3:]
+    theta = np.linalg.norm(rotvec)
+    omega = np.zeros(3) if theta == 0 else rotvec / theta
+    K = tangent_so3(omega)
+    I = np.eye(3)
+    if theta < 1e-16:
+        V = I + K * theta / 2 + np.dot(K, K) * pow(theta, 2) / 6
+    else:
+        V = (I + (1 - np.cos(theta)) / theta * K +
+             (theta - np.sin(theta)) / theta * np.dot(K, K))
+    return np.dot(V, v)
+
+
+def motion_matrix(R, t):
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return T
+
+
+def solve_lstsq(J, r, w=None):
+    """tadataka/math.py:32-45 with method='lstsq'."""
+    if w is None:
+        return np.linalg.lstsq(J, r, rcond=None)[0]
+    sw = np.sqrt(w)
+    return np.linalg.lstsq(J * sw.reshape(-1, 1), r * sw, rcond=None)[0]
+
+
+def dvo_estimate_level(I0, D0, I1, cam0, cam1, rotation, t, weights=None,
+                       max_iter=20, trace=None):
+    """_PoseChangeEstimator.__call__ (tadataka/vo/dvo/__init__.py:79-111).
+
+    rotation is a scipy Rotation, t a 3-vector (the reference's Pose fields).
+    Returns (rotation, t).  `trace`, if a list, receives one dict per
+    iteration with the intermediates."""
+    GX1, GY1 = image_gradient(I1)
+    prev_error = photometric_error(I0, D0, I1, cam0, cam1,
+                                   motion_matrix(rotation.as_matrix(), t))
+    if trace is not None:
+        trace.append({"error0": prev_error})
+    for _ in range(max_iter):
+        J, r, w = dvo_rows(I0, D0, I1, GX1, GY1, cam0, cam1,
+                           rotation.as_matrix(), t, weights)
+        if J.shape[0] == 0:
+            return rotation, t
+        xi = solve_lstsq(J, r, None if weights is None else w)
+        drot = Rotation.from_rotvec(xi[3:])
+        cand_rot = drot * rotation
+        cand_t = np.dot(drot.as_matrix(), t) + exp_se3_t(xi)
+        curr_error = photometric_error(I0, D0, I1, cam0, cam1,
+                                       motion_matrix(cand_rot.as_matrix(), cand_t))
+        if trace is not None:
+            trace.append({"n_valid": J.shape[0], "xi": xi, "error": curr_error})
+        if curr_error > prev_error:
+            break
+        prev_error = curr_error
+        rotation, t = cand_rot, cand_t
+    return rotation, t
+
+
+def dvo_estimate(I0, D0, I1, cam0, cam1, weights=None, n_coarse_to_fine=5,
+                 max_iter=20, layer_size_ratio=1.5, rotation=None, t=None):
+    """PoseChangeEstimator.__call__ (tadataka/vo/dvo/__init__.py:125-150) with
+    the build's own bilinear pyramid in place of skimage.rescale."""
+    rotation = Rotation.from_rotvec(np.zeros(3)) if rotation is None else rotation
+    t = np.zeros(3) if t is None else t
+    cam0 = np.asarray(cam0, dtype=np.float64); cam1 = np.asarray(cam1, dtype=np.float64)
+    for level in reversed(range(n_coarse_to_fine)):
+        scale = 1 / pow(layer_size_ratio, level)
+        W0 = rescale(weights, scale) if isinstance(weights, np.ndarray) else weights
+        rotation, t = dvo_estimate_level(
+            rescale(I0, scale), rescale(D0, scale), rescale(I1, scale),
+            cam0 * scale, cam1 * scale, rotation, t, W0, max_iter)
+    return rotation, t
+
+
+# ---- semi-dense ------------------------------------------------------------
+def make_params(min_depth, max_depth, geo_coeff, photo_coeff, ref_step_size,
+                min_gradient):
+    p = Params()
+    lib().orc_make_params(C.c_double(min_depth), C.c_double(max_depth),
+                          C.c_double(geo_coeff), C.c_double(photo_coeff),
+                          C.c_double(ref_step_size), C.c_double(min_gradient),
+                          C.byref(p))
+    return p
+
+
+def sobel(img):
+    img, p = _d(img)
+    gx = np.empty_like(img); gy = np.empty_like(img)
+    lib().orc_sobel(p, C.c_int(img.shape[0]), C.c_int(img.shape[1]),
+                    gx.ctypes.data_as(_dp), gy.ctypes.data_as(_dp))
+    return gx, gy
+
+
+def increment_age(age0, cam0, cam1, T10, depth0):
+    age0 = np.ascontiguousarray(age0, dtype=np.uint64)
+    cam0, pc0 = _cam(cam0); cam1, pc1 = _cam(cam1)
+    T10, pt = _d(T10); depth0, pd = _d(depth0)
+    age1 = np.empty_like(age0)
+    lib().orc_increment_age(age0.ctypes.data_as(_u64p), C.c_int(age0.shape[0]),
+                            C.c_int(age0.shape[1]), pc0, pc1, pt, pd,
+                            age1.ctypes.data_as(_u64p))
+    return age1
+
+
+def propagate(T10, cam0, cam1, depth0, var0, default_depth, default_variance,
+              uncertaintity_bias):
+    cam0, pc0 = _cam(cam0); cam1, pc1 = _cam(cam1)
+    T10, pt = _d(T10); depth0, pd = _d(depth0); var0, pv = _d(var0)
+    depth1 = np.empty_like(depth0); var1 = np.empty_like(var0)
+    lib().orc_propagate(pt, pc0, pc1, pd, pv, C.c_int(depth0.shape[0]),
+                        C.c_int(depth0.shape[1]), C.c_double(default_depth),
+                        C.c_double(default_variance), C.c_double(uncertaintity_bias),
+                        depth1.ctypes.data_as(_dp), var1.ctypes.data_as(_dp))
+    return depth1, var1
+
+
+def transform_rk(T_wk, T_wr):
+    T_wk, pk = _d(T_wk); T_wr, pr = _d(T_wr)
+    out = np.empty((4, 4))
+    lib().orc_transform_rk(pk, pr, out.ctypes.data_as(_dp))
+    return out
+
+
+def estimate_debug(u_key, prior_depth, prior_variance, key, ref, params):
+    """key / ref = (cam[4], image, T_wf[4,4])."""
+    u = np.ascontiguousarray(u_key, dtype=np.int64)
+    kc, pkc = _cam(key[0]); ki, pki = _d(key[1]); kT, pkT = _d(key[2])
+    rc, prc = _cam(ref[0]); ri, pri = _d(ref[1]); rT, prT = _d(ref[2])
+    od = C.c_double(); ov = C.c_double()
+    f = lib().orc_estimate_debug(u.ctypes.data_as(_i64p), C.c_double(prior_depth),
+                                 C.c_double(prior_variance), pkc, pki, pkT, prc, pri,
+                                 prT, C.c_int(ki.shape[0]), C.c_int(ki.shape[1]),
+                                 C.byref(params), C.byref(od), C.byref(ov))
+    return float(od.value), float(ov.value), int(f)
+
+
+def update_depth(key, refs, age, prior_depth, prior_variance, params):
+    """key = (cam, image, T); refs = list of (cam, image, T).
+    Returns (depth, variance, flag) like src/py/semi_dense.rs:182-186."""
+    kc, pkc = _cam(key[0]); ki, pki = _d(key[1]); kT, pkT = _d(key[2])
+    H, W = ki.shape
+    n_ref = len(refs)
+    rcams = np.ascontiguousarray([np.asarray(r[0], dtype=np.float64) for r in refs]).reshape(n_ref, 4)
+    rimgs = np.ascontiguousarray([r[1] for r in refs], dtype=np.float64).reshape(n_ref, H, W)
+    rTs = np.ascontiguousarray([r[2] for r in refs], dtype=np.float64).reshape(n_ref, 4, 4)
+    age = np.ascontiguousarray(age, dtype=np.uint64)
+    pd_, ppd = _d(prior_depth); pv_, ppv = _d(prior_variance)
+    depth = np.empty((H, W)); var = np.empty((H, W)); flag = np.empty((H, W), dtype=np.int64)
+    rc = lib().orc_update_depth(pkc, pki, pkT, C.c_int(n_ref), rcams.ctypes.data_as(_dp),
+                                rimgs.ctypes.data_as(_dp), rTs.ctypes.data_as(_dp),
+                                age.ctypes.data_as(_u64p), ppd, ppv, C.c_int(H), C.c_int(W),
+                                C.byref(params), depth.ctypes.data_as(_dp),
+                                var.ctypes.data_as(_dp), flag.ctypes.data_as(_i64p))
+    if rc != 0:
+        raise RuntimeError("Age exceeds the refframe size")
+    return depth, var, flag
+
+
+# ---- bundle adjustment -------------------------------------------------------
+def exp_so3(rotvec):
+    r, p = _d(rotvec)
+    out = np.empty((3, 3))
+    lib().orc_exp_so3(p, out.ctypes.data_as(_dp))
+    return out
+
+
+def ba_transform_project(pose, point):
+    a, pa = _d(pose); b, pb = _d(point)
+    out = np.empty(2)
+    lib().orc_ba_transform_project(pa, pb, out.ctypes.data_as(_dp))
+    return out
+
+
+def ba_pose_jacobian(pose, point):
+    a, pa = _d(pose); b, pb = _d(point)
+    out = np.empty((2, 6))
+    lib().orc_ba_pose_jacobian(pa, pb, out.ctypes.data_as(_dp))
+    return out
+
+
+def ba_point_jacobian(pose, point):
+    a, pa = _d(pose); b, pb = _d(point)
+    out = np.empty((2, 3))
+    lib().orc_ba_point_jacobian(pa, pb, out.ctypes.data_as(_dp))
+    return out
+
+
+def ba_projection(poses, points, vp_idx, pt_idx, jacobians=True):
+    poses, pp = _d(poses); points, pq = _d(points)
+    vp = np.ascontiguousarray(vp_idx, dtype=np.int64)
+    pt = np.ascontiguousarray(pt_idx, dtype=np.int64)
+    n = vp.shape[0]
+    x = np.empty((n, 2))
+    A = np.empty((n, 2, 6)) if jacobians else None
+    B = np.empty((n, 2, 3)) if jacobians else None
+    lib().orc_ba_projection(pp, pq, vp.ctypes.data_as(_i64p), pt.ctypes.data_as(_i64p),
+                            C.c_int64(n), x.ctypes.data_as(_dp),
+                            A.ctypes.data_as(_dp) if jacobians else None,
+                            B.ctypes.data_as(_dp) if jacobians else None)
+    return (x, A, B) if jacobians else x
+
+
+def ba_block_reduce(poses, points, x_true, vp_idx, pt_idx):
+    poses, pp = _d(poses); points, pq = _d(points); x_true, px = _d(x_true)
+    vp = np.ascontiguousarray(vp_idx, dtype=np.int64)
+    pt = np.ascontiguousarray(pt_idx, dtype=np.int64)
+    nP, nQ = poses.shape[0], points.shape[0]
+    U = np.empty((nP, 21)); ea = np.empty((nP, 6)); V = np.empty((nQ, 6)); eb = np.empty((nQ, 3))
+    err = lib().orc_ba_block_reduce(pp, C.c_int64(nP), pq, C.c_int64(nQ), px,
+                                    vp.ctypes.data_as(_i64p), pt.ctypes.data_as(_i64p),
+                                    C.c_int64(vp.shape[0]), U.ctypes.data_as(_dp),
+                                    ea.ctypes.data_as(_dp), V.ctypes.data_as(_dp),
+                                    eb.ctypes.data_as(_dp))
+    return U, ea, V, eb, float(err)

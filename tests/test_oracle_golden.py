@@ -1,0 +1,145 @@
+"""Pins the CPU oracle (oracle/tdk_oracle.c + oracle/oracle.py) against the
+fixtures captured from the reference itself (tests/golden/generate_golden.py).
+CPU only."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from oracle import oracle as orc
+from tadataka_amd import synthetic
+from conftest import rel_err
+
+WEIGHTS = [None, "huber", "student-t", "tukey", "map"]
+
+
+def _weights(d, name):
+    return d["weight_map"] if name == "map" else name
+
+
+@pytest.fixture(scope="module")
+def small(golden):
+    return golden("dvo_small.npz")
+
+
+def test_dvo_rows_match_reference(small):
+    d = small
+    cam = d["cam"]
+    GX, GY = orc.image_gradient(d["I1"])
+    for k in range(int(d["s_None_n_updates"])):
+        T = d["s_None_err_T"][k]
+        J, r, w = orc.dvo_rows(d["I0"], d["D0"], d["I1"], GX, GY, cam, cam,
+                               T[:3, :3], T[:3, 3], None)
+        assert J.shape[0] == int(d[f"s_None_u{k}_n_valid"])
+        assert rel_err(J, d[f"s_None_u{k}_J"]) < 1e-10
+        # the residual is the un-warped I0 - I1 (F3): bit-exact
+        assert np.array_equal(r, d[f"s_None_u{k}_r"])
+
+
+@pytest.mark.parametrize("wname", WEIGHTS)
+def test_dvo_weights_and_normal_equations(small, wname):
+    d = small
+    cam = d["cam"]
+    key = f"s_{wname}"
+    GX, GY = orc.image_gradient(d["I1"])
+    for k in range(int(d[f"{key}_n_updates"])):
+        T = d[f"{key}_err_T"][k]
+        weights = _weights(d, wname)
+        J, r, w = orc.dvo_rows(d["I0"], d["D0"], d["I1"], GX, GY, cam, cam,
+                               T[:3, :3], T[:3, 3], weights)
+        assert J.shape[0] == int(d[f"{key}_u{k}_n_valid"])
+        assert rel_err(w, d[f"{key}_u{k}_w"]) < 1e-10
+        H, b, n = orc.dvo_normal_equations(d["I0"], d["D0"], d["I1"], GX, GY, cam, cam,
+                                           T[:3, :3], T[:3, 3], weights)
+        # solve_linear_equation applies sqrt(w) to rows => normal eqs carry w
+        Href = d[f"{key}_u{k}_H"]
+        iu = np.triu_indices(6)
+        assert n == J.shape[0]
+        assert rel_err(H, Href[iu]) < 1e-9
+        assert rel_err(b, d[f"{key}_u{k}_b"]) < 1e-9
+        # and the lstsq solution of the reference equals the normal-eq solve
+        Hm = np.zeros((6, 6)); Hm[iu] = H; Hm = Hm + Hm.T - np.diag(np.diag(Hm))
+        xi = np.linalg.solve(Hm, b)
+        assert np.allclose(xi, d[f"{key}_u{k}_xi"], rtol=1e-7, atol=1e-10)
+
+
+@pytest.mark.parametrize("wname", WEIGHTS)
+def test_photometric_error_matches_reference(small, wname):
+    d = small
+    cam = d["cam"]
+    Ts, vals = d[f"s_{wname}_err_T"], d[f"s_{wname}_err_val"]
+    for T, v in zip(Ts, vals):
+        e = orc.photometric_error(d["I0"], d["D0"], d["I1"], cam, cam, T)
+        assert abs(e - v) <= 1e-10 * abs(v)
+
+
+@pytest.mark.parametrize("wname", WEIGHTS)
+def test_dvo_level_loop_matches_reference(small, wname):
+    d = small
+    cam = d["cam"]
+    rot, t = orc.dvo_estimate_level(d["I0"], d["D0"], d["I1"], cam, cam,
+                                    Rotation.from_rotvec(np.zeros(3)), np.zeros(3),
+                                    _weights(d, wname), max_iter=20)
+    assert np.allclose(rot.as_rotvec(), d[f"s_{wname}_final_rotvec"], atol=1e-9)
+    assert np.allclose(t, d[f"s_{wname}_final_t"], atol=1e-9)
+
+
+def test_dvo_vga_matches_reference(golden):
+    v = golden("dvo_vga.npz")
+    pair = synthetic.make_pair(480, 640, seed=0)
+    assert np.allclose(pair["omega"], v["omega_true"]) and np.allclose(pair["t"], v["t_true"])
+    cam = pair["cam"]
+    GX, GY = orc.image_gradient(pair["I1"])
+    iu = np.triu_indices(6)
+    for wname in (None, "huber"):
+        key = f"v_{wname}"
+        for k in range(int(v[f"{key}_n_updates"])):
+            T = v[f"{key}_err_T"][k]
+            H, b, n = orc.dvo_normal_equations(pair["I0"], pair["D0"], pair["I1"], GX, GY,
+                                               cam, cam, T[:3, :3], T[:3, 3], wname)
+            assert n == int(v[f"{key}_u{k}_n_valid"])
+            assert rel_err(H, v[f"{key}_u{k}_H"][iu]) < 1e-9
+            assert rel_err(b, v[f"{key}_u{k}_b"]) < 1e-9
+        for T, val in zip(v[f"{key}_err_T"], v[f"{key}_err_val"]):
+            e = orc.photometric_error(pair["I0"], pair["D0"], pair["I1"], cam, cam, T)
+            assert abs(e - val) <= 1e-10 * abs(val)
+
+
+def test_dvo_pyramid_matches_reference(golden):
+    p = golden("dvo_pyramid.npz")
+    pair = synthetic.make_pair(120, 160, seed=4)
+    for wname in (None, "huber"):
+        rot, t = orc.dvo_estimate(pair["I0"], pair["D0"], pair["I1"], pair["cam"], pair["cam"],
+                                  wname, n_coarse_to_fine=3, max_iter=20)
+        assert np.allclose(rot.as_rotvec(), p[f"pyr_{wname}_rotvec"], atol=1e-9)
+        assert np.allclose(t, p[f"pyr_{wname}_t"], atol=1e-9)
+
+
+def test_pure_python_reference_numerics(golden):
+    g = golden("pyref.npz")
+    # np.gradient (tadataka/vo/dvo/jacobian.py:27-29)
+    gx, gy = orc.image_gradient(g["grad_img"])
+    assert np.array_equal(gx, g["grad_gx"]) and np.array_equal(gy, g["grad_gy"])
+    # is_in_image_range (tadataka/utils.py:35-54)
+    assert np.array_equal(orc.is_in_image_range(g["rng_kp"], (9, 13)), g["rng_mask"])
+    # exp_se3_t_ (tadataka/se3.py:15-29)
+    for xi, t in zip(g["se3_xi"], g["se3_t"]):
+        assert np.allclose(orc.exp_se3_t(xi), t, rtol=0, atol=1e-14)
+    # lstsq (tadataka/math.py:32-45)
+    assert np.allclose(orc.solve_lstsq(g["ls_A"], g["ls_b"]), g["ls_x"], atol=1e-12)
+    assert np.allclose(orc.solve_lstsq(g["ls_A"], g["ls_b"], g["ls_w"]), g["ls_xw"], atol=1e-12)
+
+
+def test_ba_matches_cython_reference(golden):
+    g = golden("ba_vectors.npz")
+    poses, points = g["poses"], g["points"]
+    n = poses.shape[0]
+    idx = np.arange(n, dtype=np.int64)
+    x, A, B = orc.ba_projection(poses, points, idx, idx)
+    scale = lambda ref: np.maximum(np.abs(ref).max(axis=tuple(range(1, ref.ndim)), keepdims=True), 1.0)
+    assert np.max(np.abs(x - g["x"]) / scale(g["x"])) < 1e-12
+    assert np.max(np.abs(B - g["B"]) / scale(g["B"])) < 1e-11
+    # the symbolic derivative and the analytic chain rule agree to rounding
+    # everywhere, including |omega| -> 0 and |omega| = pi
+    assert np.max(np.abs(A - g["A"]) / scale(g["A"])) < 1e-8
+    R = np.array([orc.exp_so3(p[:3]) for p in poses])
+    assert np.max(np.abs(R - g["R"])) < 1e-12
