@@ -1,0 +1,187 @@
+/*
+ * tadataka_hip.h -- C ABI of libtadataka_hip.so, the MI355X (gfx950) native
+ * replacement of Tadataka's per-pixel DVO / semi-dense / BA hot path.
+ *
+ * This is the drop-in boundary: the reference reaches the same functionality
+ * through its compiled extension modules (pyo3 crate `rust_bindings`,
+ * pybind11 `tadataka.camera._normalizer`, Cython `tadataka.transform_project`).
+ * Each entry point below names the reference interface it replaces
+ * (file:line in the reference checkout).  INTEGRATION.md shows the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - extern "C", POD arguments only, caller-allocated outputs.
+ *   - every function returns a tdk_status (0 = ok, < 0 = error); nothing
+ *     throws, aborts or exits.  tdk_last_error() gives a message.
+ *   - arrays are C-contiguous float64 unless stated; images are [row=y][col=x];
+ *     coordinates are (x, y) pairs; camera = {fx, fy, ox, oy}; transforms are
+ *     row-major 4x4; poses for DVO are 12 doubles {R row-major (9), t (3)}.
+ *   - pointers are HOST pointers unless the name ends in `_dev`.
+ *   - calls are serialised on one HIP stream per process; they block until the
+ *     result is in the output buffers unless stated otherwise.
+ */
+#ifndef TADATAKA_HIP_H
+#define TADATAKA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int tdk_status;
+enum {
+    TDK_OK = 0,
+    TDK_ERR_INVALID_ARGUMENT = -1,
+    TDK_ERR_HIP = -2,            /* a HIP runtime call failed */
+    TDK_ERR_OUT_OF_RANGE = -3,   /* coordinates outside the image (ValueError in the reference) */
+    TDK_ERR_AGE_EXCEEDS_REFFRAMES = -4, /* reference: process::exit(1), semi_dense.rs:202-205 */
+    TDK_ERR_NO_DEVICE = -5,
+    TDK_ERR_SINGULAR = -6
+};
+
+/* ---- runtime ------------------------------------------------------------ */
+const char *tdk_version(void);
+const char *tdk_last_error(void);
+tdk_status tdk_device_count(int *count);
+tdk_status tdk_set_device(int device);
+tdk_status tdk_get_device(int *device);
+tdk_status tdk_sync(void);
+tdk_status tdk_device_name(char *buf, int buflen);
+
+/* ---- parity-granular per-point operators (1:1 with rust_bindings.*) ------- */
+/* tadataka.camera._normalizer.normalize/unnormalize (tadataka/camera/_normalizer.cpp:12-27),
+ * src/camera.rs:32-63 */
+tdk_status tdk_normalize(const double *keypoints, int64_t n, const double *camera, double *out);
+tdk_status tdk_unnormalize(const double *keypoints, int64_t n, const double *camera, double *out);
+/* rust_bindings.projection.project_vecs / inv_project_vecs (src/py/projection.rs:7-41) */
+tdk_status tdk_project_vecs(const double *points, int64_t n, double *out);
+tdk_status tdk_inv_project_vecs(const double *xs, const double *depths, int64_t n, double *out);
+/* rust_bindings.transform.transform (src/py/transform.rs:6-15) */
+tdk_status tdk_transform(const double *transform10, const double *points, int64_t n, double *out);
+/* rust_bindings.warp.warp_vecs (src/py/warp.rs:51-67) */
+tdk_status tdk_warp_vecs(const double *transform10, const double *xs, const double *depths,
+                         int64_t n, double *out_xs, double *out_depths);
+/* rust_bindings.interpolation.interpolation behind tadataka.interpolation.interpolation
+ * (src/py/interpolation.rs:6-15, tadataka/interpolation/__init__.py:13-29).
+ * Returns TDK_ERR_OUT_OF_RANGE where the Python wrapper raises ValueError. */
+tdk_status tdk_interpolation(const double *image, int height, int width,
+                             const double *coordinates, int64_t m, double *out);
+/* rust_bindings.triangulation.calc_depth0 (src/py/triangulation.rs:7-19) */
+tdk_status tdk_calc_depth0(const double *transform10, const double *x0, const double *x1, double *depth);
+/* tadataka.vo.dvo.jacobian.calc_image_gradient = np.gradient (jacobian.py:27-29); out (DX, DY) */
+tdk_status tdk_image_gradient(const double *image, int height, int width, double *gx, double *gy);
+/* Pyramid level: bilinear rescale to (out_height, out_width) (stand-in for
+ * skimage.transform.rescale, tadataka/vo/dvo/__init__.py:144-148) */
+tdk_status tdk_rescale(const double *image, int height, int width, double *out,
+                       int out_height, int out_width);
+
+/* ---- DVO: device-resident batch of frame pairs (new, fused) ---------------
+ * Replaces, for all pairs at once, the per-iteration body of
+ * _PoseChangeEstimator.__call__ (tadataka/vo/dvo/__init__.py:79-111):
+ * calc_pose_update (:46-70) + PhotometricError (tadataka/metric.py:13-39). */
+typedef struct tdk_dvo tdk_dvo;
+
+enum { TDK_W_NONE = 0, TDK_W_HUBER = 1, TDK_W_STUDENT_T = 2, TDK_W_TUKEY = 3, TDK_W_MAP = 4 };
+
+/* Allocates device storage for n_pairs pairs of height x width frames
+ * (I0, D0, I1 and, if with_weight_map, W0) plus an n_levels-deep pyramid with
+ * scale 1/ratio^level. */
+tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, double ratio,
+                          int with_weight_map, tdk_dvo **out);
+tdk_status tdk_dvo_destroy(tdk_dvo *h);
+/* Host -> device copy of one pair (level 0).  weight_map may be NULL. */
+tdk_status tdk_dvo_upload(tdk_dvo *h, int pair, const double *I0, const double *D0,
+                          const double *I1, const double *weight_map);
+/* Fills every pair on the device from the analytic synthetic scene of
+ * tadataka_amd/synthetic.py (bench inputs "generated on device"): pair i uses
+ * poses12[i] as ground truth and seed seed0+i for the noise. */
+tdk_status tdk_dvo_fill_synthetic(tdk_dvo *h, const double *camera, const double *poses12,
+                                  uint64_t seed0, double noise);
+/* Builds pyramid levels 1..n_levels-1 on the device from level 0. */
+tdk_status tdk_dvo_build_pyramid(tdk_dvo *h);
+/* Device -> host copy of one array of one pair/level: which = 0 I0, 1 D0, 2 I1, 3 W0. */
+tdk_status tdk_dvo_download(tdk_dvo *h, int pair, int level, int which, double *out);
+tdk_status tdk_dvo_level_shape(tdk_dvo *h, int level, int *height, int *width);
+
+/* One evaluation per pair at `level`:
+ *   normal equations of calc_pose_update at poses12[pair]:
+ *       Hout[pair][21] (upper triangle, row-major), bout[pair][6], n_update[pair]
+ *   photometric error at the same pose: sum_sq[pair], n_error[pair]
+ * cameras are [n_pairs][4] at FULL resolution (scaled per level internally as
+ * tadataka.camera.resize does, camera/model.py:69-74).  Any output may be NULL. */
+tdk_status tdk_dvo_evaluate(tdk_dvo *h, int level, const double *camera0, const double *camera1,
+                            const double *poses12, int weight_mode, double *Hout, double *bout,
+                            int64_t *n_update, double *sum_sq, int64_t *n_error);
+/* Gauss-Newton loop of one level for all pairs, accept/reject on the device.
+ * poses12 is updated in place; n_evals[pair] (optional) = evaluations used. */
+tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0,
+                                  const double *camera1, double *poses12, int weight_mode,
+                                  int max_iter, int *n_evals);
+/* Coarse-to-fine over all levels (PoseChangeEstimator.__call__, :125-150). */
+tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *camera1,
+                            double *poses12, int weight_mode, int max_iter, int64_t *pixel_evals);
+/* The hipStream_t every kernel of this library is queued on (bench.py records
+ * its HIP events there). */
+tdk_status tdk_dvo_get_stream(void **stream_out);
+/* Per-launch timing of the full-resolution evaluation kernel with HIP events
+ * recorded inside the library, on its own stream, around each launch:
+ * launches, summed milliseconds and summed source pixels since enabling. */
+tdk_status tdk_dvo_set_profiling(tdk_dvo *h, int enabled);
+tdk_status tdk_dvo_get_profile(tdk_dvo *h, int64_t *launches, double *total_ms, int64_t *pixels);
+
+/* ---- semi-dense (rust_bindings.semi_dense) --------------------------------- */
+typedef struct {
+    double min_depth, max_depth, geo_coeff, photo_coeff, ref_step_size, min_gradient;
+} tdk_semi_dense_params; /* Params.new, src/py/semi_dense.rs:93-108 */
+
+/* increment_age (src/py/semi_dense.rs:35-51 -> src/semi_dense/age.rs:6-32) */
+tdk_status tdk_increment_age(const uint64_t *age0, int height, int width, const double *camera0,
+                             const double *camera1, const double *transform10,
+                             const double *depth0, uint64_t *age1);
+/* propagate (src/py/semi_dense.rs:189-218 -> src/semi_dense/propagation.rs:48-92) */
+tdk_status tdk_propagate(const double *transform10, const double *camera0, const double *camera1,
+                         const double *depth0, const double *variance0, int height, int width,
+                         double default_depth, double default_variance, double uncertaintity_bias,
+                         double *depth1, double *variance1);
+/* update_depth (src/py/semi_dense.rs:157-187 -> src/semi_dense/semi_dense.rs:160-234).
+ * ref_* hold n_ref frames back to back; outputs in Python order (depth, variance, flag). */
+tdk_status tdk_update_depth(const double *key_camera, const double *key_image,
+                            const double *key_transform_wf, int n_ref, const double *ref_cameras,
+                            const double *ref_images, const double *ref_transforms_wf,
+                            const uint64_t *age, const double *prior_depth,
+                            const double *prior_variance, int height, int width,
+                            const tdk_semi_dense_params *params, double *depth, double *variance,
+                            int64_t *flag);
+/* estimate_debug_ (src/py/semi_dense.rs:126-155) */
+tdk_status tdk_estimate_one(const int64_t *u_key, double prior_depth, double prior_variance,
+                            const double *key_camera, const double *key_image,
+                            const double *key_transform_wf, const double *ref_camera,
+                            const double *ref_image, const double *ref_transform_wf, int height,
+                            int width, const tdk_semi_dense_params *params, double *depth,
+                            double *variance, int64_t *flag);
+/* Sobel maps of ImageGradient::new (src/semi_dense/gradient.rs:11-15) */
+tdk_status tdk_sobel(const double *image, int height, int width, double *gx, double *gy);
+
+/* ---- bundle adjustment (tadataka.transform_project, tadataka/local_ba.py) -- */
+/* Projection.compute / .jacobians over n observations (local_ba.py:23-39);
+ * x_pred [n][2], A [n][2][6], B [n][2][3]; any output may be NULL. */
+tdk_status tdk_ba_projection(const double *poses, int64_t n_poses, const double *points,
+                             int64_t n_points, const int64_t *viewpoint_indices,
+                             const int64_t *point_indices, int64_t n, double *x_pred, double *A,
+                             double *B);
+/* transform_project.exp_so3 (transform_project.pyx:46-50) for n rotation vectors */
+tdk_status tdk_ba_exp_so3(const double *rotvecs, int64_t n, double *R);
+/* Fused residual + Jacobian + block reduce (the sums sparseba.SBA.compute
+ * starts from, call site local_ba.py:74-77): U [n_poses][21], ea [n_poses][6],
+ * V [n_points][6], eb [n_points][3], err = sum ||x_true - x_pred||^2. */
+tdk_status tdk_ba_block_reduce(const double *poses, int64_t n_poses, const double *points,
+                               int64_t n_points, const double *x_true,
+                               const int64_t *viewpoint_indices, const int64_t *point_indices,
+                               int64_t n, double *U, double *ea, double *V, double *eb,
+                               double *err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TADATAKA_HIP_H */

@@ -1,0 +1,135 @@
+"""ctypes binding of libtadataka_hip.so (include/tadataka_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or a compute entry
+is called without a usable MI355X, the call raises.  Nothing here imports or
+calls the test oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtadataka_hip.so")
+
+c_double_p = C.POINTER(C.c_double)
+c_int64_p = C.POINTER(C.c_int64)
+c_uint64_p = C.POINTER(C.c_uint64)
+c_int_p = C.POINTER(C.c_int)
+
+
+class SemiDenseParams(C.Structure):
+    """tdk_semi_dense_params (Params.new, src/py/semi_dense.rs:93-108)."""
+    _fields_ = [("min_depth", C.c_double), ("max_depth", C.c_double),
+                ("geo_coeff", C.c_double), ("photo_coeff", C.c_double),
+                ("ref_step_size", C.c_double), ("min_gradient", C.c_double)]
+
+
+class TdkError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"libtadataka_hip: status {status}: {message}")
+        self.status = status
+
+
+TDK_OK = 0
+TDK_ERR_INVALID_ARGUMENT = -1
+TDK_ERR_HIP = -2
+TDK_ERR_OUT_OF_RANGE = -3
+TDK_ERR_AGE_EXCEEDS_REFFRAMES = -4
+TDK_ERR_NO_DEVICE = -5
+
+W_NONE, W_HUBER, W_STUDENT_T, W_TUKEY, W_MAP = 0, 1, 2, 3, 4
+
+_d, _i, _i64, _u64, _vp = c_double_p, C.c_int, C.c_int64, C.c_uint64, C.c_void_p
+
+# name -> argtypes; every entry of include/tadataka_hip.h returning tdk_status
+PROTOTYPES = {
+    "tdk_device_count": [c_int_p],
+    "tdk_set_device": [_i],
+    "tdk_get_device": [c_int_p],
+    "tdk_sync": [],
+    "tdk_device_name": [C.c_char_p, _i],
+    "tdk_normalize": [_d, _i64, _d, _d],
+    "tdk_unnormalize": [_d, _i64, _d, _d],
+    "tdk_project_vecs": [_d, _i64, _d],
+    "tdk_inv_project_vecs": [_d, _d, _i64, _d],
+    "tdk_transform": [_d, _d, _i64, _d],
+    "tdk_warp_vecs": [_d, _d, _d, _i64, _d, _d],
+    "tdk_interpolation": [_d, _i, _i, _d, _i64, _d],
+    "tdk_calc_depth0": [_d, _d, _d, _d],
+    "tdk_image_gradient": [_d, _i, _i, _d, _d],
+    "tdk_rescale": [_d, _i, _i, _d, _i, _i],
+    "tdk_dvo_create": [_i, _i, _i, _i, C.c_double, _i, C.POINTER(_vp)],
+    "tdk_dvo_destroy": [_vp],
+    "tdk_dvo_upload": [_vp, _i, _d, _d, _d, _d],
+    "tdk_dvo_fill_synthetic": [_vp, _d, _d, _u64, C.c_double],
+    "tdk_dvo_build_pyramid": [_vp],
+    "tdk_dvo_download": [_vp, _i, _i, _i, _d],
+    "tdk_dvo_level_shape": [_vp, _i, c_int_p, c_int_p],
+    "tdk_dvo_evaluate": [_vp, _i, _d, _d, _d, _i, _d, _d, c_int64_p, _d, c_int64_p],
+    "tdk_dvo_estimate_level": [_vp, _i, _d, _d, _d, _i, _i, c_int_p],
+    "tdk_dvo_estimate": [_vp, _d, _d, _d, _i, _i, c_int64_p],
+    "tdk_dvo_get_stream": [C.POINTER(_vp)],
+    "tdk_dvo_set_profiling": [_vp, _i],
+    "tdk_dvo_get_profile": [_vp, c_int64_p, _d, c_int64_p],
+    "tdk_increment_age": [c_uint64_p, _i, _i, _d, _d, _d, _d, c_uint64_p],
+    "tdk_propagate": [_d, _d, _d, _d, _d, _i, _i, C.c_double, C.c_double, C.c_double, _d, _d],
+    "tdk_update_depth": [_d, _d, _d, _i, _d, _d, _d, c_uint64_p, _d, _d, _i, _i,
+                         C.POINTER(SemiDenseParams), _d, _d, c_int64_p],
+    "tdk_estimate_one": [c_int64_p, C.c_double, C.c_double, _d, _d, _d, _d, _d, _d, _i, _i,
+                         C.POINTER(SemiDenseParams), _d, _d, c_int64_p],
+    "tdk_sobel": [_d, _i, _i, _d, _d],
+    "tdk_ba_projection": [_d, _i64, _d, _i64, c_int64_p, c_int64_p, _i64, _d, _d, _d],
+    "tdk_ba_exp_so3": [_d, _i64, _d],
+    "tdk_ba_block_reduce": [_d, _i64, _d, _i64, _d, c_int64_p, c_int64_p, _i64, _d, _d, _d, _d, _d],
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (or `make -C tadataka_amd/csrc`).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.tdk_version.restype = C.c_char_p
+    lib.tdk_last_error.restype = C.c_char_p
+    for name, argtypes in PROTOTYPES.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(status):
+    if status == TDK_OK:
+        return
+    msg = load().tdk_last_error().decode("utf-8", "replace")
+    if status == TDK_ERR_OUT_OF_RANGE:
+        raise ValueError(msg)        # what tadataka.interpolation raises
+    raise TdkError(status, msg)
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))
+
+
+def device_count():
+    n = C.c_int(0)
+    call("tdk_device_count", C.byref(n))
+    return n.value
+
+
+def require_gpu():
+    if device_count() <= 0:
+        raise TdkError(TDK_ERR_NO_DEVICE, "no MI355X / HIP device visible; there is no CPU fallback")
+
+
+def device_name():
+    buf = C.create_string_buffer(256)
+    call("tdk_device_name", buf, 256)
+    return buf.value.decode()

@@ -1,0 +1,769 @@
+// dvo.hip -- the fused, device-resident DVO path for batches of frame pairs.
+//
+// One "evaluation" of a pose does, in ONE pass over the source pixels, what the
+// reference does in two separate passes per Gauss-Newton iteration
+// (tadataka/vo/dvo/__init__.py:93-110):
+//   * calc_pose_update (:46-70): warp, mask (in range & z > 0), bilinear
+//     samples of the image gradient, Jacobian row (jacobian.py:8-24), weights,
+//     and the reduction sum w J^T J / sum w J^T r that solve_linear_equation
+//     (tadataka/math.py:32-45) solves by lstsq;
+//   * photometric_error (tadataka/metric.py:13-27): warp, mask (in range),
+//     bilinear sample of I1, mean squared difference.
+// The candidate pose whose error is tested is also the pose the next update
+// is linearised at, so error(pose) and the normal equations at the same pose
+// share one read of (D0, I0, I1[, W0]).
+//
+// HBM layout: per pyramid level, struct-of-arrays I0 | D0 | I1 | W0, each
+// [n_pairs][stride] float64 with stride = N rounded up to even so that every
+// pair starts 16-byte aligned.  The image gradient (np.gradient of I1) is NOT
+// materialised: its 4+4 bilinear taps are rebuilt from 12 neighbouring I1
+// texels, bit-identical to sampling precomputed DX/DY maps, which removes 16 of
+// the 40 B/px the unfused update would read.
+//
+// Kernels (gfx950, wave64):
+//   k_dvo_eval    grid (nblk, n_pairs) x 256 threads; each thread walks its
+//                 block's contiguous pixel range two pixels at a time (16-byte
+//                 loads), keeps 30 f64 accumulators, wave __shfl_down reduce,
+//                 LDS across the 4 waves, one 30-double partial per block.
+//   k_dvo_reduce  grid n_pairs x 256: fixed-order sum of the partials
+//                 (bit-reproducible), then -- in loop mode -- lane 0 performs the
+//                 monotone accept/reject, the 6x6 solve and the SE(3) update,
+//                 so a Gauss-Newton iteration needs no host round trip.
+#include "tdk_math.h"
+#include "tdk_runtime.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+namespace {
+
+using tdk::Cam;
+
+constexpr int kBlock = 256;
+constexpr int kAcc = 30;       // 21 H + 6 b + sum_sq + n_update + n_error
+constexpr int kAccPad = 32;
+constexpr int kMaxLevels = 16;
+constexpr double kHuberK = 1.345;  // tadataka/robust/weights.py:38
+
+struct LevelPtrs {
+    const double *I0, *D0, *I1, *W0;
+    int64_t stride;  // elements between consecutive pairs
+    int H, W;
+    int64_t N;
+};
+
+struct PairParams {  // per pair, device memory
+    double cam0[4];
+    double cam1[4];
+};
+
+enum { ST_RUNNING = 0, ST_DONE = 1 };
+
+struct Accum {
+    double v[kAcc];
+};
+
+// One source pixel.  (x, y) integer pixel of frame 0 with normalised
+// coordinates (xn, yn); d0/i0/i1/w0 its depth, intensities (I0 and the
+// *unwarped* I1, F3) and weight-map entry.
+//
+// The warped coordinate decides mask membership with an inclusive float
+// comparison, and at the identity pose the whole right/bottom border sits
+// exactly on that boundary -- so the coordinate chain is evaluated with the
+// reference's elementwise operations, one IEEE rounding each and no FMA
+// contraction: (u - o) / f (table), x * d, q / (z + 1e-16), x * f + o.
+template <int WMODE>
+__device__ __forceinline__ void accumulate_pixel(Accum &a, double xn, double yn, double d0, double i0,
+                                                 double i1, double w0, const double *__restrict__ I1,
+                                                 int H, int W, const double *P /*R,t*/,
+                                                 const double *c /*fx1, fy1, ox1, oy1*/) {
+    double qx, qy, qz, u, v;
+    {
+#pragma clang fp contract(off)
+        double px = xn * d0, py = yn * d0, pz = 1.0 * d0;
+        qx = ((P[0] * px + P[1] * py) + P[2] * pz) + P[9];
+        qy = ((P[3] * px + P[4] * py) + P[5] * pz) + P[10];
+        qz = ((P[6] * px + P[7] * py) + P[8] * pz) + P[11];
+        double z = qz + tdk::kEps16;
+        u = (qx / z) * c[0] + c[2];
+        v = (qy / z) * c[1] + c[3];
+    }
+    // inclusive float range test (tadataka/utils.py:35-44)
+    if (!(u >= 0.0 && u <= (double)(W - 1) && v >= 0.0 && v <= (double)(H - 1))) return;
+
+    double lx = floor(u), ly = floor(v);
+    int c0 = (int)lx, r0 = (int)ly;
+    double wx1 = u - lx, wx0 = (lx + 1.0) - u;
+    double wy1 = v - ly, wy0 = (ly + 1.0) - v;
+    double w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+
+    // 4 x 2 + 2 x 2 texels of I1 around (c0, r0), indices clamped to the image
+    int cm = max(c0 - 1, 0), c1 = min(c0 + 1, W - 1), c2 = min(c0 + 2, W - 1);
+    int rm = max(r0 - 1, 0), r1 = min(r0 + 1, H - 1), r2 = min(r0 + 2, H - 1);
+    const double *row0 = I1 + r0 * W, *row1 = I1 + r1 * W;
+    double a0 = row0[cm], a1 = row0[c0], a2 = row0[c1], a3 = row0[c2];
+    double b0 = row1[cm], b1 = row1[c0], b2 = row1[c1], b3 = row1[c2];
+
+    // photometric error term (metric.py:24-27): no z test here
+    double i1w = a1 * w00 + a2 * w01 + b1 * w10 + b2 * w11;
+    double e = i0 - i1w;
+    a.v[27] += e * e;
+    a.v[29] += 1.0;
+
+    if (!(qz > 0.0)) return;  // update mask adds P1z > 0 (vo/dvo/__init__.py:49)
+
+    const double *rowm = I1 + rm * W, *row2 = I1 + r2 * W;
+    double t0 = rowm[c0], t1 = rowm[c1], u0 = row2[c0], u1 = row2[c1];
+
+    // np.gradient at the four corner texels: central difference inside,
+    // one-sided on the border rows/columns
+    double sx0 = (c0 == 0 || c0 == W - 1) ? 1.0 : 0.5;
+    double sx1 = (c1 == 0 || c1 == W - 1) ? 1.0 : 0.5;
+    double sy0 = (r0 == 0 || r0 == H - 1) ? 1.0 : 0.5;
+    double sy1 = (r1 == 0 || r1 == H - 1) ? 1.0 : 0.5;
+    double gx00 = (a2 - a0) * sx0, gx01 = (a3 - a1) * sx1;
+    double gx10 = (b2 - b0) * sx0, gx11 = (b3 - b1) * sx1;
+    double gy00 = (b1 - t0) * sy0, gy01 = (b2 - t1) * sy0;
+    double gy10 = (u0 - a1) * sy1, gy11 = (u1 - a2) * sy1;
+    double gx = gx00 * w00 + gx01 * w01 + gx10 * w10 + gx11 * w11;
+    double gy = gy00 * w00 + gy01 * w01 + gy10 * w10 + gy11 * w11;
+
+    // Jacobian row (vo/dvo/jacobian.py:8-24), twist order [v, omega]
+    double fgx = c[0] * gx, fgy = c[1] * gy;
+    double izz = 1.0 / qz;
+    double iz2 = izz * izz;
+    double z2 = qz * qz, xy = qx * qy;
+    double J[6];
+    J[0] = fgx * izz;
+    J[1] = fgy * izz;
+    J[2] = -(fgx * qx + fgy * qy) * iz2;
+    J[3] = -(fgx * xy + fgy * (z2 + qy * qy)) * iz2;
+    J[4] = (fgx * (z2 + qx * qx) + fgy * xy) * iz2;
+    J[5] = (-fgx * qy + fgy * qx) * izz;
+
+    double r = i0 - i1;  // un-warped residual (vo/dvo/__init__.py:90)
+    double w = 1.0;
+    if (WMODE == TDK_W_HUBER) {
+        double ar = fabs(r);
+        w = ar > kHuberK ? kHuberK / ar : 1.0;
+    } else if (WMODE == TDK_W_MAP) {
+        w = w0;
+    }
+    int k = 0;
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+        double wj = (WMODE == TDK_W_NONE) ? J[p] : w * J[p];
+#pragma unroll
+        for (int q = p; q < 6; q++) a.v[k++] += wj * J[q];
+        a.v[21 + p] += wj * r;
+    }
+    a.v[28] += 1.0;
+}
+
+template <int WMODE>
+__global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairParams *__restrict__ params,
+                                                     const double *__restrict__ poses,
+                                                     const int *__restrict__ state, double scale,
+                                                     int64_t chunk, double *__restrict__ partials) {
+    const int pair = blockIdx.y;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+
+    // uniform per block: pose and cameras (scaled to this level as
+    // tadataka.camera.resize does, camera/model.py:69-74)
+    double P[12], c[4];
+#pragma unroll
+    for (int i = 0; i < 12; i++) P[i] = poses[12 * pair + i];
+    const PairParams pp = params[pair];
+    c[0] = pp.cam1[0] * scale;
+    c[1] = pp.cam1[1] * scale;
+    c[2] = pp.cam1[2] * scale;
+    c[3] = pp.cam1[3] * scale;
+
+    // LDS: [0, 1 KiB) cross-wave reduction scratch, then the normalised
+    // coordinate tables xn[W], yn[H] = (u - o) / f of camera 0 (one true
+    // division per row / column instead of two per pixel)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double(*red)[kAccPad] = reinterpret_cast<double(*)[kAccPad]>(smem);
+    double *xn_tab = reinterpret_cast<double *>(smem + sizeof(double) * (kBlock / 64) * kAccPad);
+    double *yn_tab = xn_tab + L.W;
+    {
+        const double fx0 = pp.cam0[0] * scale, fy0 = pp.cam0[1] * scale;
+        const double ox0 = pp.cam0[2] * scale, oy0 = pp.cam0[3] * scale;
+        for (int i = threadIdx.x; i < L.W; i += kBlock) xn_tab[i] = ((double)i - ox0) / fx0;
+        for (int i = threadIdx.x; i < L.H; i += kBlock) yn_tab[i] = ((double)i - oy0) / fy0;
+    }
+    __syncthreads();
+
+    const int64_t base = (int64_t)pair * L.stride;
+    const double *__restrict__ I0 = L.I0 + base;
+    const double *__restrict__ D0 = L.D0 + base;
+    const double *__restrict__ I1 = L.I1 + base;
+    const double *__restrict__ W0 = (WMODE == TDK_W_MAP) ? L.W0 + base : nullptr;
+    const int W = L.W, H = L.H;
+    const int N = (int)L.N;
+
+    Accum acc;
+#pragma unroll
+    for (int i = 0; i < kAcc; i++) acc.v[i] = 0.0;
+
+    const int start = (int)(blockIdx.x * chunk);
+    const int end = (int)min((int64_t)N, (int64_t)start + chunk);
+    for (int i = start + 2 * (int)threadIdx.x; i < end; i += 2 * kBlock) {
+        int y = i / W, x = i - y * W;
+        if (i + 1 < end) {
+            double2 d = *reinterpret_cast<const double2 *>(D0 + i);
+            double2 p0 = *reinterpret_cast<const double2 *>(I0 + i);
+            double2 p1 = *reinterpret_cast<const double2 *>(I1 + i);
+            double2 w = make_double2(1.0, 1.0);
+            if (WMODE == TDK_W_MAP) w = *reinterpret_cast<const double2 *>(W0 + i);
+            accumulate_pixel<WMODE>(acc, xn_tab[x], yn_tab[y], d.x, p0.x, p1.x, w.x, I1, H, W, P, c);
+            int x2 = x + 1, y2 = y;
+            if (x2 == W) { x2 = 0; y2 = y + 1; }
+            accumulate_pixel<WMODE>(acc, xn_tab[x2], yn_tab[y2], d.y, p0.y, p1.y, w.y, I1, H, W, P, c);
+        } else {
+            double w = (WMODE == TDK_W_MAP) ? W0[i] : 1.0;
+            accumulate_pixel<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w, I1, H, W, P, c);
+        }
+    }
+
+    // wave64 reduction, then across the block's 4 waves through LDS
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kAcc; k++) {
+        double s = acc.v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kAcc) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) s += red[w][threadIdx.x];
+        partials[((int64_t)pair * gridDim.x + blockIdx.x) * kAccPad + threadIdx.x] = s;
+    }
+}
+
+struct LoopState {   // device arrays, one entry per pair
+    double *pose;      // [n][12] last accepted pose
+    double *cand;      // [n][12] pose being evaluated
+    double *prev_err;  // [n]
+    int *state;        // [n]
+    int *n_evals;      // [n]
+    int *active;       // [1] number of pairs still running
+};
+
+// Fixed-order reduction of the per-block partials of one pair; in loop mode the
+// Gauss-Newton bookkeeping of _PoseChangeEstimator.__call__ (:92-111) follows.
+__global__ __launch_bounds__(kBlock) void k_dvo_reduce(const double *__restrict__ partials, int nblk,
+                                                       double *__restrict__ results, LoopState ls,
+                                                       int loop_mode, int iter, int max_iter) {
+    const int pair = blockIdx.x;
+    if (loop_mode && ls.state[pair] != ST_RUNNING) return;
+    __shared__ double red[kBlock / 32][kAccPad];
+    const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double s = 0.0;
+    if (k < kAcc)
+        for (int b = g; b < nblk; b += kBlock / 32) s += partials[((int64_t)pair * nblk + b) * kAccPad + k];
+    red[g][k] = s;
+    __syncthreads();
+    if (threadIdx.x < kAccPad) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < kBlock / 32; i++) t += red[i][threadIdx.x];
+        red[0][threadIdx.x] = t;
+        results[(int64_t)pair * kAccPad + threadIdx.x] = (threadIdx.x < kAcc) ? t : 0.0;
+    }
+    __syncthreads();
+    if (!loop_mode || threadIdx.x != 0) return;
+
+    const double *R = red[0];
+    double err = R[27] / R[29];  // mean over the error mask; 0/0 = NaN like np.mean([])
+    double *pose = ls.pose + 12 * pair, *cand = ls.cand + 12 * pair;
+    ls.n_evals[pair] += 1;
+    bool finished = false;
+    if (iter > 0) {
+        if (err > ls.prev_err[pair]) {
+            finished = true;  // candidate rejected: keep the last accepted pose (:105-106)
+        } else {
+            for (int i = 0; i < 12; i++) pose[i] = cand[i];  // accepted (:107-110)
+            if (iter == max_iter) finished = true;
+        }
+    }
+    if (!finished) {
+        ls.prev_err[pair] = err;
+        if (R[28] == 0.0) {
+            finished = true;  // empty update mask: "pose change is too large" (:98-100)
+        } else {
+            double xi[6];
+            tdk::solve6(R, R + 21, xi);
+            double next[12];
+            tdk::compose_update(xi, pose, next);
+            for (int i = 0; i < 12; i++) cand[i] = next[i];
+        }
+    }
+    if (finished) {
+        ls.state[pair] = ST_DONE;
+        atomicSub(ls.active, 1);
+    }
+}
+
+__global__ void k_loop_init(LoopState ls, const double *__restrict__ poses_in, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < 12; k++) {
+        double v = poses_in[12 * i + k];
+        ls.pose[12 * i + k] = v;
+        ls.cand[12 * i + k] = v;
+    }
+    ls.prev_err[i] = 0.0;
+    ls.state[i] = ST_RUNNING;
+    ls.n_evals[i] = 0;
+    if (i == 0) *ls.active = n;
+}
+
+// ---- synthetic scene on the device (tadataka_amd/synthetic.py) ------------
+__device__ __forceinline__ double tex(double x, double y) {
+    return 0.5 + 0.25 * sin(x / 7.0) * cos(y / 5.0) + 0.2 * sin((x + y) / 11.0);
+}
+
+__device__ __forceinline__ double unit_noise(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed * 0x9E3779B97F4A7C15ull + idx * 0xBF58476D1CE4E5B9ull + 0x94D049BB133111EBull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (double)(z >> 11) * (2.0 / 9007199254740992.0) - 1.0;  // U(-1, 1)
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_synthetic(double *I0, double *D0, double *I1, double *W0,
+                                                           int64_t stride, int H, int W, Cam cam,
+                                                           const double *__restrict__ poses,
+                                                           uint64_t seed0, double noise) {
+    const int pair = blockIdx.y;
+    const int64_t N = (int64_t)H * W;
+    const double *P = poses + 12 * pair;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
+        int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        double d = 2.0 + 0.3 * sin((double)x / 40.0) + 0.2 * cos((double)y / 30.0);
+        double xn = ((double)x - cam.ox) / cam.fx, yn = ((double)y - cam.oy) / cam.fy;
+        double px = xn * d, py = yn * d, pz = d;
+        double qx = P[0] * px + P[1] * py + P[2] * pz + P[9];
+        double qy = P[3] * px + P[4] * py + P[5] * pz + P[10];
+        double qz = P[6] * px + P[7] * py + P[8] * pz + P[11];
+        double u = qx / qz * cam.fx + cam.ox, v = qy / qz * cam.fy + cam.oy;
+        uint64_t s = seed0 + (uint64_t)pair;
+        int64_t o = (int64_t)pair * stride + i;
+        D0[o] = d;
+        I1[o] = tex((double)x, (double)y) + noise * unit_noise(2 * s, (uint64_t)i);
+        I0[o] = tex(u, v) + noise * unit_noise(2 * s + 1, (uint64_t)i);
+        if (W0) W0[o] = 1.0;
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+struct tdk_dvo {
+    int n_pairs, H, W, n_levels;
+    double ratio;
+    bool with_w;
+    struct Level {
+        int H, W;
+        int64_t N, stride;
+        double scale;
+        double *I0, *D0, *I1, *W0;
+    } lv[kMaxLevels];
+    PairParams *d_params;
+    double *d_poses_in;  // [n][12] host-provided poses for evaluate()
+    double *d_partials, *d_results;
+    LoopState ls;
+    int max_blocks;
+    // profiling of the finest-level evaluation kernel (bench.py roofline leg)
+    bool profiling;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used;
+    double prof_ms;
+    int64_t prof_launches, prof_pixels;
+};
+
+namespace {
+
+int level_dim(int full, double scale) {
+    // skimage.transform.rescale: output shape = round(shape * scale) (np.round)
+    int v = (int)nearbyint((double)full * scale);
+    return v < 1 ? 1 : v;
+}
+
+void plan_blocks(const tdk_dvo *h, const tdk_dvo::Level &L, int *nblk, int64_t *chunk) {
+    // ~8 pixels per thread, but no more than ~8192 blocks in the whole grid
+    int64_t per_block = (int64_t)kBlock * 2 * 4;
+    int64_t nb = (L.N + per_block - 1) / per_block;
+    int64_t cap = 8192 / h->n_pairs;
+    if (cap < 1) cap = 1;
+    if (nb > cap) nb = cap;
+    if (nb > h->max_blocks) nb = h->max_blocks;
+    if (nb < 1) nb = 1;
+    int64_t c = (L.N + nb - 1) / nb;
+    c = (c + 2 * kBlock - 1) / (2 * kBlock) * (2 * kBlock);  // even, whole block sweeps
+    nb = (L.N + c - 1) / c;
+    *nblk = (int)nb;
+    *chunk = c;
+}
+
+LevelPtrs ptrs_of(const tdk_dvo::Level &L) {
+    LevelPtrs p;
+    p.I0 = L.I0; p.D0 = L.D0; p.I1 = L.I1; p.W0 = L.W0;
+    p.stride = L.stride; p.H = L.H; p.W = L.W; p.N = L.N;
+    return p;
+}
+
+tdk_status upload_params(tdk_dvo *h, const double *cam0, const double *cam1) {
+    void *stage;
+    TDK_TRY(tdk::pinned(0, sizeof(PairParams) * h->n_pairs, &stage));
+    PairParams *pp = (PairParams *)stage;
+    for (int i = 0; i < h->n_pairs; i++) {
+        for (int k = 0; k < 4; k++) {
+            pp[i].cam0[k] = cam0[4 * i + k];
+            pp[i].cam1[k] = cam1[4 * i + k];
+        }
+    }
+    TDK_HIP(hipMemcpyAsync(h->d_params, pp, sizeof(PairParams) * h->n_pairs, hipMemcpyHostToDevice,
+                           tdk::stream()));
+    // the staging buffer is reused by the next call: wait for the copy
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    return TDK_OK;
+}
+
+tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *d_state, int weight_mode) {
+    const tdk_dvo::Level &L = h->lv[level];
+    int nblk;
+    int64_t chunk;
+    plan_blocks(h, L, &nblk, &chunk);
+    dim3 grid(nblk, h->n_pairs);
+    LevelPtrs P = ptrs_of(L);
+    const size_t lds = sizeof(double) * ((kBlock / 64) * kAccPad + (size_t)L.W + (size_t)L.H);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->profiling && level == 0) {
+        while (h->ev_pool.size() < h->ev_used + 2) {
+            hipEvent_t e;
+            TDK_HIP(hipEventCreate(&e));
+            h->ev_pool.push_back(e);
+        }
+        e0 = h->ev_pool[h->ev_used++];
+        e1 = h->ev_pool[h->ev_used++];
+        TDK_HIP(hipEventRecord(e0, tdk::stream()));
+    }
+    switch (weight_mode) {
+        case TDK_W_NONE:
+            k_dvo_eval<TDK_W_NONE><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state,
+                                                                       L.scale, chunk, h->d_partials);
+            break;
+        case TDK_W_HUBER:
+            k_dvo_eval<TDK_W_HUBER><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state,
+                                                                        L.scale, chunk, h->d_partials);
+            break;
+        case TDK_W_MAP:
+            k_dvo_eval<TDK_W_MAP><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state,
+                                                                      L.scale, chunk, h->d_partials);
+            break;
+        default:
+            tdk::set_error("weight mode %d is not available on the fused path", weight_mode);
+            return TDK_ERR_INVALID_ARGUMENT;
+    }
+    TDK_LAUNCH_CHECK();
+    if (e1) TDK_HIP(hipEventRecord(e1, tdk::stream()));
+    return TDK_OK;
+}
+
+tdk_status launch_reduce(tdk_dvo *h, int level, int loop_mode, int iter, int max_iter) {
+    int nblk;
+    int64_t chunk;
+    plan_blocks(h, h->lv[level], &nblk, &chunk);
+    k_dvo_reduce<<<h->n_pairs, kBlock, 0, tdk::stream()>>>(h->d_partials, nblk, h->d_results, h->ls,
+                                                           loop_mode, iter, max_iter);
+    TDK_LAUNCH_CHECK();
+    return TDK_OK;
+}
+
+tdk_status check_level(const tdk_dvo *h, int level) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    TDK_REQUIRE(level >= 0 && level < h->n_levels, "level out of range");
+    return TDK_OK;
+}
+
+tdk_status check_weight_mode(const tdk_dvo *h, int weight_mode) {
+    if (weight_mode == TDK_W_MAP && !h->with_w) {
+        tdk::set_error("weight map requested but the batch was created without one");
+        return TDK_ERR_INVALID_ARGUMENT;
+    }
+    if (weight_mode != TDK_W_NONE && weight_mode != TDK_W_HUBER && weight_mode != TDK_W_MAP) {
+        tdk::set_error("weight mode %d is not available on the fused path", weight_mode);
+        return TDK_ERR_INVALID_ARGUMENT;
+    }
+    return TDK_OK;
+}
+
+tdk_status collect_profile(tdk_dvo *h) {
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        float ms = 0.f;
+        TDK_HIP(hipEventElapsedTime(&ms, h->ev_pool[i], h->ev_pool[i + 1]));
+        h->prof_ms += ms;
+        h->prof_launches += 1;
+    }
+    h->ev_used = 0;
+    return TDK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, double ratio,
+                          int with_weight_map, tdk_dvo **out) {
+    TDK_REQUIRE(out != nullptr, "out is NULL");
+    TDK_REQUIRE(n_pairs >= 1 && n_pairs <= 65535, "n_pairs must be in [1, 65535]");
+    TDK_REQUIRE(height >= 2 && width >= 2, "frames must be at least 2x2");
+    TDK_REQUIRE((int64_t)height * width < (1ll << 30), "frame too large");
+    TDK_REQUIRE(n_levels >= 1 && n_levels <= kMaxLevels, "n_levels must be in [1, 16]");
+    TDK_REQUIRE(ratio > 1.0 || n_levels == 1, "layer_size_ratio must be > 1");
+    TDK_TRY(tdk::ensure_device());
+    tdk_dvo *h = new tdk_dvo();
+    h->n_pairs = n_pairs; h->H = height; h->W = width; h->n_levels = n_levels;
+    h->ratio = ratio; h->with_w = with_weight_map != 0;
+    h->max_blocks = 1024;
+    h->profiling = false; h->ev_used = 0; h->prof_ms = 0; h->prof_launches = 0; h->prof_pixels = 0;
+    for (int l = 0; l < n_levels; l++) {
+        tdk_dvo::Level &L = h->lv[l];
+        L.scale = 1.0 / pow(ratio, (double)l);  // level_to_scale, vo/dvo/__init__.py:42-43
+        L.H = l == 0 ? height : level_dim(height, L.scale);
+        L.W = l == 0 ? width : level_dim(width, L.scale);
+        if (L.H < 2 || L.W < 2) {
+            tdk::set_error("pyramid level %d would be %dx%d", l, L.H, L.W);
+            delete h;
+            return TDK_ERR_INVALID_ARGUMENT;
+        }
+        L.N = (int64_t)L.H * L.W;
+        L.stride = (L.N + 1) & ~1ll;
+        size_t bytes = (size_t)L.stride * n_pairs * sizeof(double);
+        L.W0 = nullptr;
+        TDK_HIP(hipMalloc(&L.I0, bytes));
+        TDK_HIP(hipMalloc(&L.D0, bytes));
+        TDK_HIP(hipMalloc(&L.I1, bytes));
+        if (h->with_w) TDK_HIP(hipMalloc(&L.W0, bytes));
+    }
+    TDK_HIP(hipMalloc(&h->d_params, sizeof(PairParams) * n_pairs));
+    TDK_HIP(hipMalloc(&h->d_poses_in, sizeof(double) * 12 * n_pairs));
+    TDK_HIP(hipMalloc(&h->d_partials, sizeof(double) * kAccPad * (size_t)h->max_blocks * n_pairs));
+    TDK_HIP(hipMalloc(&h->d_results, sizeof(double) * kAccPad * n_pairs));
+    TDK_HIP(hipMalloc(&h->ls.pose, sizeof(double) * 12 * n_pairs));
+    TDK_HIP(hipMalloc(&h->ls.cand, sizeof(double) * 12 * n_pairs));
+    TDK_HIP(hipMalloc(&h->ls.prev_err, sizeof(double) * n_pairs));
+    TDK_HIP(hipMalloc(&h->ls.state, sizeof(int) * n_pairs));
+    TDK_HIP(hipMalloc(&h->ls.n_evals, sizeof(int) * n_pairs));
+    TDK_HIP(hipMalloc(&h->ls.active, sizeof(int)));
+    *out = h;
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_destroy(tdk_dvo *h) {
+    if (!h) return TDK_OK;
+    (void)hipStreamSynchronize(tdk::stream());
+    for (int l = 0; l < h->n_levels; l++) {
+        (void)hipFree(h->lv[l].I0); (void)hipFree(h->lv[l].D0); (void)hipFree(h->lv[l].I1);
+        if (h->lv[l].W0) (void)hipFree(h->lv[l].W0);
+    }
+    (void)hipFree(h->d_params); (void)hipFree(h->d_poses_in); (void)hipFree(h->d_partials);
+    (void)hipFree(h->d_results); (void)hipFree(h->ls.pose); (void)hipFree(h->ls.cand);
+    (void)hipFree(h->ls.prev_err); (void)hipFree(h->ls.state); (void)hipFree(h->ls.n_evals);
+    (void)hipFree(h->ls.active);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    delete h;
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_upload(tdk_dvo *h, int pair, const double *I0, const double *D0, const double *I1,
+                          const double *weight_map) {
+    TDK_REQUIRE(h && I0 && D0 && I1, "null pointer");
+    TDK_REQUIRE(pair >= 0 && pair < h->n_pairs, "pair out of range");
+    TDK_REQUIRE(weight_map == nullptr || h->with_w, "batch was created without a weight map");
+    const tdk_dvo::Level &L = h->lv[0];
+    size_t bytes = (size_t)L.N * sizeof(double);
+    int64_t off = (int64_t)pair * L.stride;
+    TDK_HIP(hipMemcpyAsync(L.I0 + off, I0, bytes, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(L.D0 + off, D0, bytes, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(L.I1 + off, I1, bytes, hipMemcpyHostToDevice, tdk::stream()));
+    if (weight_map)
+        TDK_HIP(hipMemcpyAsync(L.W0 + off, weight_map, bytes, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_fill_synthetic(tdk_dvo *h, const double *camera, const double *poses12, uint64_t seed0,
+                                  double noise) {
+    TDK_REQUIRE(h && camera && poses12, "null pointer");
+    TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * h->n_pairs, hipMemcpyHostToDevice,
+                           tdk::stream()));
+    const tdk_dvo::Level &L = h->lv[0];
+    int gx = (int)((L.N + kBlock * 4 - 1) / (kBlock * 4));
+    dim3 grid(gx < 1 ? 1 : gx, h->n_pairs);
+    Cam cam{camera[0], camera[1], camera[2], camera[3]};
+    k_fill_synthetic<<<grid, kBlock, 0, tdk::stream()>>>(L.I0, L.D0, L.I1, L.W0, L.stride, L.H, L.W, cam,
+                                                         h->d_poses_in, seed0, noise);
+    TDK_LAUNCH_CHECK();
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_build_pyramid(tdk_dvo *h) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    const tdk_dvo::Level &S = h->lv[0];
+    for (int l = 1; l < h->n_levels; l++) {
+        const tdk_dvo::Level &L = h->lv[l];
+        // every level is resampled from the full-resolution frame, exactly as
+        // _estimate_at rescales the original I0/D0/I1/W0 (vo/dvo/__init__.py:144-148)
+        TDK_TRY(tdk::launch_rescale(S.I0, S.H, S.W, L.I0, L.H, L.W, h->n_pairs, S.stride, L.stride));
+        TDK_TRY(tdk::launch_rescale(S.D0, S.H, S.W, L.D0, L.H, L.W, h->n_pairs, S.stride, L.stride));
+        TDK_TRY(tdk::launch_rescale(S.I1, S.H, S.W, L.I1, L.H, L.W, h->n_pairs, S.stride, L.stride));
+        if (h->with_w)
+            TDK_TRY(tdk::launch_rescale(S.W0, S.H, S.W, L.W0, L.H, L.W, h->n_pairs, S.stride, L.stride));
+    }
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_level_shape(tdk_dvo *h, int level, int *height, int *width) {
+    TDK_TRY(check_level(h, level));
+    if (height) *height = h->lv[level].H;
+    if (width) *width = h->lv[level].W;
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_download(tdk_dvo *h, int pair, int level, int which, double *out) {
+    TDK_TRY(check_level(h, level));
+    TDK_REQUIRE(out && pair >= 0 && pair < h->n_pairs && which >= 0 && which <= 3, "bad argument");
+    const tdk_dvo::Level &L = h->lv[level];
+    const double *src = which == 0 ? L.I0 : which == 1 ? L.D0 : which == 2 ? L.I1 : L.W0;
+    TDK_REQUIRE(src != nullptr, "no weight map in this batch");
+    TDK_HIP(hipMemcpyAsync(out, src + (int64_t)pair * L.stride, (size_t)L.N * sizeof(double),
+                           hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_evaluate(tdk_dvo *h, int level, const double *camera0, const double *camera1,
+                            const double *poses12, int weight_mode, double *Hout, double *bout,
+                            int64_t *n_update, double *sum_sq, int64_t *n_error) {
+    TDK_TRY(check_level(h, level));
+    TDK_REQUIRE(camera0 && camera1 && poses12, "null pointer");
+    TDK_TRY(check_weight_mode(h, weight_mode));
+    TDK_TRY(upload_params(h, camera0, camera1));
+    TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * h->n_pairs, hipMemcpyHostToDevice,
+                           tdk::stream()));
+    if (h->profiling && level == 0) h->prof_pixels += h->lv[0].N * (int64_t)h->n_pairs;
+    TDK_TRY(launch_eval(h, level, h->d_poses_in, nullptr, weight_mode));
+    TDK_TRY(launch_reduce(h, level, 0, 0, 0));
+    void *stage;
+    TDK_TRY(tdk::pinned(1, sizeof(double) * kAccPad * h->n_pairs, &stage));
+    TDK_HIP(hipMemcpyAsync(stage, h->d_results, sizeof(double) * kAccPad * h->n_pairs, hipMemcpyDeviceToHost,
+                           tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    const double *r = (const double *)stage;
+    for (int i = 0; i < h->n_pairs; i++) {
+        const double *ri = r + (size_t)kAccPad * i;
+        if (Hout) memcpy(Hout + 21 * i, ri, sizeof(double) * 21);
+        if (bout) memcpy(bout + 6 * i, ri + 21, sizeof(double) * 6);
+        if (sum_sq) sum_sq[i] = ri[27];
+        if (n_update) n_update[i] = (int64_t)ri[28];
+        if (n_error) n_error[i] = (int64_t)ri[29];
+    }
+    if (h->profiling) TDK_TRY(collect_profile(h));
+    return TDK_OK;
+}
+
+// One pyramid level for the whole batch; poses live in h->ls.pose on entry and exit.
+static tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64_t *pixel_evals) {
+    int running = h->n_pairs;
+    for (int iter = 0; iter <= max_iter; iter++) {
+        if (h->profiling && level == 0) h->prof_pixels += h->lv[0].N * (int64_t)running;
+        if (pixel_evals) *pixel_evals += h->lv[level].N * (int64_t)running;
+        TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, weight_mode));
+        TDK_TRY(launch_reduce(h, level, 1, iter, max_iter));
+        void *stage;
+        TDK_TRY(tdk::pinned(2, sizeof(int), &stage));
+        TDK_HIP(hipMemcpyAsync(stage, h->ls.active, sizeof(int), hipMemcpyDeviceToHost, tdk::stream()));
+        TDK_HIP(hipStreamSynchronize(tdk::stream()));
+        running = *(int *)stage;
+        if (running <= 0) break;
+    }
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0, const double *camera1,
+                                  double *poses12, int weight_mode, int max_iter, int *n_evals) {
+    TDK_TRY(check_level(h, level));
+    TDK_REQUIRE(camera0 && camera1 && poses12 && max_iter >= 0, "bad argument");
+    TDK_TRY(check_weight_mode(h, weight_mode));
+    TDK_TRY(upload_params(h, camera0, camera1));
+    TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * h->n_pairs, hipMemcpyHostToDevice,
+                           tdk::stream()));
+    int n = h->n_pairs;
+    k_loop_init<<<(n + 255) / 256, 256, 0, tdk::stream()>>>(h->ls, h->d_poses_in, n);
+    TDK_LAUNCH_CHECK();
+    TDK_TRY(run_level(h, level, weight_mode, max_iter, nullptr));
+    TDK_HIP(hipMemcpyAsync(poses12, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, tdk::stream()));
+    if (n_evals)
+        TDK_HIP(hipMemcpyAsync(n_evals, h->ls.n_evals, sizeof(int) * n, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    if (h->profiling) TDK_TRY(collect_profile(h));
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *camera1, double *poses12,
+                            int weight_mode, int max_iter, int64_t *pixel_evals) {
+    TDK_REQUIRE(h && camera0 && camera1 && poses12 && max_iter >= 0, "bad argument");
+    TDK_TRY(check_weight_mode(h, weight_mode));
+    TDK_TRY(upload_params(h, camera0, camera1));
+    int n = h->n_pairs;
+    TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * n, hipMemcpyHostToDevice,
+                           tdk::stream()));
+    if (pixel_evals) *pixel_evals = 0;
+    for (int level = h->n_levels - 1; level >= 0; level--) {
+        // the prior of a level is the result of the coarser one (:131-134)
+        const double *src = (level == h->n_levels - 1) ? h->d_poses_in : h->ls.pose;
+        if (src != h->d_poses_in) {
+            TDK_HIP(hipMemcpyAsync(h->d_poses_in, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToDevice,
+                                   tdk::stream()));
+        }
+        k_loop_init<<<(n + 255) / 256, 256, 0, tdk::stream()>>>(h->ls, h->d_poses_in, n);
+        TDK_LAUNCH_CHECK();
+        TDK_TRY(run_level(h, level, weight_mode, max_iter, pixel_evals));
+    }
+    TDK_HIP(hipMemcpyAsync(poses12, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    if (h->profiling) TDK_TRY(collect_profile(h));
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_set_profiling(tdk_dvo *h, int enabled) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    h->profiling = enabled != 0;
+    h->ev_used = 0;
+    h->prof_ms = 0;
+    h->prof_launches = 0;
+    h->prof_pixels = 0;
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_get_profile(tdk_dvo *h, int64_t *launches, double *total_ms, int64_t *pixels) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    if (launches) *launches = h->prof_launches;
+    if (total_ms) *total_ms = h->prof_ms;
+    if (pixels) *pixels = h->prof_pixels;
+    return TDK_OK;
+}
+
+}  // extern "C"

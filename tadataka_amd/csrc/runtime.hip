@@ -1,0 +1,150 @@
+// runtime.hip -- device selection, stream, error string, scratch pools.
+#include "tdk_runtime.h"
+
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+
+namespace tdk {
+
+static thread_local char g_err[512] = "";
+static hipStream_t g_stream = nullptr;
+static bool g_ready = false;
+static std::mutex g_mu;
+
+static void *g_scratch[kScratchSlots] = {};
+static size_t g_scratch_bytes[kScratchSlots] = {};
+static void *g_pinned[kScratchSlots] = {};
+static size_t g_pinned_bytes[kScratchSlots] = {};
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+hipStream_t stream() { return g_stream; }
+
+tdk_status ensure_device() {
+    if (g_ready) return TDK_OK;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (g_ready) return TDK_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        return TDK_ERR_NO_DEVICE;
+    }
+    TDK_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_ready = true;
+    return TDK_OK;
+}
+
+static void release_pools() {
+    for (int i = 0; i < kScratchSlots; i++) {
+        if (g_scratch[i]) (void)hipFree(g_scratch[i]);
+        if (g_pinned[i]) (void)hipHostFree(g_pinned[i]);
+        g_scratch[i] = g_pinned[i] = nullptr;
+        g_scratch_bytes[i] = g_pinned_bytes[i] = 0;
+    }
+}
+
+tdk_status scratch(int slot, size_t bytes, void **ptr) {
+    TDK_TRY(ensure_device());
+    if (bytes == 0) bytes = 8;
+    if (g_scratch_bytes[slot] < bytes) {
+        if (g_scratch[slot]) {
+            TDK_HIP(hipStreamSynchronize(g_stream));
+            TDK_HIP(hipFree(g_scratch[slot]));
+            g_scratch[slot] = nullptr;
+            g_scratch_bytes[slot] = 0;
+        }
+        size_t cap = bytes + bytes / 4;
+        TDK_HIP(hipMalloc(&g_scratch[slot], cap));
+        g_scratch_bytes[slot] = cap;
+    }
+    *ptr = g_scratch[slot];
+    return TDK_OK;
+}
+
+tdk_status pinned(int slot, size_t bytes, void **ptr) {
+    TDK_TRY(ensure_device());
+    if (bytes == 0) bytes = 8;
+    if (g_pinned_bytes[slot] < bytes) {
+        if (g_pinned[slot]) {
+            TDK_HIP(hipStreamSynchronize(g_stream));
+            TDK_HIP(hipHostFree(g_pinned[slot]));
+            g_pinned[slot] = nullptr;
+            g_pinned_bytes[slot] = 0;
+        }
+        size_t cap = bytes + bytes / 4;
+        TDK_HIP(hipHostMalloc(&g_pinned[slot], cap, hipHostMallocDefault));
+        g_pinned_bytes[slot] = cap;
+    }
+    *ptr = g_pinned[slot];
+    return TDK_OK;
+}
+
+}  // namespace tdk
+
+extern "C" {
+
+const char *tdk_version(void) { return "tadataka_hip 0.1 (gfx950)"; }
+
+const char *tdk_last_error(void) { return tdk::g_err; }
+
+tdk_status tdk_device_count(int *count) {
+    TDK_REQUIRE(count != nullptr, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    *count = (e == hipSuccess) ? n : 0;
+    return TDK_OK;
+}
+
+tdk_status tdk_set_device(int device) {
+    // Pools and the stream belong to the current device: drop them first.
+    if (tdk::g_ready) {
+        TDK_HIP(hipStreamSynchronize(tdk::g_stream));
+        tdk::release_pools();
+        TDK_HIP(hipStreamDestroy(tdk::g_stream));
+        tdk::g_stream = nullptr;
+        tdk::g_ready = false;
+    }
+    TDK_HIP(hipSetDevice(device));
+    return tdk::ensure_device();
+}
+
+tdk_status tdk_get_device(int *device) {
+    TDK_REQUIRE(device != nullptr, "device is NULL");
+    TDK_HIP(hipGetDevice(device));
+    return TDK_OK;
+}
+
+tdk_status tdk_sync(void) {
+    TDK_TRY(tdk::ensure_device());
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    return TDK_OK;
+}
+
+tdk_status tdk_device_name(char *buf, int buflen) {
+    TDK_REQUIRE(buf != nullptr && buflen > 0, "bad buffer");
+    TDK_TRY(tdk::ensure_device());
+    int dev = 0;
+    TDK_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    TDK_HIP(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
+             prop.multiProcessorCount);
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_get_stream(void **stream_out) {
+    TDK_REQUIRE(stream_out != nullptr, "stream_out is NULL");
+    TDK_TRY(tdk::ensure_device());
+    *stream_out = (void *)tdk::stream();
+    return TDK_OK;
+}
+
+}  // extern "C"

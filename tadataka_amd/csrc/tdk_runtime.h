@@ -1,0 +1,56 @@
+// tdk_runtime.h -- process-wide HIP state of libtadataka_hip.so: one stream,
+// error reporting, and a small grow-only device scratch pool so the
+// parity-granular entry points do not hipMalloc on every call.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/tadataka_hip.h"
+
+namespace tdk {
+
+void set_error(const char *fmt, ...);
+hipStream_t stream();
+tdk_status ensure_device();
+
+// Grow-only device buffers, indexed by slot; contents are undefined between calls.
+constexpr int kScratchSlots = 16;
+tdk_status scratch(int slot, size_t bytes, void **ptr);
+
+// Pinned host staging buffer (grow-only) for small D2H results.
+tdk_status pinned(int slot, size_t bytes, void **ptr);
+
+// granular.hip: bilinear rescale of `batch` images laid out with the given strides
+tdk_status launch_rescale(const double *src, int H, int W, double *dst, int Ho, int Wo, int batch,
+                          int64_t src_stride, int64_t dst_stride);
+
+}  // namespace tdk
+
+#define TDK_HIP(call)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            tdk::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),       \
+                           __FILE__, __LINE__);                                         \
+            return TDK_ERR_HIP;                                                         \
+        }                                                                               \
+    } while (0)
+
+#define TDK_TRY(call)                     \
+    do {                                  \
+        tdk_status s_ = (call);           \
+        if (s_ != TDK_OK) return s_;      \
+    } while (0)
+
+#define TDK_REQUIRE(cond, msg)                                   \
+    do {                                                         \
+        if (!(cond)) {                                           \
+            tdk::set_error("invalid argument: %s", msg);         \
+            return TDK_ERR_INVALID_ARGUMENT;                     \
+        }                                                        \
+    } while (0)
+
+// Launch check: catches bad configurations right after the <<<>>>.
+#define TDK_LAUNCH_CHECK() TDK_HIP(hipGetLastError())

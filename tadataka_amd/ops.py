@@ -1,0 +1,329 @@
+"""NumPy-facing wrappers over the C ABI (tadataka_amd/_lib.py).
+
+Everything here runs on the MI355X through libtadataka_hip.so; there is no CPU
+implementation behind these functions.
+"""
+import ctypes as C
+
+import numpy as np
+
+from tadataka_amd import _lib
+from tadataka_amd._lib import (W_HUBER, W_MAP, W_NONE, W_STUDENT_T, W_TUKEY, SemiDenseParams,
+                               c_double_p, c_int64_p, c_int_p, c_uint64_p, call)
+
+WEIGHT_MODES = {None: W_NONE, "huber": W_HUBER, "student-t": W_STUDENT_T, "tukey": W_TUKEY}
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+def camera_vec(camera):
+    """Accepts (fx, fy, ox, oy) or an object with .focal_length/.offset (duck
+    typing as src/py/semi_dense.rs:19-33)."""
+    if hasattr(camera, "focal_length") and hasattr(camera, "offset"):
+        return _f64(np.concatenate([np.asarray(camera.focal_length, dtype=np.float64),
+                                    np.asarray(camera.offset, dtype=np.float64)]), (4,))
+    if hasattr(camera, "camera_parameters"):
+        return camera_vec(camera.camera_parameters)
+    return _f64(camera, (4,))
+
+
+# ---- parity-granular operators ---------------------------------------------
+def normalize(keypoints, camera):
+    kp = _f64(keypoints).reshape(-1, 2)
+    out = np.empty_like(kp)
+    cam = camera_vec(camera)
+    call("tdk_normalize", _p(kp), kp.shape[0], _p(cam), _p(out))
+    return out
+
+
+def unnormalize(keypoints, camera):
+    kp = _f64(keypoints).reshape(-1, 2)
+    out = np.empty_like(kp)
+    cam = camera_vec(camera)
+    call("tdk_unnormalize", _p(kp), kp.shape[0], _p(cam), _p(out))
+    return out
+
+
+def project_vecs(points):
+    P = _f64(points).reshape(-1, 3)
+    out = np.empty((P.shape[0], 2))
+    call("tdk_project_vecs", _p(P), P.shape[0], _p(out))
+    return out
+
+
+def inv_project_vecs(xs, depths):
+    xs = _f64(xs).reshape(-1, 2)
+    d = _f64(depths).reshape(-1)
+    if d.shape[0] != xs.shape[0]:
+        raise ValueError("xs and depths must have the same length")
+    out = np.empty((xs.shape[0], 3))
+    call("tdk_inv_project_vecs", _p(xs), _p(d), xs.shape[0], _p(out))
+    return out
+
+
+def transform(T, points):
+    T = _f64(T, (4, 4))
+    P = _f64(points).reshape(-1, 3)
+    out = np.empty_like(P)
+    call("tdk_transform", _p(T), _p(P), P.shape[0], _p(out))
+    return out
+
+
+def warp_vecs(T10, xs, depths):
+    T10 = _f64(T10, (4, 4))
+    xs = _f64(xs).reshape(-1, 2)
+    d = _f64(depths).reshape(-1)
+    if d.shape[0] != xs.shape[0]:
+        raise ValueError("xs and depths must have the same length")
+    oxs = np.empty_like(xs)
+    od = np.empty_like(d)
+    call("tdk_warp_vecs", _p(T10), _p(xs), _p(d), xs.shape[0], _p(oxs), _p(od))
+    return oxs, od
+
+
+def interpolation(image, coordinates):
+    image = _f64(image)
+    if image.ndim != 2:
+        raise ValueError("Image have to be a two dimensional array")
+    c = _f64(coordinates).reshape(-1, 2)
+    out = np.empty(c.shape[0])
+    call("tdk_interpolation", _p(image), image.shape[0], image.shape[1], _p(c), c.shape[0], _p(out))
+    return out
+
+
+def calc_depth0(T10, x0, x1):
+    T10 = _f64(T10, (4, 4)); x0 = _f64(x0, (2,)); x1 = _f64(x1, (2,))
+    out = C.c_double()
+    call("tdk_calc_depth0", _p(T10), _p(x0), _p(x1), C.byref(out))
+    return float(out.value)
+
+
+def image_gradient(image):
+    image = _f64(image)
+    gx = np.empty_like(image); gy = np.empty_like(image)
+    call("tdk_image_gradient", _p(image), image.shape[0], image.shape[1], _p(gx), _p(gy))
+    return gx, gy
+
+
+def rescale_shape(shape, scale):
+    return (max(1, int(np.round(shape[0] * scale))), max(1, int(np.round(shape[1] * scale))))
+
+
+def rescale(image, scale):
+    image = _f64(image)
+    Ho, Wo = rescale_shape(image.shape, scale)
+    out = np.empty((Ho, Wo))
+    call("tdk_rescale", _p(image), image.shape[0], image.shape[1], _p(out), Ho, Wo)
+    return out
+
+
+# ---- DVO batch ----------------------------------------------------------------
+def pose12(R, t):
+    return np.concatenate([_f64(R, (9,)), _f64(t, (3,))])
+
+
+class DvoBatch(object):
+    """Device-resident batch of frame pairs (tdk_dvo)."""
+
+    def __init__(self, n_pairs, height, width, n_levels=1, ratio=1.5, with_weight_map=False):
+        self.n_pairs, self.height, self.width, self.n_levels = n_pairs, height, width, n_levels
+        self.with_weight_map = bool(with_weight_map)
+        self._h = C.c_void_p()
+        call("tdk_dvo_create", n_pairs, height, width, n_levels, float(ratio),
+             int(self.with_weight_map), C.byref(self._h))
+
+    def close(self):
+        if self._h:
+            call("tdk_dvo_destroy", self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, pair, I0, D0, I1, weight_map=None):
+        shape = (self.height, self.width)
+        I0 = _f64(I0, shape); D0 = _f64(D0, shape); I1 = _f64(I1, shape)
+        w = None if weight_map is None else _f64(weight_map, shape)
+        call("tdk_dvo_upload", self._h, pair, _p(I0), _p(D0), _p(I1), None if w is None else _p(w))
+
+    def fill_synthetic(self, camera, poses12, seed0=0, noise=0.02):
+        cam = camera_vec(camera)
+        P = _f64(poses12, (self.n_pairs, 12))
+        call("tdk_dvo_fill_synthetic", self._h, _p(cam), _p(P), C.c_uint64(seed0), float(noise))
+
+    def build_pyramid(self):
+        call("tdk_dvo_build_pyramid", self._h)
+
+    def level_shape(self, level):
+        h, w = C.c_int(), C.c_int()
+        call("tdk_dvo_level_shape", self._h, level, C.byref(h), C.byref(w))
+        return h.value, w.value
+
+    def download(self, pair, level, which):
+        out = np.empty(self.level_shape(level))
+        call("tdk_dvo_download", self._h, pair, level, {"I0": 0, "D0": 1, "I1": 2, "W0": 3}[which], _p(out))
+        return out
+
+    def _cams(self, camera):
+        cam = np.asarray(camera, dtype=np.float64)
+        if cam.ndim == 1:
+            cam = np.tile(camera_vec(cam), (self.n_pairs, 1))
+        return _f64(cam, (self.n_pairs, 4))
+
+    def evaluate(self, level, camera0, camera1, poses12, weight_mode=W_NONE):
+        """Returns dict(H [n,21], b [n,6], n_update [n], sum_sq [n], n_error [n])."""
+        n = self.n_pairs
+        c0, c1 = self._cams(camera0), self._cams(camera1)
+        P = _f64(poses12, (n, 12))
+        H = np.empty((n, 21)); b = np.empty((n, 6)); ss = np.empty(n)
+        nu = np.empty(n, dtype=np.int64); ne = np.empty(n, dtype=np.int64)
+        call("tdk_dvo_evaluate", self._h, level, _p(c0), _p(c1), _p(P), weight_mode, _p(H), _p(b),
+             nu.ctypes.data_as(c_int64_p), _p(ss), ne.ctypes.data_as(c_int64_p))
+        return dict(H=H, b=b, n_update=nu, sum_sq=ss, n_error=ne)
+
+    def estimate_level(self, level, camera0, camera1, poses12, weight_mode=W_NONE, max_iter=20):
+        n = self.n_pairs
+        c0, c1 = self._cams(camera0), self._cams(camera1)
+        P = _f64(poses12, (n, 12)).copy()
+        ne = np.zeros(n, dtype=np.int32)
+        call("tdk_dvo_estimate_level", self._h, level, _p(c0), _p(c1), _p(P), weight_mode, max_iter,
+             ne.ctypes.data_as(c_int_p))
+        return P, ne
+
+    def estimate(self, camera0, camera1, poses12, weight_mode=W_NONE, max_iter=20):
+        """Coarse-to-fine over the pyramid built by build_pyramid()."""
+        n = self.n_pairs
+        c0, c1 = self._cams(camera0), self._cams(camera1)
+        P = _f64(poses12, (n, 12)).copy()
+        px = C.c_int64(0)
+        call("tdk_dvo_estimate", self._h, _p(c0), _p(c1), _p(P), weight_mode, max_iter, C.byref(px))
+        return P, int(px.value)
+
+    def set_profiling(self, enabled):
+        call("tdk_dvo_set_profiling", self._h, int(bool(enabled)))
+
+    def get_profile(self):
+        n = C.c_int64(); ms = C.c_double(); px = C.c_int64()
+        call("tdk_dvo_get_profile", self._h, C.byref(n), C.byref(ms), C.byref(px))
+        return dict(launches=int(n.value), total_ms=float(ms.value), pixels=int(px.value))
+
+
+def upper21_to_matrix(H21):
+    H = np.zeros((6, 6))
+    H[np.triu_indices(6)] = H21
+    return H + H.T - np.diag(np.diag(H))
+
+
+# ---- semi-dense -------------------------------------------------------------------
+def make_params(min_depth, max_depth, geo_coeff, photo_coeff, ref_step_size, min_gradient):
+    return SemiDenseParams(float(min_depth), float(max_depth), float(geo_coeff), float(photo_coeff),
+                           float(ref_step_size), float(min_gradient))
+
+
+def sobel(image):
+    image = _f64(image)
+    gx = np.empty_like(image); gy = np.empty_like(image)
+    call("tdk_sobel", _p(image), image.shape[0], image.shape[1], _p(gx), _p(gy))
+    return gx, gy
+
+
+def increment_age(age0, camera0, camera1, T10, depth0):
+    age0 = np.ascontiguousarray(age0, dtype=np.uint64)
+    H, W = age0.shape
+    c0, c1 = camera_vec(camera0), camera_vec(camera1)
+    T10 = _f64(T10, (4, 4)); d0 = _f64(depth0, (H, W))
+    age1 = np.empty_like(age0)
+    call("tdk_increment_age", age0.ctypes.data_as(c_uint64_p), H, W, _p(c0), _p(c1), _p(T10), _p(d0),
+         age1.ctypes.data_as(c_uint64_p))
+    return age1
+
+
+def propagate(T10, camera0, camera1, depth0, variance0, default_depth, default_variance,
+              uncertaintity_bias):
+    d0 = _f64(depth0)
+    H, W = d0.shape
+    v0 = _f64(variance0, (H, W))
+    c0, c1 = camera_vec(camera0), camera_vec(camera1)
+    T10 = _f64(T10, (4, 4))
+    d1 = np.empty_like(d0); v1 = np.empty_like(d0)
+    call("tdk_propagate", _p(T10), _p(c0), _p(c1), _p(d0), _p(v0), H, W, float(default_depth),
+         float(default_variance), float(uncertaintity_bias), _p(d1), _p(v1))
+    return d1, v1
+
+
+def update_depth(key, refs, age, prior_depth, prior_variance, params):
+    """key = (camera, image, T_wf); refs = list of the same.  Returns
+    (depth, variance, flag) in the order of src/py/semi_dense.rs:182-186."""
+    kc = camera_vec(key[0]); ki = _f64(key[1]); kT = _f64(key[2], (4, 4))
+    H, W = ki.shape
+    n_ref = len(refs)
+    rc = _f64([camera_vec(r[0]) for r in refs] if n_ref else np.zeros((0, 4)), (n_ref, 4))
+    ri = _f64([r[1] for r in refs] if n_ref else np.zeros((0, H, W)), (n_ref, H, W))
+    rT = _f64([r[2] for r in refs] if n_ref else np.zeros((0, 4, 4)), (n_ref, 4, 4))
+    age = np.ascontiguousarray(age, dtype=np.uint64).reshape(H, W)
+    pd_ = _f64(prior_depth, (H, W)); pv = _f64(prior_variance, (H, W))
+    depth = np.empty((H, W)); var = np.empty((H, W)); flag = np.empty((H, W), dtype=np.int64)
+    call("tdk_update_depth", _p(kc), _p(ki), _p(kT), n_ref, _p(rc), _p(ri), _p(rT),
+         age.ctypes.data_as(c_uint64_p), _p(pd_), _p(pv), H, W, C.byref(params), _p(depth), _p(var),
+         flag.ctypes.data_as(c_int64_p))
+    return depth, var, flag
+
+
+def estimate_one(u_key, prior_depth, prior_variance, key, ref, params):
+    u = np.ascontiguousarray(u_key, dtype=np.int64).reshape(2)
+    kc = camera_vec(key[0]); ki = _f64(key[1]); kT = _f64(key[2], (4, 4))
+    rc = camera_vec(ref[0]); ri = _f64(ref[1]); rT = _f64(ref[2], (4, 4))
+    H, W = ki.shape
+    d = C.c_double(); v = C.c_double(); f = C.c_int64()
+    call("tdk_estimate_one", u.ctypes.data_as(c_int64_p), float(prior_depth), float(prior_variance),
+         _p(kc), _p(ki), _p(kT), _p(rc), _p(ri), _p(rT), H, W, C.byref(params), C.byref(d), C.byref(v),
+         C.byref(f))
+    return float(d.value), float(v.value), int(f.value)
+
+
+# ---- bundle adjustment ------------------------------------------------------------------
+def ba_projection(poses, points, viewpoint_indices, point_indices, jacobians=True):
+    poses = _f64(poses).reshape(-1, 6); points = _f64(points).reshape(-1, 3)
+    vp = np.ascontiguousarray(viewpoint_indices, dtype=np.int64)
+    pt = np.ascontiguousarray(point_indices, dtype=np.int64)
+    n = vp.shape[0]
+    x = np.empty((n, 2))
+    A = np.empty((n, 2, 6)) if jacobians else None
+    B = np.empty((n, 2, 3)) if jacobians else None
+    call("tdk_ba_projection", _p(poses), poses.shape[0], _p(points), points.shape[0],
+         vp.ctypes.data_as(c_int64_p), pt.ctypes.data_as(c_int64_p), n, _p(x),
+         _p(A) if jacobians else None, _p(B) if jacobians else None)
+    return (x, A, B) if jacobians else x
+
+
+def ba_exp_so3(rotvecs):
+    r = _f64(rotvecs).reshape(-1, 3)
+    R = np.empty((r.shape[0], 3, 3))
+    call("tdk_ba_exp_so3", _p(r), r.shape[0], _p(R))
+    return R
+
+
+def ba_block_reduce(poses, points, x_true, viewpoint_indices, point_indices):
+    poses = _f64(poses).reshape(-1, 6); points = _f64(points).reshape(-1, 3)
+    vp = np.ascontiguousarray(viewpoint_indices, dtype=np.int64)
+    pt = np.ascontiguousarray(point_indices, dtype=np.int64)
+    n = vp.shape[0]
+    xt = _f64(x_true, (n, 2))
+    nP, nQ = poses.shape[0], points.shape[0]
+    U = np.empty((nP, 21)); ea = np.empty((nP, 6)); V = np.empty((nQ, 6)); eb = np.empty((nQ, 3))
+    err = C.c_double()
+    call("tdk_ba_block_reduce", _p(poses), nP, _p(points), nQ, _p(xt), vp.ctypes.data_as(c_int64_p),
+         pt.ctypes.data_as(c_int64_p), n, _p(U), _p(ea), _p(V), _p(eb), C.byref(err))
+    return U, ea, V, eb, float(err.value)

@@ -1,0 +1,78 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and
+exports every symbol include/tadataka_hip.h declares; without a GPU the compute
+entries fail loudly (there is no CPU fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import REPO, _has_gpu
+
+
+def _header_symbols():
+    hdr = open(os.path.join(REPO, "include", "tadataka_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(tdk_[a-z0-9_]+)\s*\(", hdr)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    if not os.path.exists(os.path.join(REPO, "tadataka_amd", "lib", "libtadataka_hip.so")):
+        g.build()
+    from tadataka_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    handle = lib.load()
+    syms = _header_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(handle, s), f"{s} declared in include/tadataka_hip.h but not exported"
+    # and the ctypes prototypes cover the header exactly
+    declared = set(syms) - {"tdk_version", "tdk_last_error"}
+    assert declared == set(lib.PROTOTYPES)
+    assert b"gfx950" in handle.tdk_version()
+
+
+def test_no_product_code_touches_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+    use oracle/."""
+    bad = []
+    for root, _, files in os.walk(os.path.join(REPO, "tadataka_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(root, f), errors="replace").read()
+                if re.search(r"(from|import)\s+oracle|liboracle|tdk_oracle|orc_", text):
+                    bad.append(os.path.join(root, f))
+    assert not bad, bad
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
+def test_compute_fails_loudly_without_gpu(lib):
+    from tadataka_amd import ops
+    assert lib.device_count() == 0
+    with pytest.raises(lib.TdkError):
+        lib.require_gpu()
+    with pytest.raises(lib.TdkError):
+        ops.warp_vecs(np.eye(4), np.zeros((2, 2)), np.ones(2))
+    with pytest.raises(lib.TdkError):
+        ops.DvoBatch(1, 8, 8)
+
+
+def test_argument_validation_needs_no_gpu(lib):
+    import ctypes as C
+    h = lib.load()
+    out = C.c_void_p()
+    assert h.tdk_dvo_create(0, 8, 8, 1, 1.5, 0, C.byref(out)) == lib.TDK_ERR_INVALID_ARGUMENT
+    assert h.tdk_dvo_create(1, 1, 8, 1, 1.5, 0, C.byref(out)) == lib.TDK_ERR_INVALID_ARGUMENT
+    assert b"invalid argument" in h.tdk_last_error()
+    d = C.c_double()
+    T = (C.c_double * 16)(*np.array([[1., 0., 0., 2.], [0., 1., 0., 0.], [0., 0., 1., 0.], [0., 0., 0., 1.]]).ravel())
+    x0 = (C.c_double * 2)(0.1, 0.2); x1 = (C.c_double * 2)(0.3, 0.2)
+    # calc_depth0 is scalar host arithmetic inside the library
+    assert h.tdk_calc_depth0(T, x0, x1, C.byref(d)) == 0
+    from oracle import oracle as orc
+    assert d.value == orc.calc_depth0(np.array(T).reshape(4, 4), [0.1, 0.2], [0.3, 0.2])

@@ -1,0 +1,440 @@
+"""GPU parity tests: the HIP path (through the C ABI, via tadataka_amd.ops)
+against the CPU oracle on the same seeded inputs and against the committed
+golden fixtures.  Bars: bit-exact for integer / index / flag outputs and for the
+parity-granular operators; <= 1e-4 relative on residual sums / J^T J (we hold
+1e-9) and <= 1e-6 on the recovered SE(3) pose."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+RTOL_SUMS = 1e-9      # required: 1e-4
+POSE_ATOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tadataka_amd import _lib, ops as o
+    _lib.require_gpu()
+    return o
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+# ---------------------------------------------------------------------------
+# parity-granular operators: bit-exact
+# ---------------------------------------------------------------------------
+def test_granular_ops_bit_exact(ops, orc):
+    rng = np.random.default_rng(0)
+    n = 10007
+    cam = np.array([525.0, 520.0, 319.5, 239.5])
+    kp = rng.uniform(-50, 700, (n, 2))
+    assert np.array_equal(ops.normalize(kp, cam), orc.normalize(kp, cam))
+    assert np.array_equal(ops.unnormalize(kp / 500, cam), orc.unnormalize(kp / 500, cam))
+    P = rng.uniform(-3, 3, (n, 3)); P[:, 2] += 4
+    assert np.array_equal(ops.project_vecs(P), orc.project_vecs(P))
+    xs = rng.uniform(-1, 1, (n, 2)); d = rng.uniform(0.5, 5, n)
+    assert np.array_equal(ops.inv_project_vecs(xs, d), orc.inv_project_vecs(xs, d))
+    T = np.eye(4); T[:3, :3] = Rotation.from_rotvec([0.1, -0.2, 0.05]).as_matrix(); T[:3, 3] = [0.1, 0.2, -0.3]
+    assert np.array_equal(ops.transform(T, P), orc.transform(T, P))
+    a, b = ops.warp_vecs(T, xs, d)
+    c, e = orc.warp_vecs(T, xs, d)
+    assert np.array_equal(a, c) and np.array_equal(b, e)
+    assert ops.calc_depth0(T, xs[0], xs[1]) == orc.calc_depth0(T, xs[0], xs[1])
+
+
+def test_granular_empty_and_single(ops):
+    assert ops.normalize(np.zeros((0, 2)), [1, 1, 0, 0]).shape == (0, 2)
+    assert ops.warp_vecs(np.eye(4), np.zeros((0, 2)), np.zeros(0))[0].shape == (0, 2)
+    xs1, d1 = ops.warp_vecs([[0., 0., 1., 0.], [0., 1., 0., 0.], [-1., 0., 0., 4.], [0., 0., 0., 1.]],
+                            [[0., 0.], [2., -1.]], [2., 4.])          # src/warp.rs:117-135
+    assert np.array_equal(xs1, [[0.5, 0.0], [-1.0, 1.0]]) and np.array_equal(d1, [4., -4.])
+
+
+def test_interpolation_bit_exact_and_errors(ops, orc):
+    rng = np.random.default_rng(1)
+    img = rng.uniform(0, 1, (37, 53))
+    c = np.column_stack([rng.uniform(0, 52, 5000), rng.uniform(0, 36, 5000)])
+    c[:200] = np.floor(c[:200]); c[200:400, 0] = np.floor(c[200:400, 0]); c[400:600, 1] = np.floor(c[400:600, 1])
+    c[600] = [52., 36.]; c[601] = [0., 0.]; c[602] = [52., 0.5]; c[603] = [0.5, 36.]
+    assert np.array_equal(ops.interpolation(img, c), orc.interpolation(img, c))
+    image = np.array([[0., 1., 5.], [0., 0., 2.], [4., 3., 2.], [5., 6., 1.]])   # tests/test_interpolation.py
+    for bad in ([3.0, 2.01], [3.01, 2.0], [-0.01, 0.0], [0.0, -0.01]):
+        with pytest.raises(ValueError):
+            ops.interpolation(image, [bad])
+    assert ops.interpolation(image, [[2.0, 3.0]])[0] == image[3, 2]
+
+
+def test_image_gradient_and_rescale_bit_exact(ops, orc):
+    rng = np.random.default_rng(2)
+    img = rng.uniform(0, 1, (33, 47))
+    gx, gy = ops.image_gradient(img)
+    ogx, ogy = orc.image_gradient(img)
+    assert np.array_equal(gx, ogx) and np.array_equal(gy, ogy)
+    for scale in (1 / 1.5, 1 / 2.25, 0.5):
+        assert np.array_equal(ops.rescale(img, scale), orc.rescale(img, scale))
+
+
+# ---------------------------------------------------------------------------
+# DVO
+# ---------------------------------------------------------------------------
+def _pose12(T):
+    return np.concatenate([T[:3, :3].ravel(), T[:3, 3]])
+
+
+@pytest.mark.parametrize("wname", [None, "huber", "map"])
+def test_dvo_evaluate_vs_golden_small(ops, golden, wname):
+    d = golden("dvo_small.npz")
+    cam = d["cam"]
+    H, W = d["I0"].shape
+    batch = ops.DvoBatch(1, H, W, with_weight_map=(wname == "map"))
+    batch.upload(0, d["I0"], d["D0"], d["I1"], d["weight_map"] if wname == "map" else None)
+    mode = ops.W_MAP if wname == "map" else ops.WEIGHT_MODES[wname]
+    key = f"s_{wname}"
+    iu = np.triu_indices(6)
+    for k in range(int(d[f"{key}_n_updates"])):
+        T = d[f"{key}_err_T"][k]
+        ev = batch.evaluate(0, cam, cam, _pose12(T)[None], mode)
+        assert ev["n_update"][0] == int(d[f"{key}_u{k}_n_valid"])
+        assert rel_err(ev["H"][0], d[f"{key}_u{k}_H"][iu]) < RTOL_SUMS
+        assert rel_err(ev["b"][0], d[f"{key}_u{k}_b"]) < RTOL_SUMS
+    for T, val in zip(d[f"{key}_err_T"], d[f"{key}_err_val"]):
+        ev = batch.evaluate(0, cam, cam, _pose12(T)[None], mode)
+        assert abs(ev["sum_sq"][0] / ev["n_error"][0] - val) <= RTOL_SUMS * abs(val)
+    batch.close()
+
+
+@pytest.mark.parametrize("wname", [None, "huber", "map"])
+def test_dvo_level_loop_vs_golden_small(ops, golden, wname):
+    d = golden("dvo_small.npz")
+    cam = d["cam"]
+    H, W = d["I0"].shape
+    batch = ops.DvoBatch(1, H, W, with_weight_map=(wname == "map"))
+    batch.upload(0, d["I0"], d["D0"], d["I1"], d["weight_map"] if wname == "map" else None)
+    mode = ops.W_MAP if wname == "map" else ops.WEIGHT_MODES[wname]
+    P, n_evals = batch.estimate_level(0, cam, cam, _pose12(np.eye(4))[None], mode, max_iter=20)
+    R = Rotation.from_rotvec(d[f"s_{wname}_final_rotvec"]).as_matrix()
+    assert np.max(np.abs(P[0, :9].reshape(3, 3) - R)) < POSE_ATOL
+    assert np.max(np.abs(P[0, 9:] - d[f"s_{wname}_final_t"])) < POSE_ATOL
+    # the reference ran n_updates updates and n_updates + 1 error evaluations
+    assert n_evals[0] == int(d[f"s_{wname}_n_updates"]) + 1
+    batch.close()
+
+
+def test_dvo_vga_vs_golden_and_oracle(ops, orc, golden):
+    from tadataka_amd import synthetic
+    v = golden("dvo_vga.npz")
+    pair = synthetic.make_pair(480, 640, seed=0)
+    cam = pair["cam"]
+    batch = ops.DvoBatch(1, 480, 640)
+    batch.upload(0, pair["I0"], pair["D0"], pair["I1"])
+    iu = np.triu_indices(6)
+    for wname in (None, "huber"):
+        key = f"v_{wname}"
+        for k in range(int(v[f"{key}_n_updates"])):
+            T = v[f"{key}_err_T"][k]
+            ev = batch.evaluate(0, cam, cam, _pose12(T)[None], ops.WEIGHT_MODES[wname])
+            assert ev["n_update"][0] == int(v[f"{key}_u{k}_n_valid"])
+            assert rel_err(ev["H"][0], v[f"{key}_u{k}_H"][iu]) < RTOL_SUMS
+            assert rel_err(ev["b"][0], v[f"{key}_u{k}_b"]) < RTOL_SUMS
+        for T, val in zip(v[f"{key}_err_T"], v[f"{key}_err_val"]):
+            ev = batch.evaluate(0, cam, cam, _pose12(T)[None], ops.WEIGHT_MODES[wname])
+            assert abs(ev["sum_sq"][0] / ev["n_error"][0] - val) <= RTOL_SUMS * abs(val)
+        P, _ = batch.estimate_level(0, cam, cam, _pose12(np.eye(4))[None], ops.WEIGHT_MODES[wname], 20)
+        R = Rotation.from_rotvec(v[f"{key}_final_rotvec"]).as_matrix()
+        assert np.max(np.abs(P[0, :9].reshape(3, 3) - R)) < POSE_ATOL
+        assert np.max(np.abs(P[0, 9:] - v[f"{key}_final_t"])) < POSE_ATOL
+    batch.close()
+
+
+def test_dvo_pyramid_vs_golden(ops, orc, golden):
+    from tadataka_amd import synthetic
+    p = golden("dvo_pyramid.npz")
+    pair = synthetic.make_pair(120, 160, seed=4)
+    batch = ops.DvoBatch(1, 120, 160, n_levels=3, ratio=1.5)
+    batch.upload(0, pair["I0"], pair["D0"], pair["I1"])
+    batch.build_pyramid()
+    # the device pyramid equals the oracle's (bit-exact), level by level
+    for level in (1, 2):
+        scale = 1 / 1.5 ** level
+        for name in ("I0", "D0", "I1"):
+            assert np.array_equal(batch.download(0, level, name), orc.rescale(pair[name], scale))
+    for wname in (None, "huber"):
+        P, px = batch.estimate(pair["cam"], pair["cam"], _pose12(np.eye(4))[None], ops.WEIGHT_MODES[wname], 20)
+        R = Rotation.from_rotvec(p[f"pyr_{wname}_rotvec"]).as_matrix()
+        assert np.max(np.abs(P[0, :9].reshape(3, 3) - R)) < POSE_ATOL
+        assert np.max(np.abs(P[0, 9:] - p[f"pyr_{wname}_t"])) < POSE_ATOL
+        assert px > 0
+    batch.close()
+
+
+def test_dvo_batch_ragged_shapes_and_independence(ops, orc):
+    """Odd widths/heights (pyramid levels are 213x284, 427 wide, ...), several
+    pairs in one launch, every pair checked against the oracle on its own."""
+    from tadataka_amd import synthetic
+    H, W, B = 61, 83, 5          # N odd: exercises the scalar tail and the padded stride
+    pairs = [synthetic.make_pair(H, W, seed=10 + i) for i in range(B)]
+    cam = pairs[0]["cam"]
+    batch = ops.DvoBatch(B, H, W)
+    for i, pr in enumerate(pairs):
+        batch.upload(i, pr["I0"], pr["D0"], pr["I1"])
+    rng = np.random.default_rng(5)
+    poses = []
+    for i in range(B):
+        T = np.eye(4)
+        T[:3, :3] = Rotation.from_rotvec(rng.uniform(-0.01, 0.01, 3)).as_matrix()
+        T[:3, 3] = rng.uniform(-0.02, 0.02, 3)
+        poses.append(T)
+    ev = batch.evaluate(0, cam, cam, np.array([_pose12(T) for T in poses]), ops.W_HUBER)
+    for i, (pr, T) in enumerate(zip(pairs, poses)):
+        GX, GY = orc.image_gradient(pr["I1"])
+        Hm, b, n = orc.dvo_normal_equations(pr["I0"], pr["D0"], pr["I1"], GX, GY, cam, cam,
+                                            T[:3, :3], T[:3, 3], "huber")
+        ss, ne = orc.photometric_error_sums(pr["I0"], pr["D0"], pr["I1"], cam, cam, T)
+        assert ev["n_update"][i] == n and ev["n_error"][i] == ne
+        assert rel_err(ev["H"][i], Hm) < RTOL_SUMS and rel_err(ev["b"][i], b) < RTOL_SUMS
+        assert abs(ev["sum_sq"][i] - ss) <= RTOL_SUMS * ss
+    # the whole Gauss-Newton loop, all pairs in lock step on the device
+    P, n_evals = batch.estimate_level(0, cam, cam, np.tile(_pose12(np.eye(4)), (B, 1)), ops.W_NONE, 20)
+    for i, pr in enumerate(pairs):
+        rot, t = orc.dvo_estimate_level(pr["I0"], pr["D0"], pr["I1"], cam, cam,
+                                        Rotation.from_rotvec(np.zeros(3)), np.zeros(3), None, 20)
+        assert np.max(np.abs(P[i, :9].reshape(3, 3) - rot.as_matrix())) < POSE_ATOL
+        assert np.max(np.abs(P[i, 9:] - t)) < POSE_ATOL
+    batch.close()
+
+
+def test_dvo_out_of_view_pose_and_masks(ops, orc):
+    """A pose that throws every pixel out of the image: empty masks, the loop
+    returns the prior (vo/dvo/__init__.py:51-53,98-100); and a pose that puts
+    some points behind the camera (update mask has z > 0, error mask does not)."""
+    from tadataka_amd import synthetic
+    pr = synthetic.make_pair(40, 56, seed=3)
+    cam = pr["cam"]
+    batch = ops.DvoBatch(1, 40, 56)
+    batch.upload(0, pr["I0"], pr["D0"], pr["I1"])
+    far = np.eye(4); far[0, 3] = 1e3
+    ev = batch.evaluate(0, cam, cam, _pose12(far)[None])
+    assert ev["n_update"][0] == 0 and ev["n_error"][0] == 0
+    P, n_evals = batch.estimate_level(0, cam, cam, _pose12(far)[None], ops.W_NONE, 20)
+    assert np.array_equal(P[0], _pose12(far)) and n_evals[0] == 1
+    flip = np.eye(4); flip[:3, :3] = Rotation.from_rotvec([0, np.pi, 0]).as_matrix()
+    ev = batch.evaluate(0, cam, cam, _pose12(flip)[None])
+    GX, GY = orc.image_gradient(pr["I1"])
+    Hm, b, n = orc.dvo_normal_equations(pr["I0"], pr["D0"], pr["I1"], GX, GY, cam, cam,
+                                        flip[:3, :3], flip[:3, 3], None)
+    ss, ne = orc.photometric_error_sums(pr["I0"], pr["D0"], pr["I1"], cam, cam, flip)
+    assert ev["n_update"][0] == n == 0 and ev["n_error"][0] == ne and ne > 0
+    assert abs(ev["sum_sq"][0] - ss) <= RTOL_SUMS * ss
+    batch.close()
+
+
+def test_dvo_full_size_properties(ops):
+    """BASELINE sizes (64 x 720p is bench-only; here 8 x 720p): size-independent
+    properties -- counts are exact integers, H is symmetric positive
+    semi-definite, evaluation is permutation-equivariant over pairs and
+    bit-reproducible run to run."""
+    from tadataka_amd import synthetic
+    B, H, W = 8, 720, 1280
+    cam = synthetic.camera_for(W, H)
+    rng = np.random.default_rng(0)
+    poses = []
+    for i in range(B):
+        T = np.eye(4)
+        T[:3, :3] = synthetic.rodrigues(rng.uniform(-0.005, 0.005, 3))
+        T[:3, 3] = rng.uniform(-0.01, 0.01, 3)
+        poses.append(_pose12(T))
+    poses = np.array(poses)
+    batch = ops.DvoBatch(B, H, W)
+    batch.fill_synthetic(cam, poses, seed0=0, noise=0.02)
+    ident = np.tile(_pose12(np.eye(4)), (B, 1))
+    ev1 = batch.evaluate(0, cam, cam, ident, ops.W_HUBER)
+    ev2 = batch.evaluate(0, cam, cam, ident, ops.W_HUBER)
+    for k in ("H", "b", "sum_sq", "n_update", "n_error"):
+        assert np.array_equal(ev1[k], ev2[k])                     # deterministic reduction
+    # identity warp: everything stays in view except border pixels lost to rounding
+    assert np.all(ev1["n_update"] <= H * W) and np.all(ev1["n_update"] > 0.99 * H * W)
+    assert np.array_equal(ev1["n_update"], ev1["n_error"])
+    for i in range(B):
+        Hm = ops.upper21_to_matrix(ev1["H"][i])
+        assert np.all(np.linalg.eigvalsh(Hm) > -1e-9 * np.abs(Hm).max())
+    # evaluating at the true pose must reduce the photometric error of every pair
+    ev_true = batch.evaluate(0, cam, cam, poses, ops.W_HUBER)
+    assert np.all(ev_true["sum_sq"] / ev_true["n_error"] < ev1["sum_sq"] / ev1["n_error"])
+    # and the device loop lowers the error of every pair and moves towards the truth
+    P, _ = batch.estimate_level(0, cam, cam, ident, ops.W_HUBER, 20)
+    ev_est = batch.evaluate(0, cam, cam, P, ops.W_HUBER)
+    assert np.all(ev_est["sum_sq"] / ev_est["n_error"] < ev1["sum_sq"] / ev1["n_error"])
+    assert np.all(np.linalg.norm(P[:, 9:] - poses[:, 9:], axis=1) < np.linalg.norm(poses[:, 9:], axis=1))
+    batch.close()
+
+
+# ---------------------------------------------------------------------------
+# semi-dense
+# ---------------------------------------------------------------------------
+def test_sobel_bit_exact(ops, orc):
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 1, (29, 41))
+    gx, gy = ops.sobel(img)
+    ogx, ogy = orc.sobel(img)
+    assert np.array_equal(gx, ogx) and np.array_equal(gy, ogy)
+    m = np.array([[1., 2., -1., 0.], [0., 0., -1., 1.], [3., -2., 0., -1.], [-2., 1., 1., 2.]])  # src/gradient.rs:44-63
+    gx, gy = ops.sobel(m)
+    assert np.array_equal(gx, [[0, 0, 0, 0], [0, 7, -1, 0], [0, 4, -4, 0], [0, 0, 0, 0]])
+    assert np.array_equal(gy, [[0, 0, 0, 0], [0, 5, 3, 0], [0, -2, -6, 0], [0, 0, 0, 0]])
+
+
+def test_increment_age_bit_exact(ops, orc):
+    W, H = 12, 16                                                  # src/semi_dense/age.rs:39-63
+    cam = [10., 10., W / 2., H / 2.]
+    T = np.eye(4); T[2, 3] = 10.
+    age1 = ops.increment_age(np.zeros((H, W), dtype=np.uint64), cam, cam, T, 10.0 * np.ones((H, W)))
+    exp = np.zeros((H, W), dtype=np.uint64); exp[4:12, 3:9] = 1
+    assert np.array_equal(age1, exp)
+    # random scene with collisions: last raster writer must win
+    from tadataka_amd import synthetic
+    rng = np.random.default_rng(4)
+    H, W = 120, 160
+    cam = synthetic.camera_for(W, H)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    depth = synthetic.depth_map(xs, ys) * rng.uniform(0.8, 1.2, (H, W))
+    age0 = rng.integers(0, 7, (H, W)).astype(np.uint64)
+    T = np.eye(4); T[:3, :3] = Rotation.from_rotvec([0.01, -0.02, 0.03]).as_matrix(); T[:3, 3] = [0.05, -0.02, 0.8]
+    assert np.array_equal(ops.increment_age(age0, cam, cam, T, depth), orc.increment_age(age0, cam, cam, T, depth))
+
+
+def test_propagate_bit_exact(ops, orc):
+    W = H = 8                                                      # src/semi_dense/propagation.rs:117-183
+    cam = [100., 100., W / 2., H / 2.]
+    T = np.eye(4); T[2, 3] = 300.
+    args = (T, cam, cam, np.full((H, W), 100.), np.full((H, W), 20.), 60., 8., 3.)
+    d1, v1 = ops.propagate(*args)
+    od1, ov1 = orc.propagate(*args)
+    assert np.array_equal(d1, od1) and np.array_equal(v1, ov1)
+    exp_d = np.full((H, W), 60.); exp_d[3:5, 3:5] = 400.
+    assert np.max(np.abs(d1 - exp_d)) < 1e-4
+    # random zoom-out scene: many-to-one collisions, both fusion and occlusion branches
+    from tadataka_amd import synthetic
+    rng = np.random.default_rng(6)
+    H, W = 96, 128
+    cam = synthetic.camera_for(W, H)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    depth = synthetic.depth_map(xs, ys) * rng.choice([1.0, 1.0, 0.5], (H, W))
+    var = rng.uniform(1e-4, 0.5, (H, W))
+    T = np.eye(4); T[:3, :3] = Rotation.from_rotvec([0.0, 0.01, -0.02]).as_matrix(); T[:3, 3] = [0.02, 0.01, 1.5]
+    args = (T, cam, cam, depth, var, 1.0, 10.0, 0.01)
+    d1, v1 = ops.propagate(*args)
+    od1, ov1 = orc.propagate(*args)
+    assert np.array_equal(d1, od1) and np.array_equal(v1, ov1)
+
+
+def _semi_dense_case(H, W, seed):
+    from tadataka_amd import synthetic
+    c = synthetic.make_semi_dense_case(H, W, seed=seed)
+    key = (c["cam"], c["key_image"], c["T_wk"])
+    ref = (c["cam"], c["ref_image"], c["T_wr"])
+    return c, key, ref
+
+
+def test_update_depth_bit_exact_flags_and_values(ops, orc):
+    c, key, ref = _semi_dense_case(120, 160, seed=1)
+    args = (0.5, 10.0, 0.01, 0.01, 0.002, 0.005)
+    pg, po = ops.make_params(*args), orc.make_params(*args)
+    d, v, f = ops.update_depth(key, [ref], c["age"], c["prior_depth"], c["prior_variance"], pg)
+    od, ov, of = orc.update_depth(key, [ref], c["age"], c["prior_depth"], c["prior_variance"], po)
+    assert np.array_equal(f, of)
+    assert np.array_equal(d, od) and np.array_equal(v, ov)
+    hist = dict(zip(*np.unique(f, return_counts=True)))
+    assert hist.get(0, 0) > 1000 and hist.get(-9, 0) > 1000 and hist.get(-6, 0) > 100   # a real mix of outcomes
+    ok = f == 0                                          # and the depths it finds are sensible
+    assert np.median(np.abs(d[ok] - c["depth_gt"][ok]) / c["depth_gt"][ok]) < 0.1
+    # two reference frames, ages 1 and 2 select refframes[len - age]
+    ref2 = (c["cam"], c["key_image"] * 0.9 + 0.05, np.array(c["T_wr"]) + np.diag([0, 0, 0, 0.0]))
+    ref2[2][0, 3] = 0.2
+    age2 = c["age"].copy(); age2[::3, ::2] *= 2
+    d, v, f = ops.update_depth(key, [ref2, ref], age2, c["prior_depth"], c["prior_variance"], pg)
+    od, ov, of = orc.update_depth(key, [ref2, ref], age2, c["prior_depth"], c["prior_variance"], po)
+    assert np.array_equal(f, of) and np.array_equal(d, od) and np.array_equal(v, ov)
+
+
+def test_update_depth_edge_cases(ops, orc):
+    c, key, ref = _semi_dense_case(48, 64, seed=2)
+    args = (0.5, 10.0, 0.01, 0.01, 0.01, 0.02)
+    pg, po = ops.make_params(*args), orc.make_params(*args)
+    # no reference frames and an all-zero age map: everything NotProcessed (-9)
+    zero = np.zeros((48, 64), dtype=np.uint64)
+    d, v, f = ops.update_depth(key, [], zero, c["prior_depth"], c["prior_variance"], pg)
+    assert np.all(f == -9) and np.array_equal(d, c["prior_depth"]) and np.array_equal(v, c["prior_variance"])
+    # an age larger than the number of reference frames: error, not process exit
+    bad = zero.copy(); bad[3, 4] = 2
+    from tadataka_amd._lib import TdkError
+    with pytest.raises(TdkError):
+        ops.update_depth(key, [ref], bad, c["prior_depth"], c["prior_variance"], pg)
+    # negative / out-of-range priors produce the -7 / -1 flags
+    pd_ = c["prior_depth"].copy(); pd_[0, :] = -1.0; pd_[1, :] = 1e6
+    age = np.ones((48, 64), dtype=np.uint64)
+    d, v, f = ops.update_depth(key, [ref], age, pd_, c["prior_variance"], pg)
+    od, ov, of = orc.update_depth(key, [ref], age, pd_, c["prior_variance"], po)
+    assert np.array_equal(f, of) and np.array_equal(d, od) and np.array_equal(v, ov)
+    assert np.all(f[0] == -7)
+
+
+def test_estimate_one_matches_oracle(ops, orc):
+    c, key, ref = _semi_dense_case(60, 80, seed=3)
+    args = (0.5, 10.0, 0.01, 0.01, 0.002, 0.005)
+    pg, po = ops.make_params(*args), orc.make_params(*args)
+    rng = np.random.default_rng(0)
+    for _ in range(40):
+        u = np.array([rng.integers(0, 80), rng.integers(0, 60)])
+        pd_ = float(c["prior_depth"][u[1], u[0]])
+        got = ops.estimate_one(u, pd_, 0.05, key, ref, pg)
+        exp = orc.estimate_debug(u, pd_, 0.05, key, ref, po)
+        assert got == exp
+    assert ops.estimate_one([5, 5], -1.0, 0.05, key, ref, pg) == orc.estimate_debug([5, 5], -1.0, 0.05, key, ref, po)
+
+
+# ---------------------------------------------------------------------------
+# bundle adjustment
+# ---------------------------------------------------------------------------
+def test_ba_projection_vs_cython_reference(ops, golden):
+    g = golden("ba_vectors.npz")
+    poses, points = g["poses"], g["points"]
+    n = poses.shape[0]
+    idx = np.arange(n, dtype=np.int64)
+    x, A, B = ops.ba_projection(poses, points, idx, idx)
+    scale = lambda ref: np.maximum(np.abs(ref).max(axis=tuple(range(1, ref.ndim)), keepdims=True), 1.0)
+    assert np.max(np.abs(x - g["x"]) / scale(g["x"])) < 1e-11
+    assert np.max(np.abs(B - g["B"]) / scale(g["B"])) < 1e-10
+    assert np.max(np.abs(A - g["A"]) / scale(g["A"])) < 1e-7
+    assert np.max(np.abs(ops.ba_exp_so3(poses[:, :3]) - g["R"])) < 1e-12
+    assert np.array_equal(ops.ba_projection(poses, points, idx, idx, jacobians=False), x)
+
+
+def test_ba_block_reduce_vs_oracle(ops, orc):
+    from tadataka_amd import synthetic
+    c = synthetic.make_ba_case(n_poses=5, n_points=700, seed=2)
+    x_true = orc.ba_projection(c["poses"], c["points"], c["vp_idx"], c["pt_idx"], jacobians=False)
+    for order in ("viewpoint-major", "shuffled"):
+        vp, pt, xt = c["vp_idx"], c["pt_idx"], x_true
+        if order == "shuffled":
+            perm = np.random.default_rng(1).permutation(len(vp))
+            vp, pt, xt = vp[perm], pt[perm], xt[perm]
+        U, ea, V, eb, err = ops.ba_block_reduce(c["poses_noisy"], c["points_noisy"], xt, vp, pt)
+        oU, oea, oV, oeb, oerr = orc.ba_block_reduce(c["poses_noisy"], c["points_noisy"], xt, vp, pt)
+        assert rel_err(U, oU) < 1e-9 and rel_err(ea, oea) < 1e-8
+        assert rel_err(V, oV) < 1e-9 and rel_err(eb, oeb) < 1e-8
+        assert abs(err - oerr) <= 1e-9 * oerr
+    # ragged visibility: a pose with no observation and a point seen once
+    vp = np.array([0, 0, 2, 2, 2], dtype=np.int64); pt = np.array([0, 1, 0, 1, 3], dtype=np.int64)
+    xt = orc.ba_projection(c["poses"], c["points"], vp, pt, jacobians=False)
+    U, ea, V, eb, err = ops.ba_block_reduce(c["poses_noisy"][:3], c["points_noisy"][:4], xt, vp, pt)
+    oU, oea, oV, oeb, oerr = orc.ba_block_reduce(c["poses_noisy"][:3], c["points_noisy"][:4], xt, vp, pt)
+    assert np.all(U[1] == 0) and np.all(V[2] == 0)
+    assert rel_err(U, oU) < 1e-9 and rel_err(V, oV) < 1e-9 and abs(err - oerr) <= 1e-9 * oerr
