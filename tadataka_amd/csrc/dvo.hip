@@ -66,105 +66,309 @@ struct Accum {
     double v[kAcc];
 };
 
-// One source pixel.  (x, y) integer pixel of frame 0 with normalised
-// coordinates (xn, yn); d0/i0/i1/w0 its depth, intensities (I0 and the
-// *unwarped* I1, F3) and weight-map entry.
+// q / z for two numerators sharing one denominator, correctly rounded: the
+// v_rcp_f64 seed refined by two Newton steps, then one Markstein correction per
+// quotient -- the same fma sequence the compiler emits for an IEEE f64 `/`
+// (minus the range scaling, irrelevant for depths), with the reciprocal shared.
+// `rcp` returns the refined reciprocal (used for the Jacobian's 1/z).
+__device__ __forceinline__ void div2_shared(double nx, double ny, double z, double &qx, double &qy,
+                                            double &rcp) {
+    double y = __builtin_amdgcn_rcp(z);
+    double e = __builtin_fma(-z, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-z, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    double a = nx * y, b = ny * y;
+    double ra = __builtin_fma(-z, a, nx), rb = __builtin_fma(-z, b, ny);
+    qx = __builtin_fma(ra, y, a);
+    qy = __builtin_fma(rb, y, b);
+    rcp = y;
+}
+
+// ---------------------------------------------------------------------------
+// Per-pixel work, written branch-free so that the loads of several pixels can be
+// in flight together (the kernel is latency- and FP64-issue-bound, not
+// HBM-bound): invalid pixels are carried along with sanitised coordinates and
+// their contributions selected to zero at the end.
 //
 // The warped coordinate decides mask membership with an inclusive float
 // comparison, and at the identity pose the whole right/bottom border sits
-// exactly on that boundary -- so the coordinate chain is evaluated with the
-// reference's elementwise operations, one IEEE rounding each and no FMA
-// contraction: (u - o) / f (table), x * d, q / (z + 1e-16), x * f + o.
-template <int WMODE>
-__device__ __forceinline__ void accumulate_pixel(Accum &a, double xn, double yn, double d0, double i0,
-                                                 double i1, double w0, const double *__restrict__ I1,
-                                                 int H, int W, const double *P /*R,t*/,
-                                                 const double *c /*fx1, fy1, ox1, oy1*/) {
-    double qx, qy, qz, u, v;
+// exactly on that boundary -- so the projection chain keeps the reference's
+// elementwise roundings: (u - o) / f (tables), x * d, q / (z + 1e-16) as a true
+// division, x * f + o as a separate multiply and add.
+// ---------------------------------------------------------------------------
+struct Warped {
+    double qx, qy, qz, rz;       // P1 = R P0 + t and 1 / (z + 1e-16)
+    double w00, w01, w10, w11;   // bilinear weights
+    int c0, r0;                  // lower texel
+    bool valid;                  // in image range (metric.py:22)
+    bool inside;                 // 4x4 neighbourhood strictly inside the image
+};
+
+__device__ __forceinline__ Warped warp_pixel(double xn, double yn, double d0, int H, int W,
+                                             const double *P, const double *c) {
+    Warped o;
+    double px = xn * d0, py = yn * d0;
+    o.qx = P[0] * px + P[1] * py + P[2] * d0 + P[9];
+    o.qy = P[3] * px + P[4] * py + P[5] * d0 + P[10];
+    o.qz = P[6] * px + P[7] * py + P[8] * d0 + P[11];
+    double u, v;
     {
 #pragma clang fp contract(off)
-        double px = xn * d0, py = yn * d0, pz = 1.0 * d0;
-        qx = ((P[0] * px + P[1] * py) + P[2] * pz) + P[9];
-        qy = ((P[3] * px + P[4] * py) + P[5] * pz) + P[10];
-        qz = ((P[6] * px + P[7] * py) + P[8] * pz) + P[11];
-        double z = qz + tdk::kEps16;
-        u = (qx / z) * c[0] + c[2];
-        v = (qy / z) * c[1] + c[3];
+        double z = o.qz + tdk::kEps16, sx, sy;
+        div2_shared(o.qx, o.qy, z, sx, sy, o.rz);
+        u = sx * c[0] + c[2];
+        v = sy * c[1] + c[3];
     }
-    // inclusive float range test (tadataka/utils.py:35-44)
-    if (!(u >= 0.0 && u <= (double)(W - 1) && v >= 0.0 && v <= (double)(H - 1))) return;
-
+    // inclusive float range test (tadataka/utils.py:35-44); NaN compares false
+    o.valid = u >= 0.0 && u <= (double)(W - 1) && v >= 0.0 && v <= (double)(H - 1);
+    u = o.valid ? u : 0.0;
+    v = o.valid ? v : 0.0;
     double lx = floor(u), ly = floor(v);
-    int c0 = (int)lx, r0 = (int)ly;
+    o.c0 = (int)lx;
+    o.r0 = (int)ly;
     double wx1 = u - lx, wx0 = (lx + 1.0) - u;
     double wy1 = v - ly, wy0 = (ly + 1.0) - v;
-    double w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+    o.w00 = wx0 * wy0; o.w01 = wx1 * wy0; o.w10 = wx0 * wy1; o.w11 = wx1 * wy1;
+    o.inside = o.c0 >= 1 && o.c0 <= W - 3 && o.r0 >= 1 && o.r0 <= H - 3;
+    return o;
+}
 
-    // 4 x 2 + 2 x 2 texels of I1 around (c0, r0), indices clamped to the image
-    int cm = max(c0 - 1, 0), c1 = min(c0 + 1, W - 1), c2 = min(c0 + 2, W - 1);
-    int rm = max(r0 - 1, 0), r1 = min(r0 + 1, H - 1), r2 = min(r0 + 2, H - 1);
-    const double *row0 = I1 + r0 * W, *row1 = I1 + r1 * W;
-    double a0 = row0[cm], a1 = row0[c0], a2 = row0[c1], a3 = row0[c2];
-    double b0 = row1[cm], b1 = row1[c0], b2 = row1[c1], b3 = row1[c2];
+// Load base[byte_off / 8] with a 32-bit unsigned byte offset from a
+// block-uniform base: lowers to global_load_dwordx2 v, voffset, s[base] (no
+// 64-bit per-lane address arithmetic).
+__device__ __forceinline__ double ldo(const double *__restrict__ base, uint32_t byte_off) {
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
+}
 
-    // photometric error term (metric.py:24-27): no z test here
-    double i1w = a1 * w00 + a2 * w01 + b1 * w10 + b2 * w11;
-    double e = i0 - i1w;
-    a.v[27] += e * e;
-    a.v[29] += 1.0;
+struct Taps {   // the 12 I1 texels around (c0, r0): rows r0-1 .. r0+2
+    double t0, t1, a0, a1, a2, a3, b0, b1, b2, b3, u0, u1;
+};
 
-    if (!(qz > 0.0)) return;  // update mask adds P1z > 0 (vo/dvo/__init__.py:49)
+__device__ __forceinline__ Taps load_taps_inside(const double *__restrict__ I1, int W, const Warped &p) {
+    const uint32_t rowb = (uint32_t)W * 8u;
+    const uint32_t o0 = (uint32_t)(p.r0 * W + p.c0) * 8u;   // texel (r0, c0)
+    const uint32_t om = o0 - rowb, o1 = o0 + rowb, o2 = o1 + rowb;
+    Taps t;
+    t.t0 = ldo(I1, om); t.t1 = ldo(I1, om + 8u);
+    t.a0 = ldo(I1, o0 - 8u); t.a1 = ldo(I1, o0); t.a2 = ldo(I1, o0 + 8u); t.a3 = ldo(I1, o0 + 16u);
+    t.b0 = ldo(I1, o1 - 8u); t.b1 = ldo(I1, o1); t.b2 = ldo(I1, o1 + 8u); t.b3 = ldo(I1, o1 + 16u);
+    t.u0 = ldo(I1, o2); t.u1 = ldo(I1, o2 + 8u);
+    return t;
+}
 
-    const double *rowm = I1 + rm * W, *row2 = I1 + r2 * W;
-    double t0 = rowm[c0], t1 = rowm[c1], u0 = row2[c0], u1 = row2[c1];
+__device__ __forceinline__ Taps load_taps_clamped(const double *__restrict__ I1, int H, int W,
+                                                  const Warped &p) {
+    int c0 = p.c0, r0 = p.r0;
+    uint32_t cm = (uint32_t)max(c0 - 1, 0) * 8u, cc = (uint32_t)c0 * 8u;
+    uint32_t c1 = (uint32_t)min(c0 + 1, W - 1) * 8u, c2 = (uint32_t)min(c0 + 2, W - 1) * 8u;
+    const uint32_t rowb = (uint32_t)W * 8u;
+    uint32_t row0 = (uint32_t)r0 * rowb, row1 = (uint32_t)min(r0 + 1, H - 1) * rowb;
+    uint32_t rowm = (uint32_t)max(r0 - 1, 0) * rowb, row2 = (uint32_t)min(r0 + 2, H - 1) * rowb;
+    Taps t;
+    t.a0 = ldo(I1, row0 + cm); t.a1 = ldo(I1, row0 + cc); t.a2 = ldo(I1, row0 + c1); t.a3 = ldo(I1, row0 + c2);
+    t.b0 = ldo(I1, row1 + cm); t.b1 = ldo(I1, row1 + cc); t.b2 = ldo(I1, row1 + c1); t.b3 = ldo(I1, row1 + c2);
+    t.t0 = ldo(I1, rowm + cc); t.t1 = ldo(I1, rowm + c1);
+    t.u0 = ldo(I1, row2 + cc); t.u1 = ldo(I1, row2 + c1);
+    return t;
+}
 
-    // np.gradient at the four corner texels: central difference inside,
-    // one-sided on the border rows/columns
+// np.gradient of I1 sampled bilinearly at the warped coordinate
+// (vo/dvo/jacobian.py:27-29 + interpolation): central differences inside
+// (x 0.5 is exact, so it is factored out of the blend) ...
+__device__ __forceinline__ void gradient_inside(const Taps &t, const Warped &p, double &gx, double &gy) {
+    gx = 0.5 * ((t.a2 - t.a0) * p.w00 + (t.a3 - t.a1) * p.w01 + (t.b2 - t.b0) * p.w10 + (t.b3 - t.b1) * p.w11);
+    gy = 0.5 * ((t.b1 - t.t0) * p.w00 + (t.b2 - t.t1) * p.w01 + (t.u0 - t.a1) * p.w10 + (t.u1 - t.a2) * p.w11);
+}
+
+// ... and one-sided differences on the border rows / columns.
+__device__ __forceinline__ void gradient_clamped(const Taps &t, const Warped &p, int H, int W, double &gx,
+                                                 double &gy) {
+    int c0 = p.c0, r0 = p.r0, c1 = min(c0 + 1, W - 1), r1 = min(r0 + 1, H - 1);
     double sx0 = (c0 == 0 || c0 == W - 1) ? 1.0 : 0.5;
     double sx1 = (c1 == 0 || c1 == W - 1) ? 1.0 : 0.5;
     double sy0 = (r0 == 0 || r0 == H - 1) ? 1.0 : 0.5;
     double sy1 = (r1 == 0 || r1 == H - 1) ? 1.0 : 0.5;
-    double gx00 = (a2 - a0) * sx0, gx01 = (a3 - a1) * sx1;
-    double gx10 = (b2 - b0) * sx0, gx11 = (b3 - b1) * sx1;
-    double gy00 = (b1 - t0) * sy0, gy01 = (b2 - t1) * sy0;
-    double gy10 = (u0 - a1) * sy1, gy11 = (u1 - a2) * sy1;
-    double gx = gx00 * w00 + gx01 * w01 + gx10 * w10 + gx11 * w11;
-    double gy = gy00 * w00 + gy01 * w01 + gy10 * w10 + gy11 * w11;
+    gx = (t.a2 - t.a0) * sx0 * p.w00 + (t.a3 - t.a1) * sx1 * p.w01 + (t.b2 - t.b0) * sx0 * p.w10 +
+         (t.b3 - t.b1) * sx1 * p.w11;
+    gy = (t.b1 - t.t0) * sy0 * p.w00 + (t.b2 - t.t1) * sy0 * p.w01 + (t.u0 - t.a1) * sy1 * p.w10 +
+         (t.u1 - t.a2) * sy1 * p.w11;
+}
 
-    // Jacobian row (vo/dvo/jacobian.py:8-24), twist order [v, omega]
-    double fgx = c[0] * gx, fgy = c[1] * gy;
-    double izz = 1.0 / qz;
-    double iz2 = izz * izz;
+template <int WMODE>
+__device__ __forceinline__ void accumulate(Accum &a, const Warped &p, const Taps &t, double gx, double gy,
+                                           double i0, double i1, double w0, const double *c) {
+    // photometric error term (metric.py:24-27): no z test here
+    double i1w = t.a1 * p.w00 + t.a2 * p.w01 + t.b1 * p.w10 + t.b2 * p.w11;
+    double e = i0 - i1w;
+    a.v[27] += p.valid ? e * e : 0.0;
+    a.v[29] += p.valid ? 1.0 : 0.0;
+
+    // update mask adds P1z > 0 (vo/dvo/__init__.py:49); everything an excluded
+    // pixel could poison the sums with is selected to zero here
+    const bool upd = p.valid && p.qz > 0.0;
+    double qx = upd ? p.qx : 0.0, qy = upd ? p.qy : 0.0, qz = upd ? p.qz : 0.0;
+    double rz = upd ? p.rz : 0.0;
+    // Jacobian row (vo/dvo/jacobian.py:8-24), twist order [v, omega]; rz is the
+    // reciprocal of z + 1e-16, i.e. 1/z to 1e-16 relative
+    double fgx = upd ? c[0] * gx : 0.0, fgy = upd ? c[1] * gy : 0.0;
+    double iz2 = rz * rz;
     double z2 = qz * qz, xy = qx * qy;
     double J[6];
-    J[0] = fgx * izz;
-    J[1] = fgy * izz;
+    J[0] = fgx * rz;
+    J[1] = fgy * rz;
     J[2] = -(fgx * qx + fgy * qy) * iz2;
     J[3] = -(fgx * xy + fgy * (z2 + qy * qy)) * iz2;
     J[4] = (fgx * (z2 + qx * qx) + fgy * xy) * iz2;
-    J[5] = (-fgx * qy + fgy * qx) * izz;
+    J[5] = (fgy * qx - fgx * qy) * rz;
 
-    double r = i0 - i1;  // un-warped residual (vo/dvo/__init__.py:90)
+    double r = upd ? i0 - i1 : 0.0;  // un-warped residual (vo/dvo/__init__.py:90)
     double w = 1.0;
     if (WMODE == TDK_W_HUBER) {
         double ar = fabs(r);
-        w = ar > kHuberK ? kHuberK / ar : 1.0;
+        // |r| <= 1 < k on [0, 1] images (F4): the division is off the hot path
+        if (__builtin_amdgcn_ballot_w64(ar > kHuberK) != 0) w = ar > kHuberK ? kHuberK / ar : 1.0;
+    } else if (WMODE == TDK_W_MAP) {
+        w = upd ? w0 : 0.0;
+    }
+    const bool unit_w = (WMODE == TDK_W_NONE) ||
+                        (WMODE == TDK_W_HUBER && __builtin_amdgcn_ballot_w64(w != 1.0) == 0);
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double wj = unit_w ? J[i] : w * J[i];
+#pragma unroll
+        for (int q = i; q < 6; q++) a.v[k++] += wj * J[q];
+        a.v[21 + i] += wj * r;
+    }
+    a.v[28] += upd ? 1.0 : 0.0;
+}
+
+// Early-exit form of the same per-pixel work (VAR 4/5): excluded pixels leave
+// through a divergent branch instead of being carried along with selects.
+template <int WMODE>
+__device__ __forceinline__ void process_one_branchy(Accum &a, double xn, double yn, double d0, double i0,
+                                                    double i1, double w0, const double *__restrict__ I1,
+                                                    int H, int W, const double *P, const double *c) {
+    double px = xn * d0, py = yn * d0;
+    double qx = P[0] * px + P[1] * py + P[2] * d0 + P[9];
+    double qy = P[3] * px + P[4] * py + P[5] * d0 + P[10];
+    double qz = P[6] * px + P[7] * py + P[8] * d0 + P[11];
+    double u, v, rz;
+    {
+#pragma clang fp contract(off)
+        double z = qz + tdk::kEps16, sx, sy;
+        div2_shared(qx, qy, z, sx, sy, rz);
+        u = sx * c[0] + c[2];
+        v = sy * c[1] + c[3];
+    }
+    if (!(u >= 0.0 && u <= (double)(W - 1) && v >= 0.0 && v <= (double)(H - 1))) return;
+
+    double lx = floor(u), ly = floor(v);
+    Warped p;
+    p.c0 = (int)lx;
+    p.r0 = (int)ly;
+    double wx1 = u - lx, wx0 = (lx + 1.0) - u;
+    double wy1 = v - ly, wy0 = (ly + 1.0) - v;
+    p.w00 = wx0 * wy0; p.w01 = wx1 * wy0; p.w10 = wx0 * wy1; p.w11 = wx1 * wy1;
+    const bool inside = p.c0 >= 1 && p.c0 <= W - 3 && p.r0 >= 1 && p.r0 <= H - 3;
+    Taps t;
+    double gx, gy;
+    if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
+        t = load_taps_inside(I1, W, p);
+        gradient_inside(t, p, gx, gy);
+    } else {
+        t = load_taps_clamped(I1, H, W, p);
+        gradient_clamped(t, p, H, W, gx, gy);
+    }
+    double i1w = t.a1 * p.w00 + t.a2 * p.w01 + t.b1 * p.w10 + t.b2 * p.w11;
+    double e = i0 - i1w;
+    a.v[27] += e * e;
+    a.v[29] += 1.0;
+    if (!(qz > 0.0)) return;
+
+    double fgx = c[0] * gx, fgy = c[1] * gy;
+    double iz2 = rz * rz;
+    double z2 = qz * qz, xy = qx * qy;
+    double J[6];
+    J[0] = fgx * rz;
+    J[1] = fgy * rz;
+    J[2] = -(fgx * qx + fgy * qy) * iz2;
+    J[3] = -(fgx * xy + fgy * (z2 + qy * qy)) * iz2;
+    J[4] = (fgx * (z2 + qx * qx) + fgy * xy) * iz2;
+    J[5] = (fgy * qx - fgx * qy) * rz;
+    double r = i0 - i1;
+    double w = 1.0;
+    if (WMODE == TDK_W_HUBER) {
+        double ar = fabs(r);
+        if (__builtin_amdgcn_ballot_w64(ar > kHuberK) != 0) w = ar > kHuberK ? kHuberK / ar : 1.0;
     } else if (WMODE == TDK_W_MAP) {
         w = w0;
     }
+    const bool unit_w = (WMODE == TDK_W_NONE) ||
+                        (WMODE == TDK_W_HUBER && __builtin_amdgcn_ballot_w64(w != 1.0) == 0);
     int k = 0;
 #pragma unroll
-    for (int p = 0; p < 6; p++) {
-        double wj = (WMODE == TDK_W_NONE) ? J[p] : w * J[p];
+    for (int i = 0; i < 6; i++) {
+        double wj = unit_w ? J[i] : w * J[i];
 #pragma unroll
-        for (int q = p; q < 6; q++) a.v[k++] += wj * J[q];
-        a.v[21 + p] += wj * r;
+        for (int q = i; q < 6; q++) a.v[k++] += wj * J[q];
+        a.v[21 + i] += wj * r;
     }
     a.v[28] += 1.0;
 }
 
+// Two adjacent source pixels: warp both, then ONE wave-uniform choice between
+// the unclamped and the clamped tap pattern, so that all 24 gathers are issued
+// back to back.
 template <int WMODE>
-__global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairParams *__restrict__ params,
+__device__ __forceinline__ void process_two(Accum &acc, double xnA, double ynA, double xnB, double ynB,
+                                            double2 d, double2 p0, double2 p1, double2 w,
+                                            const double *__restrict__ I1, int H, int W, const double *P,
+                                            const double *c) {
+    Warped A = warp_pixel(xnA, ynA, d.x, H, W, P, c);
+    Warped B = warp_pixel(xnB, ynB, d.y, H, W, P, c);
+    Taps ta, tb;
+    double gxa, gya, gxb, gyb;
+    if (__builtin_amdgcn_ballot_w64(!(A.inside && B.inside)) == 0) {
+        ta = load_taps_inside(I1, W, A);
+        tb = load_taps_inside(I1, W, B);
+        gradient_inside(ta, A, gxa, gya);
+        gradient_inside(tb, B, gxb, gyb);
+    } else {
+        ta = load_taps_clamped(I1, H, W, A);
+        tb = load_taps_clamped(I1, H, W, B);
+        gradient_clamped(ta, A, H, W, gxa, gya);
+        gradient_clamped(tb, B, H, W, gxb, gyb);
+    }
+    accumulate<WMODE>(acc, A, ta, gxa, gya, p0.x, p1.x, w.x, c);
+    accumulate<WMODE>(acc, B, tb, gxb, gyb, p0.y, p1.y, w.y, c);
+}
+
+template <int WMODE>
+__device__ __forceinline__ void process_one(Accum &acc, double xn, double yn, double d0, double i0, double i1,
+                                            double w0, const double *__restrict__ I1, int H, int W,
+                                            const double *P, const double *c) {
+    Warped A = warp_pixel(xn, yn, d0, H, W, P, c);
+    Taps ta;
+    double gx, gy;
+    if (__builtin_amdgcn_ballot_w64(!A.inside) == 0) {
+        ta = load_taps_inside(I1, W, A);
+        gradient_inside(ta, A, gx, gy);
+    } else {
+        ta = load_taps_clamped(I1, H, W, A);
+        gradient_clamped(ta, A, H, W, gx, gy);
+    }
+    accumulate<WMODE>(acc, A, ta, gx, gy, i0, i1, w0, c);
+}
+
+// VAR selects the sweep structure (A/B-able at run time with TDK_DVO_VARIANT):
+//   0  two pixels per thread and sweep (16-byte loads), next sweep prefetched
+//   1  same, register budget capped for 3 waves/SIMD
+//   2  one pixel per thread and sweep, no prefetch
+//   3  same, register budget capped for 4 waves/SIMD
+template <int WMODE, int VAR>
+__global__ __launch_bounds__(kBlock, (VAR == 1 ? 3 : VAR == 3 ? 4 : 1)) void k_dvo_eval(LevelPtrs L, const PairParams *__restrict__ params,
                                                      const double *__restrict__ poses,
                                                      const int *__restrict__ state, double scale,
                                                      int64_t chunk, double *__restrict__ partials) {
@@ -211,24 +415,146 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
 
     const int start = (int)(blockIdx.x * chunk);
     const int end = (int)min((int64_t)N, (int64_t)start + chunk);
-    for (int i = start + 2 * (int)threadIdx.x; i < end; i += 2 * kBlock) {
+    // (x, y) of pixel i, advanced incrementally by the block sweep of 2*kBlock
+    // pixels: one integer division per thread instead of one per pixel
+    if (VAR == 4) {
+        int i = start + 2 * (int)threadIdx.x;
         int y = i / W, x = i - y * W;
+        const int step_y = (2 * kBlock) / W, step_x = (2 * kBlock) - step_y * W;
+        for (; i < end; i += 2 * kBlock) {
+            if (i + 1 < end) {
+                double2 d = *reinterpret_cast<const double2 *>(D0 + i);
+                double2 p0 = *reinterpret_cast<const double2 *>(I0 + i);
+                double2 p1 = *reinterpret_cast<const double2 *>(I1 + i);
+                double2 w = make_double2(1.0, 1.0);
+                if (WMODE == TDK_W_MAP) w = *reinterpret_cast<const double2 *>(W0 + i);
+                process_one_branchy<WMODE>(acc, xn_tab[x], yn_tab[y], d.x, p0.x, p1.x, w.x, I1, H, W, P, c);
+                int x2 = x + 1, y2 = y;
+                if (x2 == W) { x2 = 0; y2 = y + 1; }
+                process_one_branchy<WMODE>(acc, xn_tab[x2], yn_tab[y2], d.y, p0.y, p1.y, w.y, I1, H, W, P, c);
+            } else {
+                double w1 = (WMODE == TDK_W_MAP) ? W0[i] : 1.0;
+                process_one_branchy<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w1, I1, H, W, P, c);
+            }
+            x += step_x;
+            y += step_y;
+            if (x >= W) { x -= W; y += 1; }
+        }
+    } else if (VAR == 6) {
+        int i = start + (int)threadIdx.x;
+        int y = i / W, x = i - y * W;
+        const int step_y = kBlock / W, step_x = kBlock - step_y * W;
+        double d = 1.0, q0 = 0.0, q1 = 0.0, w1 = 1.0;
+        if (i < end) {
+            d = ldo(D0, (uint32_t)i * 8u); q0 = ldo(I0, (uint32_t)i * 8u); q1 = ldo(I1, (uint32_t)i * 8u);
+            if (WMODE == TDK_W_MAP) w1 = ldo(W0, (uint32_t)i * 8u);
+        }
+        for (; i < end; i += kBlock) {
+            const int in = i + kBlock;
+            double dn = d, q0n = q0, q1n = q1, wn = w1;
+            if (in < end) {
+                dn = ldo(D0, (uint32_t)in * 8u); q0n = ldo(I0, (uint32_t)in * 8u); q1n = ldo(I1, (uint32_t)in * 8u);
+                if (WMODE == TDK_W_MAP) wn = ldo(W0, (uint32_t)in * 8u);
+            }
+            process_one_branchy<WMODE>(acc, xn_tab[x], yn_tab[y], d, q0, q1, w1, I1, H, W, P, c);
+            d = dn; q0 = q0n; q1 = q1n; w1 = wn;
+            x += step_x;
+            y += step_y;
+            if (x >= W) { x -= W; y += 1; }
+        }
+    } else if (VAR == 7) {
+        int i = start + 2 * (int)threadIdx.x;
+        int y = i / W, x = i - y * W;
+        const int step_y = (2 * kBlock) / W, step_x = (2 * kBlock) - step_y * W;
+        double2 d = make_double2(1.0, 1.0), p0 = d, p1 = d, w = d;
         if (i + 1 < end) {
-            double2 d = *reinterpret_cast<const double2 *>(D0 + i);
-            double2 p0 = *reinterpret_cast<const double2 *>(I0 + i);
-            double2 p1 = *reinterpret_cast<const double2 *>(I1 + i);
-            double2 w = make_double2(1.0, 1.0);
+            d = *reinterpret_cast<const double2 *>(D0 + i);
+            p0 = *reinterpret_cast<const double2 *>(I0 + i);
+            p1 = *reinterpret_cast<const double2 *>(I1 + i);
             if (WMODE == TDK_W_MAP) w = *reinterpret_cast<const double2 *>(W0 + i);
-            accumulate_pixel<WMODE>(acc, xn_tab[x], yn_tab[y], d.x, p0.x, p1.x, w.x, I1, H, W, P, c);
+        }
+        for (; i < end; i += 2 * kBlock) {
+            if (i + 1 < end) {
+                const int in = i + 2 * kBlock;
+                double2 dn = d, p0n = p0, p1n = p1, wn = w;
+                if (in + 1 < end) {
+                    dn = *reinterpret_cast<const double2 *>(D0 + in);
+                    p0n = *reinterpret_cast<const double2 *>(I0 + in);
+                    p1n = *reinterpret_cast<const double2 *>(I1 + in);
+                    if (WMODE == TDK_W_MAP) wn = *reinterpret_cast<const double2 *>(W0 + in);
+                }
+                process_one_branchy<WMODE>(acc, xn_tab[x], yn_tab[y], d.x, p0.x, p1.x, w.x, I1, H, W, P, c);
+                int x2 = x + 1, y2 = y;
+                if (x2 == W) { x2 = 0; y2 = y + 1; }
+                process_one_branchy<WMODE>(acc, xn_tab[x2], yn_tab[y2], d.y, p0.y, p1.y, w.y, I1, H, W, P, c);
+                d = dn; p0 = p0n; p1 = p1n; w = wn;
+            } else {
+                double w1 = (WMODE == TDK_W_MAP) ? W0[i] : 1.0;
+                process_one_branchy<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w1, I1, H, W, P, c);
+            }
+            x += step_x;
+            y += step_y;
+            if (x >= W) { x -= W; y += 1; }
+        }
+    } else if (VAR == 5) {
+        int i = start + (int)threadIdx.x;
+        int y = i / W, x = i - y * W;
+        const int step_y = kBlock / W, step_x = kBlock - step_y * W;
+        for (; i < end; i += kBlock) {
+            double w1 = (WMODE == TDK_W_MAP) ? W0[i] : 1.0;
+            process_one_branchy<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w1, I1, H, W, P, c);
+            x += step_x;
+            y += step_y;
+            if (x >= W) { x -= W; y += 1; }
+        }
+    } else if (VAR >= 2) {
+        int i = start + (int)threadIdx.x;
+        int y = i / W, x = i - y * W;
+        const int step_y = kBlock / W, step_x = kBlock - step_y * W;
+        for (; i < end; i += kBlock) {
+            double w1 = (WMODE == TDK_W_MAP) ? W0[i] : 1.0;
+            process_one<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w1, I1, H, W, P, c);
+            x += step_x;
+            y += step_y;
+            if (x >= W) { x -= W; y += 1; }
+        }
+    } else {
+    int i = start + 2 * (int)threadIdx.x;
+    int y = i / W, x = i - y * W;
+    const int step_y = (2 * kBlock) / W, step_x = (2 * kBlock) - step_y * W;
+    // software pipeline: the streaming loads of the next sweep are issued
+    // before the current pixels' dependent gathers
+    double2 d = make_double2(1.0, 1.0), p0 = d, p1 = d, w = d;
+    if (i + 1 < end) {
+        d = *reinterpret_cast<const double2 *>(D0 + i);
+        p0 = *reinterpret_cast<const double2 *>(I0 + i);
+        p1 = *reinterpret_cast<const double2 *>(I1 + i);
+        if (WMODE == TDK_W_MAP) w = *reinterpret_cast<const double2 *>(W0 + i);
+    }
+    for (; i < end; i += 2 * kBlock) {
+        if (i + 1 < end) {
+            const int in = i + 2 * kBlock;
+            double2 dn = d, p0n = p0, p1n = p1, wn = w;
+            if (in + 1 < end) {
+                dn = *reinterpret_cast<const double2 *>(D0 + in);
+                p0n = *reinterpret_cast<const double2 *>(I0 + in);
+                p1n = *reinterpret_cast<const double2 *>(I1 + in);
+                if (WMODE == TDK_W_MAP) wn = *reinterpret_cast<const double2 *>(W0 + in);
+            }
             int x2 = x + 1, y2 = y;
             if (x2 == W) { x2 = 0; y2 = y + 1; }
-            accumulate_pixel<WMODE>(acc, xn_tab[x2], yn_tab[y2], d.y, p0.y, p1.y, w.y, I1, H, W, P, c);
+            process_two<WMODE>(acc, xn_tab[x], yn_tab[y], xn_tab[x2], yn_tab[y2], d, p0, p1, w, I1, H, W, P, c);
+            d = dn; p0 = p0n; p1 = p1n; w = wn;
         } else {
-            double w = (WMODE == TDK_W_MAP) ? W0[i] : 1.0;
-            accumulate_pixel<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w, I1, H, W, P, c);
+            double w1 = (WMODE == TDK_W_MAP) ? W0[i] : 1.0;
+            process_one<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w1, I1, H, W, P, c);
         }
+        x += step_x;
+        y += step_y;
+        if (x >= W) { x -= W; y += 1; }
     }
 
+    }
     // wave64 reduction, then across the block's 4 waves through LDS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -458,23 +784,34 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
         e1 = h->ev_pool[h->ev_used++];
         TDK_HIP(hipEventRecord(e0, tdk::stream()));
     }
+    static const int variant = [] {
+        const char *v = getenv("TDK_DVO_VARIANT");
+        return v ? atoi(v) : 7;
+    }();
+#define TDK_EVAL_LAUNCH(WM, VA)                                                                        \
+    k_dvo_eval<WM, VA><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state, L.scale, \
+                                                             chunk, h->d_partials)
+#define TDK_EVAL_VARIANTS(WM)                     \
+    switch (variant) {                            \
+        case 1: TDK_EVAL_LAUNCH(WM, 1); break;    \
+        case 2: TDK_EVAL_LAUNCH(WM, 2); break;    \
+        case 3: TDK_EVAL_LAUNCH(WM, 3); break;    \
+        case 4: TDK_EVAL_LAUNCH(WM, 4); break;    \
+        case 5: TDK_EVAL_LAUNCH(WM, 5); break;    \
+        case 6: TDK_EVAL_LAUNCH(WM, 6); break;    \
+        case 0: TDK_EVAL_LAUNCH(WM, 0); break;    \
+        default: TDK_EVAL_LAUNCH(WM, 7); break;   \
+    }
     switch (weight_mode) {
-        case TDK_W_NONE:
-            k_dvo_eval<TDK_W_NONE><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state,
-                                                                       L.scale, chunk, h->d_partials);
-            break;
-        case TDK_W_HUBER:
-            k_dvo_eval<TDK_W_HUBER><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state,
-                                                                        L.scale, chunk, h->d_partials);
-            break;
-        case TDK_W_MAP:
-            k_dvo_eval<TDK_W_MAP><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state,
-                                                                      L.scale, chunk, h->d_partials);
-            break;
+        case TDK_W_NONE: TDK_EVAL_VARIANTS(TDK_W_NONE); break;
+        case TDK_W_HUBER: TDK_EVAL_VARIANTS(TDK_W_HUBER); break;
+        case TDK_W_MAP: TDK_EVAL_VARIANTS(TDK_W_MAP); break;
         default:
             tdk::set_error("weight mode %d is not available on the fused path", weight_mode);
             return TDK_ERR_INVALID_ARGUMENT;
     }
+#undef TDK_EVAL_VARIANTS
+#undef TDK_EVAL_LAUNCH
     TDK_LAUNCH_CHECK();
     if (e1) TDK_HIP(hipEventRecord(e1, tdk::stream()));
     return TDK_OK;
