@@ -130,6 +130,25 @@ tdk_status tdk_dvo_get_stream(void **stream_out);
 tdk_status tdk_dvo_set_profiling(tdk_dvo *h, int enabled);
 tdk_status tdk_dvo_get_profile(tdk_dvo *h, int64_t *launches, double *total_ms, int64_t *pixels);
 
+/* ---- least-squares pieces at the reference's own granularity -------------- */
+/* A^T W A (upper triangle, row-major, p(p+1)/2) and A^T W b (p) of an n x p
+ * system, p <= 8; w may be NULL.  The reduction behind
+ * tadataka.math.solve_linear_equation (tadataka/math.py:32-45) and each IRLS
+ * step of tadataka.irls.fit (tadataka/irls.py:186-218). */
+tdk_status tdk_weighted_normal_equations(const double *A, const double *b, const double *w,
+                                         int64_t n, int p, double *AtWA, double *AtWb);
+/* calc_pose_update (tadataka/vo/dvo/__init__.py:46-70) on the arrays the
+ * reference passes: residuals [n], GX1/GY1 [H,W], P1 [n,3]; weight_mode none /
+ * huber / map (weights [n], indexed like residuals).  Returns the normal
+ * equations and the mask count; n_valid == 0 is the reference's `return None`. */
+tdk_status tdk_dvo_pose_update(const double *camera1, const double *residuals, const double *GX1,
+                               const double *GY1, int height, int width, const double *P1,
+                               int64_t n, int weight_mode, const double *weights, double *H21,
+                               double *b6, int64_t *n_valid);
+/* compute_weights_{huber,student_t,tukey} (tadataka/robust/weights.py:4-43) of a
+ * residual vector: mode = TDK_W_HUBER / TDK_W_STUDENT_T / TDK_W_TUKEY. */
+tdk_status tdk_robust_weights(const double *residuals, int64_t m, int mode, double *weights);
+
 /* ---- semi-dense (rust_bindings.semi_dense) --------------------------------- */
 typedef struct {
     double min_depth, max_depth, geo_coeff, photo_coeff, ref_step_size, min_gradient;

@@ -1,0 +1,87 @@
+"""rust_bindings.semi_dense (src/py/semi_dense.rs:35-246): Frame, Params,
+increment_age, propagate, update_depth, estimate_debug_ on the MI355X."""
+import numpy as np
+
+from rust_bindings._check import f64, typed
+from rust_bindings.camera import CameraParameters
+from tadataka_amd import ops
+
+
+def _camera(camera_params):
+    """Duck-typed like camera_params_from_py (src/py/semi_dense.rs:19-33)."""
+    f = camera_params.focal_length
+    o = camera_params.offset
+    f64(f, 1, "camera_params.focal_length"); f64(o, 1, "camera_params.offset")
+    return np.array([f[0], f[1], o[0], o[1]])
+
+
+class Frame(object):
+    """Frame(camera_params, image, transform_wf); copies its inputs
+    (src/py/semi_dense.rs:53-91)."""
+
+    def __init__(self, camera_params, image, transform):
+        self._cam = _camera(camera_params)
+        self._image = f64(image, 2, "image").copy()
+        self._transform = f64(transform, 2, "transform").copy()
+
+    @property
+    def camera_params(self):
+        return CameraParameters(self._cam[0:2], self._cam[2:4])
+
+    @property
+    def image(self):
+        return self._image.copy()
+
+    @property
+    def transform_wf(self):
+        return self._transform.copy()
+
+    def _as_tuple(self):
+        return (self._cam, self._image, self._transform)
+
+
+class Params(object):
+    """Params(min_depth, max_depth, geo_coeff, photo_coeff, ref_step_size,
+    min_gradient) (src/py/semi_dense.rs:93-108)."""
+
+    def __init__(self, min_depth, max_depth, geo_coeff, photo_coeff, ref_step_size, min_gradient):
+        self._c = ops.make_params(min_depth, max_depth, geo_coeff, photo_coeff, ref_step_size,
+                                  min_gradient)
+
+
+def increment_age(age_map0, camera_params0, camera_params1, transform10, depth_map0):
+    typed(age_map0, np.uint64, 2, "age_map0"); f64(transform10, 2, "transform10")
+    f64(depth_map0, 2, "depth_map0")
+    if age_map0.shape != depth_map0.shape:
+        raise ValueError("age_map0 and depth_map0 must have the same shape")   # age.rs:13 assert
+    return ops.increment_age(age_map0, _camera(camera_params0), _camera(camera_params1),
+                             transform10, depth_map0)
+
+
+def propagate(transform10, camera_params0, camera_params1, depth_map0, variance_map0,
+              default_depth, default_variance, uncertaintity_bias):
+    f64(transform10, 2, "transform10"); f64(depth_map0, 2, "depth_map0")
+    f64(variance_map0, 2, "variance_map0")
+    return ops.propagate(transform10, _camera(camera_params0), _camera(camera_params1), depth_map0,
+                         variance_map0, default_depth, default_variance, uncertaintity_bias)
+
+
+def update_depth(keyframe, refframes, age_map, prior_depth, prior_variance, params):
+    """Returns (depth, variance, flag) (src/py/semi_dense.rs:182-186)."""
+    typed(age_map, np.uint64, 2, "age_map"); f64(prior_depth, 2, "prior_depth")
+    f64(prior_variance, 2, "prior_variance")
+    shape = age_map.shape
+    if prior_depth.shape != shape or prior_variance.shape != shape or keyframe._image.shape != shape:
+        raise ValueError("maps and keyframe image must share one shape")   # semi_dense.rs:168-173
+    refs = [r._as_tuple() for r in refframes]
+    if any(r[1].shape != shape for r in refs):
+        raise ValueError("reference frames must have the key frame's shape")
+    return ops.update_depth(keyframe._as_tuple(), refs, age_map, prior_depth, prior_variance,
+                            params._c)
+
+
+def estimate_debug_(u_key, prior_depth, prior_variance, keyframe, refframe, params):
+    """Single pixel; returns (depth, variance, flag) (src/py/semi_dense.rs:126-155)."""
+    typed(u_key, np.int64, 1, "u_key")
+    return ops.estimate_one(u_key, prior_depth, prior_variance, keyframe._as_tuple(),
+                            refframe._as_tuple(), params._c)

@@ -1,0 +1,107 @@
+"""tadataka.local_ba (reference tadataka/local_ba.py:14-178).
+
+Projection.compute / .jacobians evaluate every observation in ONE device launch
+(the reference loops in Python with three Cython calls per observation), and
+`block_sums` returns the fused residual + Jacobian + per-pose / per-point block
+reduction that the sparse bundle-adjustment solve starts from.
+
+The Levenberg-Marquardt driver LocalBundleAdjustment wraps the third-party
+`sparseba` Schur solver in the reference (local_ba.py:72,77); that package is
+not part of this build, so constructing it raises ImportError
+unless sparseba is importable."""
+import numpy as np
+
+from tadataka_amd import ops
+
+
+class Projection(object):
+    def __init__(self, viewpoint_indices, point_indices):
+        assert(len(viewpoint_indices) == len(point_indices))
+        self.viewpoint_indices = np.ascontiguousarray(viewpoint_indices, dtype=np.int64)
+        self.point_indices = np.ascontiguousarray(point_indices, dtype=np.int64)
+        self.n_visible = len(self.point_indices)
+
+    def compute(self, poses, points):
+        """x_pred [n_visible, 2] = transform_project(poses[j], points[i])."""
+        return ops.ba_projection(poses, points, self.viewpoint_indices, self.point_indices,
+                                 jacobians=False)
+
+    def jacobians(self, poses, points):
+        """A [n_visible, 2, 6] = d x / d pose, B [n_visible, 2, 3] = d x / d point."""
+        _, A, B = ops.ba_projection(poses, points, self.viewpoint_indices, self.point_indices)
+        return A, B
+
+    def block_sums(self, poses, points, x_true):
+        """U_j = sum A^T A, ea_j = sum A^T e, V_i = sum B^T B, eb_i = sum B^T e
+        (e = x_true - x_pred) and sum ||e||^2, fused on the device."""
+        U, ea, V, eb, err = ops.ba_block_reduce(poses, points, x_true, self.viewpoint_indices,
+                                                self.point_indices)
+        iu6, iu3 = np.triu_indices(6), np.triu_indices(3)
+        Um = np.zeros((U.shape[0], 6, 6)); Um[:, iu6[0], iu6[1]] = U; Um[:, iu6[1], iu6[0]] = U
+        Vm = np.zeros((V.shape[0], 3, 3)); Vm[:, iu3[0], iu3[1]] = V; Vm[:, iu3[1], iu3[0]] = V
+        return Um, ea, Vm, eb, err
+
+
+def calc_relative_error(current_error, new_error):
+    return np.abs((current_error - new_error) / new_error)
+
+
+def calc_errors(x_true, x_pred):
+    return np.sum(np.power(x_true - x_pred, 2), axis=1)
+
+
+def calc_error(x_true, x_pred):
+    return np.mean(calc_errors(x_true, x_pred))
+
+
+class LocalBundleAdjustment(object):
+    def __init__(self, viewpoint_indices, point_indices, x_true):
+        assert(len(viewpoint_indices) == x_true.shape[0])
+        assert(len(point_indices) == x_true.shape[0])
+        from sparseba import SBA          # third-party Schur solve, not in this build
+        self.projection = Projection(viewpoint_indices, point_indices)
+        self.x_true = x_true
+        self.sba = SBA(viewpoint_indices, point_indices)
+
+    def calc_update(self, poses, points, mu):
+        x_pred = self.projection.compute(poses, points)
+        A, B = self.projection.jacobians(poses, points)
+        return self.sba.compute(self.x_true, x_pred, A, B, weights=None, mu=mu)
+
+    def calc_error(self, poses, points):
+        return calc_error(self.x_true, self.projection.compute(poses, points))
+
+    def calc_new_error(self, poses, points, mu):
+        dposes, dpoints = self.calc_update(poses, points, mu)
+        return dposes, dpoints, self.calc_error(poses + dposes, points + dpoints)
+
+    def lm_update(self, poses, points, mu, nu):
+        error0 = self.calc_error(poses, points)
+        for trial_mu in (mu / nu, mu):
+            dposes, dpoints, error = self.calc_new_error(poses, points, trial_mu)
+            if error < error0:
+                return poses + dposes, points + dpoints, trial_mu, error
+        error, new_mu = np.inf, mu
+        while error > error0:
+            new_mu = new_mu * nu
+            dposes, dpoints, error = self.calc_new_error(poses, points, new_mu)
+        return poses + dposes, points + dpoints, new_mu, error
+
+    def compute(self, initial_rotvecs, initial_translations, initial_points,
+                max_iter=200, initial_mu=1.0, nu=100.0,
+                absolute_error_threshold=1e-8, relative_error_threshold=1e-6):
+        poses = np.hstack((initial_rotvecs, initial_translations))
+        points = initial_points
+        mu = initial_mu
+        current_error = self.calc_error(poses, points)
+        for iter_ in range(max_iter):
+            poses, points, mu, new_error = self.lm_update(poses, points, mu, nu)
+            relative_error = calc_relative_error(current_error, new_error)
+            print(f"absolute_error[{iter_}] = {new_error}")
+            print(f"relative_error[{iter_}] = {relative_error}")
+            if new_error < absolute_error_threshold:
+                break
+            if relative_error < relative_error_threshold:
+                break
+            current_error = new_error
+        return poses[:, 0:3], poses[:, 3:6], points

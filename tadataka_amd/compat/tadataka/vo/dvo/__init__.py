@@ -1,0 +1,214 @@
+"""tadataka.vo.dvo (reference tadataka/vo/dvo/__init__.py:26-150): direct visual
+odometry by Gauss-Newton on the photometric error (Kerl 2012).
+
+Same classes, arguments and behaviour as the reference; the work is done by the
+fused device kernels of libtadataka_hip.so:
+
+  * _PoseChangeEstimator / PoseChangeEstimator keep (I0, D0, I1[, W0]) resident
+    on the MI355X, build the pyramid there, and run the whole accept/reject
+    loop on the device (tdk_dvo_estimate_level / tdk_dvo_estimate);
+  * calc_pose_update works on the arrays the reference passes
+    (tdk_dvo_pose_update) and returns the twist.
+
+Note: as in the reference the residual I0 - I1 is NOT re-warped
+between iterations; only the Jacobian moves with the pose.
+"""
+import warnings
+
+import numpy as np
+
+from tadataka.math import solve_normal_equations
+from tadataka.pose import Pose
+from tadataka.robust.weights import (compute_weights_huber, compute_weights_student_t,
+                                     compute_weights_tukey)
+from tadataka.vo.dvo.jacobian import calc_image_gradient, calc_jacobian  # noqa: F401
+from tadataka_amd import ops
+
+
+def calc_error(r, weights=None):
+    if weights is None:
+        return np.dot(r, r)
+    return np.dot(r * weights, r)
+
+
+def compute_weights(name, residuals):
+    if name == "tukey":
+        return compute_weights_tukey(residuals)
+    if name == "student-t":
+        return compute_weights_student_t(residuals)
+    if name == "huber":
+        return compute_weights_huber(residuals)
+    raise ValueError(f"No such weights '{name}'")
+
+
+def level_to_scale(level, layer_size_ratio):
+    return 1 / pow(layer_size_ratio, level)
+
+
+def _check_weights_name(weights):
+    if isinstance(weights, str) and weights not in ("huber", "student-t", "tukey"):
+        raise ValueError(f"No such weights '{weights}'")
+
+
+def calc_pose_update(camera_model1, residuals, GX1, GY1, P1, weights):
+    """One Gauss-Newton step xi = argmin ||sqrt(W)(J xi - r)|| for points P1
+    (already in frame 1).  Returns None if no point projects into the image with
+    positive depth."""
+    assert(GX1.shape == GY1.shape)
+    _check_weights_name(weights)
+    cam1 = ops.camera_vec(camera_model1)
+    if weights is None:
+        H, b, n = ops.dvo_pose_update(cam1, residuals, GX1, GY1, P1, ops.W_NONE)
+    elif isinstance(weights, str) and weights == "huber":
+        H, b, n = ops.dvo_pose_update(cam1, residuals, GX1, GY1, P1, ops.W_HUBER)
+    elif isinstance(weights, str):
+        # Student-t / Tukey need statistics of the MASKED residuals first
+        mask = _update_mask(cam1, P1, GX1.shape)
+        if not np.any(mask):
+            return None
+        w = np.zeros(len(residuals))
+        w[mask] = compute_weights(weights, np.asarray(residuals, dtype=np.float64)[mask])
+        H, b, n = ops.dvo_pose_update(cam1, residuals, GX1, GY1, P1, ops.W_MAP, w)
+    else:
+        H, b, n = ops.dvo_pose_update(cam1, residuals, GX1, GY1, P1, ops.W_MAP,
+                                      np.asarray(weights, dtype=np.float64).reshape(-1))
+    if n == 0:
+        return None
+    return solve_normal_equations(H, b)
+
+
+def _update_mask(cam1, P1, shape):
+    """in_range(unnormalize(pi(P1))) & z > 0, evaluated by the device operators."""
+    from tadataka.utils import is_in_image_range
+    us1 = ops.unnormalize(ops.project_vecs(P1), cam1)
+    return is_in_image_range(us1, shape) & (np.asarray(P1)[:, 2] > 0)
+
+
+_WEIGHT_MODE = {None: ops.W_NONE, "huber": ops.W_HUBER}
+
+
+def _fused_mode(weights):
+    """Weight mode of the fused device loop, or None if it must be emulated."""
+    if weights is None or (isinstance(weights, str) and weights == "huber"):
+        return _WEIGHT_MODE[weights]
+    if isinstance(weights, np.ndarray):
+        return ops.W_MAP
+    return None
+
+
+def _pose12(pose):
+    return ops.pose12(pose.R, pose.t)[None]
+
+
+class _PoseChangeEstimator(object):
+    """Gauss-Newton at one resolution."""
+    def __init__(self, camera_model0, camera_model1, max_iter):
+        self.camera_model0 = camera_model0
+        self.camera_model1 = camera_model1
+        self.max_iter = max_iter
+
+    def __call__(self, I0, D0, I1, pose10, weights=None):
+        _check_weights_name(weights)
+        batch = ops.DvoBatch(1, I0.shape[0], I0.shape[1],
+                             with_weight_map=isinstance(weights, np.ndarray))
+        try:
+            batch.upload(0, I0, D0, I1, weights if isinstance(weights, np.ndarray) else None)
+            return _estimate_level(batch, 0, self.camera_model0, self.camera_model1, pose10,
+                                   weights, self.max_iter)
+        finally:
+            batch.close()
+
+
+def _estimate_level(batch, level, camera_model0, camera_model1, pose10, weights, max_iter):
+    cam0, cam1 = ops.camera_vec(camera_model0), ops.camera_vec(camera_model1)
+    mode = _fused_mode(weights)
+    if mode is not None:
+        P, n_evals = batch.estimate_level(level, cam0, cam1, _pose12(pose10), mode, max_iter)
+        # one evaluation only and no step taken = the update mask was empty
+        if n_evals[0] == 1 and max_iter > 0 and np.array_equal(P[0], _pose12(pose10)[0]):
+            ev = batch.evaluate(level, cam0, cam1, P, mode)
+            if ev["n_update"][0] == 0:
+                warnings.warn("Camera pose change is too large.", RuntimeWarning)
+        return Pose.from_matrix(P[0])
+    return _estimate_level_robust(batch, level, cam0, cam1, pose10, weights, max_iter)
+
+
+def _estimate_level_robust(batch, level, cam0, cam1, pose10, weights, max_iter):
+    """'student-t' / 'tukey': the weights depend on global statistics of the
+    masked residuals, so every iteration first derives a weight map on the
+    device (tdk_robust_weights) and then reduces the normal equations with it
+    (tdk_dvo_pose_update); the error test uses the fused evaluation."""
+    from tadataka.coordinates import image_coordinates
+    from tadataka.projection import inv_pi
+    from tadataka.rigid_transform import transform
+    h, w = batch.level_shape(level)
+    scale = level_to_scale(level, getattr(batch, "ratio", 1.5))
+    c0, c1 = cam0 * scale, cam1 * scale
+    I0 = batch.download(0, level, "I0")
+    D0 = batch.download(0, level, "D0")
+    I1 = batch.download(0, level, "I1")
+    residuals = (I0 - I1).reshape(-1)
+    P0 = inv_pi(ops.normalize(image_coordinates((h, w)), c0), D0.reshape(-1))
+    GX1, GY1 = calc_image_gradient(I1)
+
+    def error(pose):
+        ev = batch.evaluate(level, cam0, cam1, _pose12(pose), ops.W_NONE)
+        n = int(ev["n_error"][0])
+        return float(ev["sum_sq"][0]) / n if n else float("nan")
+
+    prev_error = error(pose10)
+    for _ in range(max_iter):
+        P1 = transform(pose10.R, pose10.t, P0)
+        mask = _update_mask(c1, P1, (h, w))
+        if not np.any(mask):
+            warnings.warn("Camera pose change is too large.", RuntimeWarning)
+            return pose10
+        wmap = np.zeros(h * w)
+        wmap[mask] = compute_weights(weights, residuals[mask])
+        H, b, _ = ops.dvo_pose_update(c1, residuals, GX1, GY1, P1, ops.W_MAP, wmap)
+        candidate = Pose.from_se3(solve_normal_equations(H, b)) * pose10
+        curr_error = error(candidate)
+        if curr_error > prev_error:
+            break
+        prev_error = curr_error
+        pose10 = candidate
+    return pose10
+
+
+class PoseChangeEstimator(object):
+    """Coarse-to-fine DVO: levels n_coarse_to_fine-1 ... 0 at scale
+    1 / layer_size_ratio**level, each level starting from the previous result."""
+    def __init__(self, camera_model0, camera_model1,
+                 n_coarse_to_fine=5, max_iter=20, layer_size_ratio=1.5):
+        self.n_coarse_to_fine = n_coarse_to_fine
+        self.max_iter = max_iter
+        self.layer_size_ratio = layer_size_ratio
+        self.camera_model0 = camera_model0
+        self.camera_model1 = camera_model1
+
+    def __call__(self, I0, D0, I1, weights=None, pose10=None):
+        assert(I0.shape == D0.shape == I1.shape)
+        assert(np.ndim(I0) == 2)
+        assert(np.ndim(D0) == 2)
+        assert(np.ndim(I1) == 2)
+        _check_weights_name(weights)
+        pose10 = Pose.identity() if pose10 is None else pose10
+        has_map = isinstance(weights, np.ndarray)
+        batch = ops.DvoBatch(1, I0.shape[0], I0.shape[1], n_levels=self.n_coarse_to_fine,
+                             ratio=self.layer_size_ratio, with_weight_map=has_map)
+        batch.ratio = self.layer_size_ratio
+        try:
+            batch.upload(0, I0, D0, I1, weights if has_map else None)
+            batch.build_pyramid()
+            mode = _fused_mode(weights)
+            if mode is not None:
+                cam0 = ops.camera_vec(self.camera_model0)
+                cam1 = ops.camera_vec(self.camera_model1)
+                P, _ = batch.estimate(cam0, cam1, _pose12(pose10), mode, self.max_iter)
+                return Pose.from_matrix(P[0])
+            for level in reversed(range(self.n_coarse_to_fine)):
+                pose10 = _estimate_level(batch, level, self.camera_model0, self.camera_model1,
+                                         pose10, weights, self.max_iter)
+            return pose10
+        finally:
+            batch.close()

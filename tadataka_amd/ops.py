@@ -226,6 +226,43 @@ def upper21_to_matrix(H21):
     return H + H.T - np.diag(np.diag(H))
 
 
+# ---- least-squares pieces -----------------------------------------------------------
+def weighted_normal_equations(A, b, w=None):
+    """(A^T W A [p,p], A^T W b [p]) reduced on the device; p <= 8."""
+    A = _f64(A); b = _f64(b).reshape(-1)
+    if A.ndim != 2 or A.shape[0] != b.shape[0]:
+        raise ValueError("A must be [n, p] and b [n]")
+    n, p = A.shape
+    wv = None if w is None else _f64(w, (n,))
+    tri = np.empty(p * (p + 1) // 2); g = np.empty(p)
+    call("tdk_weighted_normal_equations", _p(A), _p(b), None if wv is None else _p(wv), n, p,
+         _p(tri), _p(g))
+    M = np.zeros((p, p))
+    M[np.triu_indices(p)] = tri
+    return M + M.T - np.diag(np.diag(M)), g
+
+
+def dvo_pose_update(camera1, residuals, GX1, GY1, P1, weight_mode=W_NONE, weights=None):
+    """Normal equations of calc_pose_update on explicit arrays: (H [6,6], b [6], n_valid)."""
+    cam = camera_vec(camera1)
+    GX1 = _f64(GX1); GY1 = _f64(GY1, GX1.shape)
+    P1 = _f64(P1).reshape(-1, 3)
+    n = P1.shape[0]
+    r = _f64(residuals, (n,))
+    wv = None if weights is None else _f64(weights, (n,))
+    H21 = np.empty(21); b = np.empty(6); nv = C.c_int64()
+    call("tdk_dvo_pose_update", _p(cam), _p(r), _p(GX1), _p(GY1), GX1.shape[0], GX1.shape[1], _p(P1), n,
+         weight_mode, None if wv is None else _p(wv), _p(H21), _p(b), C.byref(nv))
+    return upper21_to_matrix(H21), b, int(nv.value)
+
+
+def robust_weights(residuals, mode):
+    r = _f64(residuals).reshape(-1)
+    w = np.empty_like(r)
+    call("tdk_robust_weights", _p(r), r.shape[0], mode, _p(w))
+    return w
+
+
 # ---- semi-dense -------------------------------------------------------------------
 def make_params(min_depth, max_depth, geo_coeff, photo_coeff, ref_step_size, min_gradient):
     return SemiDenseParams(float(min_depth), float(max_depth), float(geo_coeff), float(photo_coeff),

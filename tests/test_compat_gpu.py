@@ -1,0 +1,326 @@
+"""The drop-in `tadataka` / `rust_bindings` packages on the MI355X: the
+reference's own pytest cases replayed through the same API (tests/test_warp.py,
+tests/test_interpolation.py, tests/test_projection.py, tests/camera/*,
+tests/vo/test_dvo.py with a synthetic pair instead of the missing dataset),
+plus the fixtures captured from the reference."""
+import warnings
+
+import numpy as np
+import pytest
+from numpy.testing import assert_almost_equal, assert_array_almost_equal
+from scipy.spatial.transform import Rotation
+
+import tadataka_amd  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+POSE_ATOL = 1e-6
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    from tadataka_amd import _lib
+    _lib.require_gpu()
+
+
+def _camera_model(cam):
+    from tadataka.camera import CameraModel, CameraParameters
+    return CameraModel(CameraParameters(cam[0:2], cam[2:4]), distortion_model=None)
+
+
+# --- tests/test_warp.py ----------------------------------------------------------
+def test_warp3d_literals():
+    from tadataka.pose import Pose
+    from tadataka.warp import Warp3D
+    pose_w0 = Pose(Rotation.from_rotvec([0, (3 / 4) * np.pi, 0]), np.array([0, 0, 3]))
+    pose_w1 = Pose(Rotation.from_rotvec([0, -np.pi / 2, 0]), np.array([4, 0, 3]))
+    warp3d = Warp3D(pose_w0, pose_w1)
+    P0 = np.array([[0, 0, 2 * np.sqrt(2)], [0, 0, 4 * np.sqrt(2)]])
+    assert_array_almost_equal(warp3d(P0), [[-2, 0, 2], [-4, 0, 0]])
+    assert_array_almost_equal(warp3d(np.zeros(3)), [0, 0, 4])
+
+
+def test_warp2d_literals():
+    from tadataka.pose import Pose
+    from tadataka.warp import LocalWarp2D, Warp2D, Warp3D, warp2d_, warp_depth
+    from tadataka.camera import CameraModel, CameraParameters
+    rotation = Rotation.from_rotvec([0, np.pi / 2, 0])
+    pose_w0, pose_w1 = Pose(rotation, np.array([0, 0, 3])), Pose(rotation, np.array([0, 0, 4]))
+    xs0 = np.array([[0, 0], [0, -1]], dtype=np.float64)
+    depths0 = np.array([2, 4], dtype=np.float64)
+    xs1, depths1 = warp_depth(Warp3D(pose_w0, pose_w1), xs0, depths0)
+    assert_array_almost_equal(xs1, [[0.5, 0], [0.25, -1]])
+    assert_array_almost_equal(depths1, [2, 4])
+    cm0 = CameraModel(CameraParameters(focal_length=[2, 2], offset=[0, 0]), distortion_model=None)
+    cm1 = CameraModel(CameraParameters(focal_length=[3, 3], offset=[0, 0]), distortion_model=None)
+    us1, _ = Warp2D(cm0, cm1, pose_w0, pose_w1)(2.0 * xs0, depths0)
+    assert_array_almost_equal(us1, 3.0 * xs1)
+
+    pose10 = Pose(rotation, np.array([0, 0, 4]))
+    xs0 = np.array([[0, 0], [2, -1]], dtype=np.float64)
+    xs1, depths1 = warp2d_(pose10.T, xs0, depths0)
+    assert_array_almost_equal(xs1, [[0.5, 0.0], [-1.0, 1.0]])
+    assert_array_almost_equal(depths1, [4.0, -4.0])
+    us1, _ = LocalWarp2D(cm0, cm1, pose10)(2.0 * xs0, depths0)
+    assert_array_almost_equal(us1, 3.0 * xs1)
+
+
+# --- tests/test_interpolation.py ---------------------------------------------------
+def test_interpolation_literals():
+    from tadataka.interpolation import interpolation
+    image = np.array([[0, 1, 5], [0, 0, 2], [4, 3, 2], [5, 6, 1]], dtype=np.float64)
+    coordinates = np.array([[0.1, 1.2], [1.1, 2.1], [2.0, 2.3]])
+    assert(interpolation(image, coordinates).shape == (3,))
+    assert(interpolation(image, np.array([0.1, 1.2])).dtype == np.float64)
+    expected = (image[2, 1] * (2.0 - 1.3) * (3.0 - 2.6) + image[2, 2] * (1.3 - 1.0) * (3.0 - 2.6) +
+                image[3, 1] * (2.0 - 1.3) * (2.6 - 2.0) + image[3, 2] * (1.3 - 1.0) * (2.6 - 2.0))
+    assert_almost_equal(interpolation(image, np.array([[1.3, 2.6]])).squeeze(), expected)
+    assert_almost_equal(interpolation(image, np.array([1.3, 2.6])), expected)
+    assert_almost_equal(interpolation(image, np.array([0.0, 0.0])), image[0, 0])
+    assert_almost_equal(interpolation(image, np.array([2.0, 2.9])),
+                        image[2, 2] * (3.0 - 2.9) + image[3, 2] * (2.9 - 2.0))
+    assert_almost_equal(interpolation(image, np.array([1.9, 3.0])),
+                        image[3, 1] * (2.0 - 1.9) + image[3, 2] * (1.9 - 1.0))
+    assert_almost_equal(interpolation(image, np.array([2.0, 3.0])), image[3, 2])
+    for bad in ([3.0, 2.01], [3.01, 2.0], [-0.01, 0.0], [0.0, -0.01]):
+        with pytest.raises(ValueError):
+            interpolation(image, bad)
+    with pytest.raises(ValueError):
+        interpolation(np.zeros((2, 2, 2)), [0.0, 0.0])
+
+
+# --- tests/test_projection.py, tests/camera/test_normalizer.py, test_model.py ----------
+def test_projection_and_camera_literals():
+    from tadataka.projection import pi, inv_pi
+    from tadataka.camera import CameraModel, CameraParameters
+    from tadataka.camera.normalizer import Normalizer
+    P = np.array([[0, 0, 0], [1, 4, 2], [-1, 3, 5]], dtype=np.float64)
+    assert_array_almost_equal(pi(P), [[0., 0.], [0.5, 2.0], [-0.2, 0.6]])
+    assert_array_almost_equal(pi(np.array([3., 5., 5.])), [0.6, 1.0])
+    xs = np.array([[0.5, 2.0], [-0.2, 0.6]])
+    assert_array_almost_equal(inv_pi(xs, np.array([2., 5.])), [[1, 4, 2], [-1, 3, 5]])
+    assert_array_almost_equal(inv_pi(np.array([0.5, 2.0]), 2.0), [1, 4, 2])
+    cp = CameraParameters(focal_length=[10., 20.], offset=[2., 4.])
+    un = np.array([[12, 24], [0, 0], [8, 10]])           # integer keypoints are accepted
+    no = np.array([[1.0, 1.0], [-0.2, -0.2], [0.6, 0.3]])
+    assert_array_almost_equal(Normalizer(cp).normalize(un), no)
+    assert_array_almost_equal(Normalizer(cp).unnormalize(no), un)
+    cm = CameraModel(cp, distortion_model=None)
+    assert_array_almost_equal(cm.normalize(np.array([12., 24.])), [1.0, 1.0])   # 1-D input
+    assert_array_almost_equal(cm.unnormalize(no), un)
+
+
+# --- fixtures captured from the reference's DVO ------------------------------------------
+WEIGHTS = [None, "huber", "student-t", "tukey", "map"]
+
+
+def _w(d, name):
+    return d["weight_map"] if name == "map" else name
+
+
+@pytest.mark.parametrize("wname", WEIGHTS)
+def test_pose_change_estimator_level_vs_reference(golden, wname):
+    from tadataka.pose import Pose
+    from tadataka.vo.dvo import _PoseChangeEstimator
+    d = golden("dvo_small.npz")
+    cm = _camera_model(d["cam"])
+    est = _PoseChangeEstimator(cm, cm, max_iter=20)
+    pose = est(d["I0"], d["D0"], d["I1"], Pose.identity(), _w(d, wname))
+    assert np.allclose(pose.rotation.as_rotvec(), d[f"s_{wname}_final_rotvec"], atol=POSE_ATOL)
+    assert np.allclose(pose.t, d[f"s_{wname}_final_t"], atol=POSE_ATOL)
+
+
+@pytest.mark.parametrize("wname", WEIGHTS)
+def test_calc_pose_update_vs_reference(golden, wname):
+    from tadataka.coordinates import image_coordinates
+    from tadataka.projection import inv_pi
+    from tadataka.rigid_transform import transform
+    from tadataka.vo.dvo import calc_pose_update
+    from tadataka.vo.dvo.jacobian import calc_image_gradient
+    d = golden("dvo_small.npz")
+    cm = _camera_model(d["cam"])
+    I0, D0, I1 = d["I0"], d["D0"], d["I1"]
+    P0 = inv_pi(cm.normalize(image_coordinates(I0.shape)), D0.flatten())
+    GX1, GY1 = calc_image_gradient(I1)
+    residuals = (I0 - I1).flatten()
+    key = f"s_{wname}"
+    for k in range(int(d[f"{key}_n_updates"])):
+        T = d[f"{key}_err_T"][k]
+        P1 = transform(T[:3, :3], T[:3, 3].copy(), P0)
+        xi = calc_pose_update(cm, residuals, GX1, GY1, P1, _w(d, wname))
+        assert np.allclose(xi, d[f"{key}_u{k}_xi"], rtol=1e-6, atol=1e-9)
+
+
+def test_photometric_error_vs_reference(golden):
+    from tadataka.metric import PhotometricError, photometric_error
+    from tadataka.pose import Pose
+    from tadataka.warp import LocalWarp2D
+    d = golden("dvo_small.npz")
+    cm = _camera_model(d["cam"])
+    error = PhotometricError(cm, cm, d["I0"], d["D0"], d["I1"])
+    for T, val in zip(d["s_None_err_T"], d["s_None_err_val"]):
+        pose = Pose.from_matrix(T)
+        assert abs(error(pose) - val) <= 1e-9 * val
+        assert abs(photometric_error(LocalWarp2D(cm, cm, pose), d["I0"], d["D0"], d["I1"]) - val) <= 1e-9 * val
+
+
+def test_pose_change_estimator_pyramid_vs_reference(golden):
+    from tadataka.vo.dvo import PoseChangeEstimator
+    from tadataka_amd import synthetic
+    p = golden("dvo_pyramid.npz")
+    pair = synthetic.make_pair(120, 160, seed=4)
+    cm = _camera_model(pair["cam"])
+    for wname in (None, "huber"):
+        est = PoseChangeEstimator(cm, cm, n_coarse_to_fine=3, max_iter=20)
+        pose = est(pair["I0"], pair["D0"], pair["I1"], wname)
+        assert np.allclose(pose.rotation.as_rotvec(), p[f"pyr_{wname}_rotvec"], atol=POSE_ATOL)
+        assert np.allclose(pose.t, p[f"pyr_{wname}_t"], atol=POSE_ATOL)
+
+
+# --- tests/vo/test_dvo.py (synthetic pair in place of the missing New-Tsukuba depth) -------
+def test_dvo_like_reference_integration_test():
+    from tadataka.metric import PhotometricError
+    from tadataka.pose import Pose
+    from tadataka.vo.dvo import PoseChangeEstimator
+    from tadataka_amd import synthetic
+    pair = synthetic.make_pair(96, 128, seed=9, noise=0.01)
+    cm = _camera_model(pair["cam"])
+    I0, D0, I1 = pair["I0"], pair["D0"], pair["I1"]
+    pose10_true = Pose.from_matrix(pair["T10"])
+    error = PhotometricError(cm, cm, I0, D0, I1)
+    estimator = PoseChangeEstimator(cm, cm, n_coarse_to_fine=3)
+
+    def evaluate(weights, rate):
+        pose_identity = Pose.identity()
+        pose10_pred = estimator(I0, D0, I1, weights, pose_identity)
+        assert(error(pose10_pred) < error(pose_identity))
+        assert(error(pose10_pred) < error(pose10_true) * rate)
+
+    evaluate(weights=None, rate=2.)
+    evaluate(weights=np.ones(I0.shape), rate=2.)
+    evaluate(weights="tukey", rate=3.)
+    evaluate(weights="student-t", rate=2.)
+    evaluate(weights="huber", rate=2.)
+    with pytest.raises(ValueError, match="No such weights 'random'"):
+        evaluate(weights="random", rate=2.)
+
+
+def test_pose_change_too_large_warns():
+    from tadataka.pose import Pose
+    from tadataka.vo.dvo import _PoseChangeEstimator
+    from tadataka_amd import synthetic
+    pair = synthetic.make_pair(40, 56, seed=3)
+    cm = _camera_model(pair["cam"])
+    far = Pose(Rotation.from_rotvec(np.zeros(3)), np.array([1e3, 0., 0.]))
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        out = _PoseChangeEstimator(cm, cm, max_iter=20)(pair["I0"], pair["D0"], pair["I1"], far)
+    assert any(issubclass(w.category, RuntimeWarning) for w in rec)
+    assert out == far
+
+
+# --- robust weights, least squares, IRLS vs the reference's outputs -------------------------
+def test_robust_weights_vs_reference(golden):
+    from tadataka.robust.weights import (compute_weights_huber, compute_weights_student_t,
+                                         compute_weights_tukey)
+    from tadataka.vo.dvo import compute_weights
+    g = golden("pyref.npz")
+    r = g["w_r"]
+    assert np.array_equal(compute_weights_huber(r), g["w_huber"])
+    assert np.allclose(compute_weights_student_t(r), g["w_student_t"], rtol=1e-12, atol=0)
+    assert np.allclose(compute_weights_tukey(r), g["w_tukey"], rtol=1e-12, atol=1e-15)
+    assert np.array_equal(compute_weights("huber", r), g["w_huber"])
+    # even-length input: the median averages the two middle order statistics
+    assert np.allclose(compute_weights_tukey(r[:-1]),
+                       _tukey_numpy(r[:-1]), rtol=1e-12, atol=1e-15)
+    with pytest.raises(ValueError):
+        compute_weights("random", r)
+
+
+def _tukey_numpy(r, beta=4.6851, c=1.4826):
+    sigma = c * np.median(np.abs(r - np.median(r)))
+    x = r / sigma
+    w = np.zeros(r.shape)
+    m = np.abs(x) <= beta
+    w[m] = (1 - (x[m] / beta) ** 2) ** 2
+    return w
+
+
+def test_solve_linear_equation_and_irls_vs_reference(golden):
+    from tadataka.math import solve_linear_equation
+    from tadataka import irls
+    g = golden("pyref.npz")
+    assert np.allclose(solve_linear_equation(g["ls_A"], g["ls_b"]), g["ls_x"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(solve_linear_equation(g["ls_A"], g["ls_b"], g["ls_w"]), g["ls_xw"], rtol=1e-9, atol=1e-12)
+    # tests/test_math.py:17-36: the solution satisfies the weighted normal equations
+    A, b, w = g["ls_A"], g["ls_b"], g["ls_w"]
+    x = solve_linear_equation(A, b, w)
+    assert np.allclose(A.T @ (w * (A @ x - b)), 0, atol=1e-9)
+    # tests/test_irls.py:6-21 asserts rel-err < 2e-2 against the true parameters;
+    # here also agreement with the reference implementation's own result
+    beta = irls.fit(g["irls_X"], g["irls_y"])
+    assert np.allclose(beta, g["irls_beta"], rtol=1e-8, atol=1e-10)
+
+
+# --- semi-dense step as examples/semi_dense_vo.py:182-199 runs it ----------------------------
+def test_semi_dense_step_through_rust_bindings(golden):
+    from rust_bindings.camera import CameraParameters
+    from rust_bindings.semi_dense import (Frame, Params, estimate_debug_, increment_age, propagate,
+                                          update_depth)
+    from tadataka.matrix import inv_motion_matrix
+    from tadataka_amd import synthetic
+    from oracle import oracle as orc
+    c = synthetic.make_semi_dense_case(96, 128, seed=4)
+    cam = c["cam"]
+    cp = CameraParameters((cam[0], cam[1]), (cam[2], cam[3]))
+    frame0 = Frame(cp, c["ref_image"], c["T_wr"])       # older frame = reference
+    frame1 = Frame(cp, c["key_image"], c["T_wk"])       # new key frame
+    transform10 = np.dot(inv_motion_matrix(c["T_wk"]), c["T_wr"])
+    args = (0.5, 10.0, 0.01, 0.01, 0.002, 0.005)
+    params = Params(*args)
+    age0 = np.zeros((96, 128), dtype=np.uint64)
+    depth0 = c["prior_depth"]; var0 = c["prior_variance"]
+
+    age1 = increment_age(age0, frame0.camera_params, frame1.camera_params, transform10, depth0)
+    assert age1.dtype == np.uint64 and np.array_equal(age1, orc.increment_age(age0, cam, cam, transform10, depth0))
+    depth1, var1 = propagate(transform10, frame0.camera_params, frame1.camera_params, depth0, var0, 1.0, 100.0, 1.0)
+    od1, ov1 = orc.propagate(transform10, cam, cam, depth0, var0, 1.0, 100.0, 1.0)
+    assert np.array_equal(depth1, od1) and np.array_equal(var1, ov1)
+    depth2, var2, flag = update_depth(frame1, [frame0], age1, depth1, var1, params)
+    po = orc.make_params(*args)
+    od2, ov2, of = orc.update_depth((cam, c["key_image"], c["T_wk"]), [(cam, c["ref_image"], c["T_wr"])],
+                                    age1, depth1, var1, po)
+    assert flag.dtype == np.int64 and np.array_equal(flag, of)
+    assert np.array_equal(depth2, od2) and np.array_equal(var2, ov2)
+    u = np.array([60, 40], dtype=np.int64)
+    got = estimate_debug_(u, float(depth1[40, 60]), float(var1[40, 60]), frame1, frame0, params)
+    exp = orc.estimate_debug(u, float(depth1[40, 60]), float(var1[40, 60]),
+                             (cam, c["key_image"], c["T_wk"]), (cam, c["ref_image"], c["T_wr"]), po)
+    assert got == exp
+
+
+# --- bundle adjustment through tadataka.local_ba / tadataka.transform_project -------------------
+def test_local_ba_projection_and_transform_project(golden):
+    from tadataka.local_ba import Projection, calc_error
+    from tadataka.transform_project import exp_so3, point_jacobian, pose_jacobian, transform_project
+    g = golden("ba_vectors.npz")
+    poses, points = g["poses"][:64], g["points"][:64]
+    idx = np.arange(64)
+    proj = Projection(idx, idx)
+    x = proj.compute(poses, points)
+    A, B = proj.jacobians(poses, points)
+    assert np.allclose(x, g["x"][:64], rtol=1e-10, atol=1e-12)
+    assert np.allclose(A, g["A"][:64], rtol=1e-7, atol=1e-9) and np.allclose(B, g["B"][:64], rtol=1e-9, atol=1e-11)
+    # tests/test_transform_project.py:11-44
+    cases = [([0., 0., 0.], [4., -8., 1.], [4., -2., -3.], [-4.0, 5.0]),
+             ([np.pi / 2., 0., 0.], [3., -1., 2.], [-3., 2., 1.], [0.0, -0.5]),
+             ([0., 0., np.pi], [2., 0., -4.], [5., 3., -6.], [0.3, 0.3])]
+    for omega, t, point, expected in cases:
+        pose = np.concatenate((omega, t))
+        assert_array_almost_equal(transform_project(pose, np.array(point)), expected)
+    assert_array_almost_equal(exp_so3(np.array([0., -np.pi / 2., 0.])), [[0, 0, -1], [0, 1, 0], [1, 0, 0]])
+    assert pose_jacobian(poses[0], points[0]).shape == (2, 6) and point_jacobian(poses[0], points[0]).shape == (2, 3)
+    U, ea, V, eb, err = proj.block_sums(poses, points, g["x"][:64] + 1e-3)
+    assert U.shape == (64, 6, 6) and V.shape == (64, 3, 3)
+    assert np.allclose(U[3], A[3].T @ A[3], rtol=1e-9) and np.allclose(V[5], B[5].T @ B[5], rtol=1e-9)
+    assert abs(err / 64 - calc_error(g["x"][:64] + 1e-3, x)) < 1e-12

@@ -1,0 +1,122 @@
+"""Host-side logic of the drop-in `tadataka` package (no GPU needed): SE(3)
+helpers, Pose, coordinate bookkeeping -- against outputs captured from the
+reference's own pure-Python modules (tests/golden/pyref.npz) and against the
+reference's pytest literals."""
+import numpy as np
+import pytest
+
+import tadataka_amd  # noqa: F401  (puts the compat packages on sys.path)
+
+
+def test_se3_and_pose_match_reference(golden):
+    from tadataka import se3
+    from tadataka.pose import Pose, WorldPose
+    g = golden("pyref.npz")
+    for xi, t, G in zip(g["se3_xi"], g["se3_t"], g["se3_G"]):
+        assert np.allclose(se3.exp_se3_t_(xi), t, rtol=0, atol=1e-14)
+        assert np.allclose(se3.exp_se3(xi), G, rtol=0, atol=1e-14)
+        if np.linalg.norm(xi[3:]) > 0:
+            assert np.allclose(se3.log_se3(G), xi, atol=1e-10)
+    prior = Pose.from_matrix(g["pose_prior_T"])
+    for xi, T in zip(g["se3_xi"], g["pose_comp_T"]):
+        assert np.allclose((Pose.from_se3(xi) * prior).T, T, rtol=0, atol=1e-14)
+    assert WorldPose is Pose                       # examples/dvo_pose_change.py:6
+    p = Pose.from_se3(g["se3_xi"][0])
+    assert (p * p.inv()) == Pose.identity()
+    assert str(Pose.identity()).startswith("rotvec = [")
+
+
+def test_se3_vs_scipy_expm():
+    """tests/test_se3.py:18-47 of the reference: exp_se3 equals the matrix exponential."""
+    from scipy.linalg import expm
+    from tadataka import se3
+    from tadataka.so3 import tangent_so3
+    rng = np.random.default_rng(0)
+    for _ in range(10):
+        xi = rng.uniform(-1, 1, 6)
+        X = np.zeros((4, 4)); X[:3, :3] = tangent_so3(xi[3:]); X[:3, 3] = xi[:3]
+        assert np.allclose(se3.exp_se3(xi), expm(X), atol=1e-12)
+
+
+def test_coordinates_utils_decorator(golden):
+    from tadataka.coordinates import image_coordinates, get, substitute
+    from tadataka.utils import is_in_image_range
+    from tadataka.decorator import allow_1d
+    g = golden("pyref.npz")
+    c = image_coordinates((3, 4))
+    assert c.dtype == np.int64 and np.array_equal(c, g["coords_3x4"])
+    assert np.array_equal(is_in_image_range(g["rng_kp"], (9, 13)), g["rng_mask"])
+    assert is_in_image_range(np.array([12., 8.]), (9, 13)) and not is_in_image_range(np.array([12.01, 3.]), (9, 13))
+    a = np.arange(12.).reshape(3, 4)
+    assert np.array_equal(get(a, c), a.ravel())
+    assert np.array_equal(substitute(np.zeros((3, 4)), c, a.ravel()), a)
+
+    @allow_1d(which_argument=0)
+    def double(x):
+        return 2 * x
+    assert np.array_equal(double(np.array([1., 2.])), [2., 4.])
+    with pytest.raises(ValueError):
+        double(np.zeros((2, 2, 2)))
+
+
+def test_matrix_camera_numeric():
+    from tadataka import camera
+    from tadataka.camera import CameraModel, CameraParameters
+    from tadataka.matrix import (calc_relative_transform, inv_motion_matrix, motion_matrix,
+                                 from_homogeneous)
+    from tadataka.numeric import safe_invert
+    from scipy.spatial.transform import Rotation
+    R = Rotation.from_rotvec([0.1, 0.2, -0.3]).as_matrix()
+    T = motion_matrix(R, np.array([1., 2., 3.]))
+    assert np.allclose(inv_motion_matrix(T) @ T, np.eye(4), atol=1e-14)
+    assert np.allclose(calc_relative_transform(T, T), np.eye(4), atol=1e-14)
+    assert np.array_equal(from_homogeneous(np.array([[2., 3., 1.]])), [[2., 3.]])
+    cm = CameraModel(CameraParameters([10., 20.], [2., 4.]), distortion_model=None)
+    half = camera.resize(cm, 0.5)
+    assert np.array_equal(half.camera_parameters.focal_length, [5., 10.])
+    assert np.array_equal(half.camera_parameters.offset, [1., 2.])
+    assert np.array_equal(cm.camera_parameters.matrix, [[10, 0, 2], [0, 20, 4], [0, 0, 1]])
+    assert safe_invert(0.0) == 1e16 and safe_invert(np.array([1.0]))[0] == 1 / (1 + 1e-16)
+
+
+def test_jacobian_and_weights_host_helpers(golden):
+    from tadataka.vo.dvo.jacobian import calc_jacobian
+    from tadataka.vo.dvo import level_to_scale, calc_error
+    from tadataka.irls import huber_weights, mad
+    g = golden("pyref.npz")
+    J = calc_jacobian([300., 400.], g["jac_gx"], g["jac_gy"], g["jac_P"])
+    assert np.array_equal(J, g["jac_J"])
+    assert level_to_scale(2, 1.5) == 1 / 2.25
+    r = np.array([1., -2., 3.])
+    assert calc_error(r) == 14. and calc_error(r, np.array([1., 0., 2.])) == 19.
+    assert np.array_equal(huber_weights(np.array([0.5, -2.69])), [1.0, 0.5])
+    assert abs(mad(np.array([1., -2., 3., 4., 100.])) - 3.0 / 0.6744897501960817) < 1e-12
+
+
+def test_out_of_scope_names_import_but_raise():
+    from tadataka.dataset import NewTsukubaDataset
+    from tadataka.feature import Matcher
+    from tadataka.pose import estimate_pose_change
+    from tadataka.vo.semi_dense.regularization import regularize
+    from tadataka.vo.semi_dense.flag import ResultFlag
+    for f in (lambda: NewTsukubaDataset("x"), Matcher, estimate_pose_change, regularize):
+        with pytest.raises(NotImplementedError):
+            f()
+    assert ResultFlag.NOT_PROCESSED == -9 and ResultFlag.SUCCESS == 0
+
+
+def test_rust_bindings_type_strictness():
+    """rust-numpy refuses non-float64 input; so does the stand-in (before any GPU work)."""
+    from rust_bindings import warp, semi_dense
+    from rust_bindings.camera import CameraParameters
+    with pytest.raises(TypeError):
+        warp.warp_vecs(np.eye(4), np.zeros((2, 2), dtype=np.float32), np.ones(2))
+    with pytest.raises(TypeError):
+        warp.warp_vecs(np.eye(4).tolist(), np.zeros((2, 2)), np.ones(2))
+    cp = CameraParameters((1., 2.), (3., 4.))
+    assert np.array_equal(cp.focal_length, [1., 2.]) and np.array_equal(cp.offset, [3., 4.])
+    with pytest.raises(TypeError):
+        semi_dense.increment_age(np.zeros((4, 4), dtype=np.int64), cp, cp, np.eye(4), np.ones((4, 4)))
+    f = semi_dense.Frame(cp, np.ones((4, 5)), np.eye(4))
+    assert f.image.shape == (4, 5) and np.array_equal(f.transform_wf, np.eye(4))
+    assert np.array_equal(f.camera_params.focal_length, [1., 2.])
