@@ -102,10 +102,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = args.gpus > 1 or world > 1
 
-    from tadataka_amd import _lib, ops, synthetic
-    _lib.require_gpu()
-    _lib.call("tdk_set_device", local_rank)
-
+    # torch (only needed for torch.distributed / RCCL when N > 1) bundles its own
+    # libamdhip64 with the same soname as /opt/rocm's: whichever is loaded first
+    # serves the whole process, so bring torch up BEFORE libtadataka_hip.so.
     dist = torch = None
     if distributed:
         import torch
@@ -114,22 +113,25 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         world, rank = dist.get_world_size(), dist.get_rank()
 
+    from tadataka_amd import _lib, ops, sharding, synthetic
+    _lib.require_gpu()
+    _lib.call("tdk_set_device", local_rank)
+
     B, H, W = args.pairs, args.height, args.width
     cam = synthetic.camera_for(W, H)
     mode = ops.W_HUBER if args.weights == "huber" else ops.W_NONE
     batch = ops.DvoBatch(B, H, W, n_levels=args.levels, ratio=1.5)
-    batch.fill_synthetic(cam, true_poses(B, rank * B), seed0=rank * B, noise=0.02)
+    seed0 = int(sharding.pair_seeds(rank, B)[0])        # this rank's shard of the pair ids
+    batch.fill_synthetic(cam, true_poses(B, seed0), seed0=seed0, noise=0.02)
     ident = np.tile(ops.pose12(np.eye(3), np.zeros(3)), (B, 1))
-    gathered = None
-    if distributed:
-        gathered = [torch.empty((B, 12), dtype=torch.float64, device="cuda") for _ in range(world)]
+    device = torch.device("cuda", local_rank) if distributed else None
 
     def step():
         batch.build_pyramid()
         poses, px = batch.estimate(cam, cam, ident, mode, args.max_iter)
-        if distributed:
-            dist.all_gather(gathered, torch.from_numpy(poses).cuda())   # RCCL over xGMI
-        return poses, px
+        # the only exchange: the recovered poses, all-gathered (RCCL over xGMI)
+        all_poses = sharding.all_gather_poses(poses, dist, device)
+        return all_poses, px
 
     def fence():
         _lib.call("tdk_sync")
@@ -152,16 +154,12 @@ def main():
     prof = batch.get_profile()
     batch.set_profiling(False)
 
-    if distributed:
-        tt = torch.tensor([elapsed, float(pixels)], dtype=torch.float64, device="cuda")
-        tmax = tt.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        tsum = tt.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed, pixels_all = float(tmax[0]), float(tsum[1])
-    else:
-        pixels_all = float(pixels)
+    elapsed = float(sharding.reduce_scalars([elapsed], "max", dist, device)[0])
+    pixels_all = float(sharding.reduce_scalars([float(pixels)], "sum", dist, device)[0])
 
     if rank == 0:
-        truth = true_poses(B, 0)
+        truth = true_poses(B * world, 0)
+        assert poses.shape == truth.shape
         t_err = float(np.max(np.linalg.norm(poses[:, 9:] - truth[:, 9:], axis=1)))
         kernel_ms = prof["total_ms"] / max(prof["launches"], 1)
         bytes_per_launch = BYTES_PER_PX_EVAL * prof["pixels"] / max(prof["launches"], 1)

@@ -1,0 +1,42 @@
+"""Worker for tests/test_distributed_cpu.py (gloo, world_size 2, CPU): each rank
+estimates the poses of its own shard of frame pairs -- with the CPU oracle
+standing in for the GPU, this is a test -- and the shards are gathered exactly
+as bench.py does it."""
+import os
+import sys
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def estimate_pair(seed, h=32, w=40):
+    from scipy.spatial.transform import Rotation
+    from oracle import oracle as orc
+    from tadataka_amd import synthetic
+    pair = synthetic.make_pair(h, w, seed=int(seed))
+    rot, t = orc.dvo_estimate_level(pair["I0"], pair["D0"], pair["I1"], pair["cam"], pair["cam"],
+                                    Rotation.from_rotvec(np.zeros(3)), np.zeros(3), "huber", 20)
+    return np.concatenate([rot.as_matrix().ravel(), t])
+
+
+def main():
+    import torch.distributed as dist
+    from tadataka_amd import sharding
+    out_path, pairs_per_rank = sys.argv[1], int(sys.argv[2])
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    seeds = sharding.pair_seeds(rank, pairs_per_rank)
+    local = np.array([estimate_pair(s) for s in seeds])
+    gathered = sharding.all_gather_poses(local, dist)
+    stats = sharding.reduce_scalars([float(rank + 1), float(len(seeds))], "max", dist)
+    total = sharding.reduce_scalars([float(len(seeds))], "sum", dist)
+    dist.barrier()
+    if rank == 0:
+        np.savez(out_path, gathered=gathered, stats=stats, total=total, world=world)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,46 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the pair sharding + pose gather
+used by bench.py (tadataka_amd/sharding.py)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import REPO
+
+
+def test_shard_bounds_cover_everything():
+    from tadataka_amd.sharding import pair_seeds, shard_bounds
+    for n in (0, 1, 7, 512, 513):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert list(pair_seeds(3, 4)) == [12, 13, 14, 15]
+
+
+def test_single_process_passthrough():
+    from tadataka_amd.sharding import all_gather_poses, reduce_scalars
+    p = np.arange(24.).reshape(2, 12)
+    assert np.array_equal(all_gather_poses(p), p)
+    assert np.array_equal(reduce_scalars([1., 2.], "sum"), [1., 2.])
+
+
+def test_two_rank_gloo_shard_and_gather(tmp_path):
+    out = str(tmp_path / "gathered.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", "29613",
+           os.path.join(REPO, "tests", "_dist_worker.py"), out, "3"]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:]
+    got = np.load(out)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from _dist_worker import estimate_pair
+    expected = np.array([estimate_pair(s) for s in range(6)])      # single process, all pairs
+    assert got["world"] == 2
+    assert got["gathered"].shape == (6, 12)
+    assert np.array_equal(got["gathered"], expected)               # rank order, nothing lost
+    assert np.array_equal(got["stats"], [2., 3.]) and got["total"][0] == 6.
