@@ -1,6 +1,14 @@
 #!/usr/bin/env python3
-"""Condenses rocprofv3 CSV output (kernel stats + PMC passes) into a short
-text/JSON summary.  Usage: summarize.py <dir written by run_profile.sh>"""
+"""Condenses rocprofv3 CSV output (kernel trace + PMC passes written by
+profiles/run_profile.sh) into a text summary and profiles-ready JSON.
+
+Usage: summarize.py <dir written by run_profile.sh> [pixels_per_level0_launch]
+
+HBM traffic follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section):
+separate --pmc passes for FETCH_SIZE and WRITE_SIZE (KiB units); on gfx950
+FETCH_SIZE counts 64 B per 128-B request of a wide coalesced stream, i.e. half
+of the bytes, so the read side is doubled.
+"""
 import csv
 import glob
 import json
@@ -13,6 +21,11 @@ def find(root, pattern):
     return sorted(glob.glob(os.path.join(root, "**", pattern), recursive=True))
 
 
+def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0]
+
+
 def kernel_stats(root):
     rows = []
     for f in find(os.path.join(root, "trace"), "*kernel_stats.csv"):
@@ -20,34 +33,86 @@ def kernel_stats(root):
     return rows
 
 
-def pmc(root, sub):
-    """Average counter value per dispatch, per kernel."""
+def trace_by_grid(root):
+    """(kernel, grid) -> [durations ns]"""
+    acc = defaultdict(list)
+    for f in find(os.path.join(root, "trace"), "*kernel_trace.csv"):
+        for r in csv.DictReader(open(f)):
+            grid = (int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
+            acc[(short(r["Kernel_Name"]), grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return acc
+
+
+def pmc_by_grid(root, sub):
+    """(kernel, total grid size) -> counter -> [values]"""
     acc = defaultdict(lambda: defaultdict(list))
     for f in find(os.path.join(root, sub), "*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    return {k: {c: (sum(v) / len(v), len(v)) for c, v in d.items()} for k, d in acc.items()}
+            acc[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def mean(v):
+    return sum(v) / len(v) if v else 0.0
 
 
 def main():
     root = sys.argv[1]
-    out = {}
-    print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+    px = float(sys.argv[2]) if len(sys.argv) > 2 else 256 * 480 * 640
+    out = {"pixels_per_level0_launch": px}
+    print("== rocprofv3 --kernel-trace --stats ==")
+    print(f'{"kernel":42s} {"calls":>6s} {"avg_us":>10s} {"total_ms":>10s} {"pct":>7s}')
+    stats = []
     for r in kernel_stats(root):
-        name = r.get("Name", "")
-        print(f'{name[:70]:70s} calls={r.get("Calls")} avg_ns={r.get("AverageNs")} total_ns={r.get("TotalDurationNs")} pct={r.get("Percentage")}')
-        if "k_dvo_eval" in name:
-            out.setdefault("kernel_stats", []).append(r)
-    for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-        d = pmc(root, sub)
-        print(f"== {sub} (average per dispatch) ==")
-        for k, cs in d.items():
-            if "k_dvo" not in k and "rescale" not in k:
-                continue
-            print("  ", k[:90])
-            for c, (v, n) in sorted(cs.items()):
-                print(f"      {c:28s} {v:18.1f}  (n={n})")
-                out.setdefault(sub, {}).setdefault(k, {})[c] = v
+        stats.append({"kernel": short(r["Name"]), "calls": int(r["Calls"]),
+                      "avg_us": float(r["AverageNs"]) / 1e3, "total_ms": float(r["TotalDurationNs"]) / 1e6,
+                      "pct": float(r["Percentage"])})
+        s = stats[-1]
+        print(f'{s["kernel"][:42]:42s} {s["calls"]:6d} {s["avg_us"]:10.1f} {s["total_ms"]:10.2f} {s["pct"]:7.2f}')
+    out["kernel_stats"] = stats
+
+    print("\n== k_dvo_eval by grid (one grid per pyramid level; largest = full resolution) ==")
+    tr = trace_by_grid(root)
+    evals = sorted([(k, v) for k, v in tr.items() if k[0].startswith("k_dvo_eval")],
+                   key=lambda kv: -kv[0][1][0] * kv[0][1][1])
+    levels = []
+    for (name, grid), durs in evals:
+        levels.append({"kernel": name, "grid": list(grid), "launches": len(durs), "avg_us": mean(durs) / 1e3,
+                       "min_us": min(durs) / 1e3, "max_us": max(durs) / 1e3})
+        print(f'{name:28s} grid={grid} launches={len(durs)} avg={mean(durs)/1e3:9.1f} us '
+              f'min={min(durs)/1e3:9.1f} max={max(durs)/1e3:9.1f}')
+    out["dvo_eval_levels"] = levels
+
+    fetch = pmc_by_grid(root, "pmc_fetch")
+    write = pmc_by_grid(root, "pmc_write")
+    ev_f = sorted([(k, v) for k, v in fetch.items() if k[0].startswith("k_dvo_eval")], key=lambda kv: -kv[0][1])
+    ev_w = sorted([(k, v) for k, v in write.items() if k[0].startswith("k_dvo_eval")], key=lambda kv: -kv[0][1])
+    if ev_f and ev_w and levels:
+        fs = mean(ev_f[0][1]["FETCH_SIZE"])       # KiB, raw
+        ws = mean(ev_w[0][1]["WRITE_SIZE"])
+        hbm = (2.0 * fs + ws) * 1024.0
+        avg_s = levels[0]["avg_us"] * 1e-6
+        out["pmc_level0"] = {"FETCH_SIZE_KiB_raw": fs, "WRITE_SIZE_KiB_raw": ws,
+                             "hbm_bytes_per_launch": hbm, "hbm_bytes_per_px": hbm / px,
+                             "algorithmic_bytes_per_px": 24.0,
+                             "note": "read side doubled per the gfx950 FETCH_SIZE correction"}
+        print(f"\n== HBM traffic of the full-resolution k_dvo_eval launch ==")
+        print(f"FETCH_SIZE raw {fs:.0f} KiB  WRITE_SIZE raw {ws:.0f} KiB  -> {hbm/1e9:.3f} GB per launch "
+              f"= {hbm/px:.2f} B/px (algorithmic 24 B/px); at {levels[0]['avg_us']:.0f} us: "
+              f"{hbm/avg_s/1e9:.0f} GB/s moved, {24.0*px/avg_s/1e9:.0f} GB/s algorithmic")
+        json.dump({"hbm_bytes_per_launch": hbm, "pixels_per_launch": px,
+                   "kernel": levels[0]["kernel"], "source": os.path.basename(root.rstrip("/"))},
+                  open(os.path.join(root, "pmc_dvo_eval.json"), "w"), indent=1)
+
+    for sub in ("pmc_sq", "pmc_sq2"):
+        d = pmc_by_grid(root, sub)
+        ev = sorted([(k, v) for k, v in d.items() if k[0].startswith("k_dvo_eval")], key=lambda kv: -kv[0][1])
+        if not ev:
+            continue
+        print(f"\n== {sub}: full-resolution k_dvo_eval, average per launch ==")
+        for c, v in sorted(ev[0][1].items()):
+            print(f"   {c:26s} {mean(v):18.0f}   per px {mean(v)*64/px:10.2f} (x64 lanes)")
+            out.setdefault(sub, {})[c] = mean(v)
     json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
 
 
