@@ -6,7 +6,8 @@ fused device kernels of libtadataka_hip.so:
 
   * _PoseChangeEstimator / PoseChangeEstimator keep (I0, D0, I1[, W0]) resident
     on the MI355X, build the pyramid there, and run the whole accept/reject
-    loop on the device (tdk_dvo_estimate_level / tdk_dvo_estimate);
+    loop on the device (tdk_dvo_estimate_level / tdk_dvo_estimate) -- for every
+    weight option, including the Student-t / Tukey global statistics;
   * calc_pose_update works on the arrays the reference passes
     (tdk_dvo_pose_update) and returns the twist.
 
@@ -84,16 +85,11 @@ def _update_mask(cam1, P1, shape):
     return is_in_image_range(us1, shape) & (np.asarray(P1)[:, 2] > 0)
 
 
-_WEIGHT_MODE = {None: ops.W_NONE, "huber": ops.W_HUBER}
-
-
 def _fused_mode(weights):
-    """Weight mode of the fused device loop, or None if it must be emulated."""
-    if weights is None or (isinstance(weights, str) and weights == "huber"):
-        return _WEIGHT_MODE[weights]
+    """Weight mode of the fused device loop."""
     if isinstance(weights, np.ndarray):
         return ops.W_MAP
-    return None
+    return ops.WEIGHT_MODES[weights]      # None / "huber" / "student-t" / "tukey"
 
 
 def _pose12(pose):
@@ -122,57 +118,13 @@ class _PoseChangeEstimator(object):
 def _estimate_level(batch, level, camera_model0, camera_model1, pose10, weights, max_iter):
     cam0, cam1 = ops.camera_vec(camera_model0), ops.camera_vec(camera_model1)
     mode = _fused_mode(weights)
-    if mode is not None:
-        P, n_evals = batch.estimate_level(level, cam0, cam1, _pose12(pose10), mode, max_iter)
-        # one evaluation only and no step taken = the update mask was empty
-        if n_evals[0] == 1 and max_iter > 0 and np.array_equal(P[0], _pose12(pose10)[0]):
-            ev = batch.evaluate(level, cam0, cam1, P, mode)
-            if ev["n_update"][0] == 0:
-                warnings.warn("Camera pose change is too large.", RuntimeWarning)
-        return Pose.from_matrix(P[0])
-    return _estimate_level_robust(batch, level, cam0, cam1, pose10, weights, max_iter)
-
-
-def _estimate_level_robust(batch, level, cam0, cam1, pose10, weights, max_iter):
-    """'student-t' / 'tukey': the weights depend on global statistics of the
-    masked residuals, so every iteration first derives a weight map on the
-    device (tdk_robust_weights) and then reduces the normal equations with it
-    (tdk_dvo_pose_update); the error test uses the fused evaluation."""
-    from tadataka.coordinates import image_coordinates
-    from tadataka.projection import inv_pi
-    from tadataka.rigid_transform import transform
-    h, w = batch.level_shape(level)
-    scale = level_to_scale(level, getattr(batch, "ratio", 1.5))
-    c0, c1 = cam0 * scale, cam1 * scale
-    I0 = batch.download(0, level, "I0")
-    D0 = batch.download(0, level, "D0")
-    I1 = batch.download(0, level, "I1")
-    residuals = (I0 - I1).reshape(-1)
-    P0 = inv_pi(ops.normalize(image_coordinates((h, w)), c0), D0.reshape(-1))
-    GX1, GY1 = calc_image_gradient(I1)
-
-    def error(pose):
-        ev = batch.evaluate(level, cam0, cam1, _pose12(pose), ops.W_NONE)
-        n = int(ev["n_error"][0])
-        return float(ev["sum_sq"][0]) / n if n else float("nan")
-
-    prev_error = error(pose10)
-    for _ in range(max_iter):
-        P1 = transform(pose10.R, pose10.t, P0)
-        mask = _update_mask(c1, P1, (h, w))
-        if not np.any(mask):
+    P, n_evals = batch.estimate_level(level, cam0, cam1, _pose12(pose10), mode, max_iter)
+    # one evaluation only and no step taken = the update mask was empty
+    if n_evals[0] == 1 and max_iter > 0 and np.array_equal(P[0], _pose12(pose10)[0]):
+        ev = batch.evaluate(level, cam0, cam1, P, ops.W_NONE)
+        if ev["n_update"][0] == 0:
             warnings.warn("Camera pose change is too large.", RuntimeWarning)
-            return pose10
-        wmap = np.zeros(h * w)
-        wmap[mask] = compute_weights(weights, residuals[mask])
-        H, b, _ = ops.dvo_pose_update(c1, residuals, GX1, GY1, P1, ops.W_MAP, wmap)
-        candidate = Pose.from_se3(solve_normal_equations(H, b)) * pose10
-        curr_error = error(candidate)
-        if curr_error > prev_error:
-            break
-        prev_error = curr_error
-        pose10 = candidate
-    return pose10
+    return Pose.from_matrix(P[0])
 
 
 class PoseChangeEstimator(object):
@@ -200,15 +152,9 @@ class PoseChangeEstimator(object):
         try:
             batch.upload(0, I0, D0, I1, weights if has_map else None)
             batch.build_pyramid()
-            mode = _fused_mode(weights)
-            if mode is not None:
-                cam0 = ops.camera_vec(self.camera_model0)
-                cam1 = ops.camera_vec(self.camera_model1)
-                P, _ = batch.estimate(cam0, cam1, _pose12(pose10), mode, self.max_iter)
-                return Pose.from_matrix(P[0])
-            for level in reversed(range(self.n_coarse_to_fine)):
-                pose10 = _estimate_level(batch, level, self.camera_model0, self.camera_model1,
-                                         pose10, weights, self.max_iter)
-            return pose10
+            cam0 = ops.camera_vec(self.camera_model0)
+            cam1 = ops.camera_vec(self.camera_model1)
+            P, _ = batch.estimate(cam0, cam1, _pose12(pose10), _fused_mode(weights), self.max_iter)
+            return Pose.from_matrix(P[0])
         finally:
             batch.close()

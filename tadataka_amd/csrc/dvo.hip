@@ -21,14 +21,21 @@
 // the 40 B/px the unfused update would read.
 //
 // Kernels (gfx950, wave64):
-//   k_dvo_eval    grid (nblk, n_pairs) x 256 threads; each thread walks its
-//                 block's contiguous pixel range two pixels at a time (16-byte
-//                 loads), keeps 30 f64 accumulators, wave __shfl_down reduce,
-//                 LDS across the 4 waves, one 30-double partial per block.
-//   k_dvo_reduce  grid n_pairs x 256: fixed-order sum of the partials
-//                 (bit-reproducible), then -- in loop mode -- lane 0 performs the
-//                 monotone accept/reject, the 6x6 solve and the SE(3) update,
-//                 so a Gauss-Newton iteration needs no host round trip.
+//   k_dvo_eval        grid (nblk, n_pairs) x 256 threads; each thread walks its
+//                     block's contiguous pixel range two pixels at a time (16-byte
+//                     loads, next sweep prefetched), keeps 30 f64 accumulators,
+//                     wave __shfl_down reduce, LDS across the 4 waves, one
+//                     30-double partial per block.
+//   k_dvo_eval_tiled  same arithmetic, taps served from an LDS window per 64x32
+//                     tile (experimental, TDK_DVO_VARIANT=8).
+//   k_dvo_reduce      grid n_pairs x 256: fixed-order sum of the partials
+//                     (bit-reproducible), then -- in loop mode -- lane 0 performs the
+//                     monotone accept/reject, the 6x6 solve and the SE(3) update,
+//                     so a Gauss-Newton iteration needs no host round trip.
+//   k_robust_*        Student-t / Tukey need global statistics of the masked
+//                     residuals (tadataka/robust/weights.py:4-35): masked-residual
+//                     map, 10 fixed-point variance steps, medians by MSD radix
+//                     select -- all per pair, on the device.
 #include "tdk_math.h"
 #include "tdk_runtime.h"
 
@@ -43,10 +50,14 @@ namespace {
 using tdk::Cam;
 
 constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
 constexpr int kAcc = 30;       // 21 H + 6 b + sum_sq + n_update + n_error
 constexpr int kAccPad = 32;
 constexpr int kMaxLevels = 16;
-constexpr double kHuberK = 1.345;  // tadataka/robust/weights.py:38
+constexpr double kHuberK = 1.345;     // tadataka/robust/weights.py:38
+constexpr double kTukeyBeta = 4.6851; // :21
+constexpr double kTukeyC = 1.4826;
+constexpr double kStudentNu = 5.0;    // :4
 
 struct LevelPtrs {
     const double *I0, *D0, *I1, *W0;
@@ -85,29 +96,30 @@ __device__ __forceinline__ void div2_shared(double nx, double ny, double z, doub
     rcp = y;
 }
 
+// Load base[byte_off / 8] with a 32-bit unsigned byte offset from a
+// block-uniform base (global_load_dwordx2 v, voffset, s[base]).
+__device__ __forceinline__ double ldo(const double *__restrict__ base, uint32_t byte_off) {
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 // ---------------------------------------------------------------------------
-// Per-pixel work, written branch-free so that the loads of several pixels can be
-// in flight together (the kernel is latency- and FP64-issue-bound, not
-// HBM-bound): invalid pixels are carried along with sanitised coordinates and
-// their contributions selected to zero at the end.
+// Warp of one source pixel.
 //
 // The warped coordinate decides mask membership with an inclusive float
 // comparison, and at the identity pose the whole right/bottom border sits
 // exactly on that boundary -- so the projection chain keeps the reference's
 // elementwise roundings: (u - o) / f (tables), x * d, q / (z + 1e-16) as a true
-// division, x * f + o as a separate multiply and add.
+// division, x * f + o as a separate multiply and add (no FMA contraction).
 // ---------------------------------------------------------------------------
 struct Warped {
     double qx, qy, qz, rz;       // P1 = R P0 + t and 1 / (z + 1e-16)
     double w00, w01, w10, w11;   // bilinear weights
     int c0, r0;                  // lower texel
-    bool valid;                  // in image range (metric.py:22)
-    bool inside;                 // 4x4 neighbourhood strictly inside the image
 };
 
-__device__ __forceinline__ Warped warp_pixel(double xn, double yn, double d0, int H, int W,
-                                             const double *P, const double *c) {
-    Warped o;
+// returns false when the pixel leaves the image (metric.py:22, utils.py:35-44)
+__device__ __forceinline__ bool warp_pixel(Warped &o, double xn, double yn, double d0, int H, int W,
+                                           const double *P, const double *c) {
     double px = xn * d0, py = yn * d0;
     o.qx = P[0] * px + P[1] * py + P[2] * d0 + P[9];
     o.qy = P[3] * px + P[4] * py + P[5] * d0 + P[10];
@@ -120,25 +132,14 @@ __device__ __forceinline__ Warped warp_pixel(double xn, double yn, double d0, in
         u = sx * c[0] + c[2];
         v = sy * c[1] + c[3];
     }
-    // inclusive float range test (tadataka/utils.py:35-44); NaN compares false
-    o.valid = u >= 0.0 && u <= (double)(W - 1) && v >= 0.0 && v <= (double)(H - 1);
-    u = o.valid ? u : 0.0;
-    v = o.valid ? v : 0.0;
+    if (!(u >= 0.0 && u <= (double)(W - 1) && v >= 0.0 && v <= (double)(H - 1))) return false;
     double lx = floor(u), ly = floor(v);
     o.c0 = (int)lx;
     o.r0 = (int)ly;
     double wx1 = u - lx, wx0 = (lx + 1.0) - u;
     double wy1 = v - ly, wy0 = (ly + 1.0) - v;
     o.w00 = wx0 * wy0; o.w01 = wx1 * wy0; o.w10 = wx0 * wy1; o.w11 = wx1 * wy1;
-    o.inside = o.c0 >= 1 && o.c0 <= W - 3 && o.r0 >= 1 && o.r0 <= H - 3;
-    return o;
-}
-
-// Load base[byte_off / 8] with a 32-bit unsigned byte offset from a
-// block-uniform base: lowers to global_load_dwordx2 v, voffset, s[base] (no
-// 64-bit per-lane address arithmetic).
-__device__ __forceinline__ double ldo(const double *__restrict__ base, uint32_t byte_off) {
-    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
+    return true;
 }
 
 struct Taps {   // the 12 I1 texels around (c0, r0): rows r0-1 .. r0+2
@@ -195,116 +196,54 @@ __device__ __forceinline__ void gradient_clamped(const Taps &t, const Warped &p,
          (t.u1 - t.a2) * sy1 * p.w11;
 }
 
+// Robust weight of one residual; `ws` is the pair's scale statistic
+// (Student-t: variance; Tukey: sigma_mad).  What solve_linear_equation ends up
+// applying is sqrt(w)^2 of whatever compute_weights returned, i.e. the value
+// below (compute_weights_student_t itself already returns a square root).
 template <int WMODE>
-__device__ __forceinline__ void accumulate(Accum &a, const Warped &p, const Taps &t, double gx, double gy,
-                                           double i0, double i1, double w0, const double *c) {
-    // photometric error term (metric.py:24-27): no z test here
-    double i1w = t.a1 * p.w00 + t.a2 * p.w01 + t.b1 * p.w10 + t.b2 * p.w11;
-    double e = i0 - i1w;
-    a.v[27] += p.valid ? e * e : 0.0;
-    a.v[29] += p.valid ? 1.0 : 0.0;
-
-    // update mask adds P1z > 0 (vo/dvo/__init__.py:49); everything an excluded
-    // pixel could poison the sums with is selected to zero here
-    const bool upd = p.valid && p.qz > 0.0;
-    double qx = upd ? p.qx : 0.0, qy = upd ? p.qy : 0.0, qz = upd ? p.qz : 0.0;
-    double rz = upd ? p.rz : 0.0;
-    // Jacobian row (vo/dvo/jacobian.py:8-24), twist order [v, omega]; rz is the
-    // reciprocal of z + 1e-16, i.e. 1/z to 1e-16 relative
-    double fgx = upd ? c[0] * gx : 0.0, fgy = upd ? c[1] * gy : 0.0;
-    double iz2 = rz * rz;
-    double z2 = qz * qz, xy = qx * qy;
-    double J[6];
-    J[0] = fgx * rz;
-    J[1] = fgy * rz;
-    J[2] = -(fgx * qx + fgy * qy) * iz2;
-    J[3] = -(fgx * xy + fgy * (z2 + qy * qy)) * iz2;
-    J[4] = (fgx * (z2 + qx * qx) + fgy * xy) * iz2;
-    J[5] = (fgy * qx - fgx * qy) * rz;
-
-    double r = upd ? i0 - i1 : 0.0;  // un-warped residual (vo/dvo/__init__.py:90)
-    double w = 1.0;
+__device__ __forceinline__ double robust_weight(double r, double w0, double ws) {
     if (WMODE == TDK_W_HUBER) {
         double ar = fabs(r);
         // |r| <= 1 < k on [0, 1] images (F4): the division is off the hot path
-        if (__builtin_amdgcn_ballot_w64(ar > kHuberK) != 0) w = ar > kHuberK ? kHuberK / ar : 1.0;
-    } else if (WMODE == TDK_W_MAP) {
-        w = upd ? w0 : 0.0;
+        if (__builtin_amdgcn_ballot_w64(ar > kHuberK) != 0) return ar > kHuberK ? kHuberK / ar : 1.0;
+        return 1.0;
     }
-    const bool unit_w = (WMODE == TDK_W_NONE) ||
-                        (WMODE == TDK_W_HUBER && __builtin_amdgcn_ballot_w64(w != 1.0) == 0);
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        double wj = unit_w ? J[i] : w * J[i];
-#pragma unroll
-        for (int q = i; q < 6; q++) a.v[k++] += wj * J[q];
-        a.v[21 + i] += wj * r;
+    if (WMODE == TDK_W_MAP) return w0;
+    if (WMODE == TDK_W_STUDENT_T) return sqrt((kStudentNu + 1.0) / (kStudentNu + (r * r) / ws));
+    if (WMODE == TDK_W_TUKEY) {
+        double x = r / ws, q = x / kTukeyBeta, u = 1.0 - q * q;
+        return fabs(x) <= kTukeyBeta ? u * u : 0.0;
     }
-    a.v[28] += upd ? 1.0 : 0.0;
+    return 1.0;
 }
 
-// Early-exit form of the same per-pixel work (VAR 4/5): excluded pixels leave
-// through a divergent branch instead of being carried along with selects.
+// Error term + Jacobian row + weighted outer-product accumulation of one
+// in-range pixel whose taps are already loaded.
 template <int WMODE>
-__device__ __forceinline__ void process_one_branchy(Accum &a, double xn, double yn, double d0, double i0,
-                                                    double i1, double w0, const double *__restrict__ I1,
-                                                    int H, int W, const double *P, const double *c) {
-    double px = xn * d0, py = yn * d0;
-    double qx = P[0] * px + P[1] * py + P[2] * d0 + P[9];
-    double qy = P[3] * px + P[4] * py + P[5] * d0 + P[10];
-    double qz = P[6] * px + P[7] * py + P[8] * d0 + P[11];
-    double u, v, rz;
-    {
-#pragma clang fp contract(off)
-        double z = qz + tdk::kEps16, sx, sy;
-        div2_shared(qx, qy, z, sx, sy, rz);
-        u = sx * c[0] + c[2];
-        v = sy * c[1] + c[3];
-    }
-    if (!(u >= 0.0 && u <= (double)(W - 1) && v >= 0.0 && v <= (double)(H - 1))) return;
-
-    double lx = floor(u), ly = floor(v);
-    Warped p;
-    p.c0 = (int)lx;
-    p.r0 = (int)ly;
-    double wx1 = u - lx, wx0 = (lx + 1.0) - u;
-    double wy1 = v - ly, wy0 = (ly + 1.0) - v;
-    p.w00 = wx0 * wy0; p.w01 = wx1 * wy0; p.w10 = wx0 * wy1; p.w11 = wx1 * wy1;
-    const bool inside = p.c0 >= 1 && p.c0 <= W - 3 && p.r0 >= 1 && p.r0 <= H - 3;
-    Taps t;
-    double gx, gy;
-    if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
-        t = load_taps_inside(I1, W, p);
-        gradient_inside(t, p, gx, gy);
-    } else {
-        t = load_taps_clamped(I1, H, W, p);
-        gradient_clamped(t, p, H, W, gx, gy);
-    }
+__device__ __forceinline__ void accumulate(Accum &a, const Warped &p, const Taps &t, double gx, double gy,
+                                           double i0, double i1, double w0, double ws, const double *c) {
+    // photometric error term (metric.py:24-27): no z test here
     double i1w = t.a1 * p.w00 + t.a2 * p.w01 + t.b1 * p.w10 + t.b2 * p.w11;
     double e = i0 - i1w;
     a.v[27] += e * e;
     a.v[29] += 1.0;
-    if (!(qz > 0.0)) return;
+    if (!(p.qz > 0.0)) return;  // update mask adds P1z > 0 (vo/dvo/__init__.py:49)
 
+    // Jacobian row (vo/dvo/jacobian.py:8-24), twist order [v, omega]; rz is the
+    // reciprocal of z + 1e-16, i.e. 1/z to 1e-16 relative
     double fgx = c[0] * gx, fgy = c[1] * gy;
-    double iz2 = rz * rz;
-    double z2 = qz * qz, xy = qx * qy;
+    double iz2 = p.rz * p.rz;
+    double z2 = p.qz * p.qz, xy = p.qx * p.qy;
     double J[6];
-    J[0] = fgx * rz;
-    J[1] = fgy * rz;
-    J[2] = -(fgx * qx + fgy * qy) * iz2;
-    J[3] = -(fgx * xy + fgy * (z2 + qy * qy)) * iz2;
-    J[4] = (fgx * (z2 + qx * qx) + fgy * xy) * iz2;
-    J[5] = (fgy * qx - fgx * qy) * rz;
-    double r = i0 - i1;
-    double w = 1.0;
-    if (WMODE == TDK_W_HUBER) {
-        double ar = fabs(r);
-        if (__builtin_amdgcn_ballot_w64(ar > kHuberK) != 0) w = ar > kHuberK ? kHuberK / ar : 1.0;
-    } else if (WMODE == TDK_W_MAP) {
-        w = w0;
-    }
+    J[0] = fgx * p.rz;
+    J[1] = fgy * p.rz;
+    J[2] = -(fgx * p.qx + fgy * p.qy) * iz2;
+    J[3] = -(fgx * xy + fgy * (z2 + p.qy * p.qy)) * iz2;
+    J[4] = (fgx * (z2 + p.qx * p.qx) + fgy * xy) * iz2;
+    J[5] = (fgy * p.qx - fgx * p.qy) * p.rz;
+
+    double r = i0 - i1;  // un-warped residual (vo/dvo/__init__.py:90)
+    double w = robust_weight<WMODE>(r, w0, ws);
     const bool unit_w = (WMODE == TDK_W_NONE) ||
                         (WMODE == TDK_W_HUBER && __builtin_amdgcn_ballot_w64(w != 1.0) == 0);
     int k = 0;
@@ -318,87 +257,89 @@ __device__ __forceinline__ void process_one_branchy(Accum &a, double xn, double 
     a.v[28] += 1.0;
 }
 
-// Two adjacent source pixels: warp both, then ONE wave-uniform choice between
-// the unclamped and the clamped tap pattern, so that all 24 gathers are issued
-// back to back.
+// One source pixel with taps gathered from global memory.  A wave-uniform test
+// picks the unclamped tap pattern when every lane's 4x4 neighbourhood is
+// strictly inside the image.
 template <int WMODE>
-__device__ __forceinline__ void process_two(Accum &acc, double xnA, double ynA, double xnB, double ynB,
-                                            double2 d, double2 p0, double2 p1, double2 w,
-                                            const double *__restrict__ I1, int H, int W, const double *P,
-                                            const double *c) {
-    Warped A = warp_pixel(xnA, ynA, d.x, H, W, P, c);
-    Warped B = warp_pixel(xnB, ynB, d.y, H, W, P, c);
-    Taps ta, tb;
-    double gxa, gya, gxb, gyb;
-    if (__builtin_amdgcn_ballot_w64(!(A.inside && B.inside)) == 0) {
-        ta = load_taps_inside(I1, W, A);
-        tb = load_taps_inside(I1, W, B);
-        gradient_inside(ta, A, gxa, gya);
-        gradient_inside(tb, B, gxb, gyb);
-    } else {
-        ta = load_taps_clamped(I1, H, W, A);
-        tb = load_taps_clamped(I1, H, W, B);
-        gradient_clamped(ta, A, H, W, gxa, gya);
-        gradient_clamped(tb, B, H, W, gxb, gyb);
-    }
-    accumulate<WMODE>(acc, A, ta, gxa, gya, p0.x, p1.x, w.x, c);
-    accumulate<WMODE>(acc, B, tb, gxb, gyb, p0.y, p1.y, w.y, c);
-}
-
-template <int WMODE>
-__device__ __forceinline__ void process_one(Accum &acc, double xn, double yn, double d0, double i0, double i1,
-                                            double w0, const double *__restrict__ I1, int H, int W,
-                                            const double *P, const double *c) {
-    Warped A = warp_pixel(xn, yn, d0, H, W, P, c);
-    Taps ta;
+__device__ __forceinline__ void process_pixel(Accum &a, double xn, double yn, double d0, double i0, double i1,
+                                              double w0, double ws, const double *__restrict__ I1, int H,
+                                              int W, const double *P, const double *c) {
+    Warped p;
+    if (!warp_pixel(p, xn, yn, d0, H, W, P, c)) return;
+    const bool inside = p.c0 >= 1 && p.c0 <= W - 3 && p.r0 >= 1 && p.r0 <= H - 3;
+    Taps t;
     double gx, gy;
-    if (__builtin_amdgcn_ballot_w64(!A.inside) == 0) {
-        ta = load_taps_inside(I1, W, A);
-        gradient_inside(ta, A, gx, gy);
+    if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
+        t = load_taps_inside(I1, W, p);
+        gradient_inside(t, p, gx, gy);
     } else {
-        ta = load_taps_clamped(I1, H, W, A);
-        gradient_clamped(ta, A, H, W, gx, gy);
+        t = load_taps_clamped(I1, H, W, p);
+        gradient_clamped(t, p, H, W, gx, gy);
     }
-    accumulate<WMODE>(acc, A, ta, gx, gy, i0, i1, w0, c);
+    accumulate<WMODE>(a, p, t, gx, gy, i0, i1, w0, ws, c);
 }
 
-// VAR selects the sweep structure (A/B-able at run time with TDK_DVO_VARIANT):
-//   0  two pixels per thread and sweep (16-byte loads), next sweep prefetched
-//   1  same, register budget capped for 3 waves/SIMD
-//   2  one pixel per thread and sweep, no prefetch
-//   3  same, register budget capped for 4 waves/SIMD
-template <int WMODE, int VAR>
-__global__ __launch_bounds__(kBlock, (VAR == 1 ? 3 : VAR == 3 ? 4 : 1)) void k_dvo_eval(LevelPtrs L, const PairParams *__restrict__ params,
+// Block-level tail shared by both evaluation kernels: wave64 shuffle reduction,
+// LDS across the waves, one partial per block.
+__device__ __forceinline__ void store_partials(const Accum &acc, double (*red)[kAccPad], int pair,
+                                               double *__restrict__ partials) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kAcc; k++) {
+        double s = acc.v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) red[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < kAcc) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) s += red[w][threadIdx.x];
+        partials[((int64_t)pair * gridDim.x + blockIdx.x) * kAccPad + threadIdx.x] = s;
+    }
+}
+
+struct BlockSetup {   // block-uniform pose and (level-scaled) cameras
+    double P[12], c[4], fx0, fy0, ox0, oy0;
+};
+
+__device__ __forceinline__ void load_setup(BlockSetup &b, const PairParams *__restrict__ params,
+                                           const double *__restrict__ poses, int pair, double scale) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) b.P[i] = poses[12 * pair + i];
+    const PairParams pp = params[pair];
+    // tadataka.camera.resize: focal length and offset both scale (camera/model.py:69-74)
+    b.c[0] = pp.cam1[0] * scale; b.c[1] = pp.cam1[1] * scale;
+    b.c[2] = pp.cam1[2] * scale; b.c[3] = pp.cam1[3] * scale;
+    b.fx0 = pp.cam0[0] * scale; b.fy0 = pp.cam0[1] * scale;
+    b.ox0 = pp.cam0[2] * scale; b.oy0 = pp.cam0[3] * scale;
+}
+
+// ---------------------------------------------------------------------------
+// k_dvo_eval: contiguous pixel ranges, taps gathered through L1/L2.
+// ---------------------------------------------------------------------------
+template <int WMODE>
+__global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairParams *__restrict__ params,
                                                      const double *__restrict__ poses,
-                                                     const int *__restrict__ state, double scale,
+                                                     const int *__restrict__ state,
+                                                     const double *__restrict__ wscale, double scale,
                                                      int64_t chunk, double *__restrict__ partials) {
     const int pair = blockIdx.y;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
-
-    // uniform per block: pose and cameras (scaled to this level as
-    // tadataka.camera.resize does, camera/model.py:69-74)
-    double P[12], c[4];
-#pragma unroll
-    for (int i = 0; i < 12; i++) P[i] = poses[12 * pair + i];
-    const PairParams pp = params[pair];
-    c[0] = pp.cam1[0] * scale;
-    c[1] = pp.cam1[1] * scale;
-    c[2] = pp.cam1[2] * scale;
-    c[3] = pp.cam1[3] * scale;
+    BlockSetup b;
+    load_setup(b, params, poses, pair, scale);
+    const double ws = (WMODE == TDK_W_STUDENT_T || WMODE == TDK_W_TUKEY) ? wscale[pair] : 1.0;
 
     // LDS: [0, 1 KiB) cross-wave reduction scratch, then the normalised
     // coordinate tables xn[W], yn[H] = (u - o) / f of camera 0 (one true
     // division per row / column instead of two per pixel)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double(*red)[kAccPad] = reinterpret_cast<double(*)[kAccPad]>(smem);
-    double *xn_tab = reinterpret_cast<double *>(smem + sizeof(double) * (kBlock / 64) * kAccPad);
+    double *xn_tab = reinterpret_cast<double *>(smem + sizeof(double) * kWaves * kAccPad);
     double *yn_tab = xn_tab + L.W;
-    {
-        const double fx0 = pp.cam0[0] * scale, fy0 = pp.cam0[1] * scale;
-        const double ox0 = pp.cam0[2] * scale, oy0 = pp.cam0[3] * scale;
-        for (int i = threadIdx.x; i < L.W; i += kBlock) xn_tab[i] = ((double)i - ox0) / fx0;
-        for (int i = threadIdx.x; i < L.H; i += kBlock) yn_tab[i] = ((double)i - oy0) / fy0;
-    }
+    for (int i = threadIdx.x; i < L.W; i += kBlock) xn_tab[i] = ((double)i - b.ox0) / b.fx0;
+    for (int i = threadIdx.x; i < L.H; i += kBlock) yn_tab[i] = ((double)i - b.oy0) / b.fy0;
     __syncthreads();
 
     const int64_t base = (int64_t)pair * L.stride;
@@ -417,108 +358,6 @@ __global__ __launch_bounds__(kBlock, (VAR == 1 ? 3 : VAR == 3 ? 4 : 1)) void k_d
     const int end = (int)min((int64_t)N, (int64_t)start + chunk);
     // (x, y) of pixel i, advanced incrementally by the block sweep of 2*kBlock
     // pixels: one integer division per thread instead of one per pixel
-    if (VAR == 4) {
-        int i = start + 2 * (int)threadIdx.x;
-        int y = i / W, x = i - y * W;
-        const int step_y = (2 * kBlock) / W, step_x = (2 * kBlock) - step_y * W;
-        for (; i < end; i += 2 * kBlock) {
-            if (i + 1 < end) {
-                double2 d = *reinterpret_cast<const double2 *>(D0 + i);
-                double2 p0 = *reinterpret_cast<const double2 *>(I0 + i);
-                double2 p1 = *reinterpret_cast<const double2 *>(I1 + i);
-                double2 w = make_double2(1.0, 1.0);
-                if (WMODE == TDK_W_MAP) w = *reinterpret_cast<const double2 *>(W0 + i);
-                process_one_branchy<WMODE>(acc, xn_tab[x], yn_tab[y], d.x, p0.x, p1.x, w.x, I1, H, W, P, c);
-                int x2 = x + 1, y2 = y;
-                if (x2 == W) { x2 = 0; y2 = y + 1; }
-                process_one_branchy<WMODE>(acc, xn_tab[x2], yn_tab[y2], d.y, p0.y, p1.y, w.y, I1, H, W, P, c);
-            } else {
-                double w1 = (WMODE == TDK_W_MAP) ? W0[i] : 1.0;
-                process_one_branchy<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w1, I1, H, W, P, c);
-            }
-            x += step_x;
-            y += step_y;
-            if (x >= W) { x -= W; y += 1; }
-        }
-    } else if (VAR == 6) {
-        int i = start + (int)threadIdx.x;
-        int y = i / W, x = i - y * W;
-        const int step_y = kBlock / W, step_x = kBlock - step_y * W;
-        double d = 1.0, q0 = 0.0, q1 = 0.0, w1 = 1.0;
-        if (i < end) {
-            d = ldo(D0, (uint32_t)i * 8u); q0 = ldo(I0, (uint32_t)i * 8u); q1 = ldo(I1, (uint32_t)i * 8u);
-            if (WMODE == TDK_W_MAP) w1 = ldo(W0, (uint32_t)i * 8u);
-        }
-        for (; i < end; i += kBlock) {
-            const int in = i + kBlock;
-            double dn = d, q0n = q0, q1n = q1, wn = w1;
-            if (in < end) {
-                dn = ldo(D0, (uint32_t)in * 8u); q0n = ldo(I0, (uint32_t)in * 8u); q1n = ldo(I1, (uint32_t)in * 8u);
-                if (WMODE == TDK_W_MAP) wn = ldo(W0, (uint32_t)in * 8u);
-            }
-            process_one_branchy<WMODE>(acc, xn_tab[x], yn_tab[y], d, q0, q1, w1, I1, H, W, P, c);
-            d = dn; q0 = q0n; q1 = q1n; w1 = wn;
-            x += step_x;
-            y += step_y;
-            if (x >= W) { x -= W; y += 1; }
-        }
-    } else if (VAR == 7) {
-        int i = start + 2 * (int)threadIdx.x;
-        int y = i / W, x = i - y * W;
-        const int step_y = (2 * kBlock) / W, step_x = (2 * kBlock) - step_y * W;
-        double2 d = make_double2(1.0, 1.0), p0 = d, p1 = d, w = d;
-        if (i + 1 < end) {
-            d = *reinterpret_cast<const double2 *>(D0 + i);
-            p0 = *reinterpret_cast<const double2 *>(I0 + i);
-            p1 = *reinterpret_cast<const double2 *>(I1 + i);
-            if (WMODE == TDK_W_MAP) w = *reinterpret_cast<const double2 *>(W0 + i);
-        }
-        for (; i < end; i += 2 * kBlock) {
-            if (i + 1 < end) {
-                const int in = i + 2 * kBlock;
-                double2 dn = d, p0n = p0, p1n = p1, wn = w;
-                if (in + 1 < end) {
-                    dn = *reinterpret_cast<const double2 *>(D0 + in);
-                    p0n = *reinterpret_cast<const double2 *>(I0 + in);
-                    p1n = *reinterpret_cast<const double2 *>(I1 + in);
-                    if (WMODE == TDK_W_MAP) wn = *reinterpret_cast<const double2 *>(W0 + in);
-                }
-                process_one_branchy<WMODE>(acc, xn_tab[x], yn_tab[y], d.x, p0.x, p1.x, w.x, I1, H, W, P, c);
-                int x2 = x + 1, y2 = y;
-                if (x2 == W) { x2 = 0; y2 = y + 1; }
-                process_one_branchy<WMODE>(acc, xn_tab[x2], yn_tab[y2], d.y, p0.y, p1.y, w.y, I1, H, W, P, c);
-                d = dn; p0 = p0n; p1 = p1n; w = wn;
-            } else {
-                double w1 = (WMODE == TDK_W_MAP) ? W0[i] : 1.0;
-                process_one_branchy<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w1, I1, H, W, P, c);
-            }
-            x += step_x;
-            y += step_y;
-            if (x >= W) { x -= W; y += 1; }
-        }
-    } else if (VAR == 5) {
-        int i = start + (int)threadIdx.x;
-        int y = i / W, x = i - y * W;
-        const int step_y = kBlock / W, step_x = kBlock - step_y * W;
-        for (; i < end; i += kBlock) {
-            double w1 = (WMODE == TDK_W_MAP) ? W0[i] : 1.0;
-            process_one_branchy<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w1, I1, H, W, P, c);
-            x += step_x;
-            y += step_y;
-            if (x >= W) { x -= W; y += 1; }
-        }
-    } else if (VAR >= 2) {
-        int i = start + (int)threadIdx.x;
-        int y = i / W, x = i - y * W;
-        const int step_y = kBlock / W, step_x = kBlock - step_y * W;
-        for (; i < end; i += kBlock) {
-            double w1 = (WMODE == TDK_W_MAP) ? W0[i] : 1.0;
-            process_one<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w1, I1, H, W, P, c);
-            x += step_x;
-            y += step_y;
-            if (x >= W) { x -= W; y += 1; }
-        }
-    } else {
     int i = start + 2 * (int)threadIdx.x;
     int y = i / W, x = i - y * W;
     const int step_y = (2 * kBlock) / W, step_x = (2 * kBlock) - step_y * W;
@@ -541,38 +380,190 @@ __global__ __launch_bounds__(kBlock, (VAR == 1 ? 3 : VAR == 3 ? 4 : 1)) void k_d
                 p1n = *reinterpret_cast<const double2 *>(I1 + in);
                 if (WMODE == TDK_W_MAP) wn = *reinterpret_cast<const double2 *>(W0 + in);
             }
+            process_pixel<WMODE>(acc, xn_tab[x], yn_tab[y], d.x, p0.x, p1.x, w.x, ws, I1, H, W, b.P, b.c);
             int x2 = x + 1, y2 = y;
             if (x2 == W) { x2 = 0; y2 = y + 1; }
-            process_two<WMODE>(acc, xn_tab[x], yn_tab[y], xn_tab[x2], yn_tab[y2], d, p0, p1, w, I1, H, W, P, c);
+            process_pixel<WMODE>(acc, xn_tab[x2], yn_tab[y2], d.y, p0.y, p1.y, w.y, ws, I1, H, W, b.P, b.c);
             d = dn; p0 = p0n; p1 = p1n; w = wn;
-        } else {
+        } else {  // odd tail of the range
             double w1 = (WMODE == TDK_W_MAP) ? W0[i] : 1.0;
-            process_one<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w1, I1, H, W, P, c);
+            process_pixel<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w1, ws, I1, H, W, b.P, b.c);
         }
         x += step_x;
         y += step_y;
         if (x >= W) { x -= W; y += 1; }
     }
-
-    }
-    // wave64 reduction, then across the block's 4 waves through LDS
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kAcc; k++) {
-        double s = acc.v[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane == 0) red[wave][k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < kAcc) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; w++) s += red[w][threadIdx.x];
-        partials[((int64_t)pair * gridDim.x + blockIdx.x) * kAccPad + threadIdx.x] = s;
-    }
+    store_partials(acc, red, pair, partials);
 }
 
+// ---------------------------------------------------------------------------
+// k_dvo_eval_tiled (TDK_DVO_VARIANT=8): the taps come from an LDS window.
+//
+// A block walks TW x TH source tiles of one pair.  Per tile it warps the tile's
+// centre pixel to place a (TW + 2 TM + 3) x (TH + 2 TM + 3) window of I1, loads
+// the window cooperatively (coalesced rows), and every pixel whose 4x4 tap
+// neighbourhood falls inside the window reads its 12 texels from LDS with
+// immediate offsets; a wave with a lane outside the window (large parallax or
+// rotation inside one tile) takes the global-gather path, so results do not
+// depend on the window guess.  Measured slower than k_dvo_eval in round 1 (two
+// barriers and a dependent load per tile at 2 waves/SIMD); kept for the LDS-DMA
+// double-buffered version.
+// ---------------------------------------------------------------------------
+constexpr int kTW = 64, kTH = 32, kTM = 4;
+constexpr int kWW = kTW + 2 * kTM + 3;   // 75
+constexpr int kWH = kTH + 2 * kTM + 3;   // 43
+constexpr int kWS = kWW + 1;             // LDS row stride (doubles)
+
+__device__ __forceinline__ Taps load_taps_lds_inside(const double *win, int o0) {
+    Taps t;
+    const double *q = win + o0;
+    t.t0 = q[-kWS]; t.t1 = q[-kWS + 1];
+    t.a0 = q[-1]; t.a1 = q[0]; t.a2 = q[1]; t.a3 = q[2];
+    t.b0 = q[kWS - 1]; t.b1 = q[kWS]; t.b2 = q[kWS + 1]; t.b3 = q[kWS + 2];
+    t.u0 = q[2 * kWS]; t.u1 = q[2 * kWS + 1];
+    return t;
+}
+
+__device__ __forceinline__ Taps load_taps_lds_clamped(const double *win, int wx0, int wy0, int H, int W,
+                                                      const Warped &p) {
+    int c0 = p.c0 - wx0;
+    int cm = max(p.c0 - 1, 0) - wx0, c1 = min(p.c0 + 1, W - 1) - wx0, c2 = min(p.c0 + 2, W - 1) - wx0;
+    int r0 = (p.r0 - wy0) * kWS;
+    int rm = (max(p.r0 - 1, 0) - wy0) * kWS, r1 = (min(p.r0 + 1, H - 1) - wy0) * kWS;
+    int r2 = (min(p.r0 + 2, H - 1) - wy0) * kWS;
+    Taps t;
+    t.a0 = win[r0 + cm]; t.a1 = win[r0 + c0]; t.a2 = win[r0 + c1]; t.a3 = win[r0 + c2];
+    t.b0 = win[r1 + cm]; t.b1 = win[r1 + c0]; t.b2 = win[r1 + c1]; t.b3 = win[r1 + c2];
+    t.t0 = win[rm + c0]; t.t1 = win[rm + c1]; t.u0 = win[r2 + c0]; t.u1 = win[r2 + c1];
+    return t;
+}
+
+template <int WMODE>
+__device__ __forceinline__ void process_pixel_tiled(Accum &a, double xn, double yn, double d0, double i0,
+                                                    double i1, double w0, double ws,
+                                                    const double *__restrict__ I1, const double *win, int wx0,
+                                                    int wy0, int ww, int wh, int H, int W, const double *P,
+                                                    const double *c) {
+    Warped p;
+    if (!warp_pixel(p, xn, yn, d0, H, W, P, c)) return;
+    const bool inside = p.c0 >= 1 && p.c0 <= W - 3 && p.r0 >= 1 && p.r0 <= H - 3;
+    // window coverage of the (clamped) 4x4 neighbourhood
+    const int cl = max(p.c0 - 1, 0), ch = min(p.c0 + 2, W - 1);
+    const int rl = max(p.r0 - 1, 0), rh = min(p.r0 + 2, H - 1);
+    const bool in_win = cl >= wx0 && ch < wx0 + ww && rl >= wy0 && rh < wy0 + wh;
+    const bool all_inside = __builtin_amdgcn_ballot_w64(!inside) == 0;
+    const bool all_win = __builtin_amdgcn_ballot_w64(!in_win) == 0;
+    Taps t;
+    double gx, gy;
+    if (all_win && all_inside) {
+        t = load_taps_lds_inside(win, (p.r0 - wy0) * kWS + (p.c0 - wx0));
+        gradient_inside(t, p, gx, gy);
+    } else if (all_win) {
+        t = load_taps_lds_clamped(win, wx0, wy0, H, W, p);
+        gradient_clamped(t, p, H, W, gx, gy);
+    } else {
+        t = load_taps_clamped(I1, H, W, p);
+        gradient_clamped(t, p, H, W, gx, gy);
+    }
+    accumulate<WMODE>(a, p, t, gx, gy, i0, i1, w0, ws, c);
+}
+
+template <int WMODE>
+__global__ __launch_bounds__(kBlock) void k_dvo_eval_tiled(LevelPtrs L, const PairParams *__restrict__ params,
+                                                           const double *__restrict__ poses,
+                                                           const int *__restrict__ state,
+                                                           const double *__restrict__ wscale, double scale,
+                                                           int tiles_x, int n_tiles, int tiles_per_block,
+                                                           double *__restrict__ partials) {
+    const int pair = blockIdx.y;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    BlockSetup b;
+    load_setup(b, params, poses, pair, scale);
+    const double ws = (WMODE == TDK_W_STUDENT_T || WMODE == TDK_W_TUKEY) ? wscale[pair] : 1.0;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double(*red)[kAccPad] = reinterpret_cast<double(*)[kAccPad]>(smem);
+    double *xn_t = reinterpret_cast<double *>(smem + sizeof(double) * kWaves * kAccPad);
+    double *yn_t = xn_t + kTW;
+    double *win = yn_t + kTH;
+
+    const int64_t base = (int64_t)pair * L.stride;
+    const double *__restrict__ I0 = L.I0 + base;
+    const double *__restrict__ D0 = L.D0 + base;
+    const double *__restrict__ I1 = L.I1 + base;
+    const double *__restrict__ W0 = (WMODE == TDK_W_MAP) ? L.W0 + base : nullptr;
+    const int W = L.W, H = L.H;
+    const int ww = min(kWW, W), wh = min(kWH, H);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    Accum acc;
+#pragma unroll
+    for (int i = 0; i < kAcc; i++) acc.v[i] = 0.0;
+
+    const int t_begin = blockIdx.x * tiles_per_block;
+    const int t_end = min(n_tiles, t_begin + tiles_per_block);
+    for (int tile = t_begin; tile < t_end; tile++) {
+        const int ty_i = tile / tiles_x, tx_i = tile - ty_i * tiles_x;
+        const int tx0 = tx_i * kTW, ty0 = ty_i * kTH;
+        // window origin from the warp of the tile centre (block-uniform)
+        const int cxp = min(tx0 + kTW / 2, W - 1), cyp = min(ty0 + kTH / 2, H - 1);
+        int wx0, wy0;
+        {
+            double dc = D0[cyp * W + cxp];
+            double xc = ((double)cxp - b.ox0) / b.fx0 * dc, yc = ((double)cyp - b.oy0) / b.fy0 * dc;
+            double qx = b.P[0] * xc + b.P[1] * yc + b.P[2] * dc + b.P[9];
+            double qy = b.P[3] * xc + b.P[4] * yc + b.P[5] * dc + b.P[10];
+            double qz = b.P[6] * xc + b.P[7] * yc + b.P[8] * dc + b.P[11];
+            double uc = qx / qz * b.c[0] + b.c[2], vc = qy / qz * b.c[1] + b.c[3];
+            // a non-finite or absurd guess only costs speed (global fallback)
+            if (!(uc > -1e6 && uc < 1e6)) uc = (double)cxp;
+            if (!(vc > -1e6 && vc < 1e6)) vc = (double)cyp;
+            wx0 = (int)floor(uc) - (cxp - tx0) - kTM - 1;
+            wy0 = (int)floor(vc) - (cyp - ty0) - kTM - 1;
+            wx0 = max(0, min(wx0, W - ww));
+            wy0 = max(0, min(wy0, H - wh));
+        }
+        __syncthreads();  // every wave is done reading the previous window / tables
+        if (threadIdx.x < kTW) xn_t[threadIdx.x] = ((double)(tx0 + (int)threadIdx.x) - b.ox0) / b.fx0;
+        else if (threadIdx.x < kTW + kTH)
+            yn_t[threadIdx.x - kTW] = ((double)(ty0 + (int)threadIdx.x - kTW) - b.oy0) / b.fy0;
+        for (int r = wave; r < wh; r += kWaves) {
+            const double *row = I1 + (wy0 + r) * W + wx0;
+            for (int cc = lane; cc < ww; cc += 64) win[r * kWS + cc] = row[cc];
+        }
+        __syncthreads();
+
+        const int x = tx0 + lane;
+        if (x < W) {
+            const double xn = xn_t[lane];
+            int y = ty0 + wave;
+            double d = 1.0, q0 = 0.0, q1 = 0.0, w1 = 1.0;
+            if (y < H) {
+                const int i = y * W + x;
+                d = D0[i]; q0 = I0[i]; q1 = I1[i];
+                if (WMODE == TDK_W_MAP) w1 = W0[i];
+            }
+#pragma unroll 1
+            for (int k = 0; k < kTH / kWaves; k++, y += kWaves) {
+                if (y >= H) break;
+                double dn = d, q0n = q0, q1n = q1, wn = w1;
+                if (k + 1 < kTH / kWaves && y + kWaves < H) {
+                    const int in = (y + kWaves) * W + x;
+                    dn = D0[in]; q0n = I0[in]; q1n = I1[in];
+                    if (WMODE == TDK_W_MAP) wn = W0[in];
+                }
+                process_pixel_tiled<WMODE>(acc, xn, yn_t[wave + kWaves * k], d, q0, q1, w1, ws, I1, win, wx0, wy0,
+                                           ww, wh, H, W, b.P, b.c);
+                d = dn; q0 = q0n; q1 = q1n; w1 = wn;
+            }
+        }
+    }
+    store_partials(acc, red, pair, partials);
+}
+
+// ---------------------------------------------------------------------------
+// Gauss-Newton bookkeeping
+// ---------------------------------------------------------------------------
 struct LoopState {   // device arrays, one entry per pair
     double *pose;      // [n][12] last accepted pose
     double *cand;      // [n][12] pose being evaluated
@@ -583,7 +574,7 @@ struct LoopState {   // device arrays, one entry per pair
 };
 
 // Fixed-order reduction of the per-block partials of one pair; in loop mode the
-// Gauss-Newton bookkeeping of _PoseChangeEstimator.__call__ (:92-111) follows.
+// bookkeeping of _PoseChangeEstimator.__call__ (:92-111) follows.
 __global__ __launch_bounds__(kBlock) void k_dvo_reduce(const double *__restrict__ partials, int nblk,
                                                        double *__restrict__ results, LoopState ls,
                                                        int loop_mode, int iter, int max_iter) {
@@ -651,6 +642,149 @@ __global__ void k_loop_init(LoopState ls, const double *__restrict__ poses_in, i
     if (i == 0) *ls.active = n;
 }
 
+// ---------------------------------------------------------------------------
+// Robust scale statistics per pair (Student-t, Tukey)
+// ---------------------------------------------------------------------------
+// masked residual map: rm[i] = I0 - I1 where the pixel is in the UPDATE mask of
+// the pose (in range & z > 0), NaN elsewhere; count[pair] = mask size.
+__global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairParams *__restrict__ params,
+                                                        const double *__restrict__ poses,
+                                                        const int *__restrict__ state, double scale,
+                                                        double *__restrict__ rm, int *__restrict__ count) {
+    const int pair = blockIdx.y;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    BlockSetup b;
+    load_setup(b, params, poses, pair, scale);
+    const int64_t base = (int64_t)pair * L.stride;
+    const int W = L.W, H = L.H, N = (int)L.N;
+    int local = 0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+        int y = i / W, x = i - y * W;
+        double xn = ((double)x - b.ox0) / b.fx0, yn = ((double)y - b.oy0) / b.fy0;
+        Warped p;
+        bool in = warp_pixel(p, xn, yn, L.D0[base + i], H, W, b.P, b.c) && p.qz > 0.0;
+        rm[base + i] = in ? L.I0[base + i] - L.I1[base + i] : __longlong_as_double(0x7ff8000000000000ll);
+        local += in ? 1 : 0;
+    }
+    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+    if ((threadIdx.x & 63) == 0 && local) atomicAdd(&count[pair], local);
+}
+
+// one fixed-point step of compute_weights_student_t (weights.py:13-16)
+__global__ __launch_bounds__(kBlock) void k_robust_student_step(const double *__restrict__ rm, int64_t stride,
+                                                                int N, const int *__restrict__ state,
+                                                                const double *__restrict__ variance,
+                                                                double *__restrict__ partial) {
+    const int pair = blockIdx.y;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    const double var = variance[pair];
+    const double *r = rm + (int64_t)pair * stride;
+    double acc = 0.0;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+        double v = r[i];
+        if (v == v) {
+            double s = v * v;
+            acc += s * ((kStudentNu + 1.0) / (kStudentNu + s / var));
+        }
+    }
+    __shared__ double red[kWaves];
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)pair * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ void k_robust_student_update(const double *__restrict__ partial, int nblk,
+                                        const int *__restrict__ count, const int *__restrict__ state,
+                                        double *__restrict__ variance, int n_pairs, int first) {
+    int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= n_pairs) return;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    if (first) { variance[pair] = 1.0; return; }
+    double s = 0.0;
+    for (int b = 0; b < nblk; b++) s += partial[(int64_t)pair * nblk + b];
+    variance[pair] = s / (double)count[pair];
+}
+
+// MSD radix select on the order-preserving 64-bit image of a double, per pair
+__device__ __forceinline__ uint64_t ordered_key(double v) {
+    uint64_t b = (uint64_t)__double_as_longlong(v);
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__device__ __forceinline__ double key_to_double(uint64_t k) {
+    uint64_t b = (k & 0x8000000000000000ull) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+struct SelectState {
+    uint64_t prefix, rank;
+};
+
+__global__ void k_select_init(SelectState *st, const int *__restrict__ count, int n_pairs, int which) {
+    int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= n_pairs) return;
+    int m = count[pair];
+    // which: 0 = lower middle (rank (m-1)/2), 1 = upper middle (rank m/2)
+    st[pair].prefix = 0;
+    st[pair].rank = (uint64_t)(which == 0 ? (m > 0 ? (m - 1) / 2 : 0) : m / 2);
+}
+
+// values: rm (mode 0) or |rm - center[pair]| (mode 1, for the MAD)
+__global__ __launch_bounds__(kBlock) void k_select_hist(const double *__restrict__ rm, int64_t stride, int N,
+                                                        const int *__restrict__ state, int mode,
+                                                        const double *__restrict__ center,
+                                                        const SelectState *__restrict__ st, int pass,
+                                                        unsigned int *__restrict__ hist) {
+    const int pair = blockIdx.y;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int shift = 56 - 8 * pass;
+    const uint64_t prefix = st[pair].prefix;
+    const uint64_t mask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+    const double cen = mode ? center[pair] : 0.0;
+    const double *r = rm + (int64_t)pair * stride;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+        double v = r[i];
+        if (v != v) continue;
+        uint64_t k = ordered_key(mode ? fabs(v - cen) : v);
+        if ((k & mask) == prefix) atomicAdd(&h[(k >> shift) & 0xff], 1u);
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[pair * 256 + threadIdx.x], h[threadIdx.x]);
+}
+
+__global__ void k_select_pick(unsigned int *__restrict__ hist, SelectState *__restrict__ st,
+                              const int *__restrict__ state, int n_pairs, int pass, double *__restrict__ out) {
+    int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= n_pairs) return;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    const int shift = 56 - 8 * pass;
+    unsigned int *h = hist + pair * 256;
+    uint64_t rank = st[pair].rank, cum = 0;
+    int bin = 255;
+    for (int b = 0; b < 256; b++) {
+        uint64_t cnt = h[b];
+        if (rank < cum + cnt) { bin = b; break; }
+        cum += cnt;
+    }
+    st[pair].rank = rank - cum;
+    st[pair].prefix |= ((uint64_t)bin) << shift;
+    for (int b = 0; b < 256; b++) h[b] = 0;
+    if (pass == 7) out[pair] = key_to_double(st[pair].prefix);
+}
+
+// np.median = mean of the two middle order statistics; then optional scaling
+__global__ void k_median_combine(const double *lo, const double *hi, const int *__restrict__ state, int n_pairs,
+                                 double factor, double *out) {
+    int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= n_pairs) return;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    out[pair] = factor * ((lo[pair] + hi[pair]) / 2.0);
+}
+
 // ---- synthetic scene on the device (tadataka_amd/synthetic.py) ------------
 __device__ __forceinline__ double tex(double x, double y) {
     return 0.5 + 0.25 * sin(x / 7.0) * cos(y / 5.0) + 0.2 * sin((x + y) / 11.0);
@@ -709,6 +843,14 @@ struct tdk_dvo {
     double *d_partials, *d_results;
     LoopState ls;
     int max_blocks;
+    // robust statistics (allocated on first use)
+    double *d_rm;         // [n][stride0] masked residual map
+    double *d_wscale;     // [n] variance (student-t) / sigma_mad (tukey)
+    double *d_stat;       // [n][4]: lo, hi, median, spare
+    double *d_spartial;   // [n][kStatBlocks]
+    int *d_count;         // [n]
+    void *d_select;       // SelectState[n]
+    unsigned int *d_hist; // [n][256]
     // profiling of the finest-level evaluation kernel (bench.py roofline leg)
     bool profiling;
     std::vector<hipEvent_t> ev_pool;
@@ -719,13 +861,45 @@ struct tdk_dvo {
 
 namespace {
 
+constexpr int kStatBlocks = 64;
+
 int level_dim(int full, double scale) {
     // skimage.transform.rescale: output shape = round(shape * scale) (np.round)
     int v = (int)nearbyint((double)full * scale);
     return v < 1 ? 1 : v;
 }
 
+int dvo_variant() {
+    static const int variant = [] {
+        const char *v = getenv("TDK_DVO_VARIANT");
+        return v ? atoi(v) : 7;
+    }();
+    return variant;
+}
+
+struct TilePlan {
+    int tiles_x, n_tiles, tiles_per_block, nblk;
+};
+
+TilePlan plan_tiles(const tdk_dvo *h, const tdk_dvo::Level &L) {
+    TilePlan t;
+    t.tiles_x = (L.W + kTW - 1) / kTW;
+    t.n_tiles = t.tiles_x * ((L.H + kTH - 1) / kTH);
+    int cap = 16384 / h->n_pairs;          // blocks per pair
+    if (cap < 1) cap = 1;
+    if (cap > h->max_blocks) cap = h->max_blocks;
+    t.tiles_per_block = (t.n_tiles + cap - 1) / cap;
+    if (t.tiles_per_block < 1) t.tiles_per_block = 1;
+    t.nblk = (t.n_tiles + t.tiles_per_block - 1) / t.tiles_per_block;
+    return t;
+}
+
 void plan_blocks(const tdk_dvo *h, const tdk_dvo::Level &L, int *nblk, int64_t *chunk) {
+    if (dvo_variant() == 8) {
+        *nblk = plan_tiles(h, L).nblk;
+        *chunk = 0;
+        return;
+    }
     // ~8 pixels per thread, but no more than ~8192 blocks in the whole grid
     int64_t per_block = (int64_t)kBlock * 2 * 4;
     int64_t nb = (L.N + per_block - 1) / per_block;
@@ -765,14 +939,88 @@ tdk_status upload_params(tdk_dvo *h, const double *cam0, const double *cam1) {
     return TDK_OK;
 }
 
+tdk_status ensure_robust_buffers(tdk_dvo *h) {
+    if (h->d_rm) return TDK_OK;
+    const size_t n = (size_t)h->n_pairs;
+    TDK_HIP(hipMalloc(&h->d_rm, sizeof(double) * (size_t)h->lv[0].stride * n));
+    TDK_HIP(hipMalloc(&h->d_wscale, sizeof(double) * n));
+    TDK_HIP(hipMalloc(&h->d_stat, sizeof(double) * 4 * n));
+    TDK_HIP(hipMalloc(&h->d_spartial, sizeof(double) * kStatBlocks * n));
+    TDK_HIP(hipMalloc(&h->d_count, sizeof(int) * n));
+    TDK_HIP(hipMalloc(&h->d_select, sizeof(SelectState) * n));
+    TDK_HIP(hipMalloc(&h->d_hist, sizeof(unsigned int) * 256 * n));
+    TDK_HIP(hipMemsetAsync(h->d_hist, 0, sizeof(unsigned int) * 256 * n, tdk::stream()));
+    return TDK_OK;
+}
+
+// median over each running pair's masked residuals (mode 0) or absolute
+// deviations from `center` (mode 1), times `factor` -> out[pair]
+tdk_status device_median(tdk_dvo *h, int level, const int *d_state, int mode, const double *center,
+                         double factor, double *out) {
+    const tdk_dvo::Level &L = h->lv[level];
+    const int n = h->n_pairs, tpb = 256, gp = (n + tpb - 1) / tpb;
+    dim3 grid(kStatBlocks, n);
+    double *lohi[2] = {h->d_stat, h->d_stat + n};
+    for (int which = 0; which < 2; which++) {
+        k_select_init<<<gp, tpb, 0, tdk::stream()>>>((SelectState *)h->d_select, h->d_count, n, which);
+        TDK_LAUNCH_CHECK();
+        for (int pass = 0; pass < 8; pass++) {
+            k_select_hist<<<grid, kBlock, 0, tdk::stream()>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center,
+                                                              (const SelectState *)h->d_select, pass, h->d_hist);
+            TDK_LAUNCH_CHECK();
+            k_select_pick<<<gp, tpb, 0, tdk::stream()>>>(h->d_hist, (SelectState *)h->d_select, d_state, n, pass,
+                                                         lohi[which]);
+            TDK_LAUNCH_CHECK();
+        }
+    }
+    k_median_combine<<<gp, tpb, 0, tdk::stream()>>>(lohi[0], lohi[1], d_state, n, factor, out);
+    TDK_LAUNCH_CHECK();
+    return TDK_OK;
+}
+
+// Student-t variance / Tukey sigma_mad of the masked residuals at `d_poses`
+tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const int *d_state, int weight_mode) {
+    if (weight_mode != TDK_W_STUDENT_T && weight_mode != TDK_W_TUKEY) return TDK_OK;
+    TDK_TRY(ensure_robust_buffers(h));
+    const tdk_dvo::Level &L = h->lv[level];
+    const int n = h->n_pairs, tpb = 256, gp = (n + tpb - 1) / tpb;
+    dim3 grid(kStatBlocks, n);
+    TDK_HIP(hipMemsetAsync(h->d_count, 0, sizeof(int) * n, tdk::stream()));
+    k_robust_mask<<<grid, kBlock, 0, tdk::stream()>>>(ptrs_of(L), h->d_params, d_poses, d_state, L.scale, h->d_rm,
+                                                      h->d_count);
+    TDK_LAUNCH_CHECK();
+    if (weight_mode == TDK_W_STUDENT_T) {
+        k_robust_student_update<<<gp, tpb, 0, tdk::stream()>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
+                                                               h->d_wscale, n, 1);
+        TDK_LAUNCH_CHECK();
+        for (int it = 0; it < 10; it++) {   // n_iter = 10 (weights.py:4)
+            k_robust_student_step<<<grid, kBlock, 0, tdk::stream()>>>(h->d_rm, L.stride, (int)L.N, d_state,
+                                                                      h->d_wscale, h->d_spartial);
+            TDK_LAUNCH_CHECK();
+            k_robust_student_update<<<gp, tpb, 0, tdk::stream()>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
+                                                                   h->d_wscale, n, 0);
+            TDK_LAUNCH_CHECK();
+        }
+    } else {
+        double *median = h->d_stat + 2 * (size_t)n;
+        TDK_TRY(device_median(h, level, d_state, 0, nullptr, 1.0, median));
+        TDK_TRY(device_median(h, level, d_state, 1, median, kTukeyC, h->d_wscale));  // c * MAD (:34)
+    }
+    return TDK_OK;
+}
+
 tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *d_state, int weight_mode) {
     const tdk_dvo::Level &L = h->lv[level];
+    TDK_TRY(prepare_robust(h, level, d_poses, d_state, weight_mode));
     int nblk;
     int64_t chunk;
     plan_blocks(h, L, &nblk, &chunk);
     dim3 grid(nblk, h->n_pairs);
     LevelPtrs P = ptrs_of(L);
-    const size_t lds = sizeof(double) * ((kBlock / 64) * kAccPad + (size_t)L.W + (size_t)L.H);
+    const size_t lds = sizeof(double) * (kWaves * kAccPad + (size_t)L.W + (size_t)L.H);
+    const size_t lds_tiled = sizeof(double) * (kWaves * kAccPad + kTW + kTH + (size_t)kWH * kWS);
+    const TilePlan tp = plan_tiles(h, L);
+    const bool tiled = dvo_variant() == 8;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling && level == 0) {
         while (h->ev_pool.size() < h->ev_used + 2) {
@@ -784,34 +1032,26 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
         e1 = h->ev_pool[h->ev_used++];
         TDK_HIP(hipEventRecord(e0, tdk::stream()));
     }
-    static const int variant = [] {
-        const char *v = getenv("TDK_DVO_VARIANT");
-        return v ? atoi(v) : 7;
-    }();
-#define TDK_EVAL_LAUNCH(WM, VA)                                                                        \
-    k_dvo_eval<WM, VA><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state, L.scale, \
-                                                             chunk, h->d_partials)
-#define TDK_EVAL_VARIANTS(WM)                     \
-    switch (variant) {                            \
-        case 1: TDK_EVAL_LAUNCH(WM, 1); break;    \
-        case 2: TDK_EVAL_LAUNCH(WM, 2); break;    \
-        case 3: TDK_EVAL_LAUNCH(WM, 3); break;    \
-        case 4: TDK_EVAL_LAUNCH(WM, 4); break;    \
-        case 5: TDK_EVAL_LAUNCH(WM, 5); break;    \
-        case 6: TDK_EVAL_LAUNCH(WM, 6); break;    \
-        case 0: TDK_EVAL_LAUNCH(WM, 0); break;    \
-        default: TDK_EVAL_LAUNCH(WM, 7); break;   \
-    }
+#define TDK_EVAL(WM)                                                                                          \
+    if (tiled)                                                                                                \
+        k_dvo_eval_tiled<WM><<<grid, kBlock, lds_tiled, tdk::stream()>>>(P, h->d_params, d_poses, d_state,    \
+                                                                         h->d_wscale, L.scale, tp.tiles_x,    \
+                                                                         tp.n_tiles, tp.tiles_per_block,      \
+                                                                         h->d_partials);                      \
+    else                                                                                                      \
+        k_dvo_eval<WM><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state, h->d_wscale,   \
+                                                             L.scale, chunk, h->d_partials)
     switch (weight_mode) {
-        case TDK_W_NONE: TDK_EVAL_VARIANTS(TDK_W_NONE); break;
-        case TDK_W_HUBER: TDK_EVAL_VARIANTS(TDK_W_HUBER); break;
-        case TDK_W_MAP: TDK_EVAL_VARIANTS(TDK_W_MAP); break;
+        case TDK_W_NONE: TDK_EVAL(TDK_W_NONE); break;
+        case TDK_W_HUBER: TDK_EVAL(TDK_W_HUBER); break;
+        case TDK_W_STUDENT_T: TDK_EVAL(TDK_W_STUDENT_T); break;
+        case TDK_W_TUKEY: TDK_EVAL(TDK_W_TUKEY); break;
+        case TDK_W_MAP: TDK_EVAL(TDK_W_MAP); break;
         default:
-            tdk::set_error("weight mode %d is not available on the fused path", weight_mode);
+            tdk::set_error("unknown weight mode %d", weight_mode);
             return TDK_ERR_INVALID_ARGUMENT;
     }
-#undef TDK_EVAL_VARIANTS
-#undef TDK_EVAL_LAUNCH
+#undef TDK_EVAL
     TDK_LAUNCH_CHECK();
     if (e1) TDK_HIP(hipEventRecord(e1, tdk::stream()));
     return TDK_OK;
@@ -838,8 +1078,8 @@ tdk_status check_weight_mode(const tdk_dvo *h, int weight_mode) {
         tdk::set_error("weight map requested but the batch was created without one");
         return TDK_ERR_INVALID_ARGUMENT;
     }
-    if (weight_mode != TDK_W_NONE && weight_mode != TDK_W_HUBER && weight_mode != TDK_W_MAP) {
-        tdk::set_error("weight mode %d is not available on the fused path", weight_mode);
+    if (weight_mode < TDK_W_NONE || weight_mode > TDK_W_MAP) {
+        tdk::set_error("unknown weight mode %d", weight_mode);
         return TDK_ERR_INVALID_ARGUMENT;
     }
     return TDK_OK;
@@ -856,6 +1096,24 @@ tdk_status collect_profile(tdk_dvo *h) {
     return TDK_OK;
 }
 
+// One pyramid level for the whole batch; poses live in h->ls.pose on entry and exit.
+tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64_t *pixel_evals) {
+    int running = h->n_pairs;
+    for (int iter = 0; iter <= max_iter; iter++) {
+        if (h->profiling && level == 0) h->prof_pixels += h->lv[0].N * (int64_t)running;
+        if (pixel_evals) *pixel_evals += h->lv[level].N * (int64_t)running;
+        TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, weight_mode));
+        TDK_TRY(launch_reduce(h, level, 1, iter, max_iter));
+        void *stage;
+        TDK_TRY(tdk::pinned(2, sizeof(int), &stage));
+        TDK_HIP(hipMemcpyAsync(stage, h->ls.active, sizeof(int), hipMemcpyDeviceToHost, tdk::stream()));
+        TDK_HIP(hipStreamSynchronize(tdk::stream()));
+        running = *(int *)stage;
+        if (running <= 0) break;
+    }
+    return TDK_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -865,7 +1123,7 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
     TDK_REQUIRE(out != nullptr, "out is NULL");
     TDK_REQUIRE(n_pairs >= 1 && n_pairs <= 65535, "n_pairs must be in [1, 65535]");
     TDK_REQUIRE(height >= 2 && width >= 2, "frames must be at least 2x2");
-    TDK_REQUIRE((int64_t)height * width < (1ll << 30), "frame too large");
+    TDK_REQUIRE((int64_t)height * width < (1ll << 28), "frame too large");
     TDK_REQUIRE(n_levels >= 1 && n_levels <= kMaxLevels, "n_levels must be in [1, 16]");
     TDK_REQUIRE(ratio > 1.0 || n_levels == 1, "layer_size_ratio must be > 1");
     TDK_TRY(tdk::ensure_device());
@@ -873,6 +1131,8 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
     h->n_pairs = n_pairs; h->H = height; h->W = width; h->n_levels = n_levels;
     h->ratio = ratio; h->with_w = with_weight_map != 0;
     h->max_blocks = 1024;
+    h->d_rm = nullptr; h->d_wscale = nullptr; h->d_stat = nullptr; h->d_spartial = nullptr;
+    h->d_count = nullptr; h->d_select = nullptr; h->d_hist = nullptr;
     h->profiling = false; h->ev_used = 0; h->prof_ms = 0; h->prof_launches = 0; h->prof_pixels = 0;
     for (int l = 0; l < n_levels; l++) {
         tdk_dvo::Level &L = h->lv[l];
@@ -918,6 +1178,11 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     (void)hipFree(h->d_results); (void)hipFree(h->ls.pose); (void)hipFree(h->ls.cand);
     (void)hipFree(h->ls.prev_err); (void)hipFree(h->ls.state); (void)hipFree(h->ls.n_evals);
     (void)hipFree(h->ls.active);
+    if (h->d_rm) {
+        (void)hipFree(h->d_rm); (void)hipFree(h->d_wscale); (void)hipFree(h->d_stat);
+        (void)hipFree(h->d_spartial); (void)hipFree(h->d_count); (void)hipFree(h->d_select);
+        (void)hipFree(h->d_hist);
+    }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
     return TDK_OK;
@@ -1021,24 +1286,6 @@ tdk_status tdk_dvo_evaluate(tdk_dvo *h, int level, const double *camera0, const 
     return TDK_OK;
 }
 
-// One pyramid level for the whole batch; poses live in h->ls.pose on entry and exit.
-static tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64_t *pixel_evals) {
-    int running = h->n_pairs;
-    for (int iter = 0; iter <= max_iter; iter++) {
-        if (h->profiling && level == 0) h->prof_pixels += h->lv[0].N * (int64_t)running;
-        if (pixel_evals) *pixel_evals += h->lv[level].N * (int64_t)running;
-        TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, weight_mode));
-        TDK_TRY(launch_reduce(h, level, 1, iter, max_iter));
-        void *stage;
-        TDK_TRY(tdk::pinned(2, sizeof(int), &stage));
-        TDK_HIP(hipMemcpyAsync(stage, h->ls.active, sizeof(int), hipMemcpyDeviceToHost, tdk::stream()));
-        TDK_HIP(hipStreamSynchronize(tdk::stream()));
-        running = *(int *)stage;
-        if (running <= 0) break;
-    }
-    return TDK_OK;
-}
-
 tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0, const double *camera1,
                                   double *poses12, int weight_mode, int max_iter, int *n_evals) {
     TDK_TRY(check_level(h, level));
@@ -1070,8 +1317,7 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
     if (pixel_evals) *pixel_evals = 0;
     for (int level = h->n_levels - 1; level >= 0; level--) {
         // the prior of a level is the result of the coarser one (:131-134)
-        const double *src = (level == h->n_levels - 1) ? h->d_poses_in : h->ls.pose;
-        if (src != h->d_poses_in) {
+        if (level != h->n_levels - 1) {
             TDK_HIP(hipMemcpyAsync(h->d_poses_in, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToDevice,
                                    tdk::stream()));
         }

@@ -89,7 +89,7 @@ def _pose12(T):
     return np.concatenate([T[:3, :3].ravel(), T[:3, 3]])
 
 
-@pytest.mark.parametrize("wname", [None, "huber", "map"])
+@pytest.mark.parametrize("wname", [None, "huber", "map", "student-t", "tukey"])
 def test_dvo_evaluate_vs_golden_small(ops, golden, wname):
     d = golden("dvo_small.npz")
     cam = d["cam"]
@@ -111,7 +111,7 @@ def test_dvo_evaluate_vs_golden_small(ops, golden, wname):
     batch.close()
 
 
-@pytest.mark.parametrize("wname", [None, "huber", "map"])
+@pytest.mark.parametrize("wname", [None, "huber", "map", "student-t", "tukey"])
 def test_dvo_level_loop_vs_golden_small(ops, golden, wname):
     d = golden("dvo_small.npz")
     cam = d["cam"]
