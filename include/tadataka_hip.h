@@ -200,6 +200,22 @@ tdk_status tdk_ba_block_reduce(const double *poses, int64_t n_poses, const doubl
                                int64_t n, double *U, double *ea, double *V, double *eb,
                                double *err);
 
+/* Sparse bundle-adjustment step on a fixed observation graph: what
+ * LocalBundleAdjustment.calc_update / calc_error obtain from the third-party
+ * sparseba.SBA.compute in the reference (tadataka/local_ba.py:72-86).  The
+ * handle keeps the index arrays, x_true and the per-point observation lists on
+ * the device.  tdk_ba_step returns the Levenberg-Marquardt update for damping mu
+ * (added to the diagonals of U_j and V_i) via the Schur complement on the pose
+ * block, plus sum ||x_true - x_pred||^2 at the input parameters. */
+typedef struct tdk_ba tdk_ba;
+tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *viewpoint_indices,
+                         const int64_t *point_indices, const double *x_true, int64_t n,
+                         tdk_ba **out);
+tdk_status tdk_ba_destroy(tdk_ba *h);
+tdk_status tdk_ba_error(tdk_ba *h, const double *poses, const double *points, double *sum_sq);
+tdk_status tdk_ba_step(tdk_ba *h, const double *poses, const double *points, double mu,
+                       double *dposes, double *dpoints, double *sum_sq);
+
 #ifdef __cplusplus
 }
 #endif

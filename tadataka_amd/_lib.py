@@ -35,6 +35,7 @@ TDK_ERR_HIP = -2
 TDK_ERR_OUT_OF_RANGE = -3
 TDK_ERR_AGE_EXCEEDS_REFFRAMES = -4
 TDK_ERR_NO_DEVICE = -5
+TDK_ERR_SINGULAR = -6
 
 W_NONE, W_HUBER, W_STUDENT_T, W_TUKEY, W_MAP = 0, 1, 2, 3, 4
 
@@ -83,6 +84,10 @@ PROTOTYPES = {
     "tdk_ba_projection": [_d, _i64, _d, _i64, c_int64_p, c_int64_p, _i64, _d, _d, _d],
     "tdk_ba_exp_so3": [_d, _i64, _d],
     "tdk_ba_block_reduce": [_d, _i64, _d, _i64, _d, c_int64_p, c_int64_p, _i64, _d, _d, _d, _d, _d],
+    "tdk_ba_create": [_i64, _i64, c_int64_p, c_int64_p, _d, _i64, C.POINTER(_vp)],
+    "tdk_ba_destroy": [_vp],
+    "tdk_ba_error": [_vp, _d, _d, _d],
+    "tdk_ba_step": [_vp, _d, _d, C.c_double, _d, _d, _d],
 }
 
 _lib = None

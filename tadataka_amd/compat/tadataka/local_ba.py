@@ -6,9 +6,9 @@ Projection.compute / .jacobians evaluate every observation in ONE device launch
 reduction that the sparse bundle-adjustment solve starts from.
 
 The Levenberg-Marquardt driver LocalBundleAdjustment wraps the third-party
-`sparseba` Schur solver in the reference (local_ba.py:72,77); that package is
-not part of this build, so constructing it raises ImportError
-unless sparseba is importable."""
+`sparseba` Schur solver in the reference (local_ba.py:72,77); here the Schur
+complement step runs on the device as well (tdk_ba_step, standard additive
+damping -- sparseba's exact damping convention is not pinned)."""
 import numpy as np
 
 from tadataka_amd import ops
@@ -55,21 +55,34 @@ def calc_error(x_true, x_pred):
 
 
 class LocalBundleAdjustment(object):
+    """Levenberg-Marquardt bundle adjustment (reference local_ba.py:60-134).
+
+    The reference obtains each update from the third-party `sparseba.SBA`
+    (per-observation Jacobians in, Schur solve on the CPU); here one device call
+    (tdk_ba_step) computes residuals, Jacobians, the block sums, the Schur
+    complement and the back-substitution for a given damping mu."""
+
     def __init__(self, viewpoint_indices, point_indices, x_true):
         assert(len(viewpoint_indices) == x_true.shape[0])
         assert(len(point_indices) == x_true.shape[0])
-        from sparseba import SBA          # third-party Schur solve, not in this build
         self.projection = Projection(viewpoint_indices, point_indices)
         self.x_true = x_true
-        self.sba = SBA(viewpoint_indices, point_indices)
+        self._graph = None
+
+    def _device_graph(self, poses, points):
+        if self._graph is None:
+            self._graph = ops.BundleAdjustment(len(poses), len(points),
+                                               self.projection.viewpoint_indices,
+                                               self.projection.point_indices, self.x_true)
+        return self._graph
 
     def calc_update(self, poses, points, mu):
-        x_pred = self.projection.compute(poses, points)
-        A, B = self.projection.jacobians(poses, points)
-        return self.sba.compute(self.x_true, x_pred, A, B, weights=None, mu=mu)
+        dposes, dpoints, _ = self._device_graph(poses, points).step(poses, points, mu)
+        return dposes, dpoints
 
     def calc_error(self, poses, points):
-        return calc_error(self.x_true, self.projection.compute(poses, points))
+        g = self._device_graph(poses, points)
+        return g.sum_squared_error(poses, points) / g.n
 
     def calc_new_error(self, poses, points, mu):
         dposes, dpoints = self.calc_update(poses, points, mu)
@@ -105,3 +118,15 @@ class LocalBundleAdjustment(object):
                 break
             current_error = new_error
         return poses[:, 0:3], poses[:, 3:6], points
+
+
+def run_ba(viewpoint_indices, point_indices, poses, points, keypoints_true):
+    """Poses in / out are tadataka.pose.Pose objects (reference local_ba.py:137-152)."""
+    from scipy.spatial.transform import Rotation
+    from tadataka.pose import Pose
+    ba = LocalBundleAdjustment(viewpoint_indices, point_indices, keypoints_true)
+    rotvecs = np.array([p.rotation.as_rotvec() for p in poses])
+    ts = np.array([p.t for p in poses])
+    rotvecs, ts, points = ba.compute(rotvecs, ts, points, absolute_error_threshold=1e-9,
+                                     max_iter=5, relative_error_threshold=0.20)
+    return [Pose(Rotation.from_rotvec(r), t) for r, t in zip(rotvecs, ts)], points

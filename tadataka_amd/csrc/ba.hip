@@ -14,6 +14,10 @@
 #include "tdk_runtime.h"
 
 #include <math.h>
+#include <string.h>
+
+#include <utility>
+#include <vector>
 
 namespace {
 
@@ -161,7 +165,8 @@ __global__ __launch_bounds__(kBlock) void k_ba_block_reduce(const double *__rest
                                                             const int64_t *__restrict__ pt, int64_t n,
                                                             int64_t chunk, int sorted_by_viewpoint,
                                                             double *__restrict__ V, double *__restrict__ eb,
-                                                            double *__restrict__ partials) {
+                                                            double *__restrict__ partials,
+                                                            double *__restrict__ Wobs) {
     const int64_t j = blockIdx.y;
     const int64_t start = blockIdx.x * chunk;
     const int64_t end = min(n, start + chunk);
@@ -196,6 +201,12 @@ __global__ __launch_bounds__(kBlock) void k_ba_block_reduce(const double *__rest
 #pragma unroll
                 for (int b = a; b < 3; b++) atomicAdd(&V[6 * ip + m++], B[a] * B[b] + B[3 + a] * B[3 + b]);
                 atomicAdd(&eb[3 * ip + a], B[a] * e0 + B[3 + a] * e1);
+            }
+            if (Wobs != nullptr) {   // W_ij = A^T B (6x3), kept for the Schur complement
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) Wobs[18 * k + 3 * a + b] = A[a] * B[b] + A[6 + a] * B[3 + b];
             }
         }
     }
@@ -236,6 +247,158 @@ __global__ __launch_bounds__(kBlock) void k_ba_finish(const double *__restrict__
         else if (threadIdx.x < 27) ea[6 * j + threadIdx.x - 21] = t;
         else err_per_pose[j] = t;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Sparse bundle adjustment step (Lourakis & Argyros' SBA, the formulation the
+// reference delegates to the third-party `sparseba` package, call site
+// tadataka/local_ba.py:72,77): with U_j, V_i, W_ij = A_ij^T B_ij and the
+// gradients ea_j, eb_i of the block reduce, damped by mu on the diagonals,
+//   Y_ij = W_ij V*_i^-1,   S_jk = delta_jk U*_j - sum_i Y_ij W_ik^T,
+//   e_j  = ea_j - sum_i Y_ij eb_i,   S da = e,
+//   db_i = V*_i^-1 (eb_i - sum_j W_ij^T da_j).
+// ---------------------------------------------------------------------------
+constexpr int kMaxLdsPoses = 12;   // (6 * 12)^2 doubles = 41 KB of LDS for the private S
+
+// inverse of the damped symmetric 3x3 V (upper triangle in, upper triangle out)
+__global__ __launch_bounds__(kBlock) void k_ba_invert_V(const double *__restrict__ V, double mu, int64_t n_points,
+                                                        double *__restrict__ Vinv) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n_points; i += (int64_t)gridDim.x * kBlock) {
+        double a = V[6 * i] + mu, b = V[6 * i + 1], c = V[6 * i + 2];
+        double d = V[6 * i + 3] + mu, e = V[6 * i + 4], f = V[6 * i + 5] + mu;
+        double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+        double det = a * c00 + b * c01 + c * c02;
+        double id = 1.0 / det;
+        Vinv[6 * i] = c00 * id;
+        Vinv[6 * i + 1] = c01 * id;
+        Vinv[6 * i + 2] = c02 * id;
+        Vinv[6 * i + 3] = (a * f - c * c) * id;
+        Vinv[6 * i + 4] = (b * c - a * e) * id;
+        Vinv[6 * i + 5] = (a * d - b * b) * id;
+    }
+}
+
+// One thread per point walks the point's observation list (CSR): subtracts
+// Y_ij W_ik^T from the (j, k) block of S for every pair of its observers and
+// Y_ij eb_i from e_j.  S is accumulated in an LDS-private copy per block when it
+// fits (few poses, heavy collisions), else directly with global atomics.
+template <bool LDS_S>
+__global__ __launch_bounds__(kBlock) void k_ba_schur(const int64_t *__restrict__ row_ptr,
+                                                     const int64_t *__restrict__ obs_of_point,
+                                                     const int64_t *__restrict__ vp,
+                                                     const double *__restrict__ Wobs,
+                                                     const double *__restrict__ Vinv,
+                                                     const double *__restrict__ eb, int64_t n_points, int dim,
+                                                     double *__restrict__ S, double *__restrict__ evec) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *Sl = reinterpret_cast<double *>(smem);
+    if (LDS_S) {
+        for (int i = threadIdx.x; i < dim * dim + dim; i += kBlock) Sl[i] = 0.0;
+        __syncthreads();
+    }
+    double *Sacc = LDS_S ? Sl : S;
+    double *eacc = LDS_S ? Sl + dim * dim : evec;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n_points; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t b0 = row_ptr[i], b1 = row_ptr[i + 1];
+        const double vi[6] = {Vinv[6 * i], Vinv[6 * i + 1], Vinv[6 * i + 2],
+                              Vinv[6 * i + 3], Vinv[6 * i + 4], Vinv[6 * i + 5]};
+        const double ebi[3] = {eb[3 * i], eb[3 * i + 1], eb[3 * i + 2]};
+        for (int64_t pa = b0; pa < b1; pa++) {
+            const int64_t ka = obs_of_point[pa];
+            const int ja = (int)vp[ka];
+            double Y[18];
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                double w0 = Wobs[18 * ka + 3 * r], w1 = Wobs[18 * ka + 3 * r + 1], w2 = Wobs[18 * ka + 3 * r + 2];
+                Y[3 * r] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
+                Y[3 * r + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
+                Y[3 * r + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++)
+                atomicAdd(&eacc[6 * ja + r], -(Y[3 * r] * ebi[0] + Y[3 * r + 1] * ebi[1] + Y[3 * r + 2] * ebi[2]));
+            for (int64_t pb = b0; pb < b1; pb++) {
+                const int64_t kb = obs_of_point[pb];
+                const int jb = (int)vp[kb];
+                if (jb < ja) continue;   // upper block triangle; mirrored on the host
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double w0 = Wobs[18 * kb + 3 * c], w1 = Wobs[18 * kb + 3 * c + 1], w2 = Wobs[18 * kb + 3 * c + 2];
+#pragma unroll
+                    for (int r = 0; r < 6; r++)
+                        atomicAdd(&Sacc[(6 * ja + r) * dim + 6 * jb + c],
+                                  -(Y[3 * r] * w0 + Y[3 * r + 1] * w1 + Y[3 * r + 2] * w2));
+                }
+            }
+        }
+    }
+    if (LDS_S) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < dim * dim; i += kBlock)
+            if (Sl[i] != 0.0) atomicAdd(&S[i], Sl[i]);
+        for (int i = threadIdx.x; i < dim; i += kBlock)
+            if (Sl[dim * dim + i] != 0.0) atomicAdd(&evec[i], Sl[dim * dim + i]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_ba_backsub(const int64_t *__restrict__ row_ptr,
+                                                       const int64_t *__restrict__ obs_of_point,
+                                                       const int64_t *__restrict__ vp,
+                                                       const double *__restrict__ Wobs,
+                                                       const double *__restrict__ Vinv,
+                                                       const double *__restrict__ eb,
+                                                       const double *__restrict__ da, int64_t n_points,
+                                                       double *__restrict__ db) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n_points; i += (int64_t)gridDim.x * kBlock) {
+        double g[3] = {eb[3 * i], eb[3 * i + 1], eb[3 * i + 2]};
+        for (int64_t pa = row_ptr[i]; pa < row_ptr[i + 1]; pa++) {
+            const int64_t k = obs_of_point[pa];
+            const double *d = da + 6 * vp[k];
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                g[0] -= Wobs[18 * k + 3 * r] * d[r];
+                g[1] -= Wobs[18 * k + 3 * r + 1] * d[r];
+                g[2] -= Wobs[18 * k + 3 * r + 2] * d[r];
+            }
+        }
+        const double *v = Vinv + 6 * i;
+        db[3 * i] = v[0] * g[0] + v[1] * g[1] + v[2] * g[2];
+        db[3 * i + 1] = v[1] * g[0] + v[3] * g[1] + v[4] * g[2];
+        db[3 * i + 2] = v[2] * g[0] + v[4] * g[1] + v[5] * g[2];
+    }
+}
+
+// dense solve of the reduced camera system (host, dimension 6 * n_poses) by
+// Gaussian elimination with partial pivoting: S is positive definite in exact
+// arithmetic, but with small damping and near-degenerate points its computed
+// Schur complement can lose definiteness by rounding, which LU tolerates.
+int dense_solve(std::vector<double> &M, std::vector<double> &rhs, int n) {
+    for (int c = 0; c < n; c++) {
+        int p = c;
+        double best = fabs(M[(size_t)c * n + c]);
+        for (int r = c + 1; r < n; r++) {
+            double v = fabs(M[(size_t)r * n + c]);
+            if (v > best) { best = v; p = r; }
+        }
+        if (!(best > 0.0)) return -1;
+        if (p != c) {
+            for (int k = 0; k < n; k++) std::swap(M[(size_t)c * n + k], M[(size_t)p * n + k]);
+            std::swap(rhs[(size_t)c], rhs[(size_t)p]);
+        }
+        const double piv = M[(size_t)c * n + c];
+        for (int r = c + 1; r < n; r++) {
+            const double f = M[(size_t)r * n + c] / piv;
+            if (f == 0.0) continue;
+            for (int k = c; k < n; k++) M[(size_t)r * n + k] -= f * M[(size_t)c * n + k];
+            rhs[(size_t)r] -= f * rhs[(size_t)c];
+        }
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = rhs[(size_t)i];
+        for (int k = i + 1; k < n; k++) s -= M[(size_t)i * n + k] * rhs[(size_t)k];
+        rhs[(size_t)i] = s / M[(size_t)i * n + i];
+    }
+    return 0;
 }
 
 tdk_status h2d(int slot, const void *host, size_t bytes, void **dev) {
@@ -333,7 +496,7 @@ tdk_status tdk_ba_block_reduce(const double *poses, int64_t n_poses, const doubl
         dim3 grid((unsigned)nchunks, (unsigned)n_poses);
         k_ba_block_reduce<<<grid, kBlock, 0, tdk::stream()>>>(
             (const double *)d_poses, (const double *)d_points, (const double *)d_xt, (const int64_t *)d_vp,
-            (const int64_t *)d_pt, n, chunk, sorted, (double *)d_V, (double *)d_eb, (double *)d_part);
+            (const int64_t *)d_pt, n, chunk, sorted, (double *)d_V, (double *)d_eb, (double *)d_part, nullptr);
         TDK_LAUNCH_CHECK();
     } else {
         TDK_HIP(hipMemsetAsync(d_part, 0, (size_t)n_poses * nchunks * kPoseAccPad * 8, tdk::stream()));
@@ -352,6 +515,171 @@ tdk_status tdk_ba_block_reduce(const double *poses, int64_t n_poses, const doubl
     double e = 0.0;
     for (int64_t j = 0; j < n_poses; j++) e += ((const double *)stage)[j];
     *err = e;
+    return TDK_OK;
+}
+
+}  // extern "C"
+
+struct tdk_ba {
+    int64_t n_poses, n_points, n;
+    int sorted;
+    int64_t chunk, nchunks;
+    double *d_poses, *d_points, *d_xt;
+    int64_t *d_vp, *d_pt, *d_row_ptr, *d_obs;
+    double *d_U, *d_ea, *d_V, *d_eb, *d_part, *d_err, *d_W, *d_Vinv, *d_S, *d_e, *d_da, *d_db;
+};
+
+namespace {
+
+tdk_status ba_reduce(tdk_ba *h, const double *poses, const double *points, bool with_W, double *err) {
+    TDK_HIP(hipMemcpyAsync(h->d_poses, poses, (size_t)h->n_poses * 48, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(h->d_points, points, (size_t)h->n_points * 24, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipMemsetAsync(h->d_V, 0, (size_t)h->n_points * 48, tdk::stream()));
+    TDK_HIP(hipMemsetAsync(h->d_eb, 0, (size_t)h->n_points * 24, tdk::stream()));
+    dim3 grid((unsigned)h->nchunks, (unsigned)h->n_poses);
+    k_ba_block_reduce<<<grid, kBlock, 0, tdk::stream()>>>(h->d_poses, h->d_points, h->d_xt, h->d_vp, h->d_pt, h->n,
+                                                          h->chunk, h->sorted, h->d_V, h->d_eb, h->d_part,
+                                                          with_W ? h->d_W : nullptr);
+    TDK_LAUNCH_CHECK();
+    k_ba_finish<<<(unsigned)h->n_poses, kBlock, 0, tdk::stream()>>>(h->d_part, (int)h->nchunks, h->d_U, h->d_ea,
+                                                                    h->d_err);
+    TDK_LAUNCH_CHECK();
+    std::vector<double> e((size_t)h->n_poses);
+    TDK_HIP(hipMemcpyAsync(e.data(), h->d_err, (size_t)h->n_poses * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    double s = 0.0;
+    for (double v : e) s += v;
+    *err = s;
+    return TDK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *vp, const int64_t *pt,
+                         const double *x_true, int64_t n, tdk_ba **out) {
+    TDK_REQUIRE(out && vp && pt && x_true, "null pointer");
+    TDK_REQUIRE(n >= 1 && n_poses >= 1 && n_points >= 1 && n_poses <= 2048, "bad sizes");
+    int sorted = 0;
+    TDK_TRY(check_indices(vp, pt, n, n_poses, n_points, &sorted));
+    TDK_TRY(tdk::ensure_device());
+    tdk_ba *h = new tdk_ba();
+    h->n_poses = n_poses; h->n_points = n_points; h->n = n; h->sorted = sorted;
+    h->chunk = 2048;
+    h->nchunks = (n + h->chunk - 1) / h->chunk;
+    if (h->nchunks > 4096) {
+        h->nchunks = 4096;
+        h->chunk = (n + h->nchunks - 1) / h->nchunks;
+        h->nchunks = (n + h->chunk - 1) / h->chunk;
+    }
+    // observation lists per point (CSR), in increasing observation index
+    std::vector<int64_t> row_ptr((size_t)n_points + 1, 0), obs((size_t)n);
+    for (int64_t k = 0; k < n; k++) row_ptr[(size_t)pt[k] + 1]++;
+    for (int64_t i = 0; i < n_points; i++) row_ptr[(size_t)i + 1] += row_ptr[(size_t)i];
+    {
+        std::vector<int64_t> cursor(row_ptr.begin(), row_ptr.end() - 1);
+        for (int64_t k = 0; k < n; k++) obs[(size_t)cursor[(size_t)pt[k]]++] = k;
+    }
+    const int dim = (int)(6 * n_poses);
+    TDK_HIP(hipMalloc(&h->d_poses, (size_t)n_poses * 48));
+    TDK_HIP(hipMalloc(&h->d_points, (size_t)n_points * 24));
+    TDK_HIP(hipMalloc(&h->d_xt, (size_t)n * 16));
+    TDK_HIP(hipMalloc(&h->d_vp, (size_t)n * 8));
+    TDK_HIP(hipMalloc(&h->d_pt, (size_t)n * 8));
+    TDK_HIP(hipMalloc(&h->d_row_ptr, ((size_t)n_points + 1) * 8));
+    TDK_HIP(hipMalloc(&h->d_obs, (size_t)n * 8));
+    TDK_HIP(hipMalloc(&h->d_U, (size_t)n_poses * 21 * 8));
+    TDK_HIP(hipMalloc(&h->d_ea, (size_t)n_poses * 6 * 8));
+    TDK_HIP(hipMalloc(&h->d_V, (size_t)n_points * 48));
+    TDK_HIP(hipMalloc(&h->d_eb, (size_t)n_points * 24));
+    TDK_HIP(hipMalloc(&h->d_part, (size_t)n_poses * h->nchunks * kPoseAccPad * 8));
+    TDK_HIP(hipMalloc(&h->d_err, (size_t)n_poses * 8));
+    TDK_HIP(hipMalloc(&h->d_W, (size_t)n * 18 * 8));
+    TDK_HIP(hipMalloc(&h->d_Vinv, (size_t)n_points * 48));
+    TDK_HIP(hipMalloc(&h->d_S, (size_t)dim * dim * 8));
+    TDK_HIP(hipMalloc(&h->d_e, (size_t)dim * 8));
+    TDK_HIP(hipMalloc(&h->d_da, (size_t)dim * 8));
+    TDK_HIP(hipMalloc(&h->d_db, (size_t)n_points * 24));
+    TDK_HIP(hipMemcpyAsync(h->d_xt, x_true, (size_t)n * 16, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(h->d_vp, vp, (size_t)n * 8, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(h->d_pt, pt, (size_t)n * 8, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(h->d_row_ptr, row_ptr.data(), row_ptr.size() * 8, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(h->d_obs, obs.data(), obs.size() * 8, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));   // the host vectors go out of scope
+    *out = h;
+    return TDK_OK;
+}
+
+tdk_status tdk_ba_destroy(tdk_ba *h) {
+    if (!h) return TDK_OK;
+    (void)hipStreamSynchronize(tdk::stream());
+    void *ptrs[] = {h->d_poses, h->d_points, h->d_xt, h->d_vp, h->d_pt, h->d_row_ptr, h->d_obs, h->d_U, h->d_ea,
+                    h->d_V, h->d_eb, h->d_part, h->d_err, h->d_W, h->d_Vinv, h->d_S, h->d_e, h->d_da, h->d_db};
+    for (void *p : ptrs) (void)hipFree(p);
+    delete h;
+    return TDK_OK;
+}
+
+tdk_status tdk_ba_error(tdk_ba *h, const double *poses, const double *points, double *sum_sq) {
+    TDK_REQUIRE(h && poses && points && sum_sq, "null pointer");
+    return ba_reduce(h, poses, points, false, sum_sq);
+}
+
+tdk_status tdk_ba_step(tdk_ba *h, const double *poses, const double *points, double mu, double *dposes,
+                       double *dpoints, double *sum_sq) {
+    TDK_REQUIRE(h && poses && points && dposes && dpoints && sum_sq, "null pointer");
+    TDK_REQUIRE(mu >= 0.0, "mu must be non-negative");
+    TDK_TRY(ba_reduce(h, poses, points, true, sum_sq));
+    const int dim = (int)(6 * h->n_poses);
+    const int gp = grid_for(h->n_points);
+    k_ba_invert_V<<<gp, kBlock, 0, tdk::stream()>>>(h->d_V, mu, h->n_points, h->d_Vinv);
+    TDK_LAUNCH_CHECK();
+    TDK_HIP(hipMemsetAsync(h->d_S, 0, (size_t)dim * dim * 8, tdk::stream()));
+    TDK_HIP(hipMemsetAsync(h->d_e, 0, (size_t)dim * 8, tdk::stream()));
+    int gs = gp > 1024 ? 1024 : gp;
+    if (h->n_poses <= kMaxLdsPoses) {
+        size_t lds = ((size_t)dim * dim + dim) * 8;
+        k_ba_schur<true><<<gs, kBlock, lds, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv,
+                                                             h->d_eb, h->n_points, dim, h->d_S, h->d_e);
+    } else {
+        k_ba_schur<false><<<gs, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv,
+                                                            h->d_eb, h->n_points, dim, h->d_S, h->d_e);
+    }
+    TDK_LAUNCH_CHECK();
+    std::vector<double> S((size_t)dim * dim), e((size_t)dim), U((size_t)h->n_poses * 21), ea((size_t)dim);
+    TDK_HIP(hipMemcpyAsync(S.data(), h->d_S, S.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(e.data(), h->d_e, e.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(U.data(), h->d_U, U.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(ea.data(), h->d_ea, ea.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    // S = blockdiag(U + mu I) - sum Y W^T (upper block triangle from the device), mirrored
+    for (int64_t j = 0; j < h->n_poses; j++) {
+        int m = 0;
+        for (int a = 0; a < 6; a++)
+            for (int b = a; b < 6; b++) {
+                double u = U[(size_t)j * 21 + m++] + (a == b ? mu : 0.0);
+                S[(size_t)(6 * j + a) * dim + 6 * j + b] += u;
+                if (a != b) S[(size_t)(6 * j + b) * dim + 6 * j + a] += u;
+            }
+    }
+    // the device accumulated full diagonal blocks (ja == jb) and the strictly
+    // upper off-diagonal blocks; mirror the latter
+    for (int r = 0; r < dim; r++)
+        for (int c = 0; c < dim; c++)
+            if (c / 6 > r / 6) S[(size_t)c * dim + r] = S[(size_t)r * dim + c];
+    for (int i = 0; i < dim; i++) e[(size_t)i] += ea[(size_t)i];
+    if (dense_solve(S, e, dim) != 0) {
+        tdk::set_error("reduced camera system is singular (mu = %g)", mu);
+        return TDK_ERR_SINGULAR;
+    }
+    memcpy(dposes, e.data(), (size_t)dim * 8);
+    TDK_HIP(hipMemcpyAsync(h->d_da, e.data(), (size_t)dim * 8, hipMemcpyHostToDevice, tdk::stream()));
+    k_ba_backsub<<<gp, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv, h->d_eb,
+                                                   h->d_da, h->n_points, h->d_db);
+    TDK_LAUNCH_CHECK();
+    TDK_HIP(hipMemcpyAsync(dpoints, h->d_db, (size_t)h->n_points * 24, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
     return TDK_OK;
 }
 

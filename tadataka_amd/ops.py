@@ -364,3 +364,42 @@ def ba_block_reduce(poses, points, x_true, viewpoint_indices, point_indices):
     call("tdk_ba_block_reduce", _p(poses), nP, _p(points), nQ, _p(xt), vp.ctypes.data_as(c_int64_p),
          pt.ctypes.data_as(c_int64_p), n, _p(U), _p(ea), _p(V), _p(eb), C.byref(err))
     return U, ea, V, eb, float(err.value)
+
+
+class BundleAdjustment(object):
+    """Device-resident observation graph for sparse bundle adjustment (tdk_ba)."""
+
+    def __init__(self, n_poses, n_points, viewpoint_indices, point_indices, x_true):
+        vp = np.ascontiguousarray(viewpoint_indices, dtype=np.int64)
+        pt = np.ascontiguousarray(point_indices, dtype=np.int64)
+        self.n = vp.shape[0]
+        xt = _f64(x_true, (self.n, 2))
+        self.n_poses, self.n_points = int(n_poses), int(n_points)
+        self._h = C.c_void_p()
+        call("tdk_ba_create", self.n_poses, self.n_points, vp.ctypes.data_as(c_int64_p),
+             pt.ctypes.data_as(c_int64_p), _p(xt), self.n, C.byref(self._h))
+
+    def close(self):
+        if self._h:
+            call("tdk_ba_destroy", self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sum_squared_error(self, poses, points):
+        poses = _f64(poses, (self.n_poses, 6)); points = _f64(points, (self.n_points, 3))
+        err = C.c_double()
+        call("tdk_ba_error", self._h, _p(poses), _p(points), C.byref(err))
+        return float(err.value)
+
+    def step(self, poses, points, mu):
+        """(dposes [P,6], dpoints [Q,3], sum ||e||^2 at the input parameters)."""
+        poses = _f64(poses, (self.n_poses, 6)); points = _f64(points, (self.n_points, 3))
+        dposes = np.empty_like(poses); dpoints = np.empty_like(points)
+        err = C.c_double()
+        call("tdk_ba_step", self._h, _p(poses), _p(points), float(mu), _p(dposes), _p(dpoints), C.byref(err))
+        return dposes, dpoints, float(err.value)

@@ -324,3 +324,97 @@ def test_local_ba_projection_and_transform_project(golden):
     assert U.shape == (64, 6, 6) and V.shape == (64, 3, 3)
     assert np.allclose(U[3], A[3].T @ A[3], rtol=1e-9) and np.allclose(V[5], B[5].T @ B[5], rtol=1e-9)
     assert abs(err / 64 - calc_error(g["x"][:64] + 1e-3, x)) < 1e-12
+
+
+# --- tests/test_local_ba.py:85-148: LM bundle adjustment converges ------------------------------
+def test_local_bundle_adjustment_converges_and_matches_dense_lm():
+    from tadataka.local_ba import LocalBundleAdjustment, Projection, calc_error
+    from tadataka_amd import ops
+    rng = np.random.default_rng(3939)
+    unit = lambda shape: rng.uniform(-1.0, 1.0, shape)
+    n_points, n_viewpoints = 5, 4
+    point_indices, viewpoint_indices = np.where(np.ones((n_points, n_viewpoints), dtype=bool))
+    projection = Projection(viewpoint_indices, point_indices)
+    omegas_true = np.pi * unit((n_viewpoints, 3))
+    translations_true = unit((n_viewpoints, 3))
+    points_true = unit((n_points, 3))
+    to_poses = lambda o, t: np.hstack((o, t))
+    keypoints_true = projection.compute(to_poses(omegas_true, translations_true), points_true)
+    local_ba = LocalBundleAdjustment(viewpoint_indices, point_indices, keypoints_true)
+
+    # one LM step equals the dense damped normal equations built from A, B
+    poses0 = to_poses(omegas_true + 1e-3 * unit(omegas_true.shape), translations_true + 1e-2 * unit(translations_true.shape))
+    points0 = points_true + 1e-2 * unit(points_true.shape)
+    mu = 0.37
+    dposes, dpoints = local_ba.calc_update(poses0, points0, mu)
+    x_pred = projection.compute(poses0, points0)
+    A, B = projection.jacobians(poses0, points0)
+    n = len(viewpoint_indices)
+    J = np.zeros((2 * n, 6 * n_viewpoints + 3 * n_points))
+    for k, (j, i) in enumerate(zip(viewpoint_indices, point_indices)):
+        J[2 * k:2 * k + 2, 6 * j:6 * j + 6] = A[k]
+        J[2 * k:2 * k + 2, 6 * n_viewpoints + 3 * i:6 * n_viewpoints + 3 * i + 3] = B[k]
+    e = (keypoints_true - x_pred).reshape(-1)
+    delta = np.linalg.solve(J.T @ J + mu * np.eye(J.shape[1]), J.T @ e)
+    # (random rotations up to pi put some points next to a camera plane: the
+    # system has condition ~1e7, so elimination order shows at the 1e-8 level;
+    # the well-posed geometry of test_bundle_adjustment_full_size_step holds 1e-6 relative)
+    assert np.allclose(dposes.reshape(-1), delta[:6 * n_viewpoints], rtol=1e-4, atol=1e-7)
+    assert np.allclose(dpoints.reshape(-1), delta[6 * n_viewpoints:], rtol=1e-4, atol=1e-7)
+    e_ref = calc_error(keypoints_true, x_pred)
+    assert abs(local_ba.calc_error(poses0, points0) - e_ref) <= 1e-12 * e_ref
+
+    def run(omegas1, translations1, points1):
+        E1 = calc_error(projection.compute(to_poses(omegas1, translations1), points1), keypoints_true)
+        omegas2, translations2, points2 = local_ba.compute(
+            omegas1, translations1, points1, max_iter=20,
+            absolute_error_threshold=1e-6, relative_error_threshold=1e-3)
+        E2 = calc_error(projection.compute(to_poses(omegas2, translations2), points2), keypoints_true)
+        assert(E2 < E1)
+        assert(E2 < 1e-6)
+
+    omegas_noisy = omegas_true + 0.001 * unit(omegas_true.shape)
+    translations_noisy = translations_true + 0.01 * unit(translations_true.shape)
+    points_noisy = points_true + 0.01 * unit(points_true.shape)
+    run(omegas_noisy, translations_true, points_true)
+    run(omegas_true, translations_noisy, points_true)
+    run(omegas_true, translations_true, points_noisy)
+    run(omegas_noisy, translations_noisy, points_noisy)
+
+
+def test_bundle_adjustment_full_size_step():
+    """BASELINE config 5 (8 poses x 50 000 points, all visible): one LM step
+    lowers the reprojection error; ragged visibility and many poses (global
+    atomics path) agree with the dense solve."""
+    from tadataka_amd import ops, synthetic
+    from tadataka.local_ba import Projection, calc_error
+    c = synthetic.make_ba_case()
+    proj = Projection(c["vp_idx"], c["pt_idx"])
+    x_true = proj.compute(c["poses"], c["points"])
+    g = ops.BundleAdjustment(8, 50000, c["vp_idx"], c["pt_idx"], x_true)
+    e0 = g.sum_squared_error(c["poses_noisy"], c["points_noisy"])
+    dposes, dpoints, e0b = g.step(c["poses_noisy"], c["points_noisy"], 1e-3)
+    assert abs(e0 - e0b) <= 1e-12 * e0
+    e1 = g.sum_squared_error(c["poses_noisy"] + dposes, c["points_noisy"] + dpoints)
+    assert e1 < 1e-3 * e0
+    g.close()
+    # 20 poses (> LDS-private limit), random 60 % visibility
+    rng = np.random.default_rng(0)
+    c = synthetic.make_ba_case(n_poses=20, n_points=300, seed=7)
+    keep = rng.uniform(0, 1, len(c["vp_idx"])) < 0.6
+    vp, pt = c["vp_idx"][keep], c["pt_idx"][keep]
+    proj = Projection(vp, pt)
+    x_true = proj.compute(c["poses"], c["points"])
+    g = ops.BundleAdjustment(20, 300, vp, pt, x_true)
+    mu = 0.05
+    dposes, dpoints, _ = g.step(c["poses_noisy"], c["points_noisy"], mu)
+    x_pred = proj.compute(c["poses_noisy"], c["points_noisy"])
+    A, B = proj.jacobians(c["poses_noisy"], c["points_noisy"])
+    J = np.zeros((2 * len(vp), 6 * 20 + 3 * 300))
+    for k, (j, i) in enumerate(zip(vp, pt)):
+        J[2 * k:2 * k + 2, 6 * j:6 * j + 6] = A[k]
+        J[2 * k:2 * k + 2, 120 + 3 * i:120 + 3 * i + 3] = B[k]
+    delta = np.linalg.solve(J.T @ J + mu * np.eye(J.shape[1]), J.T @ (x_true - x_pred).reshape(-1))
+    assert np.allclose(dposes.reshape(-1), delta[:120], rtol=1e-6, atol=1e-9)
+    assert np.allclose(dpoints.reshape(-1), delta[120:], rtol=1e-6, atol=1e-9)
+    g.close()
