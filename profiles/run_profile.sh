@@ -12,13 +12,13 @@ export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 2"
 cd /tmp
 # 1) per-kernel time
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace_stdout.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace_stdout.log" 2>&1
 # 2) HBM traffic, separate passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $BENCH > "$OUT/pmc_fetch_stdout.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- $BENCH > "$OUT/pmc_write_stdout.log" 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $BENCH > "$OUT/pmc_fetch_stdout.log" 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- $BENCH > "$OUT/pmc_write_stdout.log" 2>&1
 # 3) issue-side picture
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD --output-format csv -d "$OUT/pmc_sq" -o bench -- $BENCH > "$OUT/pmc_sq_stdout.log" 2>&1
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d "$OUT/pmc_sq2" -o bench -- $BENCH > "$OUT/pmc_sq2_stdout.log" 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD --output-format csv -d "$OUT/pmc_sq" -o bench -- $BENCH > "$OUT/pmc_sq_stdout.log" 2>&1
+timeout 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM --output-format csv -d "$OUT/pmc_sq2" -o bench -- $BENCH > "$OUT/pmc_sq2_stdout.log" 2>&1
 cd "$ROOT"
 find "$OUT" -name "*.csv" | head -50
 python "$ROOT/profiles/summarize.py" "$OUT" > "$OUT/summary.txt" 2>&1

@@ -146,15 +146,29 @@ struct Taps {   // the 12 I1 texels around (c0, r0): rows r0-1 .. r0+2
     double t0, t1, a0, a1, a2, a3, b0, b1, b2, b3, u0, u1;
 };
 
+// Two adjacent texels with one 16-byte load (8-byte aligned only: the address
+// follows the warped coordinate).  The kernel is bound by the L1 (TCP) request
+// rate -- ~20 tag look-ups per 64-lane gather instruction -- so halving the
+// number of gather instructions matters more than the bytes they move.
+typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
+
+__device__ __forceinline__ double2_u ldo2(const double *__restrict__ base, uint32_t byte_off) {
+    return *reinterpret_cast<const double2_u *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 __device__ __forceinline__ Taps load_taps_inside(const double *__restrict__ I1, int W, const Warped &p) {
     const uint32_t rowb = (uint32_t)W * 8u;
     const uint32_t o0 = (uint32_t)(p.r0 * W + p.c0) * 8u;   // texel (r0, c0)
     const uint32_t om = o0 - rowb, o1 = o0 + rowb, o2 = o1 + rowb;
+    const double2_u tm = ldo2(I1, om);
+    const double2_u a01 = ldo2(I1, o0 - 8u), a23 = ldo2(I1, o0 + 8u);
+    const double2_u b01 = ldo2(I1, o1 - 8u), b23 = ldo2(I1, o1 + 8u);
+    const double2_u u01 = ldo2(I1, o2);
     Taps t;
-    t.t0 = ldo(I1, om); t.t1 = ldo(I1, om + 8u);
-    t.a0 = ldo(I1, o0 - 8u); t.a1 = ldo(I1, o0); t.a2 = ldo(I1, o0 + 8u); t.a3 = ldo(I1, o0 + 16u);
-    t.b0 = ldo(I1, o1 - 8u); t.b1 = ldo(I1, o1); t.b2 = ldo(I1, o1 + 8u); t.b3 = ldo(I1, o1 + 16u);
-    t.u0 = ldo(I1, o2); t.u1 = ldo(I1, o2 + 8u);
+    t.t0 = tm.x; t.t1 = tm.y;
+    t.a0 = a01.x; t.a1 = a01.y; t.a2 = a23.x; t.a3 = a23.y;
+    t.b0 = b01.x; t.b1 = b01.y; t.b2 = b23.x; t.b3 = b23.y;
+    t.u0 = u01.x; t.u1 = u01.y;
     return t;
 }
 
@@ -203,10 +217,11 @@ __device__ __forceinline__ void gradient_clamped(const Taps &t, const Warped &p,
 template <int WMODE>
 __device__ __forceinline__ double robust_weight(double r, double w0, double ws) {
     if (WMODE == TDK_W_HUBER) {
-        double ar = fabs(r);
-        // |r| <= 1 < k on [0, 1] images (F4): the division is off the hot path
-        if (__builtin_amdgcn_ballot_w64(ar > kHuberK) != 0) return ar > kHuberK ? kHuberK / ar : 1.0;
-        return 1.0;
+        // |r| <= 1 < k on [0, 1] images (F4): the division sits behind a branch
+        // that is skipped unless some lane of the wave has an outlier
+        double ar = fabs(r), w = 1.0;
+        if (ar > kHuberK) w = kHuberK / ar;
+        return w;
     }
     if (WMODE == TDK_W_MAP) return w0;
     if (WMODE == TDK_W_STUDENT_T) return sqrt((kStudentNu + 1.0) / (kStudentNu + (r * r) / ws));
@@ -244,8 +259,7 @@ __device__ __forceinline__ void accumulate(Accum &a, const Warped &p, const Taps
 
     double r = i0 - i1;  // un-warped residual (vo/dvo/__init__.py:90)
     double w = robust_weight<WMODE>(r, w0, ws);
-    const bool unit_w = (WMODE == TDK_W_NONE) ||
-                        (WMODE == TDK_W_HUBER && __builtin_amdgcn_ballot_w64(w != 1.0) == 0);
+    const bool unit_w = (WMODE == TDK_W_NONE);
     int k = 0;
 #pragma unroll
     for (int i = 0; i < 6; i++) {
@@ -1104,6 +1118,9 @@ tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64
         if (pixel_evals) *pixel_evals += h->lv[level].N * (int64_t)running;
         TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, weight_mode));
         TDK_TRY(launch_reduce(h, level, 1, iter, max_iter));
+        // (skipping this host look after evaluation 0 was measured SLOWER: 4.95 vs
+        // 4.08 ms per bench step -- back-to-back launches without the gap lose more
+        // than the 20 us round trip costs)
         void *stage;
         TDK_TRY(tdk::pinned(2, sizeof(int), &stage));
         TDK_HIP(hipMemcpyAsync(stage, h->ls.active, sizeof(int), hipMemcpyDeviceToHost, tdk::stream()));

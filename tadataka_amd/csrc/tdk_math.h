@@ -152,12 +152,53 @@ TDK_HD void compose_update(const double *xi, const double *pose, double *out) {
     }
 }
 
+// Cholesky solve of the (diagonally pre-scaled) 6x6 system; returns false when a
+// pivot is not safely positive, i.e. the system is numerically rank deficient.
+TDK_HD bool solve6_cholesky(const double *H21, const double *b, double *x) {
+    double A[6][6], s[6], y[6];
+    int k = 0;
+    for (int i = 0; i < 6; i++)
+        for (int j = i; j < 6; j++) { A[i][j] = H21[k]; A[j][i] = H21[k]; k++; }
+    for (int i = 0; i < 6; i++) {
+        if (!(A[i][i] > 0.0)) return false;
+        s[i] = 1.0 / sqrt(A[i][i]);
+    }
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 6; j++) A[i][j] *= s[i] * s[j];   // unit diagonal
+    for (int j = 0; j < 6; j++) {
+        double d = A[j][j];
+        for (int m = 0; m < j; m++) d -= A[j][m] * A[j][m];
+        if (!(d > 1e-10)) return false;   // scaled pivot: cond(J) beyond ~1e5 goes to the eigen path
+        d = sqrt(d);
+        A[j][j] = d;
+        for (int i = j + 1; i < 6; i++) {
+            double v = A[i][j];
+            for (int m = 0; m < j; m++) v -= A[i][m] * A[j][m];
+            A[i][j] = v / d;
+        }
+    }
+    for (int i = 0; i < 6; i++) {
+        double v = s[i] * b[i];
+        for (int m = 0; m < i; m++) v -= A[i][m] * y[m];
+        y[i] = v / A[i][i];
+    }
+    for (int i = 5; i >= 0; i--) {
+        double v = y[i];
+        for (int m = i + 1; m < 6; m++) v -= A[m][i] * x[m];
+        x[i] = v / A[i][i];
+    }
+    for (int i = 0; i < 6; i++) x[i] *= s[i];
+    return true;
+}
+
 // Solves the 6x6 SPD system given as upper triangle H21 (row-major) and b:
 // the normal-equation form of solve_linear_equation (tadataka/math.py:32-45).
-// Cyclic Jacobi eigen-decomposition with a relative eigenvalue cut-off, i.e.
-// the minimum-norm least-squares solution lstsq returns when J is rank
-// deficient.  Returns the number of eigenvalues kept.
+// Well-conditioned systems take the Cholesky path; otherwise a cyclic Jacobi
+// eigen-decomposition with a relative eigenvalue cut-off gives the minimum-norm
+// least-squares solution, as lstsq does when J is rank deficient.  Returns the
+// number of eigen-directions used.
 TDK_HD int solve6(const double *H21, const double *b, double *x) {
+    if (solve6_cholesky(H21, b, x)) return 6;
     double A[6][6], V[6][6];
     int k = 0;
     for (int i = 0; i < 6; i++)
