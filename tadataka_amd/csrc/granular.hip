@@ -149,6 +149,91 @@ __global__ __launch_bounds__(256) void k_rescale(const double *__restrict__ src,
 
 }  // namespace
 
+namespace {
+
+// ---------------------------------------------------------------------------
+// Whole pyramid in one pass over the full-resolution frames.
+//
+// _estimate_at rescales the ORIGINAL I0/D0/I1/W0 for every level
+// (tadataka/vo/dvo/__init__.py:144-148), so building the levels one by one reads
+// level 0 (n_levels - 1) times.  Here a block stages one source tile (plus a
+// 1-texel reflected halo) in LDS once and emits, for every level, exactly the
+// output pixels whose lower tap (floor of the sample position) lies in its tile
+// -- a partition of each level's pixels that needs no inter-block agreement.
+// Per-pixel arithmetic is k_rescale's, so the result is bit-identical.
+// ---------------------------------------------------------------------------
+constexpr int kPyrTW = 94, kPyrTH = 32;   // 94 source columns -> <= 64 outputs per row at ratio 1.5
+constexpr int kPyrLW = kPyrTW + 2, kPyrLH = kPyrTH + 2;
+
+struct PyrLevel {
+    double *dst[4];
+    int64_t stride;
+    int Ho, Wo;
+};
+
+struct PyrArgs {
+    const double *src[4];
+    int64_t src_stride;
+    int H, W, n_arrays, n_out;   // n_out = levels to produce (levels 1 .. n_out)
+    PyrLevel lv[15];
+};
+
+__device__ __forceinline__ int reflect_fast(int i, int n) {
+    return ((unsigned)i < (unsigned)n) ? i : reflect_idx((int64_t)i, n);
+}
+
+// first output index o in [0, n_out] whose lower tap max(floor((o + 0.5) s - 0.5), 0) is >= s0
+__device__ __forceinline__ int first_owned(int s0, double s, int n_out) {
+    int o = (int)ceil(((double)s0 + 0.5) / s - 0.5);
+    o = max(0, min(o, n_out));
+    while (o > 0 && max((int)floor(((double)(o - 1) + 0.5) * s - 0.5), 0) >= s0) o--;
+    while (o < n_out && max((int)floor(((double)o + 0.5) * s - 0.5), 0) < s0) o++;
+    return o;
+}
+
+__global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
+    __shared__ double tile[kPyrLH][kPyrLW];
+    const int arr = blockIdx.z % a.n_arrays, pair = blockIdx.z / a.n_arrays;
+    const double *src = a.src[arr] + (int64_t)pair * a.src_stride;
+    const int sx0 = blockIdx.x * kPyrTW, sy0 = blockIdx.y * kPyrTH;
+    const int sx1 = min(sx0 + kPyrTW, a.W), sy1 = min(sy0 + kPyrTH, a.H);
+    const int lw = sx1 - sx0 + 2, lh = sy1 - sy0 + 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // LDS position (r, c) holds source texel (sy0 - 1 + r, sx0 - 1 + c), reflected
+    for (int r = wave; r < lh; r += 4) {
+        const double *row = src + (int64_t)reflect_fast(sy0 - 1 + r, a.H) * a.W;
+        for (int c = lane; c < lw; c += 64) tile[r][c] = row[reflect_fast(sx0 - 1 + c, a.W)];
+    }
+    __syncthreads();
+    for (int l = 0; l < a.n_out; l++) {
+        const PyrLevel &L = a.lv[l];
+        const double sy = (double)a.H / (double)L.Ho, sx = (double)a.W / (double)L.Wo;
+        // this tile owns the outputs whose (clamped) lower tap lies inside it;
+        // the last tile also takes whatever maps beyond the image edge
+        const int ox_lo = first_owned(sx0, sx, L.Wo), oy_lo = first_owned(sy0, sy, L.Ho);
+        const int ox_hi = sx1 >= a.W ? L.Wo : first_owned(sx1, sx, L.Wo);
+        const int oy_hi = sy1 >= a.H ? L.Ho : first_owned(sy1, sy, L.Ho);
+        double *dst = L.dst[arr] + (int64_t)pair * L.stride;
+        for (int oy = oy_lo + wave; oy < oy_hi; oy += 4) {
+            double cy = ((double)oy + 0.5) * sy - 0.5;
+            double fy0 = floor(cy);
+            const double wy = cy - fy0;
+            const int r = (int)fy0 - (sy0 - 1);
+            for (int ox = ox_lo + lane; ox < ox_hi; ox += 64) {
+                double cx = ((double)ox + 0.5) * sx - 0.5;
+                double fx0 = floor(cx);
+                const double wx = cx - fx0;
+                const int c = (int)fx0 - (sx0 - 1);
+                double top = tile[r][c] * (1.0 - wx) + tile[r][c + 1] * wx;
+                double bot = tile[r + 1][c] * (1.0 - wx) + tile[r + 1][c + 1] * wx;
+                dst[(int64_t)oy * L.Wo + ox] = top * (1.0 - wy) + bot * wy;
+            }
+        }
+    }
+}
+
+}  // namespace
+
 namespace tdk {
 
 // Used by dvo.hip to build pyramid levels of device-resident batches; lives in
@@ -157,6 +242,33 @@ tdk_status launch_rescale(const double *src, int H, int W, double *dst, int Ho, 
                           int64_t src_stride, int64_t dst_stride) {
     dim3 grid(grid_for((int64_t)Ho * Wo), batch);
     k_rescale<<<grid, 256, 0, tdk::stream()>>>(src, H, W, dst, Ho, Wo, src_stride, dst_stride);
+    TDK_LAUNCH_CHECK();
+    return TDK_OK;
+}
+
+// All pyramid levels of all arrays of a batch in one launch.  srcs/dsts hold
+// n_arrays device pointers per level (level-major for dsts).
+tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride,
+                          int n_out, const PyramidLevelDesc *levels, int batch) {
+    if (n_out <= 0) return TDK_OK;
+    if (n_out > 15 || n_arrays > 4) {
+        set_error("pyramid too deep");
+        return TDK_ERR_INVALID_ARGUMENT;
+    }
+    PyrArgs a;
+    for (int i = 0; i < 4; i++) a.src[i] = i < n_arrays ? srcs[i] : nullptr;
+    a.src_stride = src_stride; a.H = H; a.W = W; a.n_arrays = n_arrays; a.n_out = n_out;
+    for (int l = 0; l < n_out; l++) {
+        for (int i = 0; i < 4; i++) a.lv[l].dst[i] = i < n_arrays ? levels[l].dst[i] : nullptr;
+        a.lv[l].stride = levels[l].stride; a.lv[l].Ho = levels[l].H; a.lv[l].Wo = levels[l].W;
+        // the tile partition assumes a downscale (sample step >= 1 texel)
+        if (levels[l].H > H || levels[l].W > W) {
+            set_error("pyramid levels must not be larger than level 0");
+            return TDK_ERR_INVALID_ARGUMENT;
+        }
+    }
+    dim3 grid((W + kPyrTW - 1) / kPyrTW, (H + kPyrTH - 1) / kPyrTH, batch * n_arrays);
+    k_pyramid<<<grid, 256, 0, tdk::stream()>>>(a);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }

@@ -26,6 +26,15 @@ tdk_status pinned(int slot, size_t bytes, void **ptr);
 tdk_status launch_rescale(const double *src, int H, int W, double *dst, int Ho, int Wo, int batch,
                           int64_t src_stride, int64_t dst_stride);
 
+// granular.hip: every pyramid level of `n_arrays` arrays from one pass over level 0
+struct PyramidLevelDesc {
+    double *dst[4];
+    int64_t stride;
+    int H, W;
+};
+tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride,
+                          int n_out, const PyramidLevelDesc *levels, int batch);
+
 }  // namespace tdk
 
 #define TDK_HIP(call)                                                                   \
