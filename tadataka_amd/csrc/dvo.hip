@@ -61,6 +61,7 @@ constexpr double kStudentNu = 5.0;    // :4
 
 struct LevelPtrs {
     const double *I0, *D0, *I1, *W0;
+    const double *tab;  // [n_pairs][W + H] normalised pixel coordinates of camera 0 (k_norm_tables)
     int64_t stride;  // elements between consecutive pairs
     int H, W;
     int64_t N;
@@ -293,18 +294,75 @@ __device__ __forceinline__ void process_pixel(Accum &a, double xn, double yn, do
     accumulate<WMODE>(a, p, t, gx, gy, i0, i1, w0, ws, c);
 }
 
-// Block-level tail shared by both evaluation kernels: wave64 shuffle reduction,
-// LDS across the waves, one partial per block.
+// a[lanes 32..63] <-> b[lanes 0..31] (v_permlane32_swap, gfx950)
+__device__ __forceinline__ void swap_halves(double &a, double &b) {
+    auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+// a[rows 1, 3] <-> b[rows 0, 2] (v_permlane16_swap, rows of 16 lanes)
+__device__ __forceinline__ void swap_rows(double &a, double &b) {
+    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    a = __hiloint2double((int)hi[0], (int)lo[0]);
+    b = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+// Wave64 sum of all 30 accumulators at once.  Every halving step folds two
+// accumulators into one register (each half of the lanes keeps one of them and
+// hands the other to its partner), so 32 -> 16 -> 8 -> 4 -> 2 -> 1 registers
+// take 31 exchanges instead of 30 * 6: lanes 2j and 2j+1 end up holding the
+// wave total of accumulator j.  Cross-row steps are v_permlane{32,16}_swap,
+// in-row steps are DPP mirrors; nothing goes through LDS.
+__device__ __forceinline__ double wave_sum_transposed(const Accum &acc) {
+    const int lane = threadIdx.x & 63;
+    double v[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) v[k] = k < kAcc ? acc.v[k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {   // lane bit 5 selects accumulator bit 4
+        swap_halves(v[k], v[k + 16]);
+        v[k] += v[k + 16];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {    // lane bit 4 -> bit 3
+        swap_rows(v[k], v[k + 8]);
+        v[k] += v[k + 8];
+    }
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {    // lane i <-> 15 - i within a row: bit 3 -> bit 2
+        const double keep = b3 ? v[k + 4] : v[k], send = b3 ? v[k] : v[k + 4];
+        v[k] = keep + dpp_move<0x140>(send);   // row_mirror
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {    // i <-> 7 - i within 8 lanes: bit 2 -> bit 1
+        const double keep = b2 ? v[k + 2] : v[k], send = b2 ? v[k] : v[k + 2];
+        v[k] = keep + dpp_move<0x141>(send);   // row_half_mirror
+    }
+    {                                // i <-> 3 - i within a quad: bit 1 -> bit 0
+        const double keep = b1 ? v[1] : v[0], send = b1 ? v[0] : v[1];
+        v[0] = keep + dpp_move<0x1B>(send);    // quad_perm [3,2,1,0]
+    }
+    return v[0] + dpp_move<0xB1>(v[0]);        // quad_perm [1,0,3,2]
+}
+
+// Block-level tail shared by both evaluation kernels: wave64 reduction, LDS
+// across the waves, one partial per block.
 __device__ __forceinline__ void store_partials(const Accum &acc, double (*red)[kAccPad], int pair,
                                                double *__restrict__ partials) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < kAcc; k++) {
-        double s = acc.v[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane == 0) red[wave][k] = s;
-    }
+    const double s = wave_sum_transposed(acc);
+    if ((lane & 1) == 0) red[wave][lane >> 1] = s;
     __syncthreads();
     if (threadIdx.x < kAcc) {
         double s = 0.0;
@@ -330,6 +388,21 @@ __device__ __forceinline__ void load_setup(BlockSetup &b, const PairParams *__re
     b.ox0 = pp.cam0[2] * scale; b.oy0 = pp.cam0[3] * scale;
 }
 
+// tab[pair][0 .. W) = (x - ox) / fx, tab[pair][W .. W + H) = (y - oy) / fy of the
+// level-scaled camera 0 (rust_bindings.camera.normalize_in_place, src/camera.rs):
+// they depend on the pair and the level only, so they are built when the
+// cameras are uploaded and the evaluation blocks just copy them into LDS.
+__global__ void k_norm_tables(const PairParams *__restrict__ params, double scale, int W, int H,
+                              double *__restrict__ tab) {
+    const int pair = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= W + H) return;
+    const PairParams pp = params[pair];
+    const double fx0 = pp.cam0[0] * scale, fy0 = pp.cam0[1] * scale;
+    const double ox0 = pp.cam0[2] * scale, oy0 = pp.cam0[3] * scale;
+    tab[(size_t)pair * (W + H) + i] = i < W ? ((double)i - ox0) / fx0 : ((double)(i - W) - oy0) / fy0;
+}
+
 // ---------------------------------------------------------------------------
 // k_dvo_eval: contiguous pixel ranges, taps gathered through L1/L2.
 // ---------------------------------------------------------------------------
@@ -347,13 +420,15 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
 
     // LDS: [0, 1 KiB) cross-wave reduction scratch, then the normalised
     // coordinate tables xn[W], yn[H] = (u - o) / f of camera 0 (one true
-    // division per row / column instead of two per pixel)
+    // division per row / column of the pair, done once by k_norm_tables)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double(*red)[kAccPad] = reinterpret_cast<double(*)[kAccPad]>(smem);
     double *xn_tab = reinterpret_cast<double *>(smem + sizeof(double) * kWaves * kAccPad);
     double *yn_tab = xn_tab + L.W;
-    for (int i = threadIdx.x; i < L.W; i += kBlock) xn_tab[i] = ((double)i - b.ox0) / b.fx0;
-    for (int i = threadIdx.x; i < L.H; i += kBlock) yn_tab[i] = ((double)i - b.oy0) / b.fy0;
+    {
+        const double *__restrict__ tab = L.tab + (size_t)pair * (L.W + L.H);
+        for (int i = threadIdx.x; i < L.W + L.H; i += kBlock) xn_tab[i] = tab[i];
+    }
     __syncthreads();
 
     const int64_t base = (int64_t)pair * L.stride;
@@ -851,6 +926,7 @@ struct tdk_dvo {
         int64_t N, stride;
         double scale;
         double *I0, *D0, *I1, *W0;
+        double *tab;   // [n_pairs][W + H], see k_norm_tables
     } lv[kMaxLevels];
     PairParams *d_params;
     double *d_poses_in;  // [n][12] host-provided poses for evaluate()
@@ -915,9 +991,11 @@ void plan_blocks(const tdk_dvo *h, const tdk_dvo::Level &L, int *nblk, int64_t *
         return;
     }
     // ~8 pixels per thread, but no more than ~8192 blocks in the whole grid
-    int64_t per_block = (int64_t)kBlock * 2 * 4;
+    static const int px_per_thread = getenv("TDK_DVO_PX") ? atoi(getenv("TDK_DVO_PX")) : 8;
+    static const int max_grid = getenv("TDK_DVO_GRID") ? atoi(getenv("TDK_DVO_GRID")) : 8192;
+    int64_t per_block = (int64_t)kBlock * px_per_thread;
     int64_t nb = (L.N + per_block - 1) / per_block;
-    int64_t cap = 8192 / h->n_pairs;
+    int64_t cap = max_grid / h->n_pairs;
     if (cap < 1) cap = 1;
     if (nb > cap) nb = cap;
     if (nb > h->max_blocks) nb = h->max_blocks;
@@ -931,7 +1009,7 @@ void plan_blocks(const tdk_dvo *h, const tdk_dvo::Level &L, int *nblk, int64_t *
 
 LevelPtrs ptrs_of(const tdk_dvo::Level &L) {
     LevelPtrs p;
-    p.I0 = L.I0; p.D0 = L.D0; p.I1 = L.I1; p.W0 = L.W0;
+    p.I0 = L.I0; p.D0 = L.D0; p.I1 = L.I1; p.W0 = L.W0; p.tab = L.tab;
     p.stride = L.stride; p.H = L.H; p.W = L.W; p.N = L.N;
     return p;
 }
@@ -948,6 +1026,12 @@ tdk_status upload_params(tdk_dvo *h, const double *cam0, const double *cam1) {
     }
     TDK_HIP(hipMemcpyAsync(h->d_params, pp, sizeof(PairParams) * h->n_pairs, hipMemcpyHostToDevice,
                            tdk::stream()));
+    for (int l = 0; l < h->n_levels; l++) {
+        const tdk_dvo::Level &L = h->lv[l];
+        dim3 grid((L.W + L.H + 255) / 256, h->n_pairs);
+        k_norm_tables<<<grid, 256, 0, tdk::stream()>>>(h->d_params, L.scale, L.W, L.H, L.tab);
+        TDK_LAUNCH_CHECK();
+    }
     // the staging buffer is reused by the next call: wait for the copy
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
     return TDK_OK;
@@ -1169,6 +1253,7 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
         TDK_HIP(hipMalloc(&L.D0, bytes));
         TDK_HIP(hipMalloc(&L.I1, bytes));
         if (h->with_w) TDK_HIP(hipMalloc(&L.W0, bytes));
+        TDK_HIP(hipMalloc(&L.tab, sizeof(double) * (size_t)(L.W + L.H) * n_pairs));
     }
     TDK_HIP(hipMalloc(&h->d_params, sizeof(PairParams) * n_pairs));
     TDK_HIP(hipMalloc(&h->d_poses_in, sizeof(double) * 12 * n_pairs));
@@ -1190,6 +1275,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     for (int l = 0; l < h->n_levels; l++) {
         (void)hipFree(h->lv[l].I0); (void)hipFree(h->lv[l].D0); (void)hipFree(h->lv[l].I1);
         if (h->lv[l].W0) (void)hipFree(h->lv[l].W0);
+        (void)hipFree(h->lv[l].tab);
     }
     (void)hipFree(h->d_params); (void)hipFree(h->d_poses_in); (void)hipFree(h->d_partials);
     (void)hipFree(h->d_results); (void)hipFree(h->ls.pose); (void)hipFree(h->ls.cand);
@@ -1242,13 +1328,18 @@ tdk_status tdk_dvo_build_pyramid(tdk_dvo *h) {
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     const tdk_dvo::Level &S = h->lv[0];
     // every level is resampled from the full-resolution frame, exactly as
-    // _estimate_at rescales the original I0/D0/I1/W0 (vo/dvo/__init__.py:144-148);
-    // TDK_PYRAMID_FUSED=1 selects one launch that stages level-0 tiles in LDS and
-    // emits every level (half the HBM reads, bit-identical output); measured
-    // 3 % slower than the per-level kernels, which already run at 5-6 TB/s, so
-    // it is not the default.
-    static const bool fused = getenv("TDK_PYRAMID_FUSED") != nullptr;
-    if (fused) {
+    // _estimate_at rescales the original I0/D0/I1/W0 (vo/dvo/__init__.py:144-148).
+    // Default: one launch, levels of one image dispatched together so the
+    // re-reads of level 0 stay on die.  TDK_PYRAMID=lds stages level-0 tiles in
+    // LDS (one read, slower as measured), TDK_PYRAMID=levels runs one k_rescale
+    // per (array, level).  All three are bit-identical.
+    static const int mode = [] {
+        const char *v = getenv("TDK_PYRAMID");
+        if (v && !strcmp(v, "lds")) return 1;
+        if (v && !strcmp(v, "levels")) return 2;
+        return 0;
+    }();
+    if (mode != 2) {
         const double *srcs[4] = {S.I0, S.D0, S.I1, S.W0};
         tdk::PyramidLevelDesc lv[kMaxLevels];
         for (int l = 1; l < h->n_levels; l++) {
@@ -1256,7 +1347,8 @@ tdk_status tdk_dvo_build_pyramid(tdk_dvo *h) {
             lv[l - 1].dst[0] = L.I0; lv[l - 1].dst[1] = L.D0; lv[l - 1].dst[2] = L.I1; lv[l - 1].dst[3] = L.W0;
             lv[l - 1].stride = L.stride; lv[l - 1].H = L.H; lv[l - 1].W = L.W;
         }
-        return tdk::launch_pyramid(srcs, h->with_w ? 4 : 3, S.H, S.W, S.stride, h->n_levels - 1, lv, h->n_pairs);
+        return tdk::launch_pyramid(srcs, h->with_w ? 4 : 3, S.H, S.W, S.stride, h->n_levels - 1, lv, h->n_pairs,
+                                   mode);
     }
     for (int l = 1; l < h->n_levels; l++) {
         const tdk_dvo::Level &L = h->lv[l];

@@ -232,6 +232,43 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
     }
 }
 
+// Every level of every array in one launch, one thread per output pixel
+// (k_rescale's arithmetic, bit-identical).  blockIdx.x runs over the blocks of
+// level 1, then level 2, ... of ONE (pair, array); y = array, z = pair.  Blocks
+// are dispatched x-fastest, so all the levels of an image are resampled within
+// microseconds of each other and only the first pass over its level-0 texels
+// comes from HBM -- the later ones hit the 256 MiB Infinity Cache.
+struct RescaleArgs {
+    const double *src[4];
+    int64_t src_stride;
+    int H, W, n_out;
+    int blk_end[15];   // cumulative block count per level
+    PyrLevel lv[15];
+};
+
+__global__ __launch_bounds__(256) void k_rescale_levels(RescaleArgs a) {
+    int l = 0;
+    while (l + 1 < a.n_out && (int)blockIdx.x >= a.blk_end[l]) l++;
+    const PyrLevel &L = a.lv[l];
+    const int arr = blockIdx.y, pair = blockIdx.z;
+    const int i = ((int)blockIdx.x - (l ? a.blk_end[l - 1] : 0)) * 256 + (int)threadIdx.x;
+    if (i >= L.Ho * L.Wo) return;
+    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    const int H = a.H, W = a.W;
+    const double sy = (double)H / (double)L.Ho, sx = (double)W / (double)L.Wo;
+    const int oy = i / L.Wo, ox = i - oy * L.Wo;
+    double cy = ((double)oy + 0.5) * sy - 0.5;
+    double cx = ((double)ox + 0.5) * sx - 0.5;
+    double fy0 = floor(cy), fx0 = floor(cx);
+    double wy = cy - fy0, wx = cx - fx0;
+    const int iy = (int)fy0, ix = (int)fx0;
+    const int y0 = reflect_fast(iy, H), y1 = reflect_fast(iy + 1, H);
+    const int x0 = reflect_fast(ix, W), x1 = reflect_fast(ix + 1, W);
+    double top = s[y0 * W + x0] * (1.0 - wx) + s[y0 * W + x1] * wx;
+    double bot = s[y1 * W + x0] * (1.0 - wx) + s[y1 * W + x1] * wx;
+    L.dst[arr][(int64_t)pair * L.stride + i] = top * (1.0 - wy) + bot * wy;
+}
+
 }  // namespace
 
 namespace tdk {
@@ -249,11 +286,27 @@ tdk_status launch_rescale(const double *src, int H, int W, double *dst, int Ho, 
 // All pyramid levels of all arrays of a batch in one launch.  srcs/dsts hold
 // n_arrays device pointers per level (level-major for dsts).
 tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride,
-                          int n_out, const PyramidLevelDesc *levels, int batch) {
+                          int n_out, const PyramidLevelDesc *levels, int batch, int mode) {
     if (n_out <= 0) return TDK_OK;
     if (n_out > 15 || n_arrays > 4) {
         set_error("pyramid too deep");
         return TDK_ERR_INVALID_ARGUMENT;
+    }
+    if (mode == 0) {
+        RescaleArgs r;
+        for (int i = 0; i < 4; i++) r.src[i] = i < n_arrays ? srcs[i] : nullptr;
+        r.src_stride = src_stride; r.H = H; r.W = W; r.n_out = n_out;
+        int blocks = 0;
+        for (int l = 0; l < n_out; l++) {
+            for (int i = 0; i < 4; i++) r.lv[l].dst[i] = i < n_arrays ? levels[l].dst[i] : nullptr;
+            r.lv[l].stride = levels[l].stride; r.lv[l].Ho = levels[l].H; r.lv[l].Wo = levels[l].W;
+            blocks += (int)(((int64_t)levels[l].H * levels[l].W + 255) / 256);
+            r.blk_end[l] = blocks;
+        }
+        dim3 grid(blocks, n_arrays, batch);
+        k_rescale_levels<<<grid, 256, 0, tdk::stream()>>>(r);
+        TDK_LAUNCH_CHECK();
+        return TDK_OK;
     }
     PyrArgs a;
     for (int i = 0; i < 4; i++) a.src[i] = i < n_arrays ? srcs[i] : nullptr;

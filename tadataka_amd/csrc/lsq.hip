@@ -19,7 +19,6 @@ using tdk::Cam;
 
 constexpr int kBlock = 256;
 constexpr int kMaxP = 8;
-constexpr int kMaxAcc = kMaxP * (kMaxP + 1) / 2 + kMaxP + 1;  // 45: upper triangle, rhs, count
 constexpr int kAccPad = 48;
 constexpr double kHuberK = 1.345;
 

@@ -26,14 +26,17 @@ tdk_status pinned(int slot, size_t bytes, void **ptr);
 tdk_status launch_rescale(const double *src, int H, int W, double *dst, int Ho, int Wo, int batch,
                           int64_t src_stride, int64_t dst_stride);
 
-// granular.hip: every pyramid level of `n_arrays` arrays from one pass over level 0
+// granular.hip: every pyramid level of `n_arrays` arrays in one launch.
+// mode 0: one thread per output pixel, blocks ordered so that all levels of one
+// (pair, array) are dispatched together (level 0 is re-read from the Infinity
+// Cache, not HBM); mode 1: level-0 tiles staged in LDS, one pass.
 struct PyramidLevelDesc {
     double *dst[4];
     int64_t stride;
     int H, W;
 };
 tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride,
-                          int n_out, const PyramidLevelDesc *levels, int batch);
+                          int n_out, const PyramidLevelDesc *levels, int batch, int mode);
 
 }  // namespace tdk
 

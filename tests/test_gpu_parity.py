@@ -175,6 +175,50 @@ def test_dvo_pyramid_vs_golden(ops, orc, golden):
     batch.close()
 
 
+_PYRAMID_SCRIPT = """
+import hashlib, sys
+import numpy as np
+from tadataka_amd import ops, synthetic
+H, W, B = 61, 83, 3
+batch = ops.DvoBatch(B, H, W, n_levels=4, ratio=1.5, with_weight_map=True)
+for i in range(B):
+    pr = synthetic.make_pair(H, W, seed=20 + i)
+    batch.upload(i, pr["I0"], pr["D0"], pr["I1"], np.full((H, W), 0.5 + 0.1 * i))
+batch.build_pyramid()
+h = hashlib.sha256()
+for i in range(B):
+    for level in (1, 2, 3):
+        for name in ("I0", "D0", "I1", "W0"):
+            h.update(np.ascontiguousarray(batch.download(i, level, name)).tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_dvo_pyramid_modes_bit_identical(ops, orc):
+    """The three pyramid builders (one launch / LDS tiles / one launch per
+    level) produce the same bytes, and those are the oracle's, on odd shapes,
+    several pairs, four levels and a weight map."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    from tadataka_amd import synthetic
+    H, W, B = 61, 83, 3
+    h = hashlib.sha256()
+    for i in range(B):
+        pr = synthetic.make_pair(H, W, seed=20 + i)
+        pr["W0"] = np.full((H, W), 0.5 + 0.1 * i)
+        for level in (1, 2, 3):
+            for name in ("I0", "D0", "I1", "W0"):
+                h.update(np.ascontiguousarray(orc.rescale(pr[name], 1 / 1.5 ** level)).tobytes())
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("", "lds", "levels"):
+        env = dict(os.environ, PYTHONPATH=root, TDK_PYRAMID=mode)
+        out = subprocess.run([sys.executable, "-c", _PYRAMID_SCRIPT], env=env, cwd=root, check=True,
+                             capture_output=True, text=True, timeout=300)
+        assert out.stdout.strip().splitlines()[-1] == h.hexdigest(), mode
+
+
 def test_dvo_batch_ragged_shapes_and_independence(ops, orc):
     """Odd widths/heights (pyramid levels are 213x284, 427 wide, ...), several
     pairs in one launch, every pair checked against the oracle on its own."""
