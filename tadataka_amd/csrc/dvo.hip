@@ -221,7 +221,7 @@ __device__ __forceinline__ double robust_weight(double r, double w0, double ws) 
         // |r| <= 1 < k on [0, 1] images (F4): the division sits behind a branch
         // that is skipped unless some lane of the wave has an outlier
         double ar = fabs(r), w = 1.0;
-        if (ar > kHuberK) w = kHuberK / ar;
+        if (__builtin_amdgcn_ballot_w64(ar > kHuberK) != 0) w = ar > kHuberK ? kHuberK / ar : 1.0;
         return w;
     }
     if (WMODE == TDK_W_MAP) return w0;
@@ -482,6 +482,247 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
         y += step_y;
         if (x >= W) { x -= W; y += 1; }
     }
+    store_partials(acc, red, pair, partials);
+}
+
+// ---------------------------------------------------------------------------
+// k_dvo_eval_sp (TDK_DVO_VARIANT=9): the same arithmetic as k_dvo_eval, software
+// pipelined over three pixels of a thread.  While pixel n is accumulated, the
+// 12 texels of pixel n+1 are in flight and pixel n+2 is being warped:
+//
+//     accumulate(n)        <- taps(n), issued one step earlier
+//     taps(n+1) issued     <- warp(n+1), computed one step earlier
+//     warp(n+2)            <- depth(n+2), prefetched one step earlier
+//
+// so a gather has a whole warp computation (plus the other waves' issue slots)
+// to land before it is needed, instead of being waited for right after issue.
+// One tap buffer and two ping-pong pixel records; one pixel per thread per step.
+// ---------------------------------------------------------------------------
+struct Pixel {       // what survives from the warp of one pixel until it is accumulated
+    double sx, sy, rz;   // P1x / z', P1y / z', 1 / z' with z' = P1z + 1e-16
+    bool valid;          // inside the image at this pose (error mask)
+    bool front;          // P1z > 0 (update mask)
+};
+
+struct Samples;
+
+// pixel coordinate of the warped point, the reference's un-fused x * f + o
+__device__ __forceinline__ void sp_coordinate(const Pixel &p, const double *c, double &u, double &v) {
+#pragma clang fp contract(off)
+    u = p.sx * c[0] + c[2];
+    v = p.sy * c[1] + c[3];
+}
+
+__device__ __forceinline__ void sp_warp(Pixel &p, bool live, double xn, double yn, double d0, int H, int W,
+                                        const double *P, const double *c) {
+    double px = xn * d0, py = yn * d0;
+    double qx = P[0] * px + P[1] * py + P[2] * d0 + P[9];
+    double qy = P[3] * px + P[4] * py + P[5] * d0 + P[10];
+    double qz = P[6] * px + P[7] * py + P[8] * d0 + P[11];
+    {
+#pragma clang fp contract(off)
+        double z = qz + tdk::kEps16;
+        div2_shared(qx, qy, z, p.sx, p.sy, p.rz);
+    }
+    double u, v;
+    sp_coordinate(p, c, u, v);
+    p.valid = live && u >= 0.0 && u <= (double)(W - 1) && v >= 0.0 && v <= (double)(H - 1);
+    p.front = qz > 0.0;
+}
+
+// The 12 texels of one pixel as six 16-byte loads whose addresses are clamped
+// into the image, so that they can be issued unconditionally (no branch around a
+// load: the compiler keeps exact vmcnt bookkeeping across the pipeline stages).
+// Interior pixels get exactly load_taps_inside's pattern; on the border the
+// pairs are shifted inwards and sp_fix_border() rebuilds the replicated texels.
+struct TapPairs {
+    double2_u tm, a01, a23, b01, b23, u01;
+};
+
+__device__ __forceinline__ void sp_issue_taps(TapPairs &q, const double *__restrict__ I1, int H, int W, int c0,
+                                              int r0) {
+    const uint32_t rowb = (uint32_t)W * 8u;
+    const uint32_t row0 = (uint32_t)r0 * rowb;
+    const uint32_t rowm = r0 > 0 ? row0 - rowb : row0;
+    const uint32_t row1 = r0 < H - 1 ? row0 + rowb : row0;
+    const uint32_t row2 = r0 < H - 2 ? row1 + rowb : row1;
+    const uint32_t cl = (uint32_t)max(c0 - 1, 0) * 8u;       // pair (c0-1, c0)
+    const uint32_t cm = (uint32_t)min(c0, W - 2) * 8u;       // pair (c0, c0+1)
+    const uint32_t cr = (uint32_t)min(c0 + 1, W - 2) * 8u;   // pair (c0+1, c0+2)
+    q.tm = ldo2(I1, rowm + cm);
+    q.a01 = ldo2(I1, row0 + cl);
+    q.a23 = ldo2(I1, row0 + cr);
+    q.b01 = ldo2(I1, row1 + cl);
+    q.b23 = ldo2(I1, row1 + cr);
+    q.u01 = ldo2(I1, row2 + cm);
+}
+
+__device__ __forceinline__ Taps sp_unpack(const TapPairs &q) {
+    Taps t;
+    t.t0 = q.tm.x; t.t1 = q.tm.y;
+    t.a0 = q.a01.x; t.a1 = q.a01.y; t.a2 = q.a23.x; t.a3 = q.a23.y;
+    t.b0 = q.b01.x; t.b1 = q.b01.y; t.b2 = q.b23.x; t.b3 = q.b23.y;
+    t.u0 = q.u01.x; t.u1 = q.u01.y;
+    return t;
+}
+
+// texel (r, clamp(c)) for the columns the shifted pairs could not reach
+__device__ __forceinline__ void sp_fix_border(Taps &t, int c0, int W) {
+    if (c0 == 0) { t.a1 = t.a0; t.b1 = t.b0; }                    // pair loaded at (0, 1), wanted (0, 0)
+    if (c0 >= W - 2) { t.a2 = t.a3; t.b2 = t.b3; }                // loaded at (W-2, W-1), wanted (W-1, W-1)
+    if (c0 == W - 1) { t.t0 = t.t1; t.u0 = t.u1; }                // loaded at (W-2, W-1), wanted (W-1, W-1)
+}
+
+struct Samples {     // everything that is loaded for the pixel being accumulated next
+    TapPairs q;
+    double i0, i1, w0;
+};
+
+template <int WMODE>
+__device__ __forceinline__ void sp_issue(Samples &s, const Pixel &p, uint32_t off, const double *__restrict__ I0,
+                                         const double *__restrict__ I1, const double *__restrict__ W0, int H,
+                                         int W, const double *c) {
+    s.i0 = ldo(I0, off);
+    s.i1 = ldo(I1, off);
+    if (WMODE == TDK_W_MAP) s.w0 = ldo(W0, off);
+    double u, v;
+    sp_coordinate(p, c, u, v);
+    // v_cvt_i32_f64 saturates and maps NaN to 0: masked-out pixels load from a clamped, valid address
+    const int c0 = min(max((int)u, 0), W - 1), r0 = min(max((int)v, 0), H - 1);
+    sp_issue_taps(s.q, I1, H, W, c0, r0);
+}
+
+template <int WMODE>
+__device__ __forceinline__ void sp_accumulate(Accum &a, const Samples &s, const Pixel &p, double ws, int H,
+                                              int W, const double *c) {
+    if (!p.valid) return;
+    double u, v;
+    sp_coordinate(p, c, u, v);
+    const double lx = floor(u), ly = floor(v);
+    Warped w;
+    w.c0 = (int)lx; w.r0 = (int)ly;
+    Taps t = sp_unpack(s.q);
+    const bool inside = w.c0 >= 1 && w.c0 <= W - 3 && w.r0 >= 1 && w.r0 <= H - 3;
+    const bool border = __builtin_amdgcn_ballot_w64(!inside) != 0;   // wave-uniform
+    if (border) sp_fix_border(t, w.c0, W);
+    // (lx + 1) - u and 1 - (u - lx) are the same double: u - lx is exact and a
+    // multiple of ulp(u), so 1 - (u - lx) is representable
+    const double wx1 = u - lx, wy1 = v - ly;
+    const double wx0 = 1.0 - wx1, wy0 = 1.0 - wy1;
+    w.w00 = wx0 * wy0; w.w01 = wx1 * wy0; w.w10 = wx0 * wy1; w.w11 = wx1 * wy1;
+    double gx, gy;
+    if (border) gradient_clamped(t, w, H, W, gx, gy);
+    else gradient_inside(t, w, gx, gy);
+    // photometric error term (metric.py:24-27): no z test here
+    double i1w = t.a1 * w.w00 + t.a2 * w.w01 + t.b1 * w.w10 + t.b2 * w.w11;
+    double e = s.i0 - i1w;
+    a.v[27] += e * e;
+    a.v[29] += 1.0;
+    if (!p.front) return;  // update mask adds P1z > 0 (vo/dvo/__init__.py:49)
+    // Jacobian row (vo/dvo/jacobian.py:8-24) with X = x/z, Y = y/z factored out:
+    //   [fgx/z, fgy/z, -(fgx X + fgy Y)/z, -fgx XY - fgy (1 + Y^2), fgx (1 + X^2) + fgy XY, fgy X - fgx Y]
+    const double X = p.sx, Y = p.sy;
+    const double fgx = c[0] * gx, fgy = c[1] * gy;
+    const double xy = X * Y;
+    double J[6];
+    J[0] = fgx * p.rz;
+    J[1] = fgy * p.rz;
+    J[2] = -(fgx * X + fgy * Y) * p.rz;
+    J[3] = -(fgx * xy + fgy * (1.0 + Y * Y));
+    J[4] = fgx * (1.0 + X * X) + fgy * xy;
+    J[5] = fgy * X - fgx * Y;
+    double r = s.i0 - s.i1;  // un-warped residual (vo/dvo/__init__.py:90)
+    double wgt = robust_weight<WMODE>(r, s.w0, ws);
+    const bool unit_w = (WMODE == TDK_W_NONE);
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double wj = unit_w ? J[i] : wgt * J[i];
+#pragma unroll
+        for (int q = i; q < 6; q++) a.v[k++] += wj * J[q];
+        a.v[21 + i] += wj * r;
+    }
+    a.v[28] += 1.0;
+}
+
+template <int WMODE>
+__global__ __launch_bounds__(kBlock) void k_dvo_eval_sp(LevelPtrs L, const PairParams *__restrict__ params,
+                                                        const double *__restrict__ poses,
+                                                        const int *__restrict__ state,
+                                                        const double *__restrict__ wscale, double scale,
+                                                        int64_t chunk, double *__restrict__ partials) {
+    const int pair = blockIdx.y;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    BlockSetup b;
+    load_setup(b, params, poses, pair, scale);
+    const double ws = (WMODE == TDK_W_STUDENT_T || WMODE == TDK_W_TUKEY) ? wscale[pair] : 1.0;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double(*red)[kAccPad] = reinterpret_cast<double(*)[kAccPad]>(smem);
+    double *xn_tab = reinterpret_cast<double *>(smem + sizeof(double) * kWaves * kAccPad);
+    double *yn_tab = xn_tab + L.W;
+    {
+        const double *__restrict__ tab = L.tab + (size_t)pair * (L.W + L.H);
+        for (int i = threadIdx.x; i < L.W + L.H; i += kBlock) xn_tab[i] = tab[i];
+    }
+    __syncthreads();
+
+    const int64_t base = (int64_t)pair * L.stride;
+    const double *__restrict__ I0 = L.I0 + base;
+    const double *__restrict__ D0 = L.D0 + base;
+    const double *__restrict__ I1 = L.I1 + base;
+    const double *__restrict__ W0 = (WMODE == TDK_W_MAP) ? L.W0 + base : nullptr;
+    const int W = L.W, H = L.H;
+    const int N = (int)L.N;
+
+    Accum acc;
+#pragma unroll
+    for (int i = 0; i < kAcc; i++) acc.v[i] = 0.0;
+
+    const int start = (int)(blockIdx.x * chunk);
+    const int end = (int)min((int64_t)N, (int64_t)start + chunk);
+    // iw: the next pixel to warp, (x, y) its coordinates, advanced by kBlock per step
+    int iw = start + (int)threadIdx.x;
+    int y = iw / W, x = iw - y * W;
+    const int step_y = kBlock / W, step_x = kBlock - step_y * W;
+#define TDK_ADVANCE()                      \
+    do {                                   \
+        iw += kBlock;                      \
+        x += step_x;                       \
+        y += step_y;                       \
+        if (x >= W) { x -= W; y += 1; }    \
+    } while (0)
+#define TDK_OFF(i) ((uint32_t)min((i), end - 1) * 8u)   /* clamped: loads need no branch */
+#define TDK_DEPTH() ldo(D0, TDK_OFF(iw))
+
+    Pixel pa, pb;
+    Samples s;
+    s.w0 = 1.0;
+    // prologue: warp pixels 0 and 1, issue the loads of pixel 0
+    double d = TDK_DEPTH();
+    sp_warp(pa, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
+    TDK_ADVANCE();
+    d = TDK_DEPTH();
+    sp_warp(pb, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
+    TDK_ADVANCE();
+    sp_issue<WMODE>(s, pa, TDK_OFF(iw - 2 * kBlock), I0, I1, W0, H, W, b.c);
+    // steady state: iw - 2 kBlock is the pixel being accumulated, iw the one being warped
+    while (iw - 2 * kBlock < end) {
+        d = TDK_DEPTH();
+        sp_accumulate<WMODE>(acc, s, pa, ws, H, W, b.c);
+        sp_issue<WMODE>(s, pb, TDK_OFF(iw - kBlock), I0, I1, W0, H, W, b.c);
+        sp_warp(pa, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
+        TDK_ADVANCE();
+
+        d = TDK_DEPTH();
+        sp_accumulate<WMODE>(acc, s, pb, ws, H, W, b.c);
+        sp_issue<WMODE>(s, pa, TDK_OFF(iw - kBlock), I0, I1, W0, H, W, b.c);
+        sp_warp(pb, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
+        TDK_ADVANCE();
+    }
+#undef TDK_ADVANCE
+#undef TDK_DEPTH
+#undef TDK_OFF
     store_partials(acc, red, pair, partials);
 }
 
@@ -947,6 +1188,10 @@ struct tdk_dvo {
     size_t ev_used;
     double prof_ms;
     int64_t prof_launches, prof_pixels;
+    std::vector<double> cams;   // cameras currently on the device: [cam0 (n x 4) | cam1 (n x 4)]
+    // "pairs still running" as seen by the host (pinned), one slot per iteration parity
+    int *h_flags;
+    hipEvent_t flag_ev[2];
 };
 
 namespace {
@@ -1015,6 +1260,13 @@ LevelPtrs ptrs_of(const tdk_dvo::Level &L) {
 }
 
 tdk_status upload_params(tdk_dvo *h, const double *cam0, const double *cam1) {
+    // same cameras as last time (the usual case for a sequence): nothing to do
+    const size_t n4 = (size_t)4 * h->n_pairs;
+    if (h->cams.size() == 2 * n4 && !memcmp(h->cams.data(), cam0, sizeof(double) * n4) &&
+        !memcmp(h->cams.data() + n4, cam1, sizeof(double) * n4))
+        return TDK_OK;
+    h->cams.assign(cam0, cam0 + n4);
+    h->cams.insert(h->cams.end(), cam1, cam1 + n4);
     void *stage;
     TDK_TRY(tdk::pinned(0, sizeof(PairParams) * h->n_pairs, &stage));
     PairParams *pp = (PairParams *)stage;
@@ -1136,6 +1388,9 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
                                                                          h->d_wscale, L.scale, tp.tiles_x,    \
                                                                          tp.n_tiles, tp.tiles_per_block,      \
                                                                          h->d_partials);                      \
+    else if (dvo_variant() == 9)                                                                              \
+        k_dvo_eval_sp<WM><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state,             \
+                                                                h->d_wscale, L.scale, chunk, h->d_partials);  \
     else                                                                                                      \
         k_dvo_eval<WM><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state, h->d_wscale,   \
                                                              L.scale, chunk, h->d_partials)
@@ -1195,22 +1450,38 @@ tdk_status collect_profile(tdk_dvo *h) {
 }
 
 // One pyramid level for the whole batch; poses live in h->ls.pose on entry and exit.
+//
+// The host only needs to know when every pair has finished.  It reads that
+// count one iteration late: iteration i+1 is queued before the count left by
+// iteration i is looked at, so the GPU never waits for the round trip; when the
+// count turns out to be zero the extra launch has already returned at its
+// `state != RUNNING` test.  TDK_DVO_NO_PIPELINE=1 restores the blocking read.
 tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64_t *pixel_evals) {
-    int running = h->n_pairs;
+    static const bool pipelined = getenv("TDK_DVO_NO_PIPELINE") == nullptr;
+    int running = h->n_pairs;   // pairs that enter the iteration being accounted
     for (int iter = 0; iter <= max_iter; iter++) {
-        if (h->profiling && level == 0) h->prof_pixels += h->lv[0].N * (int64_t)running;
-        if (pixel_evals) *pixel_evals += h->lv[level].N * (int64_t)running;
+        const size_t ev_mark = h->ev_used;
         TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, weight_mode));
         TDK_TRY(launch_reduce(h, level, 1, iter, max_iter));
-        // (skipping this host look after evaluation 0 was measured SLOWER: 4.95 vs
-        // 4.08 ms per bench step -- back-to-back launches without the gap lose more
-        // than the 20 us round trip costs)
-        void *stage;
-        TDK_TRY(tdk::pinned(2, sizeof(int), &stage));
-        TDK_HIP(hipMemcpyAsync(stage, h->ls.active, sizeof(int), hipMemcpyDeviceToHost, tdk::stream()));
-        TDK_HIP(hipStreamSynchronize(tdk::stream()));
-        running = *(int *)stage;
-        if (running <= 0) break;
+        const int slot = iter & 1;
+        TDK_HIP(hipMemcpyAsync(&h->h_flags[slot], h->ls.active, sizeof(int), hipMemcpyDeviceToHost,
+                               tdk::stream()));
+        TDK_HIP(hipEventRecord(h->flag_ev[slot], tdk::stream()));
+        if (pipelined && iter > 0) {
+            TDK_HIP(hipEventSynchronize(h->flag_ev[slot ^ 1]));
+            running = h->h_flags[slot ^ 1];
+            if (running <= 0) {
+                h->ev_used = ev_mark;   // the launch just queued does nothing: keep it out of the profile
+                break;
+            }
+        }
+        if (h->profiling && level == 0) h->prof_pixels += h->lv[0].N * (int64_t)running;
+        if (pixel_evals) *pixel_evals += h->lv[level].N * (int64_t)running;
+        if (!pipelined) {
+            TDK_HIP(hipEventSynchronize(h->flag_ev[slot]));
+            running = h->h_flags[slot];
+            if (running <= 0) break;
+        }
     }
     return TDK_OK;
 }
@@ -1265,6 +1536,9 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
     TDK_HIP(hipMalloc(&h->ls.state, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.n_evals, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.active, sizeof(int)));
+    TDK_HIP(hipHostMalloc(&h->h_flags, 2 * sizeof(int), hipHostMallocDefault));
+    TDK_HIP(hipEventCreateWithFlags(&h->flag_ev[0], hipEventDisableTiming));
+    TDK_HIP(hipEventCreateWithFlags(&h->flag_ev[1], hipEventDisableTiming));
     *out = h;
     return TDK_OK;
 }
@@ -1287,6 +1561,9 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
         (void)hipFree(h->d_hist);
     }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->h_flags) (void)hipHostFree(h->h_flags);
+    for (hipEvent_t e : h->flag_ev)
+        if (e) (void)hipEventDestroy(e);
     delete h;
     return TDK_OK;
 }
