@@ -22,12 +22,11 @@
 //
 // Kernels (gfx950, wave64):
 //   k_dvo_eval        grid (nblk, n_pairs) x 256 threads; each thread walks its
-//                     block's contiguous pixel range two pixels at a time (16-byte
-//                     loads, next sweep prefetched), keeps 30 f64 accumulators,
-//                     wave __shfl_down reduce, LDS across the 4 waves, one
-//                     30-double partial per block.
-//   k_dvo_eval_tiled  same arithmetic, taps served from an LDS window per 64x32
-//                     tile (experimental, TDK_DVO_VARIANT=8).
+//                     block's contiguous pixel range one pixel per step through a
+//                     three-stage software pipeline (accumulate n | gathers of n+1
+//                     in flight | warp n+2), keeps 30 f64 accumulators, transposed
+//                     wave reduction (v_permlane swaps + DPP), LDS across the 4
+//                     waves, one 30-double partial per block.
 //   k_dvo_reduce      grid n_pairs x 256: fixed-order sum of the partials
 //                     (bit-reproducible), then -- in loop mode -- lane 0 performs the
 //                     monotone accept/reject, the 6x6 solve and the SE(3) update,
@@ -103,90 +102,23 @@ __device__ __forceinline__ double ldo(const double *__restrict__ base, uint32_t 
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-// ---------------------------------------------------------------------------
-// Warp of one source pixel.
-//
-// The warped coordinate decides mask membership with an inclusive float
-// comparison, and at the identity pose the whole right/bottom border sits
-// exactly on that boundary -- so the projection chain keeps the reference's
-// elementwise roundings: (u - o) / f (tables), x * d, q / (z + 1e-16) as a true
-// division, x * f + o as a separate multiply and add (no FMA contraction).
-// ---------------------------------------------------------------------------
+// What the gradient / bilinear formulas need of the warped coordinate.
 struct Warped {
-    double qx, qy, qz, rz;       // P1 = R P0 + t and 1 / (z + 1e-16)
     double w00, w01, w10, w11;   // bilinear weights
     int c0, r0;                  // lower texel
 };
-
-// returns false when the pixel leaves the image (metric.py:22, utils.py:35-44)
-__device__ __forceinline__ bool warp_pixel(Warped &o, double xn, double yn, double d0, int H, int W,
-                                           const double *P, const double *c) {
-    double px = xn * d0, py = yn * d0;
-    o.qx = P[0] * px + P[1] * py + P[2] * d0 + P[9];
-    o.qy = P[3] * px + P[4] * py + P[5] * d0 + P[10];
-    o.qz = P[6] * px + P[7] * py + P[8] * d0 + P[11];
-    double u, v;
-    {
-#pragma clang fp contract(off)
-        double z = o.qz + tdk::kEps16, sx, sy;
-        div2_shared(o.qx, o.qy, z, sx, sy, o.rz);
-        u = sx * c[0] + c[2];
-        v = sy * c[1] + c[3];
-    }
-    if (!(u >= 0.0 && u <= (double)(W - 1) && v >= 0.0 && v <= (double)(H - 1))) return false;
-    double lx = floor(u), ly = floor(v);
-    o.c0 = (int)lx;
-    o.r0 = (int)ly;
-    double wx1 = u - lx, wx0 = (lx + 1.0) - u;
-    double wy1 = v - ly, wy0 = (ly + 1.0) - v;
-    o.w00 = wx0 * wy0; o.w01 = wx1 * wy0; o.w10 = wx0 * wy1; o.w11 = wx1 * wy1;
-    return true;
-}
 
 struct Taps {   // the 12 I1 texels around (c0, r0): rows r0-1 .. r0+2
     double t0, t1, a0, a1, a2, a3, b0, b1, b2, b3, u0, u1;
 };
 
 // Two adjacent texels with one 16-byte load (8-byte aligned only: the address
-// follows the warped coordinate).  The kernel is bound by the L1 (TCP) request
-// rate -- ~20 tag look-ups per 64-lane gather instruction -- so halving the
-// number of gather instructions matters more than the bytes they move.
+// follows the warped coordinate): six gather instructions per pixel instead of
+// twelve, and 40 % fewer L1 tag look-ups.
 typedef double double2_u __attribute__((ext_vector_type(2), aligned(8)));
 
 __device__ __forceinline__ double2_u ldo2(const double *__restrict__ base, uint32_t byte_off) {
     return *reinterpret_cast<const double2_u *>(reinterpret_cast<const char *>(base) + byte_off);
-}
-
-__device__ __forceinline__ Taps load_taps_inside(const double *__restrict__ I1, int W, const Warped &p) {
-    const uint32_t rowb = (uint32_t)W * 8u;
-    const uint32_t o0 = (uint32_t)(p.r0 * W + p.c0) * 8u;   // texel (r0, c0)
-    const uint32_t om = o0 - rowb, o1 = o0 + rowb, o2 = o1 + rowb;
-    const double2_u tm = ldo2(I1, om);
-    const double2_u a01 = ldo2(I1, o0 - 8u), a23 = ldo2(I1, o0 + 8u);
-    const double2_u b01 = ldo2(I1, o1 - 8u), b23 = ldo2(I1, o1 + 8u);
-    const double2_u u01 = ldo2(I1, o2);
-    Taps t;
-    t.t0 = tm.x; t.t1 = tm.y;
-    t.a0 = a01.x; t.a1 = a01.y; t.a2 = a23.x; t.a3 = a23.y;
-    t.b0 = b01.x; t.b1 = b01.y; t.b2 = b23.x; t.b3 = b23.y;
-    t.u0 = u01.x; t.u1 = u01.y;
-    return t;
-}
-
-__device__ __forceinline__ Taps load_taps_clamped(const double *__restrict__ I1, int H, int W,
-                                                  const Warped &p) {
-    int c0 = p.c0, r0 = p.r0;
-    uint32_t cm = (uint32_t)max(c0 - 1, 0) * 8u, cc = (uint32_t)c0 * 8u;
-    uint32_t c1 = (uint32_t)min(c0 + 1, W - 1) * 8u, c2 = (uint32_t)min(c0 + 2, W - 1) * 8u;
-    const uint32_t rowb = (uint32_t)W * 8u;
-    uint32_t row0 = (uint32_t)r0 * rowb, row1 = (uint32_t)min(r0 + 1, H - 1) * rowb;
-    uint32_t rowm = (uint32_t)max(r0 - 1, 0) * rowb, row2 = (uint32_t)min(r0 + 2, H - 1) * rowb;
-    Taps t;
-    t.a0 = ldo(I1, row0 + cm); t.a1 = ldo(I1, row0 + cc); t.a2 = ldo(I1, row0 + c1); t.a3 = ldo(I1, row0 + c2);
-    t.b0 = ldo(I1, row1 + cm); t.b1 = ldo(I1, row1 + cc); t.b2 = ldo(I1, row1 + c1); t.b3 = ldo(I1, row1 + c2);
-    t.t0 = ldo(I1, rowm + cc); t.t1 = ldo(I1, rowm + c1);
-    t.u0 = ldo(I1, row2 + cc); t.u1 = ldo(I1, row2 + c1);
-    return t;
 }
 
 // np.gradient of I1 sampled bilinearly at the warped coordinate
@@ -231,67 +163,6 @@ __device__ __forceinline__ double robust_weight(double r, double w0, double ws) 
         return fabs(x) <= kTukeyBeta ? u * u : 0.0;
     }
     return 1.0;
-}
-
-// Error term + Jacobian row + weighted outer-product accumulation of one
-// in-range pixel whose taps are already loaded.
-template <int WMODE>
-__device__ __forceinline__ void accumulate(Accum &a, const Warped &p, const Taps &t, double gx, double gy,
-                                           double i0, double i1, double w0, double ws, const double *c) {
-    // photometric error term (metric.py:24-27): no z test here
-    double i1w = t.a1 * p.w00 + t.a2 * p.w01 + t.b1 * p.w10 + t.b2 * p.w11;
-    double e = i0 - i1w;
-    a.v[27] += e * e;
-    a.v[29] += 1.0;
-    if (!(p.qz > 0.0)) return;  // update mask adds P1z > 0 (vo/dvo/__init__.py:49)
-
-    // Jacobian row (vo/dvo/jacobian.py:8-24), twist order [v, omega]; rz is the
-    // reciprocal of z + 1e-16, i.e. 1/z to 1e-16 relative
-    double fgx = c[0] * gx, fgy = c[1] * gy;
-    double iz2 = p.rz * p.rz;
-    double z2 = p.qz * p.qz, xy = p.qx * p.qy;
-    double J[6];
-    J[0] = fgx * p.rz;
-    J[1] = fgy * p.rz;
-    J[2] = -(fgx * p.qx + fgy * p.qy) * iz2;
-    J[3] = -(fgx * xy + fgy * (z2 + p.qy * p.qy)) * iz2;
-    J[4] = (fgx * (z2 + p.qx * p.qx) + fgy * xy) * iz2;
-    J[5] = (fgy * p.qx - fgx * p.qy) * p.rz;
-
-    double r = i0 - i1;  // un-warped residual (vo/dvo/__init__.py:90)
-    double w = robust_weight<WMODE>(r, w0, ws);
-    const bool unit_w = (WMODE == TDK_W_NONE);
-    int k = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        double wj = unit_w ? J[i] : w * J[i];
-#pragma unroll
-        for (int q = i; q < 6; q++) a.v[k++] += wj * J[q];
-        a.v[21 + i] += wj * r;
-    }
-    a.v[28] += 1.0;
-}
-
-// One source pixel with taps gathered from global memory.  A wave-uniform test
-// picks the unclamped tap pattern when every lane's 4x4 neighbourhood is
-// strictly inside the image.
-template <int WMODE>
-__device__ __forceinline__ void process_pixel(Accum &a, double xn, double yn, double d0, double i0, double i1,
-                                              double w0, double ws, const double *__restrict__ I1, int H,
-                                              int W, const double *P, const double *c) {
-    Warped p;
-    if (!warp_pixel(p, xn, yn, d0, H, W, P, c)) return;
-    const bool inside = p.c0 >= 1 && p.c0 <= W - 3 && p.r0 >= 1 && p.r0 <= H - 3;
-    Taps t;
-    double gx, gy;
-    if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
-        t = load_taps_inside(I1, W, p);
-        gradient_inside(t, p, gx, gy);
-    } else {
-        t = load_taps_clamped(I1, H, W, p);
-        gradient_clamped(t, p, H, W, gx, gy);
-    }
-    accumulate<WMODE>(a, p, t, gx, gy, i0, i1, w0, ws, c);
 }
 
 // a[lanes 32..63] <-> b[lanes 0..31] (v_permlane32_swap, gfx950)
@@ -356,8 +227,8 @@ __device__ __forceinline__ double wave_sum_transposed(const Accum &acc) {
     return v[0] + dpp_move<0xB1>(v[0]);        // quad_perm [1,0,3,2]
 }
 
-// Block-level tail shared by both evaluation kernels: wave64 reduction, LDS
-// across the waves, one partial per block.
+// Block-level tail of the evaluation kernel: wave64 reduction, LDS across the
+// waves, one partial per block.
 __device__ __forceinline__ void store_partials(const Accum &acc, double (*red)[kAccPad], int pair,
                                                double *__restrict__ partials) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -404,104 +275,29 @@ __global__ void k_norm_tables(const PairParams *__restrict__ params, double scal
 }
 
 // ---------------------------------------------------------------------------
-// k_dvo_eval: contiguous pixel ranges, taps gathered through L1/L2.
-// ---------------------------------------------------------------------------
-template <int WMODE>
-__global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairParams *__restrict__ params,
-                                                     const double *__restrict__ poses,
-                                                     const int *__restrict__ state,
-                                                     const double *__restrict__ wscale, double scale,
-                                                     int64_t chunk, double *__restrict__ partials) {
-    const int pair = blockIdx.y;
-    if (state != nullptr && state[pair] != ST_RUNNING) return;
-    BlockSetup b;
-    load_setup(b, params, poses, pair, scale);
-    const double ws = (WMODE == TDK_W_STUDENT_T || WMODE == TDK_W_TUKEY) ? wscale[pair] : 1.0;
-
-    // LDS: [0, 1 KiB) cross-wave reduction scratch, then the normalised
-    // coordinate tables xn[W], yn[H] = (u - o) / f of camera 0 (one true
-    // division per row / column of the pair, done once by k_norm_tables)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double(*red)[kAccPad] = reinterpret_cast<double(*)[kAccPad]>(smem);
-    double *xn_tab = reinterpret_cast<double *>(smem + sizeof(double) * kWaves * kAccPad);
-    double *yn_tab = xn_tab + L.W;
-    {
-        const double *__restrict__ tab = L.tab + (size_t)pair * (L.W + L.H);
-        for (int i = threadIdx.x; i < L.W + L.H; i += kBlock) xn_tab[i] = tab[i];
-    }
-    __syncthreads();
-
-    const int64_t base = (int64_t)pair * L.stride;
-    const double *__restrict__ I0 = L.I0 + base;
-    const double *__restrict__ D0 = L.D0 + base;
-    const double *__restrict__ I1 = L.I1 + base;
-    const double *__restrict__ W0 = (WMODE == TDK_W_MAP) ? L.W0 + base : nullptr;
-    const int W = L.W, H = L.H;
-    const int N = (int)L.N;
-
-    Accum acc;
-#pragma unroll
-    for (int i = 0; i < kAcc; i++) acc.v[i] = 0.0;
-
-    const int start = (int)(blockIdx.x * chunk);
-    const int end = (int)min((int64_t)N, (int64_t)start + chunk);
-    // (x, y) of pixel i, advanced incrementally by the block sweep of 2*kBlock
-    // pixels: one integer division per thread instead of one per pixel
-    int i = start + 2 * (int)threadIdx.x;
-    int y = i / W, x = i - y * W;
-    const int step_y = (2 * kBlock) / W, step_x = (2 * kBlock) - step_y * W;
-    // software pipeline: the streaming loads of the next sweep are issued
-    // before the current pixels' dependent gathers
-    double2 d = make_double2(1.0, 1.0), p0 = d, p1 = d, w = d;
-    if (i + 1 < end) {
-        d = *reinterpret_cast<const double2 *>(D0 + i);
-        p0 = *reinterpret_cast<const double2 *>(I0 + i);
-        p1 = *reinterpret_cast<const double2 *>(I1 + i);
-        if (WMODE == TDK_W_MAP) w = *reinterpret_cast<const double2 *>(W0 + i);
-    }
-    for (; i < end; i += 2 * kBlock) {
-        if (i + 1 < end) {
-            const int in = i + 2 * kBlock;
-            double2 dn = d, p0n = p0, p1n = p1, wn = w;
-            if (in + 1 < end) {
-                dn = *reinterpret_cast<const double2 *>(D0 + in);
-                p0n = *reinterpret_cast<const double2 *>(I0 + in);
-                p1n = *reinterpret_cast<const double2 *>(I1 + in);
-                if (WMODE == TDK_W_MAP) wn = *reinterpret_cast<const double2 *>(W0 + in);
-            }
-            process_pixel<WMODE>(acc, xn_tab[x], yn_tab[y], d.x, p0.x, p1.x, w.x, ws, I1, H, W, b.P, b.c);
-            int x2 = x + 1, y2 = y;
-            if (x2 == W) { x2 = 0; y2 = y + 1; }
-            process_pixel<WMODE>(acc, xn_tab[x2], yn_tab[y2], d.y, p0.y, p1.y, w.y, ws, I1, H, W, b.P, b.c);
-            d = dn; p0 = p0n; p1 = p1n; w = wn;
-        } else {  // odd tail of the range
-            double w1 = (WMODE == TDK_W_MAP) ? W0[i] : 1.0;
-            process_pixel<WMODE>(acc, xn_tab[x], yn_tab[y], D0[i], I0[i], I1[i], w1, ws, I1, H, W, b.P, b.c);
-        }
-        x += step_x;
-        y += step_y;
-        if (x >= W) { x -= W; y += 1; }
-    }
-    store_partials(acc, red, pair, partials);
-}
-
-// ---------------------------------------------------------------------------
-// k_dvo_eval_sp (TDK_DVO_VARIANT=9): the same arithmetic as k_dvo_eval, software
-// pipelined over three pixels of a thread.  While pixel n is accumulated, the
-// 12 texels of pixel n+1 are in flight and pixel n+2 is being warped:
+// k_dvo_eval: one evaluation F(pose) -> (error, H, b, mask sizes) for every pair.
+//
+// Software pipelined over three pixels of a thread.  While pixel n is
+// accumulated, the 12 texels of pixel n+1 are in flight and pixel n+2 is warped:
 //
 //     accumulate(n)        <- taps(n), issued one step earlier
 //     taps(n+1) issued     <- warp(n+1), computed one step earlier
-//     warp(n+2)            <- depth(n+2), prefetched one step earlier
+//     warp(n+2)            <- depth(n+2), loaded at the top of the step
 //
 // so a gather has a whole warp computation (plus the other waves' issue slots)
-// to land before it is needed, instead of being waited for right after issue.
+// to land before it is needed, instead of being waited for right after issue
+// (measured: 60 % -> 34 % of wave-cycles in s_waitcnt, VALU issue 58 % -> 80 %).
 // One tap buffer and two ping-pong pixel records; one pixel per thread per step.
+// Every load is unconditional with a clamped address -- a branch around a load
+// makes the compiler fall back to s_waitcnt vmcnt(0), which serialises the
+// stages again -- and scheduling barriers keep the stages from being interleaved
+// (that would double the live tap and pixel registers and drop to 1-2 waves/SIMD).
 // ---------------------------------------------------------------------------
 struct Pixel {       // what survives from the warp of one pixel until it is accumulated
     double sx, sy, rz;   // P1x / z', P1y / z', 1 / z' with z' = P1z + 1e-16
-    bool valid;          // inside the image at this pose (error mask)
-    bool front;          // P1z > 0 (update mask)
+    double wx1, wy1;     // fractional parts of the warped coordinate
+    int c0, r0;          // its lower texel, clamped into the image (valid or not)
+    int mask;            // 0: outside the image; 1: error mask only; 2: error and update mask (P1z > 0)
 };
 
 struct Samples;
@@ -526,15 +322,23 @@ __device__ __forceinline__ void sp_warp(Pixel &p, bool live, double xn, double y
     }
     double u, v;
     sp_coordinate(p, c, u, v);
-    p.valid = live && u >= 0.0 && u <= (double)(W - 1) && v >= 0.0 && v <= (double)(H - 1);
-    p.front = qz > 0.0;
+    // an int, not two bools: loop-carried bools end up as byte arithmetic in VGPRs
+    const bool valid = live && u >= 0.0 && u <= (double)(W - 1) && v >= 0.0 && v <= (double)(H - 1);
+    p.mask = valid ? (qz > 0.0 ? 2 : 1) : 0;
+    const double lx = floor(u), ly = floor(v);
+    p.wx1 = u - lx;
+    p.wy1 = v - ly;
+    // v_cvt_i32_f64 saturates and maps NaN to 0: masked-out pixels get a clamped, loadable texel
+    p.c0 = min(max((int)lx, 0), W - 1);
+    p.r0 = min(max((int)ly, 0), H - 1);
 }
 
 // The 12 texels of one pixel as six 16-byte loads whose addresses are clamped
 // into the image, so that they can be issued unconditionally (no branch around a
 // load: the compiler keeps exact vmcnt bookkeeping across the pipeline stages).
-// Interior pixels get exactly load_taps_inside's pattern; on the border the
-// pairs are shifted inwards and sp_fix_border() rebuilds the replicated texels.
+// Interior pixels load (c0, c0+1) on rows r0-1 and r0+2 and (c0-1, c0), (c0+1, c0+2)
+// on rows r0 and r0+1; on the border the pairs are shifted inwards and
+// sp_fix_border() rebuilds the replicated texels.
 struct TapPairs {
     double2_u tm, a01, a23, b01, b23, u01;
 };
@@ -542,19 +346,29 @@ struct TapPairs {
 __device__ __forceinline__ void sp_issue_taps(TapPairs &q, const double *__restrict__ I1, int H, int W, int c0,
                                               int r0) {
     const uint32_t rowb = (uint32_t)W * 8u;
-    const uint32_t row0 = (uint32_t)r0 * rowb;
-    const uint32_t rowm = r0 > 0 ? row0 - rowb : row0;
-    const uint32_t row1 = r0 < H - 1 ? row0 + rowb : row0;
-    const uint32_t row2 = r0 < H - 2 ? row1 + rowb : row1;
-    const uint32_t cl = (uint32_t)max(c0 - 1, 0) * 8u;       // pair (c0-1, c0)
-    const uint32_t cm = (uint32_t)min(c0, W - 2) * 8u;       // pair (c0, c0+1)
-    const uint32_t cr = (uint32_t)min(c0 + 1, W - 2) * 8u;   // pair (c0+1, c0+2)
-    q.tm = ldo2(I1, rowm + cm);
-    q.a01 = ldo2(I1, row0 + cl);
-    q.a23 = ldo2(I1, row0 + cr);
-    q.b01 = ldo2(I1, row1 + cl);
-    q.b23 = ldo2(I1, row1 + cr);
-    q.u01 = ldo2(I1, row2 + cm);
+    uint32_t om, oal, oar, obl, obr, ou;   // byte offsets of the six pairs
+    const bool inside = c0 >= 1 && c0 <= W - 3 && r0 >= 1 && r0 <= H - 3;
+    if (__builtin_amdgcn_ballot_w64(!inside) == 0) {   // wave-uniform; address arithmetic only
+        const uint32_t o0 = (uint32_t)(r0 * W + c0) * 8u;
+        om = o0 - rowb; oal = o0 - 8u; oar = o0 + 8u;
+        obl = oal + rowb; obr = oar + rowb; ou = o0 + 2u * rowb;
+    } else {
+        const uint32_t row0 = (uint32_t)r0 * rowb;
+        const uint32_t rowm = r0 > 0 ? row0 - rowb : row0;
+        const uint32_t row1 = r0 < H - 1 ? row0 + rowb : row0;
+        const uint32_t row2 = r0 < H - 2 ? row1 + rowb : row1;
+        const uint32_t cl = (uint32_t)max(c0 - 1, 0) * 8u;       // pair (c0-1, c0)
+        const uint32_t cm = (uint32_t)min(c0, W - 2) * 8u;       // pair (c0, c0+1)
+        const uint32_t cr = (uint32_t)min(c0 + 1, W - 2) * 8u;   // pair (c0+1, c0+2)
+        om = rowm + cm; oal = row0 + cl; oar = row0 + cr;
+        obl = row1 + cl; obr = row1 + cr; ou = row2 + cm;
+    }
+    q.tm = ldo2(I1, om);
+    q.a01 = ldo2(I1, oal);
+    q.a23 = ldo2(I1, oar);
+    q.b01 = ldo2(I1, obl);
+    q.b23 = ldo2(I1, obr);
+    q.u01 = ldo2(I1, ou);
 }
 
 __device__ __forceinline__ Taps sp_unpack(const TapPairs &q) {
@@ -585,29 +399,22 @@ __device__ __forceinline__ void sp_issue(Samples &s, const Pixel &p, uint32_t of
     s.i0 = ldo(I0, off);
     s.i1 = ldo(I1, off);
     if (WMODE == TDK_W_MAP) s.w0 = ldo(W0, off);
-    double u, v;
-    sp_coordinate(p, c, u, v);
-    // v_cvt_i32_f64 saturates and maps NaN to 0: masked-out pixels load from a clamped, valid address
-    const int c0 = min(max((int)u, 0), W - 1), r0 = min(max((int)v, 0), H - 1);
-    sp_issue_taps(s.q, I1, H, W, c0, r0);
+    sp_issue_taps(s.q, I1, H, W, p.c0, p.r0);
 }
 
 template <int WMODE>
 __device__ __forceinline__ void sp_accumulate(Accum &a, const Samples &s, const Pixel &p, double ws, int H,
                                               int W, const double *c) {
-    if (!p.valid) return;
-    double u, v;
-    sp_coordinate(p, c, u, v);
-    const double lx = floor(u), ly = floor(v);
+    if (p.mask == 0) return;
     Warped w;
-    w.c0 = (int)lx; w.r0 = (int)ly;
+    w.c0 = p.c0; w.r0 = p.r0;
     Taps t = sp_unpack(s.q);
     const bool inside = w.c0 >= 1 && w.c0 <= W - 3 && w.r0 >= 1 && w.r0 <= H - 3;
     const bool border = __builtin_amdgcn_ballot_w64(!inside) != 0;   // wave-uniform
     if (border) sp_fix_border(t, w.c0, W);
     // (lx + 1) - u and 1 - (u - lx) are the same double: u - lx is exact and a
     // multiple of ulp(u), so 1 - (u - lx) is representable
-    const double wx1 = u - lx, wy1 = v - ly;
+    const double wx1 = p.wx1, wy1 = p.wy1;
     const double wx0 = 1.0 - wx1, wy0 = 1.0 - wy1;
     w.w00 = wx0 * wy0; w.w01 = wx1 * wy0; w.w10 = wx0 * wy1; w.w11 = wx1 * wy1;
     double gx, gy;
@@ -618,7 +425,7 @@ __device__ __forceinline__ void sp_accumulate(Accum &a, const Samples &s, const 
     double e = s.i0 - i1w;
     a.v[27] += e * e;
     a.v[29] += 1.0;
-    if (!p.front) return;  // update mask adds P1z > 0 (vo/dvo/__init__.py:49)
+    if (p.mask != 2) return;  // update mask adds P1z > 0 (vo/dvo/__init__.py:49)
     // Jacobian row (vo/dvo/jacobian.py:8-24) with X = x/z, Y = y/z factored out:
     //   [fgx/z, fgy/z, -(fgx X + fgy Y)/z, -fgx XY - fgy (1 + Y^2), fgx (1 + X^2) + fgy XY, fgy X - fgx Y]
     const double X = p.sx, Y = p.sy;
@@ -646,7 +453,7 @@ __device__ __forceinline__ void sp_accumulate(Accum &a, const Samples &s, const 
 }
 
 template <int WMODE>
-__global__ __launch_bounds__(kBlock) void k_dvo_eval_sp(LevelPtrs L, const PairParams *__restrict__ params,
+__global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairParams *__restrict__ params,
                                                         const double *__restrict__ poses,
                                                         const int *__restrict__ state,
                                                         const double *__restrict__ wscale, double scale,
@@ -706,188 +513,33 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval_sp(LevelPtrs L, const PairP
     sp_warp(pb, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
     TDK_ADVANCE();
     sp_issue<WMODE>(s, pa, TDK_OFF(iw - 2 * kBlock), I0, I1, W0, H, W, b.c);
-    // steady state: iw - 2 kBlock is the pixel being accumulated, iw the one being warped
+    // steady state: iw - 2 kBlock is the pixel being accumulated, iw the one being warped.
+    // The scheduling barriers keep the three stages apart: interleaving them
+    // would keep two tap sets and two half-warped pixels alive at once.
+#define TDK_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
     while (iw - 2 * kBlock < end) {
         d = TDK_DEPTH();
         sp_accumulate<WMODE>(acc, s, pa, ws, H, W, b.c);
+        TDK_STAGE_FENCE();
         sp_issue<WMODE>(s, pb, TDK_OFF(iw - kBlock), I0, I1, W0, H, W, b.c);
+        TDK_STAGE_FENCE();
         sp_warp(pa, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
         TDK_ADVANCE();
+        TDK_STAGE_FENCE();
 
         d = TDK_DEPTH();
         sp_accumulate<WMODE>(acc, s, pb, ws, H, W, b.c);
+        TDK_STAGE_FENCE();
         sp_issue<WMODE>(s, pa, TDK_OFF(iw - kBlock), I0, I1, W0, H, W, b.c);
+        TDK_STAGE_FENCE();
         sp_warp(pb, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
         TDK_ADVANCE();
+        TDK_STAGE_FENCE();
     }
+#undef TDK_STAGE_FENCE
 #undef TDK_ADVANCE
 #undef TDK_DEPTH
 #undef TDK_OFF
-    store_partials(acc, red, pair, partials);
-}
-
-// ---------------------------------------------------------------------------
-// k_dvo_eval_tiled (TDK_DVO_VARIANT=8): the taps come from an LDS window.
-//
-// A block walks TW x TH source tiles of one pair.  Per tile it warps the tile's
-// centre pixel to place a (TW + 2 TM + 3) x (TH + 2 TM + 3) window of I1, loads
-// the window cooperatively (coalesced rows), and every pixel whose 4x4 tap
-// neighbourhood falls inside the window reads its 12 texels from LDS with
-// immediate offsets; a wave with a lane outside the window (large parallax or
-// rotation inside one tile) takes the global-gather path, so results do not
-// depend on the window guess.  Measured slower than k_dvo_eval in round 1 (two
-// barriers and a dependent load per tile at 2 waves/SIMD); kept for the LDS-DMA
-// double-buffered version.
-// ---------------------------------------------------------------------------
-constexpr int kTW = 64, kTH = 32, kTM = 4;
-constexpr int kWW = kTW + 2 * kTM + 3;   // 75
-constexpr int kWH = kTH + 2 * kTM + 3;   // 43
-constexpr int kWS = kWW + 1;             // LDS row stride (doubles)
-
-__device__ __forceinline__ Taps load_taps_lds_inside(const double *win, int o0) {
-    Taps t;
-    const double *q = win + o0;
-    t.t0 = q[-kWS]; t.t1 = q[-kWS + 1];
-    t.a0 = q[-1]; t.a1 = q[0]; t.a2 = q[1]; t.a3 = q[2];
-    t.b0 = q[kWS - 1]; t.b1 = q[kWS]; t.b2 = q[kWS + 1]; t.b3 = q[kWS + 2];
-    t.u0 = q[2 * kWS]; t.u1 = q[2 * kWS + 1];
-    return t;
-}
-
-__device__ __forceinline__ Taps load_taps_lds_clamped(const double *win, int wx0, int wy0, int H, int W,
-                                                      const Warped &p) {
-    int c0 = p.c0 - wx0;
-    int cm = max(p.c0 - 1, 0) - wx0, c1 = min(p.c0 + 1, W - 1) - wx0, c2 = min(p.c0 + 2, W - 1) - wx0;
-    int r0 = (p.r0 - wy0) * kWS;
-    int rm = (max(p.r0 - 1, 0) - wy0) * kWS, r1 = (min(p.r0 + 1, H - 1) - wy0) * kWS;
-    int r2 = (min(p.r0 + 2, H - 1) - wy0) * kWS;
-    Taps t;
-    t.a0 = win[r0 + cm]; t.a1 = win[r0 + c0]; t.a2 = win[r0 + c1]; t.a3 = win[r0 + c2];
-    t.b0 = win[r1 + cm]; t.b1 = win[r1 + c0]; t.b2 = win[r1 + c1]; t.b3 = win[r1 + c2];
-    t.t0 = win[rm + c0]; t.t1 = win[rm + c1]; t.u0 = win[r2 + c0]; t.u1 = win[r2 + c1];
-    return t;
-}
-
-template <int WMODE>
-__device__ __forceinline__ void process_pixel_tiled(Accum &a, double xn, double yn, double d0, double i0,
-                                                    double i1, double w0, double ws,
-                                                    const double *__restrict__ I1, const double *win, int wx0,
-                                                    int wy0, int ww, int wh, int H, int W, const double *P,
-                                                    const double *c) {
-    Warped p;
-    if (!warp_pixel(p, xn, yn, d0, H, W, P, c)) return;
-    const bool inside = p.c0 >= 1 && p.c0 <= W - 3 && p.r0 >= 1 && p.r0 <= H - 3;
-    // window coverage of the (clamped) 4x4 neighbourhood
-    const int cl = max(p.c0 - 1, 0), ch = min(p.c0 + 2, W - 1);
-    const int rl = max(p.r0 - 1, 0), rh = min(p.r0 + 2, H - 1);
-    const bool in_win = cl >= wx0 && ch < wx0 + ww && rl >= wy0 && rh < wy0 + wh;
-    const bool all_inside = __builtin_amdgcn_ballot_w64(!inside) == 0;
-    const bool all_win = __builtin_amdgcn_ballot_w64(!in_win) == 0;
-    Taps t;
-    double gx, gy;
-    if (all_win && all_inside) {
-        t = load_taps_lds_inside(win, (p.r0 - wy0) * kWS + (p.c0 - wx0));
-        gradient_inside(t, p, gx, gy);
-    } else if (all_win) {
-        t = load_taps_lds_clamped(win, wx0, wy0, H, W, p);
-        gradient_clamped(t, p, H, W, gx, gy);
-    } else {
-        t = load_taps_clamped(I1, H, W, p);
-        gradient_clamped(t, p, H, W, gx, gy);
-    }
-    accumulate<WMODE>(a, p, t, gx, gy, i0, i1, w0, ws, c);
-}
-
-template <int WMODE>
-__global__ __launch_bounds__(kBlock) void k_dvo_eval_tiled(LevelPtrs L, const PairParams *__restrict__ params,
-                                                           const double *__restrict__ poses,
-                                                           const int *__restrict__ state,
-                                                           const double *__restrict__ wscale, double scale,
-                                                           int tiles_x, int n_tiles, int tiles_per_block,
-                                                           double *__restrict__ partials) {
-    const int pair = blockIdx.y;
-    if (state != nullptr && state[pair] != ST_RUNNING) return;
-    BlockSetup b;
-    load_setup(b, params, poses, pair, scale);
-    const double ws = (WMODE == TDK_W_STUDENT_T || WMODE == TDK_W_TUKEY) ? wscale[pair] : 1.0;
-
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    double(*red)[kAccPad] = reinterpret_cast<double(*)[kAccPad]>(smem);
-    double *xn_t = reinterpret_cast<double *>(smem + sizeof(double) * kWaves * kAccPad);
-    double *yn_t = xn_t + kTW;
-    double *win = yn_t + kTH;
-
-    const int64_t base = (int64_t)pair * L.stride;
-    const double *__restrict__ I0 = L.I0 + base;
-    const double *__restrict__ D0 = L.D0 + base;
-    const double *__restrict__ I1 = L.I1 + base;
-    const double *__restrict__ W0 = (WMODE == TDK_W_MAP) ? L.W0 + base : nullptr;
-    const int W = L.W, H = L.H;
-    const int ww = min(kWW, W), wh = min(kWH, H);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-
-    Accum acc;
-#pragma unroll
-    for (int i = 0; i < kAcc; i++) acc.v[i] = 0.0;
-
-    const int t_begin = blockIdx.x * tiles_per_block;
-    const int t_end = min(n_tiles, t_begin + tiles_per_block);
-    for (int tile = t_begin; tile < t_end; tile++) {
-        const int ty_i = tile / tiles_x, tx_i = tile - ty_i * tiles_x;
-        const int tx0 = tx_i * kTW, ty0 = ty_i * kTH;
-        // window origin from the warp of the tile centre (block-uniform)
-        const int cxp = min(tx0 + kTW / 2, W - 1), cyp = min(ty0 + kTH / 2, H - 1);
-        int wx0, wy0;
-        {
-            double dc = D0[cyp * W + cxp];
-            double xc = ((double)cxp - b.ox0) / b.fx0 * dc, yc = ((double)cyp - b.oy0) / b.fy0 * dc;
-            double qx = b.P[0] * xc + b.P[1] * yc + b.P[2] * dc + b.P[9];
-            double qy = b.P[3] * xc + b.P[4] * yc + b.P[5] * dc + b.P[10];
-            double qz = b.P[6] * xc + b.P[7] * yc + b.P[8] * dc + b.P[11];
-            double uc = qx / qz * b.c[0] + b.c[2], vc = qy / qz * b.c[1] + b.c[3];
-            // a non-finite or absurd guess only costs speed (global fallback)
-            if (!(uc > -1e6 && uc < 1e6)) uc = (double)cxp;
-            if (!(vc > -1e6 && vc < 1e6)) vc = (double)cyp;
-            wx0 = (int)floor(uc) - (cxp - tx0) - kTM - 1;
-            wy0 = (int)floor(vc) - (cyp - ty0) - kTM - 1;
-            wx0 = max(0, min(wx0, W - ww));
-            wy0 = max(0, min(wy0, H - wh));
-        }
-        __syncthreads();  // every wave is done reading the previous window / tables
-        if (threadIdx.x < kTW) xn_t[threadIdx.x] = ((double)(tx0 + (int)threadIdx.x) - b.ox0) / b.fx0;
-        else if (threadIdx.x < kTW + kTH)
-            yn_t[threadIdx.x - kTW] = ((double)(ty0 + (int)threadIdx.x - kTW) - b.oy0) / b.fy0;
-        for (int r = wave; r < wh; r += kWaves) {
-            const double *row = I1 + (wy0 + r) * W + wx0;
-            for (int cc = lane; cc < ww; cc += 64) win[r * kWS + cc] = row[cc];
-        }
-        __syncthreads();
-
-        const int x = tx0 + lane;
-        if (x < W) {
-            const double xn = xn_t[lane];
-            int y = ty0 + wave;
-            double d = 1.0, q0 = 0.0, q1 = 0.0, w1 = 1.0;
-            if (y < H) {
-                const int i = y * W + x;
-                d = D0[i]; q0 = I0[i]; q1 = I1[i];
-                if (WMODE == TDK_W_MAP) w1 = W0[i];
-            }
-#pragma unroll 1
-            for (int k = 0; k < kTH / kWaves; k++, y += kWaves) {
-                if (y >= H) break;
-                double dn = d, q0n = q0, q1n = q1, wn = w1;
-                if (k + 1 < kTH / kWaves && y + kWaves < H) {
-                    const int in = (y + kWaves) * W + x;
-                    dn = D0[in]; q0n = I0[in]; q1n = I1[in];
-                    if (WMODE == TDK_W_MAP) wn = W0[in];
-                }
-                process_pixel_tiled<WMODE>(acc, xn, yn_t[wave + kWaves * k], d, q0, q1, w1, ws, I1, win, wx0, wy0,
-                                           ww, wh, H, W, b.P, b.c);
-                d = dn; q0 = q0n; q1 = q1n; w1 = wn;
-            }
-        }
-    }
     store_partials(acc, red, pair, partials);
 }
 
@@ -991,8 +643,9 @@ __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairP
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
         int y = i / W, x = i - y * W;
         double xn = ((double)x - b.ox0) / b.fx0, yn = ((double)y - b.oy0) / b.fy0;
-        Warped p;
-        bool in = warp_pixel(p, xn, yn, L.D0[base + i], H, W, b.P, b.c) && p.qz > 0.0;
+        Pixel p;
+        sp_warp(p, true, xn, yn, L.D0[base + i], H, W, b.P, b.c);
+        bool in = p.mask == 2;
         rm[base + i] = in ? L.I0[base + i] - L.I1[base + i] : __longlong_as_double(0x7ff8000000000000ll);
         local += in ? 1 : 0;
     }
@@ -1189,9 +842,7 @@ struct tdk_dvo {
     double prof_ms;
     int64_t prof_launches, prof_pixels;
     std::vector<double> cams;   // cameras currently on the device: [cam0 (n x 4) | cam1 (n x 4)]
-    // "pairs still running" as seen by the host (pinned), one slot per iteration parity
-    int *h_flags;
-    hipEvent_t flag_ev[2];
+    int *h_flag;   // "pairs still running" as read back by the host (pinned)
 };
 
 namespace {
@@ -1204,43 +855,12 @@ int level_dim(int full, double scale) {
     return v < 1 ? 1 : v;
 }
 
-int dvo_variant() {
-    static const int variant = [] {
-        const char *v = getenv("TDK_DVO_VARIANT");
-        return v ? atoi(v) : 7;
-    }();
-    return variant;
-}
-
-struct TilePlan {
-    int tiles_x, n_tiles, tiles_per_block, nblk;
-};
-
-TilePlan plan_tiles(const tdk_dvo *h, const tdk_dvo::Level &L) {
-    TilePlan t;
-    t.tiles_x = (L.W + kTW - 1) / kTW;
-    t.n_tiles = t.tiles_x * ((L.H + kTH - 1) / kTH);
-    int cap = 16384 / h->n_pairs;          // blocks per pair
-    if (cap < 1) cap = 1;
-    if (cap > h->max_blocks) cap = h->max_blocks;
-    t.tiles_per_block = (t.n_tiles + cap - 1) / cap;
-    if (t.tiles_per_block < 1) t.tiles_per_block = 1;
-    t.nblk = (t.n_tiles + t.tiles_per_block - 1) / t.tiles_per_block;
-    return t;
-}
-
 void plan_blocks(const tdk_dvo *h, const tdk_dvo::Level &L, int *nblk, int64_t *chunk) {
-    if (dvo_variant() == 8) {
-        *nblk = plan_tiles(h, L).nblk;
-        *chunk = 0;
-        return;
-    }
-    // ~8 pixels per thread, but no more than ~8192 blocks in the whole grid
-    static const int px_per_thread = getenv("TDK_DVO_PX") ? atoi(getenv("TDK_DVO_PX")) : 8;
-    static const int max_grid = getenv("TDK_DVO_GRID") ? atoi(getenv("TDK_DVO_GRID")) : 8192;
-    int64_t per_block = (int64_t)kBlock * px_per_thread;
+    // >= 8 pixels per thread, but no more than ~8192 blocks in the whole grid
+    // (measured flat between 4096 and 16384 blocks and 8 to 24 pixels per thread)
+    int64_t per_block = (int64_t)kBlock * 8;
     int64_t nb = (L.N + per_block - 1) / per_block;
-    int64_t cap = max_grid / h->n_pairs;
+    int64_t cap = 8192 / h->n_pairs;
     if (cap < 1) cap = 1;
     if (nb > cap) nb = cap;
     if (nb > h->max_blocks) nb = h->max_blocks;
@@ -1368,9 +988,6 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
     dim3 grid(nblk, h->n_pairs);
     LevelPtrs P = ptrs_of(L);
     const size_t lds = sizeof(double) * (kWaves * kAccPad + (size_t)L.W + (size_t)L.H);
-    const size_t lds_tiled = sizeof(double) * (kWaves * kAccPad + kTW + kTH + (size_t)kWH * kWS);
-    const TilePlan tp = plan_tiles(h, L);
-    const bool tiled = dvo_variant() == 8;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling && level == 0) {
         while (h->ev_pool.size() < h->ev_used + 2) {
@@ -1382,18 +999,9 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
         e1 = h->ev_pool[h->ev_used++];
         TDK_HIP(hipEventRecord(e0, tdk::stream()));
     }
-#define TDK_EVAL(WM)                                                                                          \
-    if (tiled)                                                                                                \
-        k_dvo_eval_tiled<WM><<<grid, kBlock, lds_tiled, tdk::stream()>>>(P, h->d_params, d_poses, d_state,    \
-                                                                         h->d_wscale, L.scale, tp.tiles_x,    \
-                                                                         tp.n_tiles, tp.tiles_per_block,      \
-                                                                         h->d_partials);                      \
-    else if (dvo_variant() == 9)                                                                              \
-        k_dvo_eval_sp<WM><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state,             \
-                                                                h->d_wscale, L.scale, chunk, h->d_partials);  \
-    else                                                                                                      \
-        k_dvo_eval<WM><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state, h->d_wscale,   \
-                                                             L.scale, chunk, h->d_partials)
+#define TDK_EVAL(WM)                                                                                    \
+    k_dvo_eval<WM><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state, h->d_wscale, \
+                                                         L.scale, chunk, h->d_partials)
     switch (weight_mode) {
         case TDK_W_NONE: TDK_EVAL(TDK_W_NONE); break;
         case TDK_W_HUBER: TDK_EVAL(TDK_W_HUBER); break;
@@ -1450,38 +1058,21 @@ tdk_status collect_profile(tdk_dvo *h) {
 }
 
 // One pyramid level for the whole batch; poses live in h->ls.pose on entry and exit.
-//
-// The host only needs to know when every pair has finished.  It reads that
-// count one iteration late: iteration i+1 is queued before the count left by
-// iteration i is looked at, so the GPU never waits for the round trip; when the
-// count turns out to be zero the extra launch has already returned at its
-// `state != RUNNING` test.  TDK_DVO_NO_PIPELINE=1 restores the blocking read.
+// The host only needs to know when every pair has finished: one 4-byte read per
+// iteration.  (Queueing iteration i+1 before looking at the count of iteration i
+// was tried: no gain -- the round trip is ~1 % of an iteration -- and occasional
+// millisecond stalls in the event wait, so the read is a plain blocking one.)
 tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64_t *pixel_evals) {
-    static const bool pipelined = getenv("TDK_DVO_NO_PIPELINE") == nullptr;
-    int running = h->n_pairs;   // pairs that enter the iteration being accounted
+    int running = h->n_pairs;
     for (int iter = 0; iter <= max_iter; iter++) {
-        const size_t ev_mark = h->ev_used;
-        TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, weight_mode));
-        TDK_TRY(launch_reduce(h, level, 1, iter, max_iter));
-        const int slot = iter & 1;
-        TDK_HIP(hipMemcpyAsync(&h->h_flags[slot], h->ls.active, sizeof(int), hipMemcpyDeviceToHost,
-                               tdk::stream()));
-        TDK_HIP(hipEventRecord(h->flag_ev[slot], tdk::stream()));
-        if (pipelined && iter > 0) {
-            TDK_HIP(hipEventSynchronize(h->flag_ev[slot ^ 1]));
-            running = h->h_flags[slot ^ 1];
-            if (running <= 0) {
-                h->ev_used = ev_mark;   // the launch just queued does nothing: keep it out of the profile
-                break;
-            }
-        }
         if (h->profiling && level == 0) h->prof_pixels += h->lv[0].N * (int64_t)running;
         if (pixel_evals) *pixel_evals += h->lv[level].N * (int64_t)running;
-        if (!pipelined) {
-            TDK_HIP(hipEventSynchronize(h->flag_ev[slot]));
-            running = h->h_flags[slot];
-            if (running <= 0) break;
-        }
+        TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, weight_mode));
+        TDK_TRY(launch_reduce(h, level, 1, iter, max_iter));
+        TDK_HIP(hipMemcpyAsync(h->h_flag, h->ls.active, sizeof(int), hipMemcpyDeviceToHost, tdk::stream()));
+        TDK_HIP(hipStreamSynchronize(tdk::stream()));
+        running = *h->h_flag;
+        if (running <= 0) break;
     }
     return TDK_OK;
 }
@@ -1536,9 +1127,7 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
     TDK_HIP(hipMalloc(&h->ls.state, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.n_evals, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.active, sizeof(int)));
-    TDK_HIP(hipHostMalloc(&h->h_flags, 2 * sizeof(int), hipHostMallocDefault));
-    TDK_HIP(hipEventCreateWithFlags(&h->flag_ev[0], hipEventDisableTiming));
-    TDK_HIP(hipEventCreateWithFlags(&h->flag_ev[1], hipEventDisableTiming));
+    TDK_HIP(hipHostMalloc(&h->h_flag, sizeof(int), hipHostMallocDefault));
     *out = h;
     return TDK_OK;
 }
@@ -1561,9 +1150,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
         (void)hipFree(h->d_hist);
     }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-    if (h->h_flags) (void)hipHostFree(h->h_flags);
-    for (hipEvent_t e : h->flag_ev)
-        if (e) (void)hipEventDestroy(e);
+    if (h->h_flag) (void)hipHostFree(h->h_flag);
     delete h;
     return TDK_OK;
 }
