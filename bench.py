@@ -6,7 +6,11 @@ A *step* is one full DVO pose estimation (PoseChangeEstimator: 3-level pyramid,
 ratio 1.5, max_iter 20, weights="huber" -- BASELINE configs[1]) over one batch of
 independent synthetic 640x480 frame pairs resident in HBM: build the pyramids,
 then per level the fused evaluate/solve Gauss-Newton loop, all pairs in lock
-step on the device.  `value` counts every source pixel pushed through one DVO
+step on the device.  With `--double-buffer` two batches alternate: every step
+builds the pyramid of the batch the NEXT step will estimate -- queued on that
+batch's own stream, underneath the estimation of the current batch -- and
+estimates the current one (one build + one estimation per step either way;
+measured +3 %, the estimation already saturates the chip's FP64 issue/power).  `value` counts every source pixel pushed through one DVO
 iteration (= one calc_pose_update + one photometric_error at one pose, which
 the fused kernel does in a single pass): sum over levels, iterations and still
 running pairs of the level's pixel count, divided by wall time.
@@ -45,6 +49,8 @@ def parse_args():
     ap.add_argument("--levels", type=int, default=3)
     ap.add_argument("--max-iter", type=int, default=20)
     ap.add_argument("--weights", default="huber", choices=["none", "huber"])
+    ap.add_argument("--double-buffer", action="store_true",
+                    help="two batches: the next batch's pyramid is built under the current estimation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -120,18 +126,32 @@ def main():
     B, H, W = args.pairs, args.height, args.width
     cam = synthetic.camera_for(W, H)
     mode = ops.W_HUBER if args.weights == "huber" else ops.W_NONE
-    batch = ops.DvoBatch(B, H, W, n_levels=args.levels, ratio=1.5)
-    seed0 = int(sharding.pair_seeds(rank, B)[0])        # this rank's shard of the pair ids
-    batch.fill_synthetic(cam, true_poses(B, seed0), seed0=seed0, noise=0.02)
+    n_batches = 2 if args.double_buffer else 1
+    # this rank's shard of the pair ids: n_batches consecutive blocks of B pairs
+    seeds = [int(sharding.pair_seeds(rank, n_batches * B)[0]) + k * B for k in range(n_batches)]
+    batches = []
+    for seed0 in seeds:
+        bt = ops.DvoBatch(B, H, W, n_levels=args.levels, ratio=1.5)
+        bt.fill_synthetic(cam, true_poses(B, seed0), seed0=seed0, noise=0.02)
+        batches.append(bt)
+    batch = batches[0]
     ident = np.tile(ops.pose12(np.eye(3), np.zeros(3)), (B, 1))
     device = torch.device("cuda", local_rank) if distributed else None
+    counter = [0]
+    batches[0].build_pyramid()
 
     def step():
-        batch.build_pyramid()
-        poses, px = batch.estimate(cam, cam, ident, mode, args.max_iter)
+        k = counter[0]
+        counter[0] += 1
+        cur = batches[k % n_batches]
+        if n_batches == 1:
+            cur.build_pyramid()
+        else:
+            batches[(k + 1) % n_batches].build_pyramid()   # asynchronous, on that batch's stream
+        poses, px = cur.estimate(cam, cam, ident, mode, args.max_iter)
         # the only exchange: the recovered poses, all-gathered (RCCL over xGMI)
         all_poses = sharding.all_gather_poses(poses, dist, device)
-        return all_poses, px
+        return all_poses, px, seeds[k % n_batches]
 
     def fence():
         _lib.call("tdk_sync")
@@ -142,23 +162,29 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    batch.set_profiling(True)
+    for bt in batches:
+        bt.set_profiling(True)
     fence()
     t0 = time.perf_counter()
     pixels = 0
     for _ in range(args.steps):
-        poses, px = step()
+        poses, px, last_seed = step()
         pixels += px
     fence()
     elapsed = time.perf_counter() - t0
-    prof = batch.get_profile()
-    batch.set_profiling(False)
+    prof = {"launches": 0, "total_ms": 0.0, "pixels": 0}
+    for bt in batches:
+        for key, val in bt.get_profile().items():
+            prof[key] += val
+        bt.set_profiling(False)
 
     elapsed = float(sharding.reduce_scalars([elapsed], "max", dist, device)[0])
     pixels_all = float(sharding.reduce_scalars([float(pixels)], "sum", dist, device)[0])
 
     if rank == 0:
-        truth = true_poses(B * world, 0)
+        # rank r's batch of the last step holds pairs [r * n_batches * B + offset, ... + B)
+        offset = last_seed - seeds[0]
+        truth = np.concatenate([true_poses(B, r * n_batches * B + offset) for r in range(world)])
         assert poses.shape == truth.shape
         t_err = float(np.max(np.linalg.norm(poses[:, 9:] - truth[:, 9:], axis=1)))
         kernel_ms = prof["total_ms"] / max(prof["launches"], 1)
@@ -187,7 +213,8 @@ def main():
             "config": {"workload": "DVO pose estimation (PoseChangeEstimator), batch of independent "
                                    f"{W}x{H} frame pairs, {args.levels}-level pyramid ratio 1.5, "
                                    f"weights={args.weights}, max_iter={args.max_iter}",
-                       "pairs_per_gpu": B, "height": H, "width": W, "levels": args.levels,
+                       "pairs_per_gpu": B, "batches_in_flight": n_batches,
+                       "height": H, "width": W, "levels": args.levels,
                        "weights": args.weights, "max_iter": args.max_iter,
                        "parallelism": f"pair-shard x{world}" if world > 1 else "single GPU"},
             "frame_pairs_per_s": B * world * args.steps / elapsed,
@@ -204,7 +231,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(batch, cam, args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    batch.close()
+    for bt in batches:
+        bt.close()
     if distributed:
         dist.barrier()
         dist.destroy_process_group()

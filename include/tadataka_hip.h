@@ -121,9 +121,10 @@ tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0,
 /* Coarse-to-fine over all levels (PoseChangeEstimator.__call__, :125-150). */
 tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *camera1,
                             double *poses12, int weight_mode, int max_iter, int64_t *pixel_evals);
-/* The hipStream_t every kernel of this library is queued on (bench.py records
- * its HIP events there). */
-tdk_status tdk_dvo_get_stream(void **stream_out);
+/* The hipStream_t every launch and copy of this batch is queued on.  Each batch
+ * owns its stream: calls on different batches overlap on the device (e.g. the
+ * HBM-bound pyramid of one batch under the FP64-bound estimation of another). */
+tdk_status tdk_dvo_get_stream(tdk_dvo *h, void **stream_out);
 /* Per-launch timing of the full-resolution evaluation kernel with HIP events
  * recorded inside the library, on its own stream, around each launch:
  * launches, summed milliseconds and summed source pixels since enabling. */

@@ -68,7 +68,7 @@ PROTOTYPES = {
     "tdk_dvo_evaluate": [_vp, _i, _d, _d, _d, _i, _d, _d, c_int64_p, _d, c_int64_p],
     "tdk_dvo_estimate_level": [_vp, _i, _d, _d, _d, _i, _i, c_int_p],
     "tdk_dvo_estimate": [_vp, _d, _d, _d, _i, _i, c_int64_p],
-    "tdk_dvo_get_stream": [C.POINTER(_vp)],
+    "tdk_dvo_get_stream": [_vp, C.POINTER(_vp)],
     "tdk_dvo_set_profiling": [_vp, _i],
     "tdk_dvo_get_profile": [_vp, c_int64_p, _d, c_int64_p],
     "tdk_weighted_normal_equations": [_d, _d, _d, _i64, _i, _d, _d],

@@ -812,6 +812,8 @@ __global__ __launch_bounds__(kBlock) void k_fill_synthetic(double *I0, double *D
 // host side
 // ---------------------------------------------------------------------------
 struct tdk_dvo {
+    hipStream_t stream;   // every launch and copy of this batch is queued here; batches do not share streams,
+                          // so the pyramid of one batch overlaps the (FP64-bound) estimation of another
     int n_pairs, H, W, n_levels;
     double ratio;
     bool with_w;
@@ -897,15 +899,15 @@ tdk_status upload_params(tdk_dvo *h, const double *cam0, const double *cam1) {
         }
     }
     TDK_HIP(hipMemcpyAsync(h->d_params, pp, sizeof(PairParams) * h->n_pairs, hipMemcpyHostToDevice,
-                           tdk::stream()));
+                           h->stream));
     for (int l = 0; l < h->n_levels; l++) {
         const tdk_dvo::Level &L = h->lv[l];
         dim3 grid((L.W + L.H + 255) / 256, h->n_pairs);
-        k_norm_tables<<<grid, 256, 0, tdk::stream()>>>(h->d_params, L.scale, L.W, L.H, L.tab);
+        k_norm_tables<<<grid, 256, 0, h->stream>>>(h->d_params, L.scale, L.W, L.H, L.tab);
         TDK_LAUNCH_CHECK();
     }
     // the staging buffer is reused by the next call: wait for the copy
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(h->stream));
     return TDK_OK;
 }
 
@@ -919,7 +921,7 @@ tdk_status ensure_robust_buffers(tdk_dvo *h) {
     TDK_HIP(hipMalloc(&h->d_count, sizeof(int) * n));
     TDK_HIP(hipMalloc(&h->d_select, sizeof(SelectState) * n));
     TDK_HIP(hipMalloc(&h->d_hist, sizeof(unsigned int) * 256 * n));
-    TDK_HIP(hipMemsetAsync(h->d_hist, 0, sizeof(unsigned int) * 256 * n, tdk::stream()));
+    TDK_HIP(hipMemsetAsync(h->d_hist, 0, sizeof(unsigned int) * 256 * n, h->stream));
     return TDK_OK;
 }
 
@@ -932,18 +934,18 @@ tdk_status device_median(tdk_dvo *h, int level, const int *d_state, int mode, co
     dim3 grid(kStatBlocks, n);
     double *lohi[2] = {h->d_stat, h->d_stat + n};
     for (int which = 0; which < 2; which++) {
-        k_select_init<<<gp, tpb, 0, tdk::stream()>>>((SelectState *)h->d_select, h->d_count, n, which);
+        k_select_init<<<gp, tpb, 0, h->stream>>>((SelectState *)h->d_select, h->d_count, n, which);
         TDK_LAUNCH_CHECK();
         for (int pass = 0; pass < 8; pass++) {
-            k_select_hist<<<grid, kBlock, 0, tdk::stream()>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center,
+            k_select_hist<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center,
                                                               (const SelectState *)h->d_select, pass, h->d_hist);
             TDK_LAUNCH_CHECK();
-            k_select_pick<<<gp, tpb, 0, tdk::stream()>>>(h->d_hist, (SelectState *)h->d_select, d_state, n, pass,
+            k_select_pick<<<gp, tpb, 0, h->stream>>>(h->d_hist, (SelectState *)h->d_select, d_state, n, pass,
                                                          lohi[which]);
             TDK_LAUNCH_CHECK();
         }
     }
-    k_median_combine<<<gp, tpb, 0, tdk::stream()>>>(lohi[0], lohi[1], d_state, n, factor, out);
+    k_median_combine<<<gp, tpb, 0, h->stream>>>(lohi[0], lohi[1], d_state, n, factor, out);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
@@ -955,19 +957,19 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
     const tdk_dvo::Level &L = h->lv[level];
     const int n = h->n_pairs, tpb = 256, gp = (n + tpb - 1) / tpb;
     dim3 grid(kStatBlocks, n);
-    TDK_HIP(hipMemsetAsync(h->d_count, 0, sizeof(int) * n, tdk::stream()));
-    k_robust_mask<<<grid, kBlock, 0, tdk::stream()>>>(ptrs_of(L), h->d_params, d_poses, d_state, L.scale, h->d_rm,
+    TDK_HIP(hipMemsetAsync(h->d_count, 0, sizeof(int) * n, h->stream));
+    k_robust_mask<<<grid, kBlock, 0, h->stream>>>(ptrs_of(L), h->d_params, d_poses, d_state, L.scale, h->d_rm,
                                                       h->d_count);
     TDK_LAUNCH_CHECK();
     if (weight_mode == TDK_W_STUDENT_T) {
-        k_robust_student_update<<<gp, tpb, 0, tdk::stream()>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
+        k_robust_student_update<<<gp, tpb, 0, h->stream>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
                                                                h->d_wscale, n, 1);
         TDK_LAUNCH_CHECK();
         for (int it = 0; it < 10; it++) {   // n_iter = 10 (weights.py:4)
-            k_robust_student_step<<<grid, kBlock, 0, tdk::stream()>>>(h->d_rm, L.stride, (int)L.N, d_state,
+            k_robust_student_step<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state,
                                                                       h->d_wscale, h->d_spartial);
             TDK_LAUNCH_CHECK();
-            k_robust_student_update<<<gp, tpb, 0, tdk::stream()>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
+            k_robust_student_update<<<gp, tpb, 0, h->stream>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
                                                                    h->d_wscale, n, 0);
             TDK_LAUNCH_CHECK();
         }
@@ -997,10 +999,10 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
         }
         e0 = h->ev_pool[h->ev_used++];
         e1 = h->ev_pool[h->ev_used++];
-        TDK_HIP(hipEventRecord(e0, tdk::stream()));
+        TDK_HIP(hipEventRecord(e0, h->stream));
     }
 #define TDK_EVAL(WM)                                                                                    \
-    k_dvo_eval<WM><<<grid, kBlock, lds, tdk::stream()>>>(P, h->d_params, d_poses, d_state, h->d_wscale, \
+    k_dvo_eval<WM><<<grid, kBlock, lds, h->stream>>>(P, h->d_params, d_poses, d_state, h->d_wscale, \
                                                          L.scale, chunk, h->d_partials)
     switch (weight_mode) {
         case TDK_W_NONE: TDK_EVAL(TDK_W_NONE); break;
@@ -1014,7 +1016,7 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
     }
 #undef TDK_EVAL
     TDK_LAUNCH_CHECK();
-    if (e1) TDK_HIP(hipEventRecord(e1, tdk::stream()));
+    if (e1) TDK_HIP(hipEventRecord(e1, h->stream));
     return TDK_OK;
 }
 
@@ -1022,7 +1024,7 @@ tdk_status launch_reduce(tdk_dvo *h, int level, int loop_mode, int iter, int max
     int nblk;
     int64_t chunk;
     plan_blocks(h, h->lv[level], &nblk, &chunk);
-    k_dvo_reduce<<<h->n_pairs, kBlock, 0, tdk::stream()>>>(h->d_partials, nblk, h->d_results, h->ls,
+    k_dvo_reduce<<<h->n_pairs, kBlock, 0, h->stream>>>(h->d_partials, nblk, h->d_results, h->ls,
                                                            loop_mode, iter, max_iter);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
@@ -1069,8 +1071,8 @@ tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64
         if (pixel_evals) *pixel_evals += h->lv[level].N * (int64_t)running;
         TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, weight_mode));
         TDK_TRY(launch_reduce(h, level, 1, iter, max_iter));
-        TDK_HIP(hipMemcpyAsync(h->h_flag, h->ls.active, sizeof(int), hipMemcpyDeviceToHost, tdk::stream()));
-        TDK_HIP(hipStreamSynchronize(tdk::stream()));
+        TDK_HIP(hipMemcpyAsync(h->h_flag, h->ls.active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        TDK_HIP(hipStreamSynchronize(h->stream));
         running = *h->h_flag;
         if (running <= 0) break;
     }
@@ -1091,6 +1093,7 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
     TDK_REQUIRE(ratio > 1.0 || n_levels == 1, "layer_size_ratio must be > 1");
     TDK_TRY(tdk::ensure_device());
     tdk_dvo *h = new tdk_dvo();
+    TDK_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->n_pairs = n_pairs; h->H = height; h->W = width; h->n_levels = n_levels;
     h->ratio = ratio; h->with_w = with_weight_map != 0;
     h->max_blocks = 1024;
@@ -1134,7 +1137,7 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
 
 tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     if (!h) return TDK_OK;
-    (void)hipStreamSynchronize(tdk::stream());
+    (void)hipStreamSynchronize(h->stream);
     for (int l = 0; l < h->n_levels; l++) {
         (void)hipFree(h->lv[l].I0); (void)hipFree(h->lv[l].D0); (void)hipFree(h->lv[l].I1);
         if (h->lv[l].W0) (void)hipFree(h->lv[l].W0);
@@ -1151,6 +1154,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
+    (void)hipStreamDestroy(h->stream);
     delete h;
     return TDK_OK;
 }
@@ -1163,12 +1167,12 @@ tdk_status tdk_dvo_upload(tdk_dvo *h, int pair, const double *I0, const double *
     const tdk_dvo::Level &L = h->lv[0];
     size_t bytes = (size_t)L.N * sizeof(double);
     int64_t off = (int64_t)pair * L.stride;
-    TDK_HIP(hipMemcpyAsync(L.I0 + off, I0, bytes, hipMemcpyHostToDevice, tdk::stream()));
-    TDK_HIP(hipMemcpyAsync(L.D0 + off, D0, bytes, hipMemcpyHostToDevice, tdk::stream()));
-    TDK_HIP(hipMemcpyAsync(L.I1 + off, I1, bytes, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(L.I0 + off, I0, bytes, hipMemcpyHostToDevice, h->stream));
+    TDK_HIP(hipMemcpyAsync(L.D0 + off, D0, bytes, hipMemcpyHostToDevice, h->stream));
+    TDK_HIP(hipMemcpyAsync(L.I1 + off, I1, bytes, hipMemcpyHostToDevice, h->stream));
     if (weight_map)
-        TDK_HIP(hipMemcpyAsync(L.W0 + off, weight_map, bytes, hipMemcpyHostToDevice, tdk::stream()));
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+        TDK_HIP(hipMemcpyAsync(L.W0 + off, weight_map, bytes, hipMemcpyHostToDevice, h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
     return TDK_OK;
 }
 
@@ -1176,15 +1180,15 @@ tdk_status tdk_dvo_fill_synthetic(tdk_dvo *h, const double *camera, const double
                                   double noise) {
     TDK_REQUIRE(h && camera && poses12, "null pointer");
     TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * h->n_pairs, hipMemcpyHostToDevice,
-                           tdk::stream()));
+                           h->stream));
     const tdk_dvo::Level &L = h->lv[0];
     int gx = (int)((L.N + kBlock * 4 - 1) / (kBlock * 4));
     dim3 grid(gx < 1 ? 1 : gx, h->n_pairs);
     Cam cam{camera[0], camera[1], camera[2], camera[3]};
-    k_fill_synthetic<<<grid, kBlock, 0, tdk::stream()>>>(L.I0, L.D0, L.I1, L.W0, L.stride, L.H, L.W, cam,
+    k_fill_synthetic<<<grid, kBlock, 0, h->stream>>>(L.I0, L.D0, L.I1, L.W0, L.stride, L.H, L.W, cam,
                                                          h->d_poses_in, seed0, noise);
     TDK_LAUNCH_CHECK();
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(h->stream));
     return TDK_OK;
 }
 
@@ -1212,15 +1216,15 @@ tdk_status tdk_dvo_build_pyramid(tdk_dvo *h) {
             lv[l - 1].stride = L.stride; lv[l - 1].H = L.H; lv[l - 1].W = L.W;
         }
         return tdk::launch_pyramid(srcs, h->with_w ? 4 : 3, S.H, S.W, S.stride, h->n_levels - 1, lv, h->n_pairs,
-                                   mode);
+                                   mode, h->stream);
     }
     for (int l = 1; l < h->n_levels; l++) {
         const tdk_dvo::Level &L = h->lv[l];
-        TDK_TRY(tdk::launch_rescale(S.I0, S.H, S.W, L.I0, L.H, L.W, h->n_pairs, S.stride, L.stride));
-        TDK_TRY(tdk::launch_rescale(S.D0, S.H, S.W, L.D0, L.H, L.W, h->n_pairs, S.stride, L.stride));
-        TDK_TRY(tdk::launch_rescale(S.I1, S.H, S.W, L.I1, L.H, L.W, h->n_pairs, S.stride, L.stride));
+        TDK_TRY(tdk::launch_rescale(S.I0, S.H, S.W, L.I0, L.H, L.W, h->n_pairs, S.stride, L.stride, h->stream));
+        TDK_TRY(tdk::launch_rescale(S.D0, S.H, S.W, L.D0, L.H, L.W, h->n_pairs, S.stride, L.stride, h->stream));
+        TDK_TRY(tdk::launch_rescale(S.I1, S.H, S.W, L.I1, L.H, L.W, h->n_pairs, S.stride, L.stride, h->stream));
         if (h->with_w)
-            TDK_TRY(tdk::launch_rescale(S.W0, S.H, S.W, L.W0, L.H, L.W, h->n_pairs, S.stride, L.stride));
+            TDK_TRY(tdk::launch_rescale(S.W0, S.H, S.W, L.W0, L.H, L.W, h->n_pairs, S.stride, L.stride, h->stream));
     }
     return TDK_OK;
 }
@@ -1239,8 +1243,8 @@ tdk_status tdk_dvo_download(tdk_dvo *h, int pair, int level, int which, double *
     const double *src = which == 0 ? L.I0 : which == 1 ? L.D0 : which == 2 ? L.I1 : L.W0;
     TDK_REQUIRE(src != nullptr, "no weight map in this batch");
     TDK_HIP(hipMemcpyAsync(out, src + (int64_t)pair * L.stride, (size_t)L.N * sizeof(double),
-                           hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+                           hipMemcpyDeviceToHost, h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
     return TDK_OK;
 }
 
@@ -1252,15 +1256,15 @@ tdk_status tdk_dvo_evaluate(tdk_dvo *h, int level, const double *camera0, const 
     TDK_TRY(check_weight_mode(h, weight_mode));
     TDK_TRY(upload_params(h, camera0, camera1));
     TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * h->n_pairs, hipMemcpyHostToDevice,
-                           tdk::stream()));
+                           h->stream));
     if (h->profiling && level == 0) h->prof_pixels += h->lv[0].N * (int64_t)h->n_pairs;
     TDK_TRY(launch_eval(h, level, h->d_poses_in, nullptr, weight_mode));
     TDK_TRY(launch_reduce(h, level, 0, 0, 0));
     void *stage;
     TDK_TRY(tdk::pinned(1, sizeof(double) * kAccPad * h->n_pairs, &stage));
     TDK_HIP(hipMemcpyAsync(stage, h->d_results, sizeof(double) * kAccPad * h->n_pairs, hipMemcpyDeviceToHost,
-                           tdk::stream()));
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+                           h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
     const double *r = (const double *)stage;
     for (int i = 0; i < h->n_pairs; i++) {
         const double *ri = r + (size_t)kAccPad * i;
@@ -1281,15 +1285,15 @@ tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0, 
     TDK_TRY(check_weight_mode(h, weight_mode));
     TDK_TRY(upload_params(h, camera0, camera1));
     TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * h->n_pairs, hipMemcpyHostToDevice,
-                           tdk::stream()));
+                           h->stream));
     int n = h->n_pairs;
-    k_loop_init<<<(n + 255) / 256, 256, 0, tdk::stream()>>>(h->ls, h->d_poses_in, n);
+    k_loop_init<<<(n + 255) / 256, 256, 0, h->stream>>>(h->ls, h->d_poses_in, n);
     TDK_LAUNCH_CHECK();
     TDK_TRY(run_level(h, level, weight_mode, max_iter, nullptr));
-    TDK_HIP(hipMemcpyAsync(poses12, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(poses12, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, h->stream));
     if (n_evals)
-        TDK_HIP(hipMemcpyAsync(n_evals, h->ls.n_evals, sizeof(int) * n, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+        TDK_HIP(hipMemcpyAsync(n_evals, h->ls.n_evals, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
     if (h->profiling) TDK_TRY(collect_profile(h));
     return TDK_OK;
 }
@@ -1301,21 +1305,27 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
     TDK_TRY(upload_params(h, camera0, camera1));
     int n = h->n_pairs;
     TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * n, hipMemcpyHostToDevice,
-                           tdk::stream()));
+                           h->stream));
     if (pixel_evals) *pixel_evals = 0;
     for (int level = h->n_levels - 1; level >= 0; level--) {
         // the prior of a level is the result of the coarser one (:131-134)
         if (level != h->n_levels - 1) {
             TDK_HIP(hipMemcpyAsync(h->d_poses_in, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToDevice,
-                                   tdk::stream()));
+                                   h->stream));
         }
-        k_loop_init<<<(n + 255) / 256, 256, 0, tdk::stream()>>>(h->ls, h->d_poses_in, n);
+        k_loop_init<<<(n + 255) / 256, 256, 0, h->stream>>>(h->ls, h->d_poses_in, n);
         TDK_LAUNCH_CHECK();
         TDK_TRY(run_level(h, level, weight_mode, max_iter, pixel_evals));
     }
-    TDK_HIP(hipMemcpyAsync(poses12, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(poses12, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
     if (h->profiling) TDK_TRY(collect_profile(h));
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_get_stream(tdk_dvo *h, void **stream_out) {
+    TDK_REQUIRE(h != nullptr && stream_out != nullptr, "null pointer");
+    *stream_out = (void *)h->stream;
     return TDK_OK;
 }
 

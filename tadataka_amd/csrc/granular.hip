@@ -276,9 +276,9 @@ namespace tdk {
 // Used by dvo.hip to build pyramid levels of device-resident batches; lives in
 // this translation unit so that the pyramid arithmetic is contraction-free.
 tdk_status launch_rescale(const double *src, int H, int W, double *dst, int Ho, int Wo, int batch,
-                          int64_t src_stride, int64_t dst_stride) {
+                          int64_t src_stride, int64_t dst_stride, hipStream_t stream) {
     dim3 grid(grid_for((int64_t)Ho * Wo), batch);
-    k_rescale<<<grid, 256, 0, tdk::stream()>>>(src, H, W, dst, Ho, Wo, src_stride, dst_stride);
+    k_rescale<<<grid, 256, 0, stream>>>(src, H, W, dst, Ho, Wo, src_stride, dst_stride);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
@@ -286,7 +286,7 @@ tdk_status launch_rescale(const double *src, int H, int W, double *dst, int Ho, 
 // All pyramid levels of all arrays of a batch in one launch.  srcs/dsts hold
 // n_arrays device pointers per level (level-major for dsts).
 tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride,
-                          int n_out, const PyramidLevelDesc *levels, int batch, int mode) {
+                          int n_out, const PyramidLevelDesc *levels, int batch, int mode, hipStream_t stream) {
     if (n_out <= 0) return TDK_OK;
     if (n_out > 15 || n_arrays > 4) {
         set_error("pyramid too deep");
@@ -304,7 +304,7 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
             r.blk_end[l] = blocks;
         }
         dim3 grid(blocks, n_arrays, batch);
-        k_rescale_levels<<<grid, 256, 0, tdk::stream()>>>(r);
+        k_rescale_levels<<<grid, 256, 0, stream>>>(r);
         TDK_LAUNCH_CHECK();
         return TDK_OK;
     }
@@ -321,7 +321,7 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
         }
     }
     dim3 grid((W + kPyrTW - 1) / kPyrTW, (H + kPyrTH - 1) / kPyrTH, batch * n_arrays);
-    k_pyramid<<<grid, 256, 0, tdk::stream()>>>(a);
+    k_pyramid<<<grid, 256, 0, stream>>>(a);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
@@ -473,7 +473,7 @@ tdk_status tdk_rescale(const double *image, int H, int W, double *out, int Ho, i
     void *d_img, *d_out;
     TDK_TRY(to_device(0, image, (size_t)H * W * 8, &d_img));
     TDK_TRY(tdk::scratch(1, (size_t)Ho * Wo * 8, &d_out));
-    TDK_TRY(tdk::launch_rescale((const double *)d_img, H, W, (double *)d_out, Ho, Wo, 1, 0, 0));
+    TDK_TRY(tdk::launch_rescale((const double *)d_img, H, W, (double *)d_out, Ho, Wo, 1, 0, 0, tdk::stream()));
     return to_host(out, d_out, (size_t)Ho * Wo * 8);
 }
 

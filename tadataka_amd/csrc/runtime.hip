@@ -124,7 +124,7 @@ tdk_status tdk_get_device(int *device) {
 
 tdk_status tdk_sync(void) {
     TDK_TRY(tdk::ensure_device());
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    TDK_HIP(hipDeviceSynchronize());   // the library stream and every batch's own stream
     return TDK_OK;
 }
 
@@ -137,13 +137,6 @@ tdk_status tdk_device_name(char *buf, int buflen) {
     TDK_HIP(hipGetDeviceProperties(&prop, dev));
     snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName,
              prop.multiProcessorCount);
-    return TDK_OK;
-}
-
-tdk_status tdk_dvo_get_stream(void **stream_out) {
-    TDK_REQUIRE(stream_out != nullptr, "stream_out is NULL");
-    TDK_TRY(tdk::ensure_device());
-    *stream_out = (void *)tdk::stream();
     return TDK_OK;
 }
 

@@ -24,7 +24,7 @@ tdk_status pinned(int slot, size_t bytes, void **ptr);
 
 // granular.hip: bilinear rescale of `batch` images laid out with the given strides
 tdk_status launch_rescale(const double *src, int H, int W, double *dst, int Ho, int Wo, int batch,
-                          int64_t src_stride, int64_t dst_stride);
+                          int64_t src_stride, int64_t dst_stride, hipStream_t stream);
 
 // granular.hip: every pyramid level of `n_arrays` arrays in one launch.
 // mode 0: one thread per output pixel, blocks ordered so that all levels of one
@@ -36,7 +36,7 @@ struct PyramidLevelDesc {
     int H, W;
 };
 tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride,
-                          int n_out, const PyramidLevelDesc *levels, int batch, int mode);
+                          int n_out, const PyramidLevelDesc *levels, int batch, int mode, hipStream_t stream);
 
 }  // namespace tdk
 
