@@ -553,15 +553,16 @@ struct LoopState {   // device arrays, one entry per pair
     int *state;        // [n]
     int *n_evals;      // [n]
     int *active;       // [1] number of pairs still running
+    int *ticket;       // [1] blocks of the current k_dvo_reduce launch that are through
+    int *host_flag;    // [1] mapped host memory: `active` as left by the last launch
 };
 
 // Fixed-order reduction of the per-block partials of one pair; in loop mode the
 // bookkeeping of _PoseChangeEstimator.__call__ (:92-111) follows.
-__global__ __launch_bounds__(kBlock) void k_dvo_reduce(const double *__restrict__ partials, int nblk,
-                                                       double *__restrict__ results, LoopState ls,
-                                                       int loop_mode, int iter, int max_iter) {
+__device__ __forceinline__ void reduce_pair(const double *__restrict__ partials, int nblk,
+                                            double *__restrict__ results, LoopState ls, int loop_mode, int iter,
+                                            int max_iter) {
     const int pair = blockIdx.x;
-    if (loop_mode && ls.state[pair] != ST_RUNNING) return;
     __shared__ double red[kBlock / 32][kAccPad];
     const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
     double s = 0.0;
@@ -610,6 +611,22 @@ __global__ __launch_bounds__(kBlock) void k_dvo_reduce(const double *__restrict_
     }
 }
 
+__global__ __launch_bounds__(kBlock) void k_dvo_reduce(const double *__restrict__ partials, int nblk,
+                                                       double *__restrict__ results, LoopState ls,
+                                                       int loop_mode, int iter, int max_iter) {
+    const int pair = blockIdx.x;
+    if (!loop_mode || ls.state[pair] == ST_RUNNING) reduce_pair(partials, nblk, results, ls, loop_mode, iter, max_iter);
+    if (!loop_mode || threadIdx.x != 0) return;
+    // the last block through publishes the number of running pairs to the host:
+    // no copy kernel between the iterations, the host just waits for the stream
+    __threadfence();
+    if (atomicAdd(ls.ticket, 1) == (int)gridDim.x - 1) {
+        *ls.ticket = 0;
+        *ls.host_flag = atomicAdd(ls.active, 0);
+        __threadfence_system();
+    }
+}
+
 __global__ void k_loop_init(LoopState ls, const double *__restrict__ poses_in, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -621,7 +638,10 @@ __global__ void k_loop_init(LoopState ls, const double *__restrict__ poses_in, i
     ls.prev_err[i] = 0.0;
     ls.state[i] = ST_RUNNING;
     ls.n_evals[i] = 0;
-    if (i == 0) *ls.active = n;
+    if (i == 0) {
+        *ls.active = n;
+        *ls.ticket = 0;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -844,7 +864,7 @@ struct tdk_dvo {
     double prof_ms;
     int64_t prof_launches, prof_pixels;
     std::vector<double> cams;   // cameras currently on the device: [cam0 (n x 4) | cam1 (n x 4)]
-    int *h_flag;   // "pairs still running" as read back by the host (pinned)
+    int *h_flag;   // "pairs still running", written by k_dvo_reduce (mapped pinned host memory)
 };
 
 namespace {
@@ -1071,9 +1091,8 @@ tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64
         if (pixel_evals) *pixel_evals += h->lv[level].N * (int64_t)running;
         TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, weight_mode));
         TDK_TRY(launch_reduce(h, level, 1, iter, max_iter));
-        TDK_HIP(hipMemcpyAsync(h->h_flag, h->ls.active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        TDK_HIP(hipStreamSynchronize(h->stream));
-        running = *h->h_flag;
+        TDK_HIP(hipStreamSynchronize(h->stream));   // k_dvo_reduce left the count in h_flag
+        running = *(volatile int *)h->h_flag;
         if (running <= 0) break;
     }
     return TDK_OK;
@@ -1130,7 +1149,9 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
     TDK_HIP(hipMalloc(&h->ls.state, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.n_evals, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.active, sizeof(int)));
-    TDK_HIP(hipHostMalloc(&h->h_flag, sizeof(int), hipHostMallocDefault));
+    TDK_HIP(hipMalloc(&h->ls.ticket, sizeof(int)));
+    TDK_HIP(hipHostMalloc(&h->h_flag, sizeof(int), hipHostMallocMapped));
+    TDK_HIP(hipHostGetDevicePointer((void **)&h->ls.host_flag, h->h_flag, 0));
     *out = h;
     return TDK_OK;
 }
@@ -1146,7 +1167,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     (void)hipFree(h->d_params); (void)hipFree(h->d_poses_in); (void)hipFree(h->d_partials);
     (void)hipFree(h->d_results); (void)hipFree(h->ls.pose); (void)hipFree(h->ls.cand);
     (void)hipFree(h->ls.prev_err); (void)hipFree(h->ls.state); (void)hipFree(h->ls.n_evals);
-    (void)hipFree(h->ls.active);
+    (void)hipFree(h->ls.active); (void)hipFree(h->ls.ticket);
     if (h->d_rm) {
         (void)hipFree(h->d_rm); (void)hipFree(h->d_wscale); (void)hipFree(h->d_stat);
         (void)hipFree(h->d_spartial); (void)hipFree(h->d_count); (void)hipFree(h->d_select);
