@@ -121,22 +121,24 @@ __device__ __forceinline__ double2_u ldo2(const double *__restrict__ base, uint3
     return *reinterpret_cast<const double2_u *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-// np.gradient of I1 sampled bilinearly at the warped coordinate
-// (vo/dvo/jacobian.py:27-29 + interpolation): central differences inside
-// (x 0.5 is exact, so it is factored out of the blend) ...
-__device__ __forceinline__ void gradient_inside(const Taps &t, const Warped &p, double &gx, double &gy) {
-    gx = 0.5 * ((t.a2 - t.a0) * p.w00 + (t.a3 - t.a1) * p.w01 + (t.b2 - t.b0) * p.w10 + (t.b3 - t.b1) * p.w11);
-    gy = 0.5 * ((t.b1 - t.t0) * p.w00 + (t.b2 - t.t1) * p.w01 + (t.u0 - t.a1) * p.w10 + (t.u1 - t.a2) * p.w11);
+// TWICE the np.gradient of I1 sampled bilinearly at the warped coordinate
+// (vo/dvo/jacobian.py:27-29 + interpolation): central differences inside.  The
+// factor 0.5 is an exact scaling, so it is folded into the focal length the
+// gradient is multiplied with (half_f below) instead of costing two multiplies.
+__device__ __forceinline__ void gradient2_inside(const Taps &t, const Warped &p, double &gx, double &gy) {
+    gx = (t.a2 - t.a0) * p.w00 + (t.a3 - t.a1) * p.w01 + (t.b2 - t.b0) * p.w10 + (t.b3 - t.b1) * p.w11;
+    gy = (t.b1 - t.t0) * p.w00 + (t.b2 - t.t1) * p.w01 + (t.u0 - t.a1) * p.w10 + (t.u1 - t.a2) * p.w11;
 }
 
 // ... and one-sided differences on the border rows / columns.
-__device__ __forceinline__ void gradient_clamped(const Taps &t, const Warped &p, int H, int W, double &gx,
-                                                 double &gy) {
+__device__ __forceinline__ void gradient2_clamped(const Taps &t, const Warped &p, int H, int W, double &gx,
+                                                  double &gy) {
     int c0 = p.c0, r0 = p.r0, c1 = min(c0 + 1, W - 1), r1 = min(r0 + 1, H - 1);
-    double sx0 = (c0 == 0 || c0 == W - 1) ? 1.0 : 0.5;
-    double sx1 = (c1 == 0 || c1 == W - 1) ? 1.0 : 0.5;
-    double sy0 = (r0 == 0 || r0 == H - 1) ? 1.0 : 0.5;
-    double sy1 = (r1 == 0 || r1 == H - 1) ? 1.0 : 0.5;
+    // one-sided difference: weight 1, central: 1/2 -- times two, as in gradient2_inside
+    double sx0 = (c0 == 0 || c0 == W - 1) ? 2.0 : 1.0;
+    double sx1 = (c1 == 0 || c1 == W - 1) ? 2.0 : 1.0;
+    double sy0 = (r0 == 0 || r0 == H - 1) ? 2.0 : 1.0;
+    double sy1 = (r1 == 0 || r1 == H - 1) ? 2.0 : 1.0;
     gx = (t.a2 - t.a0) * sx0 * p.w00 + (t.a3 - t.a1) * sx1 * p.w01 + (t.b2 - t.b0) * sx0 * p.w10 +
          (t.b3 - t.b1) * sx1 * p.w11;
     gy = (t.b1 - t.t0) * sy0 * p.w00 + (t.b2 - t.t1) * sy0 * p.w01 + (t.u0 - t.a1) * sy1 * p.w10 +
@@ -312,9 +314,10 @@ __device__ __forceinline__ void sp_coordinate(const Pixel &p, const double *c, d
 __device__ __forceinline__ void sp_warp(Pixel &p, bool live, double xn, double yn, double d0, int H, int W,
                                         const double *P, const double *c) {
     double px = xn * d0, py = yn * d0;
-    double qx = P[0] * px + P[1] * py + P[2] * d0 + P[9];
-    double qy = P[3] * px + P[4] * py + P[5] * d0 + P[10];
-    double qz = P[6] * px + P[7] * py + P[8] * d0 + P[11];
+    // R p + t with the translation as the first addend of the fma chain (3 instead of 4 operations per row)
+    double qx = __builtin_fma(P[2], d0, __builtin_fma(P[1], py, __builtin_fma(P[0], px, P[9])));
+    double qy = __builtin_fma(P[5], d0, __builtin_fma(P[4], py, __builtin_fma(P[3], px, P[10])));
+    double qz = __builtin_fma(P[8], d0, __builtin_fma(P[7], py, __builtin_fma(P[6], px, P[11])));
     {
 #pragma clang fp contract(off)
         double z = qz + tdk::kEps16;
@@ -403,8 +406,11 @@ __device__ __forceinline__ void sp_issue(Samples &s, const Pixel &p, uint32_t of
 }
 
 template <int WMODE>
-__device__ __forceinline__ void sp_accumulate(Accum &a, const Samples &s, const Pixel &p, double ws, int H,
-                                              int W, const double *c) {
+__device__ __forceinline__ void sp_accumulate(Accum &a, int &n_error, int &n_update, const Samples &s,
+                                              const Pixel &p, double ws, int H, int W, const double *c) {
+    // mask sizes: one scalar popcount per wave instead of two f64 adds per lane
+    n_error += __builtin_popcountll(__builtin_amdgcn_ballot_w64(p.mask != 0));
+    n_update += __builtin_popcountll(__builtin_amdgcn_ballot_w64(p.mask == 2));
     if (p.mask == 0) return;
     Warped w;
     w.c0 = p.c0; w.r0 = p.r0;
@@ -418,18 +424,17 @@ __device__ __forceinline__ void sp_accumulate(Accum &a, const Samples &s, const 
     const double wx0 = 1.0 - wx1, wy0 = 1.0 - wy1;
     w.w00 = wx0 * wy0; w.w01 = wx1 * wy0; w.w10 = wx0 * wy1; w.w11 = wx1 * wy1;
     double gx, gy;
-    if (border) gradient_clamped(t, w, H, W, gx, gy);
-    else gradient_inside(t, w, gx, gy);
+    if (border) gradient2_clamped(t, w, H, W, gx, gy);
+    else gradient2_inside(t, w, gx, gy);
     // photometric error term (metric.py:24-27): no z test here
     double i1w = t.a1 * w.w00 + t.a2 * w.w01 + t.b1 * w.w10 + t.b2 * w.w11;
     double e = s.i0 - i1w;
     a.v[27] += e * e;
-    a.v[29] += 1.0;
     if (p.mask != 2) return;  // update mask adds P1z > 0 (vo/dvo/__init__.py:49)
     // Jacobian row (vo/dvo/jacobian.py:8-24) with X = x/z, Y = y/z factored out:
     //   [fgx/z, fgy/z, -(fgx X + fgy Y)/z, -fgx XY - fgy (1 + Y^2), fgx (1 + X^2) + fgy XY, fgy X - fgx Y]
     const double X = p.sx, Y = p.sy;
-    const double fgx = c[0] * gx, fgy = c[1] * gy;
+    const double fgx = (0.5 * c[0]) * gx, fgy = (0.5 * c[1]) * gy;   // gx, gy are twice the gradient
     const double xy = X * Y;
     double J[6];
     J[0] = fgx * p.rz;
@@ -449,7 +454,6 @@ __device__ __forceinline__ void sp_accumulate(Accum &a, const Samples &s, const 
         for (int q = i; q < 6; q++) a.v[k++] += wj * J[q];
         a.v[21 + i] += wj * r;
     }
-    a.v[28] += 1.0;
 }
 
 template <int WMODE>
@@ -505,6 +509,7 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
     Pixel pa, pb;
     Samples s;
     s.w0 = 1.0;
+    int n_error = 0, n_update = 0;   // wave-uniform (SGPRs)
     // prologue: warp pixels 0 and 1, issue the loads of pixel 0
     double d = TDK_DEPTH();
     sp_warp(pa, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
 #define TDK_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
     while (iw - 2 * kBlock < end) {
         d = TDK_DEPTH();
-        sp_accumulate<WMODE>(acc, s, pa, ws, H, W, b.c);
+        sp_accumulate<WMODE>(acc, n_error, n_update, s, pa, ws, H, W, b.c);
         TDK_STAGE_FENCE();
         sp_issue<WMODE>(s, pb, TDK_OFF(iw - kBlock), I0, I1, W0, H, W, b.c);
         TDK_STAGE_FENCE();
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
         TDK_STAGE_FENCE();
 
         d = TDK_DEPTH();
-        sp_accumulate<WMODE>(acc, s, pb, ws, H, W, b.c);
+        sp_accumulate<WMODE>(acc, n_error, n_update, s, pb, ws, H, W, b.c);
         TDK_STAGE_FENCE();
         sp_issue<WMODE>(s, pa, TDK_OFF(iw - kBlock), I0, I1, W0, H, W, b.c);
         TDK_STAGE_FENCE();
@@ -540,6 +545,10 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
 #undef TDK_ADVANCE
 #undef TDK_DEPTH
 #undef TDK_OFF
+    if ((threadIdx.x & 63) == 0) {   // the wave's mask sizes ride in lane 0's accumulators
+        acc.v[28] = (double)n_update;
+        acc.v[29] = (double)n_error;
+    }
     store_partials(acc, red, pair, partials);
 }
 
@@ -878,9 +887,10 @@ int level_dim(int full, double scale) {
 }
 
 void plan_blocks(const tdk_dvo *h, const tdk_dvo::Level &L, int *nblk, int64_t *chunk) {
-    // >= 8 pixels per thread, but no more than ~8192 blocks in the whole grid
-    // (measured flat between 4096 and 16384 blocks and 8 to 24 pixels per thread)
-    int64_t per_block = (int64_t)kBlock * 8;
+    // >= 16 pixels per thread (the pipeline of k_dvo_eval takes ~3 pixel-steps to
+    // fill and drain), but no more than ~8192 blocks in the whole grid; measured
+    // flat (+-0.5 %) from 12 to 40 pixels per thread on the bench workload
+    int64_t per_block = (int64_t)kBlock * 16;
     int64_t nb = (L.N + per_block - 1) / per_block;
     int64_t cap = 8192 / h->n_pairs;
     if (cap < 1) cap = 1;
