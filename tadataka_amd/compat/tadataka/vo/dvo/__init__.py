@@ -96,6 +96,24 @@ def _pose12(pose):
     return ops.pose12(pose.R, pose.t)[None]
 
 
+# Device batches are kept between calls (one per shape / pyramid / weight-map
+# configuration, most recent two): creating one costs ~4 ms of allocations and a
+# stream, an estimation of one 640x480 pair ~0.5 ms.  Not thread-safe, like the
+# rest of this module.
+_BATCHES = {}
+
+
+def _batch_for(shape, n_levels, ratio, with_weight_map):
+    key = (int(shape[0]), int(shape[1]), int(n_levels), float(ratio), bool(with_weight_map))
+    batch = _BATCHES.pop(key, None)
+    if batch is None:
+        batch = ops.DvoBatch(1, key[0], key[1], n_levels=key[2], ratio=key[3], with_weight_map=key[4])
+    _BATCHES[key] = batch          # most recently used last
+    while len(_BATCHES) > 2:
+        _BATCHES.pop(next(iter(_BATCHES))).close()
+    return batch
+
+
 class _PoseChangeEstimator(object):
     """Gauss-Newton at one resolution."""
     def __init__(self, camera_model0, camera_model1, max_iter):
@@ -105,14 +123,11 @@ class _PoseChangeEstimator(object):
 
     def __call__(self, I0, D0, I1, pose10, weights=None):
         _check_weights_name(weights)
-        batch = ops.DvoBatch(1, I0.shape[0], I0.shape[1],
-                             with_weight_map=isinstance(weights, np.ndarray))
-        try:
-            batch.upload(0, I0, D0, I1, weights if isinstance(weights, np.ndarray) else None)
-            return _estimate_level(batch, 0, self.camera_model0, self.camera_model1, pose10,
-                                   weights, self.max_iter)
-        finally:
-            batch.close()
+        has_map = isinstance(weights, np.ndarray)
+        batch = _batch_for(I0.shape, 1, 1.5, has_map)
+        batch.upload(0, I0, D0, I1, weights if has_map else None)
+        return _estimate_level(batch, 0, self.camera_model0, self.camera_model1, pose10,
+                               weights, self.max_iter)
 
 
 def _estimate_level(batch, level, camera_model0, camera_model1, pose10, weights, max_iter):
@@ -146,15 +161,10 @@ class PoseChangeEstimator(object):
         _check_weights_name(weights)
         pose10 = Pose.identity() if pose10 is None else pose10
         has_map = isinstance(weights, np.ndarray)
-        batch = ops.DvoBatch(1, I0.shape[0], I0.shape[1], n_levels=self.n_coarse_to_fine,
-                             ratio=self.layer_size_ratio, with_weight_map=has_map)
-        batch.ratio = self.layer_size_ratio
-        try:
-            batch.upload(0, I0, D0, I1, weights if has_map else None)
-            batch.build_pyramid()
-            cam0 = ops.camera_vec(self.camera_model0)
-            cam1 = ops.camera_vec(self.camera_model1)
-            P, _ = batch.estimate(cam0, cam1, _pose12(pose10), _fused_mode(weights), self.max_iter)
-            return Pose.from_matrix(P[0])
-        finally:
-            batch.close()
+        batch = _batch_for(I0.shape, self.n_coarse_to_fine, self.layer_size_ratio, has_map)
+        batch.upload(0, I0, D0, I1, weights if has_map else None)
+        batch.build_pyramid()
+        cam0 = ops.camera_vec(self.camera_model0)
+        cam1 = ops.camera_vec(self.camera_model1)
+        P, _ = batch.estimate(cam0, cam1, _pose12(pose10), _fused_mode(weights), self.max_iter)
+        return Pose.from_matrix(P[0])

@@ -14,6 +14,7 @@
 #include "tdk_runtime.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <utility>
@@ -157,7 +158,10 @@ __global__ __launch_bounds__(kBlock) void k_ba_exp_so3(const double *__restrict_
 // and are bit-reproducible for any observation order; a chunk that holds no
 // observation of j (the common case for the viewpoint-major order np.where
 // produces) is skipped after two index reads.  The per-point sums V_i / eb_i are
-// scattered with f64 atomics (few writers per point).
+// either scattered with f64 atomics (stateless entry point: no observation
+// lists) or, for a tdk_ba handle, left to k_ba_point_sums: this kernel then only
+// stores B_ij and the residual per observation (Bobs, structure of arrays
+// [8][n]) and W_ij = A^T B (Wobs, [18][n]).
 __global__ __launch_bounds__(kBlock) void k_ba_block_reduce(const double *__restrict__ poses,
                                                             const double *__restrict__ points,
                                                             const double *__restrict__ x_true,
@@ -166,7 +170,8 @@ __global__ __launch_bounds__(kBlock) void k_ba_block_reduce(const double *__rest
                                                             int64_t chunk, int sorted_by_viewpoint,
                                                             double *__restrict__ V, double *__restrict__ eb,
                                                             double *__restrict__ partials,
-                                                            double *__restrict__ Wobs) {
+                                                            double *__restrict__ Wobs,
+                                                            double *__restrict__ Bobs) {
     const int64_t j = blockIdx.y;
     const int64_t start = blockIdx.x * chunk;
     const int64_t end = min(n, start + chunk);
@@ -195,18 +200,26 @@ __global__ __launch_bounds__(kBlock) void k_ba_block_reduce(const double *__rest
                 for (int b = a; b < 6; b++) acc[m++] += A[a] * A[b] + A[6 + a] * A[6 + b];
                 acc[21 + a] += A[a] * e0 + A[6 + a] * e1;
             }
-            m = 0;
+            if (V != nullptr) {
+                m = 0;
 #pragma unroll
-            for (int a = 0; a < 3; a++) {
+                for (int a = 0; a < 3; a++) {
 #pragma unroll
-                for (int b = a; b < 3; b++) atomicAdd(&V[6 * ip + m++], B[a] * B[b] + B[3 + a] * B[3 + b]);
-                atomicAdd(&eb[3 * ip + a], B[a] * e0 + B[3 + a] * e1);
+                    for (int b = a; b < 3; b++) atomicAdd(&V[6 * ip + m++], B[a] * B[b] + B[3 + a] * B[3 + b]);
+                    atomicAdd(&eb[3 * ip + a], B[a] * e0 + B[3 + a] * e1);
+                }
+            }
+            if (Bobs != nullptr) {
+#pragma unroll
+                for (int a = 0; a < 6; a++) Bobs[a * n + k] = B[a];
+                Bobs[6 * n + k] = e0;
+                Bobs[7 * n + k] = e1;
             }
             if (Wobs != nullptr) {   // W_ij = A^T B (6x3), kept for the Schur complement
 #pragma unroll
                 for (int a = 0; a < 6; a++)
 #pragma unroll
-                    for (int b = 0; b < 3; b++) Wobs[18 * k + 3 * a + b] = A[a] * B[b] + A[6 + a] * B[3 + b];
+                    for (int b = 0; b < 3; b++) Wobs[(3 * a + b) * n + k] = A[a] * B[b] + A[6 + a] * B[3 + b];
             }
         }
     }
@@ -260,36 +273,152 @@ __global__ __launch_bounds__(kBlock) void k_ba_finish(const double *__restrict__
 // ---------------------------------------------------------------------------
 constexpr int kMaxLdsPoses = 12;   // (6 * 12)^2 doubles = 41 KB of LDS for the private S
 
+// V_i = sum_j B_ij^T B_ij (upper triangle, 6) and eb_i = sum_j B_ij^T e_ij: one thread
+// per point walks its observation list in increasing observation index -- no
+// atomics, bit-reproducible.  Arrays per point are structure-of-arrays ([6][Q], [3][Q]).
+__global__ __launch_bounds__(kBlock) void k_ba_point_sums(const int64_t *__restrict__ row_ptr,
+                                                          const int64_t *__restrict__ obs_of_point,
+                                                          const double *__restrict__ Bobs, int64_t n,
+                                                          int64_t n_points, double *__restrict__ V,
+                                                          double *__restrict__ eb) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n_points; i += (int64_t)gridDim.x * kBlock) {
+        double v[6] = {0., 0., 0., 0., 0., 0.}, g[3] = {0., 0., 0.};
+        for (int64_t pa = row_ptr[i]; pa < row_ptr[i + 1]; pa++) {
+            const int64_t k = obs_of_point[pa];
+            double B[6];
+#pragma unroll
+            for (int a = 0; a < 6; a++) B[a] = Bobs[a * n + k];
+            const double e0 = Bobs[6 * n + k], e1 = Bobs[7 * n + k];
+            int m = 0;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+#pragma unroll
+                for (int b = a; b < 3; b++) v[m++] += B[a] * B[b] + B[3 + a] * B[3 + b];
+                g[a] += B[a] * e0 + B[3 + a] * e1;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 6; m++) V[m * n_points + i] = v[m];
+#pragma unroll
+        for (int a = 0; a < 3; a++) eb[a * n_points + i] = g[a];
+    }
+}
+
 // inverse of the damped symmetric 3x3 V (upper triangle in, upper triangle out)
 __global__ __launch_bounds__(kBlock) void k_ba_invert_V(const double *__restrict__ V, double mu, int64_t n_points,
                                                         double *__restrict__ Vinv) {
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n_points; i += (int64_t)gridDim.x * kBlock) {
-        double a = V[6 * i] + mu, b = V[6 * i + 1], c = V[6 * i + 2];
-        double d = V[6 * i + 3] + mu, e = V[6 * i + 4], f = V[6 * i + 5] + mu;
+        const int64_t Q = n_points;
+        double a = V[i] + mu, b = V[Q + i], c = V[2 * Q + i];
+        double d = V[3 * Q + i] + mu, e = V[4 * Q + i], f = V[5 * Q + i] + mu;
         double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
         double det = a * c00 + b * c01 + c * c02;
         double id = 1.0 / det;
-        Vinv[6 * i] = c00 * id;
-        Vinv[6 * i + 1] = c01 * id;
-        Vinv[6 * i + 2] = c02 * id;
-        Vinv[6 * i + 3] = (a * f - c * c) * id;
-        Vinv[6 * i + 4] = (b * c - a * e) * id;
-        Vinv[6 * i + 5] = (a * d - b * b) * id;
+        Vinv[i] = c00 * id;
+        Vinv[Q + i] = c01 * id;
+        Vinv[2 * Q + i] = c02 * id;
+        Vinv[3 * Q + i] = (a * f - c * c) * id;
+        Vinv[4 * Q + i] = (b * c - a * e) * id;
+        Vinv[5 * Q + i] = (a * d - b * b) * id;
     }
 }
 
-// One thread per point walks the point's observation list (CSR): subtracts
-// Y_ij W_ik^T from the (j, k) block of S for every pair of its observers and
-// Y_ij eb_i from e_j.  S is accumulated in an LDS-private copy per block when it
-// fits (few poses, heavy collisions), else directly with global atomics.
+// Schur complement by pose pair.  Block (chunk, pair) takes one block (ja <= jb)
+// of the upper block triangle of S and a range of points; a thread looks up the
+// two observations of its point in the dense table obs_at[pose][point] (-1: not
+// seen), forms Y = W_a V^-1 and adds Y W_b^T to 36 register accumulators (plus
+// Y eb for the 6 entries of e_ja on diagonal pairs).  No atomics: per-block
+// partials, summed in block order by k_ba_schur_finish, so S is bit-reproducible.
+// W is read as structure of arrays, consecutive points -> consecutive
+// observations for the usual pose-major order, i.e. coalesced; it is re-read
+// once per pair, from L2 / Infinity Cache after the first pass.
+constexpr int kSchurAcc = 42, kSchurAccPad = 48;
+
+__global__ __launch_bounds__(kBlock) void k_ba_schur_pairs(const int *__restrict__ obs_at,
+                                                           const double *__restrict__ Wobs,
+                                                           const double *__restrict__ Vinv,
+                                                           const double *__restrict__ eb, int64_t n,
+                                                           int64_t n_points, int n_poses, int64_t chunk,
+                                                           double *__restrict__ partials) {
+    // pair index -> (ja, jb), row-major over the upper triangle
+    int ja = 0, rem = blockIdx.y;
+    while (rem >= n_poses - ja) { rem -= n_poses - ja; ja++; }
+    const int jb = ja + rem;
+    const int64_t Q = n_points;
+    const int64_t start = blockIdx.x * chunk, end = min(Q, start + chunk);
+    double acc[kSchurAcc];
+#pragma unroll
+    for (int i = 0; i < kSchurAcc; i++) acc[i] = 0.0;
+    for (int64_t i = start + threadIdx.x; i < end; i += kBlock) {
+        const int ka = obs_at[(int64_t)ja * Q + i], kb = obs_at[(int64_t)jb * Q + i];
+        if (ka < 0 || kb < 0) continue;
+        const double vi[6] = {Vinv[i], Vinv[Q + i], Vinv[2 * Q + i], Vinv[3 * Q + i], Vinv[4 * Q + i], Vinv[5 * Q + i]};
+        double Y[18];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const double w0 = Wobs[(3 * r) * n + ka], w1 = Wobs[(3 * r + 1) * n + ka], w2 = Wobs[(3 * r + 2) * n + ka];
+            Y[3 * r] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
+            Y[3 * r + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
+            Y[3 * r + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            const double w0 = Wobs[(3 * c) * n + kb], w1 = Wobs[(3 * c + 1) * n + kb], w2 = Wobs[(3 * c + 2) * n + kb];
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[6 * r + c] += Y[3 * r] * w0 + Y[3 * r + 1] * w1 + Y[3 * r + 2] * w2;
+        }
+        if (ja == jb) {
+            const double e0 = eb[i], e1 = eb[Q + i], e2 = eb[2 * Q + i];
+#pragma unroll
+            for (int r = 0; r < 6; r++) acc[36 + r] += Y[3 * r] * e0 + Y[3 * r + 1] * e1 + Y[3 * r + 2] * e2;
+        }
+    }
+    __shared__ double red[kBlock / 64][kSchurAccPad];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < kSchurAcc; i++) {
+        double v = acc[i];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kSchurAcc) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; w++) v += red[w][threadIdx.x];
+        partials[((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kSchurAccPad + threadIdx.x] = v;
+    }
+}
+
+// S(ja, jb) = -sum of the chunk partials (fixed order); e_ja likewise on diagonal pairs
+__global__ void k_ba_schur_finish(const double *__restrict__ partials, int nchunks, int n_poses, int dim,
+                                  double *__restrict__ S, double *__restrict__ evec) {
+    int ja = 0, rem = blockIdx.x;
+    while (rem >= n_poses - ja) { rem -= n_poses - ja; ja++; }
+    const int jb = ja + rem;
+    const int t = threadIdx.x;
+    if (t >= kSchurAcc) return;
+    double v = 0.0;
+    for (int b = 0; b < nchunks; b++) v += partials[((int64_t)blockIdx.x * nchunks + b) * kSchurAccPad + t];
+    if (t < 36) S[(size_t)(6 * ja + t / 6) * dim + 6 * jb + t % 6] = -v;
+    else if (ja == jb) evec[6 * ja + t - 36] = -v;
+}
+
+// General fallback (too many poses x points for the dense observation table, or
+// duplicate observations): one thread per point walks the point's observation
+// list (CSR) and subtracts Y_ij W_ik^T from the (j, k) block of S for every
+// pair of its observers and Y_ij eb_i from e_j, with atomics -- into an
+// LDS-private copy of S per block when it fits, else into global memory.
 template <bool LDS_S>
 __global__ __launch_bounds__(kBlock) void k_ba_schur(const int64_t *__restrict__ row_ptr,
                                                      const int64_t *__restrict__ obs_of_point,
                                                      const int64_t *__restrict__ vp,
                                                      const double *__restrict__ Wobs,
                                                      const double *__restrict__ Vinv,
-                                                     const double *__restrict__ eb, int64_t n_points, int dim,
-                                                     double *__restrict__ S, double *__restrict__ evec) {
+                                                     const double *__restrict__ eb, int64_t n,
+                                                     int64_t n_points, int dim, double *__restrict__ S,
+                                                     double *__restrict__ evec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *Sl = reinterpret_cast<double *>(smem);
     if (LDS_S) {
@@ -300,16 +429,16 @@ __global__ __launch_bounds__(kBlock) void k_ba_schur(const int64_t *__restrict__
     double *eacc = LDS_S ? Sl + dim * dim : evec;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n_points; i += (int64_t)gridDim.x * kBlock) {
         const int64_t b0 = row_ptr[i], b1 = row_ptr[i + 1];
-        const double vi[6] = {Vinv[6 * i], Vinv[6 * i + 1], Vinv[6 * i + 2],
-                              Vinv[6 * i + 3], Vinv[6 * i + 4], Vinv[6 * i + 5]};
-        const double ebi[3] = {eb[3 * i], eb[3 * i + 1], eb[3 * i + 2]};
+        const int64_t Q = n_points;
+        const double vi[6] = {Vinv[i], Vinv[Q + i], Vinv[2 * Q + i], Vinv[3 * Q + i], Vinv[4 * Q + i], Vinv[5 * Q + i]};
+        const double ebi[3] = {eb[i], eb[Q + i], eb[2 * Q + i]};
         for (int64_t pa = b0; pa < b1; pa++) {
             const int64_t ka = obs_of_point[pa];
             const int ja = (int)vp[ka];
             double Y[18];
 #pragma unroll
             for (int r = 0; r < 6; r++) {
-                double w0 = Wobs[18 * ka + 3 * r], w1 = Wobs[18 * ka + 3 * r + 1], w2 = Wobs[18 * ka + 3 * r + 2];
+                double w0 = Wobs[(3 * r) * n + ka], w1 = Wobs[(3 * r + 1) * n + ka], w2 = Wobs[(3 * r + 2) * n + ka];
                 Y[3 * r] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
                 Y[3 * r + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
                 Y[3 * r + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
@@ -323,7 +452,7 @@ __global__ __launch_bounds__(kBlock) void k_ba_schur(const int64_t *__restrict__
                 if (jb < ja) continue;   // upper block triangle; mirrored on the host
 #pragma unroll
                 for (int c = 0; c < 6; c++) {
-                    double w0 = Wobs[18 * kb + 3 * c], w1 = Wobs[18 * kb + 3 * c + 1], w2 = Wobs[18 * kb + 3 * c + 2];
+                    double w0 = Wobs[(3 * c) * n + kb], w1 = Wobs[(3 * c + 1) * n + kb], w2 = Wobs[(3 * c + 2) * n + kb];
 #pragma unroll
                     for (int r = 0; r < 6; r++)
                         atomicAdd(&Sacc[(6 * ja + r) * dim + 6 * jb + c],
@@ -347,21 +476,22 @@ __global__ __launch_bounds__(kBlock) void k_ba_backsub(const int64_t *__restrict
                                                        const double *__restrict__ Wobs,
                                                        const double *__restrict__ Vinv,
                                                        const double *__restrict__ eb,
-                                                       const double *__restrict__ da, int64_t n_points,
-                                                       double *__restrict__ db) {
+                                                       const double *__restrict__ da, int64_t n,
+                                                       int64_t n_points, double *__restrict__ db) {
+    const int64_t Q = n_points;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n_points; i += (int64_t)gridDim.x * kBlock) {
-        double g[3] = {eb[3 * i], eb[3 * i + 1], eb[3 * i + 2]};
+        double g[3] = {eb[i], eb[Q + i], eb[2 * Q + i]};
         for (int64_t pa = row_ptr[i]; pa < row_ptr[i + 1]; pa++) {
             const int64_t k = obs_of_point[pa];
             const double *d = da + 6 * vp[k];
 #pragma unroll
             for (int r = 0; r < 6; r++) {
-                g[0] -= Wobs[18 * k + 3 * r] * d[r];
-                g[1] -= Wobs[18 * k + 3 * r + 1] * d[r];
-                g[2] -= Wobs[18 * k + 3 * r + 2] * d[r];
+                g[0] -= Wobs[(3 * r) * n + k] * d[r];
+                g[1] -= Wobs[(3 * r + 1) * n + k] * d[r];
+                g[2] -= Wobs[(3 * r + 2) * n + k] * d[r];
             }
         }
-        const double *v = Vinv + 6 * i;
+        const double v[6] = {Vinv[i], Vinv[Q + i], Vinv[2 * Q + i], Vinv[3 * Q + i], Vinv[4 * Q + i], Vinv[5 * Q + i]};
         db[3 * i] = v[0] * g[0] + v[1] * g[1] + v[2] * g[2];
         db[3 * i + 1] = v[1] * g[0] + v[3] * g[1] + v[4] * g[2];
         db[3 * i + 2] = v[2] * g[0] + v[4] * g[1] + v[5] * g[2];
@@ -496,7 +626,7 @@ tdk_status tdk_ba_block_reduce(const double *poses, int64_t n_poses, const doubl
         dim3 grid((unsigned)nchunks, (unsigned)n_poses);
         k_ba_block_reduce<<<grid, kBlock, 0, tdk::stream()>>>(
             (const double *)d_poses, (const double *)d_points, (const double *)d_xt, (const int64_t *)d_vp,
-            (const int64_t *)d_pt, n, chunk, sorted, (double *)d_V, (double *)d_eb, (double *)d_part, nullptr);
+            (const int64_t *)d_pt, n, chunk, sorted, (double *)d_V, (double *)d_eb, (double *)d_part, nullptr, nullptr);
         TDK_LAUNCH_CHECK();
     } else {
         TDK_HIP(hipMemsetAsync(d_part, 0, (size_t)n_poses * nchunks * kPoseAccPad * 8, tdk::stream()));
@@ -527,23 +657,31 @@ struct tdk_ba {
     double *d_poses, *d_points, *d_xt;
     int64_t *d_vp, *d_pt, *d_row_ptr, *d_obs;
     double *d_U, *d_ea, *d_V, *d_eb, *d_part, *d_err, *d_W, *d_Vinv, *d_S, *d_e, *d_da, *d_db;
+    double *d_Be;       // [8][n]: B_ij (2x3) and the residual of every observation
+    // Schur complement by pose pair (k_ba_schur_pairs): dense observation table
+    int *d_obs_at;      // [n_poses][n_points] observation index or -1; NULL -> atomics fallback
+    double *d_spart;    // [pairs][point chunks][kSchurAccPad]
+    int64_t pchunk, npchunks;
 };
 
 namespace {
 
-tdk_status ba_reduce(tdk_ba *h, const double *poses, const double *points, bool with_W, double *err) {
+tdk_status ba_reduce(tdk_ba *h, const double *poses, const double *points, bool for_step, double *err) {
     TDK_HIP(hipMemcpyAsync(h->d_poses, poses, (size_t)h->n_poses * 48, hipMemcpyHostToDevice, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(h->d_points, points, (size_t)h->n_points * 24, hipMemcpyHostToDevice, tdk::stream()));
-    TDK_HIP(hipMemsetAsync(h->d_V, 0, (size_t)h->n_points * 48, tdk::stream()));
-    TDK_HIP(hipMemsetAsync(h->d_eb, 0, (size_t)h->n_points * 24, tdk::stream()));
     dim3 grid((unsigned)h->nchunks, (unsigned)h->n_poses);
     k_ba_block_reduce<<<grid, kBlock, 0, tdk::stream()>>>(h->d_poses, h->d_points, h->d_xt, h->d_vp, h->d_pt, h->n,
-                                                          h->chunk, h->sorted, h->d_V, h->d_eb, h->d_part,
-                                                          with_W ? h->d_W : nullptr);
+                                                          h->chunk, h->sorted, nullptr, nullptr, h->d_part,
+                                                          for_step ? h->d_W : nullptr, for_step ? h->d_Be : nullptr);
     TDK_LAUNCH_CHECK();
     k_ba_finish<<<(unsigned)h->n_poses, kBlock, 0, tdk::stream()>>>(h->d_part, (int)h->nchunks, h->d_U, h->d_ea,
                                                                     h->d_err);
     TDK_LAUNCH_CHECK();
+    if (for_step) {
+        k_ba_point_sums<<<grid_for(h->n_points), kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_Be, h->n,
+                                                                             h->n_points, h->d_V, h->d_eb);
+        TDK_LAUNCH_CHECK();
+    }
     std::vector<double> e((size_t)h->n_poses);
     TDK_HIP(hipMemcpyAsync(e.data(), h->d_err, (size_t)h->n_poses * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
@@ -566,7 +704,7 @@ tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *vp, c
     TDK_TRY(tdk::ensure_device());
     tdk_ba *h = new tdk_ba();
     h->n_poses = n_poses; h->n_points = n_points; h->n = n; h->sorted = sorted;
-    h->chunk = 2048;
+    h->chunk = 2048;   // (512 was measured slower: the per-block reduction dominates small chunks)
     h->nchunks = (n + h->chunk - 1) / h->chunk;
     if (h->nchunks > 4096) {
         h->nchunks = 4096;
@@ -601,6 +739,29 @@ tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *vp, c
     TDK_HIP(hipMalloc(&h->d_e, (size_t)dim * 8));
     TDK_HIP(hipMalloc(&h->d_da, (size_t)dim * 8));
     TDK_HIP(hipMalloc(&h->d_db, (size_t)n_points * 24));
+    TDK_HIP(hipMalloc(&h->d_Be, (size_t)n * 8 * 8));
+    // dense (pose, point) -> observation table for the pair-wise Schur kernel:
+    // only when it is small (local BA windows) and no observation is repeated
+    h->d_obs_at = nullptr; h->d_spart = nullptr;
+    h->pchunk = 2048;
+    h->npchunks = (n_points + h->pchunk - 1) / h->pchunk;
+    const char *force = getenv("TDK_BA_SCHUR");   // "atomics": always take the general kernel (tests)
+    if (!(force && !strcmp(force, "atomics")) && n_poses * n_points <= (1ll << 26) && n < (1ll << 31) &&
+        n_poses <= 256) {
+        std::vector<int> table((size_t)(n_poses * n_points), -1);
+        bool unique = true;
+        for (int64_t k = 0; k < n && unique; k++) {
+            int &slot = table[(size_t)(vp[k] * n_points + pt[k])];
+            if (slot >= 0) unique = false;
+            slot = (int)k;
+        }
+        if (unique) {
+            const int64_t pairs = n_poses * (n_poses + 1) / 2;
+            TDK_HIP(hipMalloc(&h->d_obs_at, table.size() * sizeof(int)));
+            TDK_HIP(hipMalloc(&h->d_spart, (size_t)(pairs * h->npchunks) * kSchurAccPad * 8));
+            TDK_HIP(hipMemcpy(h->d_obs_at, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice));
+        }
+    }
     TDK_HIP(hipMemcpyAsync(h->d_xt, x_true, (size_t)n * 16, hipMemcpyHostToDevice, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(h->d_vp, vp, (size_t)n * 8, hipMemcpyHostToDevice, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(h->d_pt, pt, (size_t)n * 8, hipMemcpyHostToDevice, tdk::stream()));
@@ -615,7 +776,8 @@ tdk_status tdk_ba_destroy(tdk_ba *h) {
     if (!h) return TDK_OK;
     (void)hipStreamSynchronize(tdk::stream());
     void *ptrs[] = {h->d_poses, h->d_points, h->d_xt, h->d_vp, h->d_pt, h->d_row_ptr, h->d_obs, h->d_U, h->d_ea,
-                    h->d_V, h->d_eb, h->d_part, h->d_err, h->d_W, h->d_Vinv, h->d_S, h->d_e, h->d_da, h->d_db};
+                    h->d_V, h->d_eb, h->d_part, h->d_err, h->d_W, h->d_Vinv, h->d_S, h->d_e, h->d_da, h->d_db,
+                    h->d_Be, h->d_obs_at, h->d_spart};
     for (void *p : ptrs) (void)hipFree(p);
     delete h;
     return TDK_OK;
@@ -637,14 +799,24 @@ tdk_status tdk_ba_step(tdk_ba *h, const double *poses, const double *points, dou
     TDK_LAUNCH_CHECK();
     TDK_HIP(hipMemsetAsync(h->d_S, 0, (size_t)dim * dim * 8, tdk::stream()));
     TDK_HIP(hipMemsetAsync(h->d_e, 0, (size_t)dim * 8, tdk::stream()));
-    int gs = gp > 1024 ? 1024 : gp;
-    if (h->n_poses <= kMaxLdsPoses) {
-        size_t lds = ((size_t)dim * dim + dim) * 8;
-        k_ba_schur<true><<<gs, kBlock, lds, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv,
-                                                             h->d_eb, h->n_points, dim, h->d_S, h->d_e);
+    if (h->d_obs_at != nullptr) {
+        const int pairs = (int)(h->n_poses * (h->n_poses + 1) / 2);
+        dim3 grid((unsigned)h->npchunks, (unsigned)pairs);
+        k_ba_schur_pairs<<<grid, kBlock, 0, tdk::stream()>>>(h->d_obs_at, h->d_W, h->d_Vinv, h->d_eb, h->n,
+                                                             h->n_points, (int)h->n_poses, h->pchunk, h->d_spart);
+        TDK_LAUNCH_CHECK();
+        k_ba_schur_finish<<<pairs, 64, 0, tdk::stream()>>>(h->d_spart, (int)h->npchunks, (int)h->n_poses, dim, h->d_S,
+                                                           h->d_e);
     } else {
-        k_ba_schur<false><<<gs, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv,
-                                                            h->d_eb, h->n_points, dim, h->d_S, h->d_e);
+        int gs = gp > 1024 ? 1024 : gp;
+        if (h->n_poses <= kMaxLdsPoses) {
+            size_t lds = ((size_t)dim * dim + dim) * 8;
+            k_ba_schur<true><<<gs, kBlock, lds, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv,
+                                                                 h->d_eb, h->n, h->n_points, dim, h->d_S, h->d_e);
+        } else {
+            k_ba_schur<false><<<gs, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv,
+                                                                h->d_eb, h->n, h->n_points, dim, h->d_S, h->d_e);
+        }
     }
     TDK_LAUNCH_CHECK();
     std::vector<double> S((size_t)dim * dim), e((size_t)dim), U((size_t)h->n_poses * 21), ea((size_t)dim);
@@ -676,7 +848,7 @@ tdk_status tdk_ba_step(tdk_ba *h, const double *poses, const double *points, dou
     memcpy(dposes, e.data(), (size_t)dim * 8);
     TDK_HIP(hipMemcpyAsync(h->d_da, e.data(), (size_t)dim * 8, hipMemcpyHostToDevice, tdk::stream()));
     k_ba_backsub<<<gp, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv, h->d_eb,
-                                                   h->d_da, h->n_points, h->d_db);
+                                                   h->d_da, h->n, h->n_points, h->d_db);
     TDK_LAUNCH_CHECK();
     TDK_HIP(hipMemcpyAsync(dpoints, h->d_db, (size_t)h->n_points * 24, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));

@@ -890,7 +890,11 @@ void plan_blocks(const tdk_dvo *h, const tdk_dvo::Level &L, int *nblk, int64_t *
     // >= 16 pixels per thread (the pipeline of k_dvo_eval takes ~3 pixel-steps to
     // fill and drain), but no more than ~8192 blocks in the whole grid; measured
     // flat (+-0.5 %) from 12 to 40 pixels per thread on the bench workload
-    int64_t per_block = (int64_t)kBlock * 16;
+    // -- unless the batch is so small that this would leave CUs without a block
+    // (a single pair): then down to 4 pixels per thread, aiming at >= 512 blocks
+    int64_t px_per_thread = L.N * h->n_pairs / (512 * (int64_t)kBlock);
+    px_per_thread = px_per_thread < 4 ? 4 : (px_per_thread > 16 ? 16 : px_per_thread);
+    int64_t per_block = (int64_t)kBlock * px_per_thread;
     int64_t nb = (L.N + per_block - 1) / per_block;
     int64_t cap = 8192 / h->n_pairs;
     if (cap < 1) cap = 1;
