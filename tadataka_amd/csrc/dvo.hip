@@ -231,8 +231,8 @@ __device__ __forceinline__ double wave_sum_transposed(const Accum &acc) {
 
 // Block-level tail of the evaluation kernel: wave64 reduction, LDS across the
 // waves, one partial per block.
-__device__ __forceinline__ void store_partials(const Accum &acc, double (*red)[kAccPad], int pair,
-                                               double *__restrict__ partials) {
+__device__ __forceinline__ void store_partials(const Accum &acc, double (*red)[kAccPad], int pair, int blk,
+                                               int nblk, double *__restrict__ partials) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const double s = wave_sum_transposed(acc);
     if ((lane & 1) == 0) red[wave][lane >> 1] = s;
@@ -241,7 +241,7 @@ __device__ __forceinline__ void store_partials(const Accum &acc, double (*red)[k
         double s = 0.0;
 #pragma unroll
         for (int w = 0; w < kWaves; w++) s += red[w][threadIdx.x];
-        partials[((int64_t)pair * gridDim.x + blockIdx.x) * kAccPad + threadIdx.x] = s;
+        partials[((int64_t)pair * nblk + blk) * kAccPad + threadIdx.x] = s;
     }
 }
 
@@ -300,7 +300,15 @@ struct Pixel {       // what survives from the warp of one pixel until it is acc
     double wx1, wy1;     // fractional parts of the warped coordinate
     int c0, r0;          // its lower texel, clamped into the image (valid or not)
     int mask;            // 0: outside the image; 1: error mask only; 2: error and update mask (P1z > 0)
+    int inside;          // the 4x4 texel neighbourhood of (c0, r0) lies strictly inside the image
 };
+
+// clamp(v, 0, hi) in one instruction
+__device__ __forceinline__ int clamp0(int v, int hi) {
+    int r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(hi));
+    return r;
+}
 
 struct Samples;
 
@@ -332,8 +340,9 @@ __device__ __forceinline__ void sp_warp(Pixel &p, bool live, double xn, double y
     p.wx1 = u - lx;
     p.wy1 = v - ly;
     // v_cvt_i32_f64 saturates and maps NaN to 0: masked-out pixels get a clamped, loadable texel
-    p.c0 = min(max((int)lx, 0), W - 1);
-    p.r0 = min(max((int)ly, 0), H - 1);
+    p.c0 = clamp0((int)lx, W - 1);
+    p.r0 = clamp0((int)ly, H - 1);
+    p.inside = p.c0 >= 1 && p.c0 <= W - 3 && p.r0 >= 1 && p.r0 <= H - 3;
 }
 
 // The 12 texels of one pixel as six 16-byte loads whose addresses are clamped
@@ -347,10 +356,9 @@ struct TapPairs {
 };
 
 __device__ __forceinline__ void sp_issue_taps(TapPairs &q, const double *__restrict__ I1, int H, int W, int c0,
-                                              int r0) {
+                                              int r0, int inside) {
     const uint32_t rowb = (uint32_t)W * 8u;
     uint32_t om, oal, oar, obl, obr, ou;   // byte offsets of the six pairs
-    const bool inside = c0 >= 1 && c0 <= W - 3 && r0 >= 1 && r0 <= H - 3;
     if (__builtin_amdgcn_ballot_w64(!inside) == 0) {   // wave-uniform; address arithmetic only
         const uint32_t o0 = (uint32_t)(r0 * W + c0) * 8u;
         om = o0 - rowb; oal = o0 - 8u; oar = o0 + 8u;
@@ -402,7 +410,7 @@ __device__ __forceinline__ void sp_issue(Samples &s, const Pixel &p, uint32_t of
     s.i0 = ldo(I0, off);
     s.i1 = ldo(I1, off);
     if (WMODE == TDK_W_MAP) s.w0 = ldo(W0, off);
-    sp_issue_taps(s.q, I1, H, W, p.c0, p.r0);
+    sp_issue_taps(s.q, I1, H, W, p.c0, p.r0, p.inside);
 }
 
 template <int WMODE>
@@ -415,8 +423,7 @@ __device__ __forceinline__ void sp_accumulate(Accum &a, int &n_error, int &n_upd
     Warped w;
     w.c0 = p.c0; w.r0 = p.r0;
     Taps t = sp_unpack(s.q);
-    const bool inside = w.c0 >= 1 && w.c0 <= W - 3 && w.r0 >= 1 && w.r0 <= H - 3;
-    const bool border = __builtin_amdgcn_ballot_w64(!inside) != 0;   // wave-uniform
+    const bool border = __builtin_amdgcn_ballot_w64(!p.inside) != 0;   // wave-uniform
     if (border) sp_fix_border(t, w.c0, W);
     // (lx + 1) - u and 1 - (u - lx) are the same double: u - lx is exact and a
     // multiple of ulp(u), so 1 - (u - lx) is representable
@@ -461,8 +468,14 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
                                                         const double *__restrict__ poses,
                                                         const int *__restrict__ state,
                                                         const double *__restrict__ wscale, double scale,
-                                                        int64_t chunk, double *__restrict__ partials) {
-    const int pair = blockIdx.y;
+                                                        int64_t chunk, int n_pairs, int nblk,
+                                                        double *__restrict__ partials) {
+    // 1-D grid.  Workgroups are dealt to the 8 XCDs round-robin, each XCD has its own L2: XCD k
+    // takes pairs k, k + 8, ... one after the other, the blocks of a pair (whose tap halos and
+    // stream lines overlap) consecutively -- so they meet in one L2, close in time.
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int pair = (q / nblk) * 8 + xcd, blk = q - (q / nblk) * nblk;
+    if (pair >= n_pairs) return;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
     BlockSetup b;
     load_setup(b, params, poses, pair, scale);
@@ -490,7 +503,7 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
 #pragma unroll
     for (int i = 0; i < kAcc; i++) acc.v[i] = 0.0;
 
-    const int start = (int)(blockIdx.x * chunk);
+    const int start = (int)(blk * chunk);
     const int end = (int)min((int64_t)N, (int64_t)start + chunk);
     // iw: the next pixel to warp, (x, y) its coordinates, advanced by kBlock per step
     int iw = start + (int)threadIdx.x;
@@ -503,7 +516,9 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
         y += step_y;                       \
         if (x >= W) { x -= W; y += 1; }    \
     } while (0)
-#define TDK_OFF(i) ((uint32_t)min((i), end - 1) * 8u)   /* clamped: loads need no branch */
+    // stream loads run up to 3 kBlock pixels past `end` (masked out by `live`): into the
+    // next chunk or, for the last pair, into the padding every level array is allocated with
+#define TDK_OFF(i) ((uint32_t)(i) * 8u)
 #define TDK_DEPTH() ldo(D0, TDK_OFF(iw))
 
     Pixel pa, pb;
@@ -549,7 +564,7 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
         acc.v[28] = (double)n_update;
         acc.v[29] = (double)n_error;
     }
-    store_partials(acc, red, pair, partials);
+    store_partials(acc, red, pair, blk, nblk, partials);
 }
 
 // ---------------------------------------------------------------------------
@@ -1021,7 +1036,7 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
     int nblk;
     int64_t chunk;
     plan_blocks(h, L, &nblk, &chunk);
-    dim3 grid(nblk, h->n_pairs);
+    dim3 grid(8u * (unsigned)((h->n_pairs + 7) / 8) * (unsigned)nblk);   // see k_dvo_eval: XCD-major order
     LevelPtrs P = ptrs_of(L);
     const size_t lds = sizeof(double) * (kWaves * kAccPad + (size_t)L.W + (size_t)L.H);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1037,7 +1052,7 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
     }
 #define TDK_EVAL(WM)                                                                                    \
     k_dvo_eval<WM><<<grid, kBlock, lds, h->stream>>>(P, h->d_params, d_poses, d_state, h->d_wscale, \
-                                                         L.scale, chunk, h->d_partials)
+                                                         L.scale, chunk, h->n_pairs, nblk, h->d_partials)
     switch (weight_mode) {
         case TDK_W_NONE: TDK_EVAL(TDK_W_NONE); break;
         case TDK_W_HUBER: TDK_EVAL(TDK_W_HUBER); break;
@@ -1145,7 +1160,8 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
         }
         L.N = (int64_t)L.H * L.W;
         L.stride = (L.N + 1) & ~1ll;
-        size_t bytes = (size_t)L.stride * n_pairs * sizeof(double);
+        // + padding: k_dvo_eval's unconditional stream loads overrun a block's range by < 4 kBlock pixels
+        size_t bytes = ((size_t)L.stride * n_pairs + 4 * kBlock) * sizeof(double);
         L.W0 = nullptr;
         TDK_HIP(hipMalloc(&L.I0, bytes));
         TDK_HIP(hipMalloc(&L.D0, bytes));
