@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--levels", type=int, default=3)
     ap.add_argument("--max-iter", type=int, default=20)
-    ap.add_argument("--weights", default="huber", choices=["none", "huber"])
+    ap.add_argument("--weights", default="huber", choices=["none", "huber", "student-t", "tukey"])
     ap.add_argument("--double-buffer", action="store_true",
                     help="two batches: the next batch's pyramid is built under the current estimation")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -125,7 +125,7 @@ def main():
 
     B, H, W = args.pairs, args.height, args.width
     cam = synthetic.camera_for(W, H)
-    mode = ops.W_HUBER if args.weights == "huber" else ops.W_NONE
+    mode = ops.WEIGHT_MODES[None if args.weights == "none" else args.weights]
     n_batches = 2 if args.double_buffer else 1
     # this rank's shard of the pair ids: n_batches consecutive blocks of B pairs
     seeds = [int(sharding.pair_seeds(rank, n_batches * B)[0]) + k * B for k in range(n_batches)]
@@ -222,7 +222,7 @@ def main():
             "max_translation_error": t_err,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_dvo_eval<huber> (full-resolution level)",
+                         "kernel": f"k_dvo_eval<{args.weights}> (full-resolution level)",
                          "bytes_per_px": BYTES_PER_PX_EVAL,
                          "px_per_launch": prof["pixels"] / max(prof["launches"], 1),
                          "kernel_ms": kernel_ms, "launches": prof["launches"]},
