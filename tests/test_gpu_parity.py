@@ -320,6 +320,42 @@ def test_dvo_full_size_properties(ops):
     batch.close()
 
 
+def test_dvo_batch_size_independence_and_weight_linearity(ops):
+    """A pair gives the same sums alone (more, smaller blocks: the block plan
+    adapts to the batch) as inside a batch, up to the summation order; and a
+    weight map scaled by a power of two scales H and b exactly."""
+    from tadataka_amd import synthetic
+    B, H, W = 6, 480, 640
+    cam = synthetic.camera_for(W, H)
+    pairs = [synthetic.make_pair(H, W, seed=40 + i) for i in range(B)]
+    rng = np.random.default_rng(3)
+    poses = []
+    for i in range(B):
+        T = np.eye(4)
+        T[:3, :3] = synthetic.rodrigues(rng.uniform(-0.004, 0.004, 3))
+        T[:3, 3] = rng.uniform(-0.01, 0.01, 3)
+        poses.append(_pose12(T))
+    poses = np.array(poses)
+    wmap = rng.uniform(0.5, 1.5, (H, W))
+    batch = ops.DvoBatch(B, H, W, with_weight_map=True)
+    for i, pr in enumerate(pairs):
+        batch.upload(i, pr["I0"], pr["D0"], pr["I1"], wmap)
+    ev = batch.evaluate(0, cam, cam, poses, ops.W_MAP)
+    batch.close()
+    single = ops.DvoBatch(1, H, W, with_weight_map=True)
+    for i in (0, B - 1):
+        single.upload(0, pairs[i]["I0"], pairs[i]["D0"], pairs[i]["I1"], wmap)
+        e1 = single.evaluate(0, cam, cam, poses[i:i + 1], ops.W_MAP)
+        assert e1["n_update"][0] == ev["n_update"][i] and e1["n_error"][0] == ev["n_error"][i]
+        assert rel_err(e1["H"][0], ev["H"][i]) < 1e-12 and rel_err(e1["b"][0], ev["b"][i]) < 1e-12
+        assert abs(e1["sum_sq"][0] - ev["sum_sq"][i]) <= 1e-12 * ev["sum_sq"][i]
+        single.upload(0, pairs[i]["I0"], pairs[i]["D0"], pairs[i]["I1"], 4.0 * wmap)
+        e4 = single.evaluate(0, cam, cam, poses[i:i + 1], ops.W_MAP)
+        assert np.array_equal(e4["H"], 4.0 * e1["H"]) and np.array_equal(e4["b"], 4.0 * e1["b"])
+        assert np.array_equal(e4["sum_sq"], e1["sum_sq"])       # the error term is unweighted
+    single.close()
+
+
 # ---------------------------------------------------------------------------
 # semi-dense
 # ---------------------------------------------------------------------------
