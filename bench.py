@@ -138,6 +138,7 @@ def main():
     ident = np.tile(ops.pose12(np.eye(3), np.zeros(3)), (B, 1))
     device = torch.device("cuda", local_rank) if distributed else None
     counter = [0]
+    gather = sharding.PoseGather(B, dist, device)
     batches[0].build_pyramid()
 
     def step():
@@ -149,9 +150,15 @@ def main():
         else:
             batches[(k + 1) % n_batches].build_pyramid()   # asynchronous, on that batch's stream
         poses, px = cur.estimate(cam, cam, ident, mode, args.max_iter)
-        # the only exchange: the recovered poses, all-gathered (RCCL over xGMI)
-        all_poses = sharding.all_gather_poses(poses, dist, device)
-        return all_poses, px, seeds[k % n_batches]
+        # the only exchange: the recovered poses, all-gathered (RCCL over xGMI).  The gather of
+        # this step is queued now and collected after the next step's estimation (flush() below
+        # collects the last one inside the timed region).
+        previous = gather.finish() if gather.pending else None
+        gather.start(poses)
+        return previous, px, seeds[k % n_batches]
+
+    def flush():
+        return gather.finish()
 
     def fence():
         _lib.call("tdk_sync")
@@ -162,14 +169,17 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if gather.pending:
+        flush()
     for bt in batches:
         bt.set_profiling(True)
     fence()
     t0 = time.perf_counter()
     pixels = 0
     for _ in range(args.steps):
-        poses, px, last_seed = step()
+        _, px, last_seed = step()
         pixels += px
+    poses = flush() if gather.pending else None   # all-gathered poses of the last step
     fence()
     elapsed = time.perf_counter() - t0
     prof = {"launches": 0, "total_ms": 0.0, "pixels": 0}

@@ -30,6 +30,13 @@ def main():
     seeds = sharding.pair_seeds(rank, pairs_per_rank)
     local = np.array([estimate_pair(s) for s in seeds])
     gathered = sharding.all_gather_poses(local, dist)
+    # the pipelined form bench.py uses: queue the gather of "step k", collect it after "step k + 1"
+    pg = sharding.PoseGather(pairs_per_rank, dist)
+    pg.start(local)
+    first = pg.finish()
+    pg.start(local + 1.0)
+    second = pg.finish()
+    assert np.array_equal(first, gathered) and np.array_equal(second, gathered + 1.0)
     stats = sharding.reduce_scalars([float(rank + 1), float(len(seeds))], "max", dist)
     total = sharding.reduce_scalars([float(len(seeds))], "sum", dist)
     dist.barrier()
