@@ -232,9 +232,9 @@ __global__ __launch_bounds__(256) void k_pyramid(PyrArgs a) {
     }
 }
 
-// Every level of every array in one launch, one thread per output pixel
-// (k_rescale's arithmetic, bit-identical).  blockIdx.x runs over the blocks of
-// level 1, then level 2, ... of ONE (pair, array); y = array, z = pair.  Blocks
+// Every level of every array in one launch (k_rescale's arithmetic, bit-identical),
+// one output row per wave.  blockIdx.x runs over the row groups of level 1, then
+// level 2, ... of ONE (pair, array); y = array, z = pair.  Blocks
 // are dispatched x-fastest, so all the levels of an image are resampled within
 // microseconds of each other and only the first pass over its level-0 texels
 // comes from HBM -- the later ones hit the 256 MiB Infinity Cache.
@@ -251,22 +251,29 @@ __global__ __launch_bounds__(256) void k_rescale_levels(RescaleArgs a) {
     while (l + 1 < a.n_out && (int)blockIdx.x >= a.blk_end[l]) l++;
     const PyrLevel &L = a.lv[l];
     const int arr = blockIdx.y, pair = blockIdx.z;
-    const int i = ((int)blockIdx.x - (l ? a.blk_end[l - 1] : 0)) * 256 + (int)threadIdx.x;
-    if (i >= L.Ho * L.Wo) return;
-    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    // one output row per wave (4 rows per block), lanes stride along the row: no
+    // division per pixel, the row terms are wave-uniform
+    const int oy = (((int)blockIdx.x - (l ? a.blk_end[l - 1] : 0)) << 2) + (int)(threadIdx.x >> 6);
+    if (oy >= L.Ho) return;
     const int H = a.H, W = a.W;
     const double sy = (double)H / (double)L.Ho, sx = (double)W / (double)L.Wo;
-    const int oy = i / L.Wo, ox = i - oy * L.Wo;
     double cy = ((double)oy + 0.5) * sy - 0.5;
-    double cx = ((double)ox + 0.5) * sx - 0.5;
-    double fy0 = floor(cy), fx0 = floor(cx);
-    double wy = cy - fy0, wx = cx - fx0;
-    const int iy = (int)fy0, ix = (int)fx0;
-    const int y0 = reflect_fast(iy, H), y1 = reflect_fast(iy + 1, H);
-    const int x0 = reflect_fast(ix, W), x1 = reflect_fast(ix + 1, W);
-    double top = s[y0 * W + x0] * (1.0 - wx) + s[y0 * W + x1] * wx;
-    double bot = s[y1 * W + x0] * (1.0 - wx) + s[y1 * W + x1] * wx;
-    L.dst[arr][(int64_t)pair * L.stride + i] = top * (1.0 - wy) + bot * wy;
+    double fy0 = floor(cy);
+    double wy = cy - fy0;
+    const int iy = (int)fy0;
+    const double *row0 = a.src[arr] + (int64_t)pair * a.src_stride + (int64_t)reflect_fast(iy, H) * W;
+    const double *row1 = a.src[arr] + (int64_t)pair * a.src_stride + (int64_t)reflect_fast(iy + 1, H) * W;
+    double *d = L.dst[arr] + (int64_t)pair * L.stride + (int64_t)oy * L.Wo;
+    for (int ox = threadIdx.x & 63; ox < L.Wo; ox += 64) {
+        double cx = ((double)ox + 0.5) * sx - 0.5;
+        double fx0 = floor(cx);
+        double wx = cx - fx0;
+        const int ix = (int)fx0;
+        const int x0 = reflect_fast(ix, W), x1 = reflect_fast(ix + 1, W);
+        double top = row0[x0] * (1.0 - wx) + row0[x1] * wx;
+        double bot = row1[x0] * (1.0 - wx) + row1[x1] * wx;
+        d[ox] = top * (1.0 - wy) + bot * wy;
+    }
 }
 
 }  // namespace
@@ -300,7 +307,7 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
         for (int l = 0; l < n_out; l++) {
             for (int i = 0; i < 4; i++) r.lv[l].dst[i] = i < n_arrays ? levels[l].dst[i] : nullptr;
             r.lv[l].stride = levels[l].stride; r.lv[l].Ho = levels[l].H; r.lv[l].Wo = levels[l].W;
-            blocks += (int)(((int64_t)levels[l].H * levels[l].W + 255) / 256);
+            blocks += (levels[l].H + 3) / 4;   // four output rows per block
             r.blk_end[l] = blocks;
         }
         dim3 grid(blocks, n_arrays, batch);
