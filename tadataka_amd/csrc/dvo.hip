@@ -683,15 +683,24 @@ __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairP
     load_setup(b, params, poses, pair, scale);
     const int64_t base = (int64_t)pair * L.stride;
     const int W = L.W, H = L.H, N = (int)L.N;
+    const double *__restrict__ tab = L.tab + (size_t)pair * (W + H);   // (x - ox) / fx | (y - oy) / fy
+    const double *__restrict__ D0 = L.D0 + base, *__restrict__ I0 = L.I0 + base, *__restrict__ I1 = L.I1 + base;
+    double *__restrict__ out = rm + base;
     int local = 0;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
-        int y = i / W, x = i - y * W;
-        double xn = ((double)x - b.ox0) / b.fx0, yn = ((double)y - b.oy0) / b.fy0;
+    // (x, y) advanced incrementally: one division per thread, not per pixel
+    const int step = gridDim.x * kBlock;
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    int y = i / W, x = i - y * W;
+    const int step_y = step / W, step_x = step - step_y * W;
+    for (; i < N; i += step) {
         Pixel p;
-        sp_warp(p, true, xn, yn, L.D0[base + i], H, W, b.P, b.c);
+        sp_warp(p, true, tab[x], tab[W + y], D0[i], H, W, b.P, b.c);
         bool in = p.mask == 2;
-        rm[base + i] = in ? L.I0[base + i] - L.I1[base + i] : __longlong_as_double(0x7ff8000000000000ll);
+        out[i] = in ? I0[i] - I1[i] : __longlong_as_double(0x7ff8000000000000ll);
         local += in ? 1 : 0;
+        x += step_x;
+        y += step_y;
+        if (x >= W) { x -= W; y += 1; }
     }
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&count[pair], local);
@@ -744,20 +753,43 @@ __device__ __forceinline__ double key_to_double(uint64_t k) {
     return __longlong_as_double((long long)b);
 }
 
+// The 64-bit key is consumed in five digits, most significant first: four of 13
+// bits and a last one of 12 (8192-bin histograms: 32 KiB of LDS per block).
+constexpr int kSelectPasses = 5, kSelectBins = 8192;
+__host__ __device__ constexpr int select_shift(int pass) { return pass < 4 ? 51 - 13 * pass : 0; }
+__host__ __device__ constexpr int select_bits(int pass) { return pass < 4 ? 13 : 12; }
+
 struct SelectState {
     uint64_t prefix, rank;
+    uint64_t next_key;             // successor pass: smallest key above the selected one
+    unsigned int count_le, even;   // elements <= the selected one; the mask size is even
 };
 
-__global__ void k_select_init(SelectState *st, const int *__restrict__ count, int n_pairs, int which) {
+// rank of the LOWER middle order statistic; np.median averages it with its
+// successor when the count is even
+__global__ void k_select_init(SelectState *st, const int *__restrict__ count, int n_pairs) {
     int pair = blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= n_pairs) return;
     int m = count[pair];
-    // which: 0 = lower middle (rank (m-1)/2), 1 = upper middle (rank m/2)
     st[pair].prefix = 0;
-    st[pair].rank = (uint64_t)(which == 0 ? (m > 0 ? (m - 1) / 2 : 0) : m / 2);
+    st[pair].rank = (uint64_t)(m > 0 ? (m - 1) / 2 : 0);
+    st[pair].next_key = ~0ull;
+    st[pair].count_le = 0;
+    st[pair].even = (m > 0 && (m & 1) == 0) ? 1u : 0u;
 }
 
 // values: rm (mode 0) or |rm - center[pair]| (mode 1, for the MAD)
+__device__ __forceinline__ bool select_key(const double *r, int i, int mode, double cen, uint64_t &k) {
+    double v = r[i];
+    if (v != v) return false;
+    k = ordered_key(mode ? fabs(v - cen) : v);
+    return true;
+}
+
+// One digit: histogram of the keys that match the prefix found so far, in LDS
+// per block, then merged into the pair's global histogram.  A wave whose active
+// lanes all hit one bin (exact ties: a noise-free scene has thousands of equal
+// residuals) adds its count once instead of serialising 64 atomics on one address.
 __global__ __launch_bounds__(kBlock) void k_select_hist(const double *__restrict__ rm, int64_t stride, int N,
                                                         const int *__restrict__ state, int mode,
                                                         const double *__restrict__ center,
@@ -765,51 +797,123 @@ __global__ __launch_bounds__(kBlock) void k_select_hist(const double *__restrict
                                                         unsigned int *__restrict__ hist) {
     const int pair = blockIdx.y;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
-    __shared__ unsigned int h[256];
-    h[threadIdx.x] = 0;
+    __shared__ unsigned int h[kSelectBins];
+    for (int i = threadIdx.x; i < kSelectBins; i += kBlock) h[i] = 0;
     __syncthreads();
-    const int shift = 56 - 8 * pass;
+    const int shift = select_shift(pass);
+    const unsigned int digit_mask = (1u << select_bits(pass)) - 1u;
     const uint64_t prefix = st[pair].prefix;
-    const uint64_t mask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+    const uint64_t mask = pass == 0 ? 0ull : (~0ull << select_shift(pass - 1));
     const double cen = mode ? center[pair] : 0.0;
     const double *r = rm + (int64_t)pair * stride;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
-        double v = r[i];
-        if (v != v) continue;
-        uint64_t k = ordered_key(mode ? fabs(v - cen) : v);
-        if ((k & mask) == prefix) atomicAdd(&h[(k >> shift) & 0xff], 1u);
+    const int lane = threadIdx.x & 63;
+    for (int i0 = blockIdx.x * kBlock; i0 < N; i0 += gridDim.x * kBlock) {
+        const int i = i0 + (int)threadIdx.x;
+        uint64_t k = 0;
+        const bool hit = i < N && select_key(r, i, mode, cen, k) && (k & mask) == prefix;
+        const unsigned int bin = (unsigned int)(k >> shift) & digit_mask;
+        const uint64_t hits = __builtin_amdgcn_ballot_w64(hit);
+        if (hits == 0) continue;
+        const int leader = __builtin_ctzll(hits);
+        const unsigned int lb = (unsigned int)__builtin_amdgcn_readlane((int)bin, leader);
+        if (__builtin_amdgcn_ballot_w64(hit && bin == lb) == hits) {
+            if (lane == leader) atomicAdd(&h[lb], (unsigned int)__builtin_popcountll(hits));
+        } else if (hit) {
+            atomicAdd(&h[bin], 1u);
+        }
     }
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[pair * 256 + threadIdx.x], h[threadIdx.x]);
+    for (int i = threadIdx.x; i < kSelectBins; i += kBlock)
+        if (h[i]) atomicAdd(&hist[(size_t)pair * kSelectBins + i], h[i]);
 }
 
-__global__ void k_select_pick(unsigned int *__restrict__ hist, SelectState *__restrict__ st,
-                              const int *__restrict__ state, int n_pairs, int pass, double *__restrict__ out) {
-    int pair = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= n_pairs) return;
+// one block per pair: find the bin that holds the rank, extend the prefix, clear the histogram
+__global__ __launch_bounds__(kBlock) void k_select_pick(unsigned int *__restrict__ hist,
+                                                        SelectState *__restrict__ st,
+                                                        const int *__restrict__ state, int pass) {
+    const int pair = blockIdx.x;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
-    const int shift = 56 - 8 * pass;
-    unsigned int *h = hist + pair * 256;
-    uint64_t rank = st[pair].rank, cum = 0;
-    int bin = 255;
-    for (int b = 0; b < 256; b++) {
-        uint64_t cnt = h[b];
-        if (rank < cum + cnt) { bin = b; break; }
-        cum += cnt;
+    unsigned int *h = hist + (size_t)pair * kSelectBins;
+    constexpr int kPer = kSelectBins / kBlock;   // consecutive bins per thread
+    __shared__ unsigned int sums[kBlock];
+    __shared__ unsigned long long rank_in_owner;
+    __shared__ int owner;
+    unsigned int local[kPer], total = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+        local[j] = h[threadIdx.x * kPer + j];
+        h[threadIdx.x * kPer + j] = 0;
+        total += local[j];
+    }
+    sums[threadIdx.x] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t rank = st[pair].rank, cum = 0;
+        int t = 0;
+        for (; t < kBlock - 1; t++) {
+            if (rank < cum + sums[t]) break;
+            cum += sums[t];
+        }
+        owner = t;
+        rank_in_owner = rank - cum;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x != owner) return;
+    uint64_t rank = rank_in_owner, cum = 0;
+    int bin = kPer - 1;
+    for (int j = 0; j < kPer; j++) {
+        if (rank < cum + local[j]) { bin = j; break; }
+        cum += local[j];
     }
     st[pair].rank = rank - cum;
-    st[pair].prefix |= ((uint64_t)bin) << shift;
-    for (int b = 0; b < 256; b++) h[b] = 0;
-    if (pass == 7) out[pair] = key_to_double(st[pair].prefix);
+    st[pair].prefix |= ((uint64_t)(threadIdx.x * kPer + bin)) << select_shift(pass);
 }
 
-// np.median = mean of the two middle order statistics; then optional scaling
-__global__ void k_median_combine(const double *lo, const double *hi, const int *__restrict__ state, int n_pairs,
-                                 double factor, double *out) {
+// successor of the selected key: number of keys <= it and the smallest key above it
+__global__ __launch_bounds__(kBlock) void k_select_successor(const double *__restrict__ rm, int64_t stride, int N,
+                                                             const int *__restrict__ state, int mode,
+                                                             const double *__restrict__ center,
+                                                             SelectState *__restrict__ st) {
+    const int pair = blockIdx.y;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    if (!st[pair].even) return;                      // odd count: the median is the selected key itself
+    const uint64_t sel = st[pair].prefix;
+    const double cen = mode ? center[pair] : 0.0;
+    const double *r = rm + (int64_t)pair * stride;
+    unsigned int le = 0;
+    uint64_t next = ~0ull;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+        uint64_t k;
+        if (!select_key(r, i, mode, cen, k)) continue;
+        if (k <= sel) le++;
+        else if (k < next) next = k;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        le += __shfl_down(le, off, 64);
+        const uint64_t o = __shfl_down(next, off, 64);
+        next = o < next ? o : next;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (le) atomicAdd(&st[pair].count_le, le);
+        if (next != ~0ull) atomicMin((unsigned long long *)&st[pair].next_key, (unsigned long long)next);
+    }
+}
+
+// np.median: the selected (lower middle) order statistic, averaged with its
+// successor in sorted order when the count is even -- the successor is the same
+// value if more than rank + 1 elements are <= it.  Then the optional scaling.
+__global__ void k_median_combine(const SelectState *__restrict__ st, const int *__restrict__ count,
+                                 const int *__restrict__ state, int n_pairs, double factor, double *out) {
     int pair = blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= n_pairs) return;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
-    out[pair] = factor * ((lo[pair] + hi[pair]) / 2.0);
+    const double lo = key_to_double(st[pair].prefix);
+    double hi = lo;
+    if (st[pair].even) {
+        const unsigned int lower_rank = (unsigned int)((count[pair] - 1) / 2);
+        if (st[pair].count_le < lower_rank + 2) hi = key_to_double(st[pair].next_key);
+    }
+    out[pair] = factor * ((lo + hi) / 2.0);
 }
 
 // ---- synthetic scene on the device (tadataka_amd/synthetic.py) ------------
@@ -880,7 +984,7 @@ struct tdk_dvo {
     double *d_spartial;   // [n][kStatBlocks]
     int *d_count;         // [n]
     void *d_select;       // SelectState[n]
-    unsigned int *d_hist; // [n][256]
+    unsigned int *d_hist; // [n][kSelectBins]
     // profiling of the finest-level evaluation kernel (bench.py roofline leg)
     bool profiling;
     std::vector<hipEvent_t> ev_pool;
@@ -894,6 +998,7 @@ struct tdk_dvo {
 namespace {
 
 constexpr int kStatBlocks = 64;
+constexpr int kSelectBlocks = 16;
 
 int level_dim(int full, double scale) {
     // skimage.transform.rescale: output shape = round(shape * scale) (np.round)
@@ -969,8 +1074,8 @@ tdk_status ensure_robust_buffers(tdk_dvo *h) {
     TDK_HIP(hipMalloc(&h->d_spartial, sizeof(double) * kStatBlocks * n));
     TDK_HIP(hipMalloc(&h->d_count, sizeof(int) * n));
     TDK_HIP(hipMalloc(&h->d_select, sizeof(SelectState) * n));
-    TDK_HIP(hipMalloc(&h->d_hist, sizeof(unsigned int) * 256 * n));
-    TDK_HIP(hipMemsetAsync(h->d_hist, 0, sizeof(unsigned int) * 256 * n, h->stream));
+    TDK_HIP(hipMalloc(&h->d_hist, sizeof(unsigned int) * kSelectBins * n));
+    TDK_HIP(hipMemsetAsync(h->d_hist, 0, sizeof(unsigned int) * kSelectBins * n, h->stream));
     return TDK_OK;
 }
 
@@ -981,20 +1086,22 @@ tdk_status device_median(tdk_dvo *h, int level, const int *d_state, int mode, co
     const tdk_dvo::Level &L = h->lv[level];
     const int n = h->n_pairs, tpb = 256, gp = (n + tpb - 1) / tpb;
     dim3 grid(kStatBlocks, n);
-    double *lohi[2] = {h->d_stat, h->d_stat + n};
-    for (int which = 0; which < 2; which++) {
-        k_select_init<<<gp, tpb, 0, h->stream>>>((SelectState *)h->d_select, h->d_count, n, which);
+    SelectState *st = (SelectState *)h->d_select;
+    k_select_init<<<gp, tpb, 0, h->stream>>>(st, h->d_count, n);
+    TDK_LAUNCH_CHECK();
+    // few, long blocks for the histogram passes: zeroing and merging 8192 bins is a
+    // fixed cost per block
+    dim3 hgrid(kSelectBlocks, n);
+    for (int pass = 0; pass < kSelectPasses; pass++) {
+        k_select_hist<<<hgrid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center, st, pass,
+                                                       h->d_hist);
         TDK_LAUNCH_CHECK();
-        for (int pass = 0; pass < 8; pass++) {
-            k_select_hist<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center,
-                                                              (const SelectState *)h->d_select, pass, h->d_hist);
-            TDK_LAUNCH_CHECK();
-            k_select_pick<<<gp, tpb, 0, h->stream>>>(h->d_hist, (SelectState *)h->d_select, d_state, n, pass,
-                                                         lohi[which]);
-            TDK_LAUNCH_CHECK();
-        }
+        k_select_pick<<<n, kBlock, 0, h->stream>>>(h->d_hist, st, d_state, pass);
+        TDK_LAUNCH_CHECK();
     }
-    k_median_combine<<<gp, tpb, 0, h->stream>>>(lohi[0], lohi[1], d_state, n, factor, out);
+    k_select_successor<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center, st);
+    TDK_LAUNCH_CHECK();
+    k_median_combine<<<gp, tpb, 0, h->stream>>>(st, h->d_count, d_state, n, factor, out);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }

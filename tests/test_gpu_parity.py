@@ -320,6 +320,31 @@ def test_dvo_full_size_properties(ops):
     batch.close()
 
 
+@pytest.mark.parametrize("shape", [(37, 52), (36, 51), (48, 64)])
+def test_dvo_tukey_and_student_t_statistics_with_ties(ops, orc, shape):
+    """Quantised images: most residuals are exact ties (many equal keys in the
+    radix select, successor == selected value), with odd and even mask sizes.
+    The fused device statistics must reproduce np.median / the fixed point."""
+    from tadataka_amd import synthetic
+    H, W = shape
+    pr = synthetic.make_pair(H, W, seed=H)
+    I0 = np.round(pr["I0"] * 64) / 64     # 7 distinct residual values, median 0, MAD 1/64
+    I1 = np.round(pr["I1"] * 64) / 64
+    cam = pr["cam"]
+    T = np.eye(4)
+    T[:3, :3] = Rotation.from_rotvec([0.002, -0.003, 0.001]).as_matrix()
+    T[:3, 3] = [0.004, -0.002, 0.003]
+    batch = ops.DvoBatch(1, H, W)
+    batch.upload(0, I0, pr["D0"], I1)
+    GX, GY = orc.image_gradient(I1)
+    for wname in ("tukey", "student-t"):
+        ev = batch.evaluate(0, cam, cam, _pose12(T)[None], ops.WEIGHT_MODES[wname])
+        Hm, b, n = orc.dvo_normal_equations(I0, pr["D0"], I1, GX, GY, cam, cam, T[:3, :3], T[:3, 3], wname)
+        assert ev["n_update"][0] == n
+        assert rel_err(ev["H"][0], Hm) < RTOL_SUMS and rel_err(ev["b"][0], b) < RTOL_SUMS
+    batch.close()
+
+
 def test_dvo_batch_size_independence_and_weight_linearity(ops):
     """A pair gives the same sums alone (more, smaller blocks: the block plan
     adapts to the batch) as inside a batch, up to the summation order; and a
