@@ -216,6 +216,16 @@ tdk_status tdk_ba_destroy(tdk_ba *h);
 tdk_status tdk_ba_error(tdk_ba *h, const double *poses, const double *points, double *sum_sq);
 tdk_status tdk_ba_step(tdk_ba *h, const double *poses, const double *points, double mu,
                        double *dposes, double *dpoints, double *sum_sq);
+/* The whole Levenberg-Marquardt loop of LocalBundleAdjustment.compute
+ * (tadataka/local_ba.py:91-134: damping trials mu/nu, mu, mu nu, ... per
+ * iteration; stop on mean squared error < absolute_error_threshold or relative
+ * change < relative_error_threshold) with poses [n_poses][6] and points
+ * [n_points][3] resident on the device; both are updated in place.
+ * error_history (optional, max_iter + 1 doubles): [0] the initial mean squared
+ * error, [k] the error accepted by iteration k - 1; n_iter (optional): iterations run. */
+tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, double initial_mu,
+                        double nu, double absolute_error_threshold,
+                        double relative_error_threshold, double *error_history, int *n_iter);
 
 #ifdef __cplusplus
 }

@@ -88,6 +88,7 @@ PROTOTYPES = {
     "tdk_ba_destroy": [_vp],
     "tdk_ba_error": [_vp, _d, _d, _d],
     "tdk_ba_step": [_vp, _d, _d, C.c_double, _d, _d, _d],
+    "tdk_ba_solve": [_vp, _d, _d, _i, C.c_double, C.c_double, C.c_double, C.c_double, _d, C.POINTER(C.c_int)],
 }
 
 _lib = None

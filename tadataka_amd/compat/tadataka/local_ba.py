@@ -104,19 +104,17 @@ class LocalBundleAdjustment(object):
                 max_iter=200, initial_mu=1.0, nu=100.0,
                 absolute_error_threshold=1e-8, relative_error_threshold=1e-6):
         poses = np.hstack((initial_rotvecs, initial_translations))
-        points = initial_points
-        mu = initial_mu
-        current_error = self.calc_error(poses, points)
-        for iter_ in range(max_iter):
-            poses, points, mu, new_error = self.lm_update(poses, points, mu, nu)
-            relative_error = calc_relative_error(current_error, new_error)
-            print(f"absolute_error[{iter_}] = {new_error}")
-            print(f"relative_error[{iter_}] = {relative_error}")
-            if new_error < absolute_error_threshold:
-                break
-            if relative_error < relative_error_threshold:
-                break
-            current_error = new_error
+        points = np.asarray(initial_points, dtype=np.float64)
+        # the loop of the reference (lm_update per iteration, :115-134) runs inside
+        # the library with the parameters resident on the device (tdk_ba_solve);
+        # its per-iteration report is printed from the returned error history
+        poses, points, errors = self._device_graph(poses, points).solve(
+            poses, points, max_iter=max_iter, initial_mu=initial_mu, nu=nu,
+            absolute_error_threshold=absolute_error_threshold,
+            relative_error_threshold=relative_error_threshold)
+        for iter_ in range(len(errors) - 1):
+            print(f"absolute_error[{iter_}] = {errors[iter_ + 1]}")
+            print(f"relative_error[{iter_}] = {calc_relative_error(errors[iter_], errors[iter_ + 1])}")
         return poses[:, 0:3], poses[:, 3:6], points
 
 

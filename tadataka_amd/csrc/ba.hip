@@ -657,6 +657,7 @@ struct tdk_ba {
     double *d_poses, *d_points, *d_xt;
     int64_t *d_vp, *d_pt, *d_row_ptr, *d_obs;
     double *d_U, *d_ea, *d_V, *d_eb, *d_part, *d_err, *d_W, *d_Vinv, *d_S, *d_e, *d_da, *d_db;
+    double *d_cposes, *d_cpoints;   // candidate parameters of tdk_ba_solve
     double *d_Be;       // [8][n]: B_ij (2x3) and the residual of every observation
     // Schur complement by pose pair (k_ba_schur_pairs): dense observation table
     int *d_obs_at;      // [n_poses][n_points] observation index or -1; NULL -> atomics fallback
@@ -666,11 +667,11 @@ struct tdk_ba {
 
 namespace {
 
-tdk_status ba_reduce(tdk_ba *h, const double *poses, const double *points, bool for_step, double *err) {
-    TDK_HIP(hipMemcpyAsync(h->d_poses, poses, (size_t)h->n_poses * 48, hipMemcpyHostToDevice, tdk::stream()));
-    TDK_HIP(hipMemcpyAsync(h->d_points, points, (size_t)h->n_points * 24, hipMemcpyHostToDevice, tdk::stream()));
+// residuals, per-pose block sums (and, for a step, B / W per observation and the
+// per-point sums) at parameters that are already on the device
+tdk_status ba_reduce_dev(tdk_ba *h, const double *d_poses, const double *d_points, bool for_step, double *err) {
     dim3 grid((unsigned)h->nchunks, (unsigned)h->n_poses);
-    k_ba_block_reduce<<<grid, kBlock, 0, tdk::stream()>>>(h->d_poses, h->d_points, h->d_xt, h->d_vp, h->d_pt, h->n,
+    k_ba_block_reduce<<<grid, kBlock, 0, tdk::stream()>>>(d_poses, d_points, h->d_xt, h->d_vp, h->d_pt, h->n,
                                                           h->chunk, h->sorted, nullptr, nullptr, h->d_part,
                                                           for_step ? h->d_W : nullptr, for_step ? h->d_Be : nullptr);
     TDK_LAUNCH_CHECK();
@@ -689,6 +690,93 @@ tdk_status ba_reduce(tdk_ba *h, const double *poses, const double *points, bool 
     for (double v : e) s += v;
     *err = s;
     return TDK_OK;
+}
+
+tdk_status ba_reduce(tdk_ba *h, const double *poses, const double *points, bool for_step, double *err) {
+    TDK_HIP(hipMemcpyAsync(h->d_poses, poses, (size_t)h->n_poses * 48, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(h->d_points, points, (size_t)h->n_points * 24, hipMemcpyHostToDevice, tdk::stream()));
+    return ba_reduce_dev(h, h->d_poses, h->d_points, for_step, err);
+}
+
+// Levenberg-Marquardt update for damping mu from the sums of the last
+// ba_reduce_dev(..., for_step = true): V*^-1, Schur complement, dense solve of the
+// reduced camera system on the host, back-substitution.  U / ea are the host
+// copies of the per-pose sums of THAT reduce (an error evaluation at candidate
+// parameters in between overwrites the device ones).  Leaves dpoints in h->d_db.
+tdk_status ba_update_dev(tdk_ba *h, double mu, const std::vector<double> &U, const std::vector<double> &ea,
+                         std::vector<double> &dposes) {
+    const int dim = (int)(6 * h->n_poses);
+    const int gp = grid_for(h->n_points);
+    k_ba_invert_V<<<gp, kBlock, 0, tdk::stream()>>>(h->d_V, mu, h->n_points, h->d_Vinv);
+    TDK_LAUNCH_CHECK();
+    TDK_HIP(hipMemsetAsync(h->d_S, 0, (size_t)dim * dim * 8, tdk::stream()));
+    TDK_HIP(hipMemsetAsync(h->d_e, 0, (size_t)dim * 8, tdk::stream()));
+    if (h->d_obs_at != nullptr) {
+        const int pairs = (int)(h->n_poses * (h->n_poses + 1) / 2);
+        dim3 grid((unsigned)h->npchunks, (unsigned)pairs);
+        k_ba_schur_pairs<<<grid, kBlock, 0, tdk::stream()>>>(h->d_obs_at, h->d_W, h->d_Vinv, h->d_eb, h->n,
+                                                             h->n_points, (int)h->n_poses, h->pchunk, h->d_spart);
+        TDK_LAUNCH_CHECK();
+        k_ba_schur_finish<<<pairs, 64, 0, tdk::stream()>>>(h->d_spart, (int)h->npchunks, (int)h->n_poses, dim, h->d_S,
+                                                           h->d_e);
+    } else {
+        int gs = gp > 1024 ? 1024 : gp;
+        if (h->n_poses <= kMaxLdsPoses) {
+            size_t lds = ((size_t)dim * dim + dim) * 8;
+            k_ba_schur<true><<<gs, kBlock, lds, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv,
+                                                                 h->d_eb, h->n, h->n_points, dim, h->d_S, h->d_e);
+        } else {
+            k_ba_schur<false><<<gs, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv,
+                                                                h->d_eb, h->n, h->n_points, dim, h->d_S, h->d_e);
+        }
+    }
+    TDK_LAUNCH_CHECK();
+    std::vector<double> S((size_t)dim * dim), e((size_t)dim);
+    TDK_HIP(hipMemcpyAsync(S.data(), h->d_S, S.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(e.data(), h->d_e, e.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    // S = blockdiag(U + mu I) - sum Y W^T (upper block triangle from the device), mirrored
+    for (int64_t j = 0; j < h->n_poses; j++) {
+        int m = 0;
+        for (int a = 0; a < 6; a++)
+            for (int b = a; b < 6; b++) {
+                double u = U[(size_t)j * 21 + m++] + (a == b ? mu : 0.0);
+                S[(size_t)(6 * j + a) * dim + 6 * j + b] += u;
+                if (a != b) S[(size_t)(6 * j + b) * dim + 6 * j + a] += u;
+            }
+    }
+    // the device accumulated full diagonal blocks (ja == jb) and the strictly
+    // upper off-diagonal blocks; mirror the latter
+    for (int r = 0; r < dim; r++)
+        for (int c = 0; c < dim; c++)
+            if (c / 6 > r / 6) S[(size_t)c * dim + r] = S[(size_t)r * dim + c];
+    for (int i = 0; i < dim; i++) e[(size_t)i] += ea[(size_t)i];
+    if (dense_solve(S, e, dim) != 0) {
+        tdk::set_error("reduced camera system is singular (mu = %g)", mu);
+        return TDK_ERR_SINGULAR;
+    }
+    dposes = e;
+    TDK_HIP(hipMemcpyAsync(h->d_da, dposes.data(), (size_t)dim * 8, hipMemcpyHostToDevice, tdk::stream()));
+    k_ba_backsub<<<gp, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv, h->d_eb,
+                                                   h->d_da, h->n, h->n_points, h->d_db);
+    TDK_LAUNCH_CHECK();
+    return TDK_OK;
+}
+
+// host copies of the per-pose sums of the last reduce
+tdk_status ba_fetch_pose_sums(tdk_ba *h, std::vector<double> &U, std::vector<double> &ea) {
+    U.resize((size_t)h->n_poses * 21);
+    ea.resize((size_t)h->n_poses * 6);
+    TDK_HIP(hipMemcpyAsync(U.data(), h->d_U, U.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(ea.data(), h->d_ea, ea.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    return TDK_OK;
+}
+
+__global__ void k_ba_add(const double *__restrict__ a, const double *__restrict__ b, int64_t n,
+                         double *__restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
 }
 
 }  // namespace
@@ -740,6 +828,8 @@ tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *vp, c
     TDK_HIP(hipMalloc(&h->d_da, (size_t)dim * 8));
     TDK_HIP(hipMalloc(&h->d_db, (size_t)n_points * 24));
     TDK_HIP(hipMalloc(&h->d_Be, (size_t)n * 8 * 8));
+    TDK_HIP(hipMalloc(&h->d_cposes, (size_t)n_poses * 48));
+    TDK_HIP(hipMalloc(&h->d_cpoints, (size_t)n_points * 24));
     // dense (pose, point) -> observation table for the pair-wise Schur kernel:
     // only when it is small (local BA windows) and no observation is repeated
     h->d_obs_at = nullptr; h->d_spart = nullptr;
@@ -777,7 +867,7 @@ tdk_status tdk_ba_destroy(tdk_ba *h) {
     (void)hipStreamSynchronize(tdk::stream());
     void *ptrs[] = {h->d_poses, h->d_points, h->d_xt, h->d_vp, h->d_pt, h->d_row_ptr, h->d_obs, h->d_U, h->d_ea,
                     h->d_V, h->d_eb, h->d_part, h->d_err, h->d_W, h->d_Vinv, h->d_S, h->d_e, h->d_da, h->d_db,
-                    h->d_Be, h->d_obs_at, h->d_spart};
+                    h->d_Be, h->d_obs_at, h->d_spart, h->d_cposes, h->d_cpoints};
     for (void *p : ptrs) (void)hipFree(p);
     delete h;
     return TDK_OK;
@@ -793,64 +883,74 @@ tdk_status tdk_ba_step(tdk_ba *h, const double *poses, const double *points, dou
     TDK_REQUIRE(h && poses && points && dposes && dpoints && sum_sq, "null pointer");
     TDK_REQUIRE(mu >= 0.0, "mu must be non-negative");
     TDK_TRY(ba_reduce(h, poses, points, true, sum_sq));
-    const int dim = (int)(6 * h->n_poses);
-    const int gp = grid_for(h->n_points);
-    k_ba_invert_V<<<gp, kBlock, 0, tdk::stream()>>>(h->d_V, mu, h->n_points, h->d_Vinv);
-    TDK_LAUNCH_CHECK();
-    TDK_HIP(hipMemsetAsync(h->d_S, 0, (size_t)dim * dim * 8, tdk::stream()));
-    TDK_HIP(hipMemsetAsync(h->d_e, 0, (size_t)dim * 8, tdk::stream()));
-    if (h->d_obs_at != nullptr) {
-        const int pairs = (int)(h->n_poses * (h->n_poses + 1) / 2);
-        dim3 grid((unsigned)h->npchunks, (unsigned)pairs);
-        k_ba_schur_pairs<<<grid, kBlock, 0, tdk::stream()>>>(h->d_obs_at, h->d_W, h->d_Vinv, h->d_eb, h->n,
-                                                             h->n_points, (int)h->n_poses, h->pchunk, h->d_spart);
-        TDK_LAUNCH_CHECK();
-        k_ba_schur_finish<<<pairs, 64, 0, tdk::stream()>>>(h->d_spart, (int)h->npchunks, (int)h->n_poses, dim, h->d_S,
-                                                           h->d_e);
-    } else {
-        int gs = gp > 1024 ? 1024 : gp;
-        if (h->n_poses <= kMaxLdsPoses) {
-            size_t lds = ((size_t)dim * dim + dim) * 8;
-            k_ba_schur<true><<<gs, kBlock, lds, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv,
-                                                                 h->d_eb, h->n, h->n_points, dim, h->d_S, h->d_e);
-        } else {
-            k_ba_schur<false><<<gs, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv,
-                                                                h->d_eb, h->n, h->n_points, dim, h->d_S, h->d_e);
+    std::vector<double> U, ea, da;
+    TDK_TRY(ba_fetch_pose_sums(h, U, ea));
+    TDK_TRY(ba_update_dev(h, mu, U, ea, da));
+    memcpy(dposes, da.data(), da.size() * 8);
+    TDK_HIP(hipMemcpyAsync(dpoints, h->d_db, (size_t)h->n_points * 24, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    return TDK_OK;
+}
+
+// LocalBundleAdjustment.compute (tadataka/local_ba.py:91-134) with the
+// parameters resident on the device: per trial damping only the reduced camera
+// system (6P x 6P) and the pose update cross the bus.  The block sums at the
+// current parameters are computed once per accepted step -- every damping trial
+// reuses them (the reference recomputes projection and Jacobians per trial).
+tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, double initial_mu, double nu,
+                        double absolute_error_threshold, double relative_error_threshold,
+                        double *error_history, int *n_iter) {
+    TDK_REQUIRE(h && poses && points, "null pointer");
+    TDK_REQUIRE(max_iter >= 0 && initial_mu > 0.0 && nu > 1.0, "bad Levenberg-Marquardt parameters");
+    const size_t np6 = (size_t)h->n_poses * 6, nq3 = (size_t)h->n_points * 3;
+    const double inv_n = 1.0 / (double)h->n;                    // calc_error is the MEAN squared error (:51-56)
+    std::vector<double> cur(poses, poses + np6), cand(np6), da, U, ea;
+    double sum_sq = 0.0;
+    TDK_TRY(ba_reduce(h, poses, points, true, &sum_sq));        // uploads the parameters as well
+    TDK_TRY(ba_fetch_pose_sums(h, U, ea));
+    double current_error = sum_sq * inv_n, mu = initial_mu;
+    if (error_history) error_history[0] = current_error;
+    int it = 0;
+    for (; it < max_iter; it++) {
+        const double error0 = current_error;                    // lm_update's calc_error(poses, points)
+        double new_error = 0.0, new_mu = mu;
+        // trial dampings of lm_update (:96-113): mu / nu, mu, then mu nu, mu nu^2, ... until no worse
+        for (int trial = 0;; trial++) {
+            new_mu = trial == 0 ? mu / nu : (trial == 1 ? mu : new_mu * nu);
+            TDK_TRY(ba_update_dev(h, new_mu, U, ea, da));
+            for (size_t i = 0; i < np6; i++) cand[i] = cur[i] + da[i];
+            TDK_HIP(hipMemcpyAsync(h->d_cposes, cand.data(), np6 * 8, hipMemcpyHostToDevice, tdk::stream()));
+            k_ba_add<<<grid_for((int64_t)nq3), kBlock, 0, tdk::stream()>>>(h->d_points, h->d_db, (int64_t)nq3,
+                                                                           h->d_cpoints);
+            TDK_LAUNCH_CHECK();
+            TDK_TRY(ba_reduce_dev(h, h->d_cposes, h->d_cpoints, false, &sum_sq));
+            new_error = sum_sq * inv_n;
+            if (trial < 2 ? new_error < error0 : !(new_error > error0)) break;
+            if (trial > 400) {                                   // mu overflowed to inf long ago
+                tdk::set_error("Levenberg-Marquardt damping search does not terminate");
+                return TDK_ERR_SINGULAR;
+            }
+        }
+        // accept: the candidate becomes the current parameter set
+        std::swap(h->d_poses, h->d_cposes);
+        std::swap(h->d_points, h->d_cpoints);
+        cur = cand;
+        mu = new_mu;
+        if (error_history) error_history[it + 1] = new_error;
+        const double relative_error = fabs((current_error - new_error) / new_error);
+        if (new_error < absolute_error_threshold || relative_error < relative_error_threshold) {
+            it++;
+            break;
+        }
+        current_error = new_error;
+        if (it + 1 < max_iter) {                                 // sums for the next step at the accepted parameters
+            TDK_TRY(ba_reduce_dev(h, h->d_poses, h->d_points, true, &sum_sq));
+            TDK_TRY(ba_fetch_pose_sums(h, U, ea));
         }
     }
-    TDK_LAUNCH_CHECK();
-    std::vector<double> S((size_t)dim * dim), e((size_t)dim), U((size_t)h->n_poses * 21), ea((size_t)dim);
-    TDK_HIP(hipMemcpyAsync(S.data(), h->d_S, S.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipMemcpyAsync(e.data(), h->d_e, e.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipMemcpyAsync(U.data(), h->d_U, U.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipMemcpyAsync(ea.data(), h->d_ea, ea.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
-    // S = blockdiag(U + mu I) - sum Y W^T (upper block triangle from the device), mirrored
-    for (int64_t j = 0; j < h->n_poses; j++) {
-        int m = 0;
-        for (int a = 0; a < 6; a++)
-            for (int b = a; b < 6; b++) {
-                double u = U[(size_t)j * 21 + m++] + (a == b ? mu : 0.0);
-                S[(size_t)(6 * j + a) * dim + 6 * j + b] += u;
-                if (a != b) S[(size_t)(6 * j + b) * dim + 6 * j + a] += u;
-            }
-    }
-    // the device accumulated full diagonal blocks (ja == jb) and the strictly
-    // upper off-diagonal blocks; mirror the latter
-    for (int r = 0; r < dim; r++)
-        for (int c = 0; c < dim; c++)
-            if (c / 6 > r / 6) S[(size_t)c * dim + r] = S[(size_t)r * dim + c];
-    for (int i = 0; i < dim; i++) e[(size_t)i] += ea[(size_t)i];
-    if (dense_solve(S, e, dim) != 0) {
-        tdk::set_error("reduced camera system is singular (mu = %g)", mu);
-        return TDK_ERR_SINGULAR;
-    }
-    memcpy(dposes, e.data(), (size_t)dim * 8);
-    TDK_HIP(hipMemcpyAsync(h->d_da, e.data(), (size_t)dim * 8, hipMemcpyHostToDevice, tdk::stream()));
-    k_ba_backsub<<<gp, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv, h->d_eb,
-                                                   h->d_da, h->n, h->n_points, h->d_db);
-    TDK_LAUNCH_CHECK();
-    TDK_HIP(hipMemcpyAsync(dpoints, h->d_db, (size_t)h->n_points * 24, hipMemcpyDeviceToHost, tdk::stream()));
+    if (n_iter) *n_iter = it;
+    memcpy(poses, cur.data(), np6 * 8);
+    TDK_HIP(hipMemcpyAsync(points, h->d_points, nq3 * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
     return TDK_OK;
 }

@@ -396,6 +396,19 @@ class BundleAdjustment(object):
         call("tdk_ba_error", self._h, _p(poses), _p(points), C.byref(err))
         return float(err.value)
 
+    def solve(self, poses, points, max_iter=200, initial_mu=1.0, nu=100.0,
+              absolute_error_threshold=1e-8, relative_error_threshold=1e-6):
+        """Levenberg-Marquardt loop on the device.  Returns (poses [P,6], points [Q,3],
+        errors): errors[0] is the initial mean squared error, errors[k] the one
+        accepted by iteration k - 1."""
+        poses = np.array(_f64(poses, (self.n_poses, 6)))
+        points = np.array(_f64(points, (self.n_points, 3)))
+        hist = np.zeros(int(max_iter) + 1)
+        n_iter = C.c_int()
+        call("tdk_ba_solve", self._h, _p(poses), _p(points), int(max_iter), float(initial_mu), float(nu),
+             float(absolute_error_threshold), float(relative_error_threshold), _p(hist), C.byref(n_iter))
+        return poses, points, hist[:n_iter.value + 1]
+
     def step(self, poses, points, mu):
         """(dposes [P,6], dpoints [Q,3], sum ||e||^2 at the input parameters)."""
         poses = _f64(poses, (self.n_poses, 6)); points = _f64(points, (self.n_points, 3))

@@ -66,6 +66,18 @@ def main():
     tg = timeit(lambda: ops.ba_projection(b["poses_noisy"], b["points_noisy"], b["vp_idx"], b["pt_idx"]))
     to = timeit(lambda: orc.ba_projection(b["poses_noisy"], b["points_noisy"], b["vp_idx"], b["pt_idx"]), reps=2)
     print(f"cfg5 BA Projection.compute+jacobians 400k obs host buffers: gpu {tg*1e3:.2f} ms, cpu oracle {to*1e3:.1f} ms, x{to/tg:.1f}")
+    # cfg5, the whole Levenberg-Marquardt loop (LocalBundleAdjustment.compute) on the device
+    g = ops.BundleAdjustment(len(b["poses"]), len(b["points"]), b["vp_idx"], b["pt_idx"], x_true)
+    box = {}
+
+    def solve():
+        box["r"] = g.solve(b["poses_noisy"], b["points_noisy"], max_iter=10, absolute_error_threshold=1e-20,
+                           relative_error_threshold=1e-6)
+    tg = timeit(solve)
+    errs = box["r"][2]
+    print(f"cfg5 BA Levenberg-Marquardt 8x50000, {len(errs) - 1} iterations on the device: gpu {tg*1e3:.2f} ms "
+          f"({tg*1e3/(len(errs)-1):.2f} ms/iteration), mean sq. error {errs[0]:.3e} -> {errs[-1]:.3e}")
+    g.close()
 
 
 if __name__ == "__main__":
