@@ -763,7 +763,14 @@ struct SelectState {
     uint64_t prefix, rank;
     uint64_t next_key;             // successor pass: smallest key above the selected one
     unsigned int count_le, even;   // elements <= the selected one; the mask size is even
+    // short cut after two digits (26 bits): the keys that still match are few, they are
+    // collected and the selection finishes on them (k_select_collect / k_select_finish)
+    uint64_t min_above;            // smallest key whose 26-bit prefix is larger than the selected one
+    unsigned int group;            // number of keys that share the 26-bit prefix
+    unsigned int n_cand;           // keys collected so far
+    unsigned int done, pad;        // the median of this pair is final
 };
+constexpr int kSelectCap = 2048;   // candidates kept per pair; a larger group takes all five digit passes
 
 // rank of the LOWER middle order statistic; np.median averages it with its
 // successor when the count is even
@@ -776,6 +783,10 @@ __global__ void k_select_init(SelectState *st, const int *__restrict__ count, in
     st[pair].next_key = ~0ull;
     st[pair].count_le = 0;
     st[pair].even = (m > 0 && (m & 1) == 0) ? 1u : 0u;
+    st[pair].min_above = ~0ull;
+    st[pair].group = 0;
+    st[pair].n_cand = 0;
+    st[pair].done = 0;
 }
 
 // values: rm (mode 0) or |rm - center[pair]| (mode 1, for the MAD)
@@ -797,6 +808,7 @@ __global__ __launch_bounds__(kBlock) void k_select_hist(const double *__restrict
                                                         unsigned int *__restrict__ hist) {
     const int pair = blockIdx.y;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
+    if (st[pair].done) return;
     __shared__ unsigned int h[kSelectBins];
     for (int i = threadIdx.x; i < kSelectBins; i += kBlock) h[i] = 0;
     __syncthreads();
@@ -833,6 +845,7 @@ __global__ __launch_bounds__(kBlock) void k_select_pick(unsigned int *__restrict
                                                         const int *__restrict__ state, int pass) {
     const int pair = blockIdx.x;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
+    if (st[pair].done) return;
     unsigned int *h = hist + (size_t)pair * kSelectBins;
     constexpr int kPer = kSelectBins / kBlock;   // consecutive bins per thread
     __shared__ unsigned int sums[kBlock];
@@ -867,6 +880,79 @@ __global__ __launch_bounds__(kBlock) void k_select_pick(unsigned int *__restrict
     }
     st[pair].rank = rank - cum;
     st[pair].prefix |= ((uint64_t)(threadIdx.x * kPer + bin)) << select_shift(pass);
+    st[pair].group = local[bin];
+}
+
+// After two digits: gather the keys that share the 26-bit prefix (at most
+// kSelectCap of them) and the smallest key above the group.
+__global__ __launch_bounds__(kBlock) void k_select_collect(const double *__restrict__ rm, int64_t stride, int N,
+                                                           const int *__restrict__ state, int mode,
+                                                           const double *__restrict__ center,
+                                                           SelectState *__restrict__ st,
+                                                           uint64_t *__restrict__ cand) {
+    const int pair = blockIdx.y;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    if (st[pair].group > (unsigned int)kSelectCap) return;    // the digit passes go on instead
+    const int shift = select_shift(1);
+    const uint64_t group_prefix = st[pair].prefix >> shift;
+    const double cen = mode ? center[pair] : 0.0;
+    const double *r = rm + (int64_t)pair * stride;
+    uint64_t *mine = cand + (size_t)pair * kSelectCap;
+    uint64_t above = ~0ull;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+        uint64_t k;
+        if (!select_key(r, i, mode, cen, k)) continue;
+        const uint64_t top = k >> shift;
+        if (top == group_prefix) {
+            const unsigned int slot = atomicAdd(&st[pair].n_cand, 1u);
+            if (slot < (unsigned int)kSelectCap) mine[slot] = k;
+        } else if (top > group_prefix && k < above) {
+            above = k;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint64_t o = __shfl_down(above, off, 64);
+        above = o < above ? o : above;
+    }
+    if ((threadIdx.x & 63) == 0 && above != ~0ull)
+        atomicMin((unsigned long long *)&st[pair].min_above, (unsigned long long)above);
+}
+
+// One block per pair: rank the collected keys (position = keys smaller, ties by
+// slot) and read off the lower middle order statistic and, for an even count,
+// its successor -- inside the group, or the smallest key above it.
+__global__ __launch_bounds__(kBlock) void k_select_finish(SelectState *__restrict__ st,
+                                                          const uint64_t *__restrict__ cand,
+                                                          const int *__restrict__ state, double factor,
+                                                          double *__restrict__ out) {
+    const int pair = blockIdx.x;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    const unsigned int c = st[pair].group;
+    if (c == 0 || c > (unsigned int)kSelectCap) return;
+    __shared__ uint64_t keys[kSelectCap];
+    __shared__ uint64_t lo_s, hi_s;
+    const uint64_t *mine = cand + (size_t)pair * kSelectCap;
+    for (unsigned int i = threadIdx.x; i < c; i += kBlock) keys[i] = mine[i];
+    if (threadIdx.x == 0) { lo_s = ~0ull; hi_s = ~0ull; }
+    __syncthreads();
+    const unsigned int rank = (unsigned int)st[pair].rank;
+    for (unsigned int i = threadIdx.x; i < c; i += kBlock) {
+        const uint64_t k = keys[i];
+        unsigned int pos = 0;
+        for (unsigned int j = 0; j < c; j++) {
+            const uint64_t o = keys[j];
+            pos += (o < k || (o == k && j < i)) ? 1u : 0u;
+        }
+        if (pos == rank) lo_s = k;
+        if (pos == rank + 1) hi_s = k;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const double lo = key_to_double(lo_s);
+    double hi = lo;
+    if (st[pair].even) hi = key_to_double(rank + 1 < c ? hi_s : st[pair].min_above);
+    out[pair] = factor * ((lo + hi) / 2.0);
+    st[pair].done = 1;
 }
 
 // successor of the selected key: number of keys <= it and the smallest key above it
@@ -876,7 +962,7 @@ __global__ __launch_bounds__(kBlock) void k_select_successor(const double *__res
                                                              SelectState *__restrict__ st) {
     const int pair = blockIdx.y;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
-    if (!st[pair].even) return;                      // odd count: the median is the selected key itself
+    if (st[pair].done || !st[pair].even) return;     // odd count: the median is the selected key itself
     const uint64_t sel = st[pair].prefix;
     const double cen = mode ? center[pair] : 0.0;
     const double *r = rm + (int64_t)pair * stride;
@@ -907,6 +993,7 @@ __global__ void k_median_combine(const SelectState *__restrict__ st, const int *
     int pair = blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= n_pairs) return;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
+    if (st[pair].done) return;
     const double lo = key_to_double(st[pair].prefix);
     double hi = lo;
     if (st[pair].even) {
@@ -985,6 +1072,7 @@ struct tdk_dvo {
     int *d_count;         // [n]
     void *d_select;       // SelectState[n]
     unsigned int *d_hist; // [n][kSelectBins]
+    uint64_t *d_cand;     // [n][kSelectCap] keys that share 26 bits with the median
     // profiling of the finest-level evaluation kernel (bench.py roofline leg)
     bool profiling;
     std::vector<hipEvent_t> ev_pool;
@@ -1074,6 +1162,7 @@ tdk_status ensure_robust_buffers(tdk_dvo *h) {
     TDK_HIP(hipMalloc(&h->d_spartial, sizeof(double) * kStatBlocks * n));
     TDK_HIP(hipMalloc(&h->d_count, sizeof(int) * n));
     TDK_HIP(hipMalloc(&h->d_select, sizeof(SelectState) * n));
+    TDK_HIP(hipMalloc(&h->d_cand, sizeof(uint64_t) * kSelectCap * n));
     TDK_HIP(hipMalloc(&h->d_hist, sizeof(unsigned int) * kSelectBins * n));
     TDK_HIP(hipMemsetAsync(h->d_hist, 0, sizeof(unsigned int) * kSelectBins * n, h->stream));
     return TDK_OK;
@@ -1098,6 +1187,16 @@ tdk_status device_median(tdk_dvo *h, int level, const int *d_state, int mode, co
         TDK_LAUNCH_CHECK();
         k_select_pick<<<n, kBlock, 0, h->stream>>>(h->d_hist, st, d_state, pass);
         TDK_LAUNCH_CHECK();
+        if (pass == 1) {
+            // usually a handful of keys share 26 bits with the median: finish on those.  Pairs
+            // whose group is larger than kSelectCap (exact ties) are left for the remaining
+            // passes, which return at once for every pair that is done.
+            k_select_collect<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center, st,
+                                                             h->d_cand);
+            TDK_LAUNCH_CHECK();
+            k_select_finish<<<n, kBlock, 0, h->stream>>>(st, h->d_cand, d_state, factor, out);
+            TDK_LAUNCH_CHECK();
+        }
     }
     k_select_successor<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center, st);
     TDK_LAUNCH_CHECK();
@@ -1308,7 +1407,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     if (h->d_rm) {
         (void)hipFree(h->d_rm); (void)hipFree(h->d_wscale); (void)hipFree(h->d_stat);
         (void)hipFree(h->d_spartial); (void)hipFree(h->d_count); (void)hipFree(h->d_select);
-        (void)hipFree(h->d_hist);
+        (void)hipFree(h->d_hist); (void)hipFree(h->d_cand);
     }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_flag) (void)hipHostFree(h->h_flag);

@@ -320,11 +320,13 @@ def test_dvo_full_size_properties(ops):
     batch.close()
 
 
-@pytest.mark.parametrize("shape", [(37, 52), (36, 51), (48, 64)])
+@pytest.mark.parametrize("shape", [(37, 52), (36, 51), (48, 64), (120, 161), (121, 160)])
 def test_dvo_tukey_and_student_t_statistics_with_ties(ops, orc, shape):
     """Quantised images: most residuals are exact ties (many equal keys in the
     radix select, successor == selected value), with odd and even mask sizes.
-    The fused device statistics must reproduce np.median / the fixed point."""
+    The fused device statistics must reproduce np.median / the fixed point.
+    The two large shapes have more than 2048 equal keys around the median, which
+    takes the radix select past its candidate short cut through all five digits."""
     from tadataka_amd import synthetic
     H, W = shape
     pr = synthetic.make_pair(H, W, seed=H)
