@@ -15,26 +15,31 @@
 //
 // HBM layout: per pyramid level, struct-of-arrays I0 | D0 | I1 | W0, each
 // [n_pairs][stride] float64 with stride = N rounded up to even so that every
-// pair starts 16-byte aligned.  The image gradient (np.gradient of I1) is NOT
-// materialised: its 4+4 bilinear taps are rebuilt from 12 neighbouring I1
-// texels, bit-identical to sampling precomputed DX/DY maps, which removes 16 of
-// the 40 B/px the unfused update would read.
+// pair starts 16-byte aligned, plus 4 kBlock doubles of padding per array (the
+// evaluation's stream loads overrun a block's range).  The image gradient
+// (np.gradient of I1) is NOT materialised: its 4+4 bilinear taps are rebuilt
+// from 12 neighbouring I1 texels, which removes 16 of the 40 B/px the unfused
+// update would read.
 //
 // Kernels (gfx950, wave64):
-//   k_dvo_eval        grid (nblk, n_pairs) x 256 threads; each thread walks its
+//   k_norm_tables     per (pair, level): (x - ox) / fx and (y - oy) / fy, once per
+//                     camera upload.
+//   k_dvo_eval        1-D XCD-major grid, 256 threads; each thread walks its
 //                     block's contiguous pixel range one pixel per step through a
 //                     three-stage software pipeline (accumulate n | gathers of n+1
-//                     in flight | warp n+2), keeps 30 f64 accumulators, transposed
-//                     wave reduction (v_permlane swaps + DPP), LDS across the 4
-//                     waves, one 30-double partial per block.
+//                     in flight | warp n+2), keeps 28 f64 accumulators and two
+//                     scalar mask counters, transposed wave reduction
+//                     (v_permlane swaps + DPP), LDS across the 4 waves, one
+//                     30-double partial per block.
 //   k_dvo_reduce      grid n_pairs x 256: fixed-order sum of the partials
 //                     (bit-reproducible), then -- in loop mode -- lane 0 performs the
-//                     monotone accept/reject, the 6x6 solve and the SE(3) update,
-//                     so a Gauss-Newton iteration needs no host round trip.
-//   k_robust_*        Student-t / Tukey need global statistics of the masked
-//                     residuals (tadataka/robust/weights.py:4-35): masked-residual
+//                     monotone accept/reject, the 6x6 solve and the SE(3) update;
+//                     the last block publishes the running-pair count to mapped
+//                     host memory.
+//   k_robust_*,       Student-t / Tukey need global statistics of the masked
+//   k_select_*        residuals (tadataka/robust/weights.py:4-35): masked-residual
 //                     map, 10 fixed-point variance steps, medians by MSD radix
-//                     select -- all per pair, on the device.
+//                     select with a candidate short cut -- all per pair, on the device.
 #include "tdk_math.h"
 #include "tdk_runtime.h"
 
