@@ -463,7 +463,8 @@ def test_bundle_adjustment_schur_kernels_agree(tmp_path):
         assert np.allclose(a[key], b[key], rtol=1e-8, atol=1e-11), key
 
 
-def test_local_ba_device_loop_matches_host_loop(capsys):
+@pytest.mark.parametrize("initial_mu, noise, seed", [(1.0, 1.0, 5), (1e-9, 20.0, 6)])
+def test_local_ba_device_loop_matches_host_loop(capsys, initial_mu, noise, seed):
     """LocalBundleAdjustment.compute runs its Levenberg-Marquardt loop inside the
     library (tdk_ba_solve, parameters resident on the device).  The same loop
     driven from Python through lm_update / calc_update / calc_error -- the
@@ -472,13 +473,15 @@ def test_local_ba_device_loop_matches_host_loop(capsys):
     from tadataka_amd import synthetic
     from tadataka.local_ba import LocalBundleAdjustment, Projection, calc_relative_error
     rng = np.random.default_rng(11)
-    c = synthetic.make_ba_case(n_poses=6, n_points=500, seed=5)
+    c = synthetic.make_ba_case(n_poses=6, n_points=500, seed=seed)
     keep = rng.uniform(0, 1, len(c["vp_idx"])) < 0.8
     vp, pt = c["vp_idx"][keep], c["pt_idx"][keep]
     x_true = Projection(vp, pt).compute(c["poses"], c["points"])
-    poses0 = c["poses"] + 0.01 * rng.standard_normal(c["poses"].shape)
-    points0 = c["points"] + 0.05 * rng.standard_normal(c["points"].shape)
-    kw = dict(max_iter=12, initial_mu=1.0, nu=100.0, absolute_error_threshold=1e-14,
+    # the second case starts far away with next to no damping: the first trial steps
+    # overshoot and the loop has to raise mu (the `while error > error0` branch, :108-112)
+    poses0 = c["poses"] + 0.01 * noise * rng.standard_normal(c["poses"].shape)
+    points0 = c["points"] + 0.05 * noise * rng.standard_normal(c["points"].shape)
+    kw = dict(max_iter=12, initial_mu=initial_mu, nu=100.0, absolute_error_threshold=1e-14,
               relative_error_threshold=1e-9)
 
     ba = LocalBundleAdjustment(vp, pt, x_true)
@@ -487,16 +490,21 @@ def test_local_ba_device_loop_matches_host_loop(capsys):
 
     host = LocalBundleAdjustment(vp, pt, x_true)
     p, q, mu = poses0.copy(), points0.copy(), kw["initial_mu"]
-    current, errors = host.calc_error(p, q), []
+    current, errors, mus = host.calc_error(p, q), [], []
     for _ in range(kw["max_iter"]):
         p, q, mu, new = host.lm_update(p, q, mu, kw["nu"])
         errors.append(new)
+        mus.append(mu)
         if new < kw["absolute_error_threshold"] or calc_relative_error(current, new) < kw["relative_error_threshold"]:
             break
         current = new
     assert len(printed) == 2 * len(errors)
     device_errors = [float(line.split("=")[1]) for line in printed[0::2]]
     assert np.allclose(device_errors, errors, rtol=1e-6, atol=1e-18)
-    assert errors[-1] < 1e-3 * host.calc_error(poses0, points0)
+    assert np.all(np.diff([host.calc_error(poses0, points0)] + errors) <= 0)      # monotone, as LM guarantees
+    if noise > 1.0:
+        assert max(mus) > kw["initial_mu"] * kw["nu"]          # the damping was raised at least twice in one step
+    else:
+        assert errors[-1] < 1e-3 * host.calc_error(poses0, points0)
     assert np.allclose(np.hstack((rot, trans)), p, rtol=1e-7, atol=1e-9)
     assert np.allclose(points, q, rtol=1e-7, atol=1e-9)
