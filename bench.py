@@ -235,7 +235,8 @@ def main():
                          "kernel": f"k_dvo_eval<{args.weights}> (full-resolution level)",
                          "bytes_per_px": BYTES_PER_PX_EVAL,
                          "px_per_launch": prof["pixels"] / max(prof["launches"], 1),
-                         "kernel_ms": kernel_ms, "launches": prof["launches"]},
+                         "kernel_ms": kernel_ms, "launches": prof["launches"],
+                         "limiter": "FP64 issue at the 1400 W package power cap (DESIGN.md 5.1), not HBM"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(batch, cam, args.cpu_seconds)
