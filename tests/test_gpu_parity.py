@@ -280,6 +280,60 @@ def test_dvo_out_of_view_pose_and_masks(ops, orc):
     batch.close()
 
 
+@pytest.mark.parametrize("shape", [(2, 2), (2, 9), (3, 5), (7, 2), (5, 300)])
+def test_dvo_tiny_and_thin_images(ops, orc, shape):
+    """Frames smaller than one wave / one tap neighbourhood: every pixel is a
+    border pixel (clamped taps, one-sided gradients), ranges shorter than the
+    pipeline depth, rows shorter than a block step."""
+    from tadataka_amd import synthetic
+    H, W = shape
+    pr = synthetic.make_pair(max(H, 8), max(W, 8), seed=H * 31 + W)
+    I0, D0, I1 = (np.ascontiguousarray(pr[k][:H, :W]) for k in ("I0", "D0", "I1"))
+    cam = np.array([30.0, 28.0, (W - 1) / 2.0, (H - 1) / 2.0])
+    T = np.eye(4)
+    T[:3, :3] = Rotation.from_rotvec([0.003, -0.002, 0.004]).as_matrix()
+    T[:3, 3] = [0.002, 0.001, -0.003]
+    GX, GY = orc.image_gradient(I1)
+    batch = ops.DvoBatch(1, H, W)
+    batch.upload(0, I0, D0, I1)
+    for Tm in (np.eye(4), T):
+        ev = batch.evaluate(0, cam, cam, _pose12(Tm)[None], ops.W_HUBER)
+        Hm, b, n = orc.dvo_normal_equations(I0, D0, I1, GX, GY, cam, cam, Tm[:3, :3], Tm[:3, 3], "huber")
+        ss, ne = orc.photometric_error_sums(I0, D0, I1, cam, cam, Tm)
+        assert ev["n_update"][0] == n and ev["n_error"][0] == ne
+        if n:
+            assert rel_err(ev["H"][0], Hm) < RTOL_SUMS and rel_err(ev["b"][0], b) < RTOL_SUMS
+        assert abs(ev["sum_sq"][0] - ss) <= RTOL_SUMS * max(ss, 1e-300)
+    batch.close()
+
+
+def test_dvo_zero_and_negative_depth(ops, orc):
+    """Depth 0 puts a point at the camera centre (P1 = t: at a pure rotation z is
+    exactly 0, inside the error mask -- which has no z test -- but outside the
+    update mask), negative depth behind it; both must be masked as the reference does."""
+    from tadataka_amd import synthetic
+    H, W = 33, 47
+    pr = synthetic.make_pair(H, W, seed=9)
+    D0 = pr["D0"].copy()
+    rng = np.random.default_rng(2)
+    D0[rng.uniform(0, 1, D0.shape) < 0.2] = 0.0
+    D0[rng.uniform(0, 1, D0.shape) < 0.1] *= -1.0
+    cam = pr["cam"]
+    GX, GY = orc.image_gradient(pr["I1"])
+    R = np.eye(4); R[:3, :3] = Rotation.from_rotvec([0.002, 0.001, -0.003]).as_matrix()
+    Tt = R.copy(); Tt[:3, 3] = [0.01, -0.02, 0.015]
+    batch = ops.DvoBatch(1, H, W)
+    batch.upload(0, pr["I0"], D0, pr["I1"])
+    for Tm in (np.eye(4), R, Tt):
+        ev = batch.evaluate(0, cam, cam, _pose12(Tm)[None], ops.W_NONE)
+        Hm, b, n = orc.dvo_normal_equations(pr["I0"], D0, pr["I1"], GX, GY, cam, cam, Tm[:3, :3], Tm[:3, 3], None)
+        ss, ne = orc.photometric_error_sums(pr["I0"], D0, pr["I1"], cam, cam, Tm)
+        assert ev["n_update"][0] == n and ev["n_error"][0] == ne and ne >= n
+        assert rel_err(ev["H"][0], Hm) < RTOL_SUMS and rel_err(ev["b"][0], b) < RTOL_SUMS
+        assert abs(ev["sum_sq"][0] - ss) <= RTOL_SUMS * ss
+    batch.close()
+
+
 def test_dvo_full_size_properties(ops):
     """BASELINE sizes (64 x 720p is bench-only; here 8 x 720p): size-independent
     properties -- counts are exact integers, H is symmetric positive
