@@ -1261,7 +1261,15 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
         e1 = h->ev_pool[h->ev_used++];
         TDK_HIP(hipEventRecord(e0, h->stream));
     }
+    if (lds > 160 * 1024) {
+        tdk::set_error("frames of %d x %d need %zu bytes of LDS for the coordinate tables (limit 160 KiB)", L.W, L.H,
+                       lds);
+        return TDK_ERR_INVALID_ARGUMENT;
+    }
 #define TDK_EVAL(WM)                                                                                    \
+    if (lds > 64 * 1024)   /* beyond the default dynamic-LDS limit of a launch */                      \
+        TDK_HIP(hipFuncSetAttribute((const void *)k_dvo_eval<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                    (int)lds));                                                         \
     k_dvo_eval<WM><<<grid, kBlock, lds, h->stream>>>(P, h->d_params, d_poses, d_state, h->d_wscale, \
                                                          L.scale, chunk, h->n_pairs, nblk, h->d_partials)
     switch (weight_mode) {
@@ -1348,6 +1356,8 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
     TDK_REQUIRE(n_pairs >= 1 && n_pairs <= 65535, "n_pairs must be in [1, 65535]");
     TDK_REQUIRE(height >= 2 && width >= 2, "frames must be at least 2x2");
     TDK_REQUIRE((int64_t)height * width < (1ll << 28), "frame too large");
+    TDK_REQUIRE((size_t)(height + width + kWaves * kAccPad) * sizeof(double) <= 160 * 1024,
+                "height + width must stay below 20 000 (per-block coordinate tables live in LDS)");
     TDK_REQUIRE(n_levels >= 1 && n_levels <= kMaxLevels, "n_levels must be in [1, 16]");
     TDK_REQUIRE(ratio > 1.0 || n_levels == 1, "layer_size_ratio must be > 1");
     TDK_TRY(tdk::ensure_device());

@@ -280,11 +280,12 @@ def test_dvo_out_of_view_pose_and_masks(ops, orc):
     batch.close()
 
 
-@pytest.mark.parametrize("shape", [(2, 2), (2, 9), (3, 5), (7, 2), (5, 300)])
+@pytest.mark.parametrize("shape", [(2, 2), (2, 9), (3, 5), (7, 2), (5, 300), (2, 9000)])
 def test_dvo_tiny_and_thin_images(ops, orc, shape):
     """Frames smaller than one wave / one tap neighbourhood: every pixel is a
     border pixel (clamped taps, one-sided gradients), ranges shorter than the
-    pipeline depth, rows shorter than a block step."""
+    pipeline depth, rows shorter than a block step; 2 x 9000 needs 72 KiB of LDS for
+    the coordinate tables (above the default dynamic-LDS limit of a launch)."""
     from tadataka_amd import synthetic
     H, W = shape
     pr = synthetic.make_pair(max(H, 8), max(W, 8), seed=H * 31 + W)
