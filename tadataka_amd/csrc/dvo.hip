@@ -735,16 +735,23 @@ __global__ __launch_bounds__(kBlock) void k_robust_student_step(const double *__
     if (threadIdx.x == 0) partial[(int64_t)pair * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ void k_robust_student_update(const double *__restrict__ partial, int nblk,
-                                        const int *__restrict__ count, const int *__restrict__ state,
-                                        double *__restrict__ variance, int n_pairs, int first) {
-    int pair = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pair >= n_pairs) return;
+// variance <- (sum of the block partials) / count: one wave per pair, lane b holds
+// partial b, fixed shuffle tree (bit-reproducible); `first`: variance 1 (weights.py:10)
+__global__ __launch_bounds__(64) void k_robust_student_update(const double *__restrict__ partial, int nblk,
+                                                              const int *__restrict__ count,
+                                                              const int *__restrict__ state,
+                                                              double *__restrict__ variance, int n_pairs,
+                                                              int first) {
+    const int pair = blockIdx.x;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
-    if (first) { variance[pair] = 1.0; return; }
+    if (first) {
+        if (threadIdx.x == 0) variance[pair] = 1.0;
+        return;
+    }
     double s = 0.0;
-    for (int b = 0; b < nblk; b++) s += partial[(int64_t)pair * nblk + b];
-    variance[pair] = s / (double)count[pair];
+    for (int b = threadIdx.x; b < nblk; b += 64) s += partial[(int64_t)pair * nblk + b];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (threadIdx.x == 0) variance[pair] = s / (double)count[pair];
 }
 
 // MSD radix select on the order-preserving 64-bit image of a double, per pair
@@ -1215,22 +1222,22 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
     if (weight_mode != TDK_W_STUDENT_T && weight_mode != TDK_W_TUKEY) return TDK_OK;
     TDK_TRY(ensure_robust_buffers(h));
     const tdk_dvo::Level &L = h->lv[level];
-    const int n = h->n_pairs, tpb = 256, gp = (n + tpb - 1) / tpb;
+    const int n = h->n_pairs;
     dim3 grid(kStatBlocks, n);
     TDK_HIP(hipMemsetAsync(h->d_count, 0, sizeof(int) * n, h->stream));
     k_robust_mask<<<grid, kBlock, 0, h->stream>>>(ptrs_of(L), h->d_params, d_poses, d_state, L.scale, h->d_rm,
                                                       h->d_count);
     TDK_LAUNCH_CHECK();
     if (weight_mode == TDK_W_STUDENT_T) {
-        k_robust_student_update<<<gp, tpb, 0, h->stream>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
-                                                               h->d_wscale, n, 1);
+        k_robust_student_update<<<n, 64, 0, h->stream>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
+                                                         h->d_wscale, n, 1);
         TDK_LAUNCH_CHECK();
         for (int it = 0; it < 10; it++) {   // n_iter = 10 (weights.py:4)
             k_robust_student_step<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state,
                                                                       h->d_wscale, h->d_spartial);
             TDK_LAUNCH_CHECK();
-            k_robust_student_update<<<gp, tpb, 0, h->stream>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
-                                                                   h->d_wscale, n, 0);
+            k_robust_student_update<<<n, 64, 0, h->stream>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
+                                                             h->d_wscale, n, 0);
             TDK_LAUNCH_CHECK();
         }
     } else {
