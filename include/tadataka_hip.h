@@ -75,6 +75,13 @@ tdk_status tdk_image_gradient(const double *image, int height, int width, double
  * skimage.transform.rescale, tadataka/vo/dvo/__init__.py:144-148) */
 tdk_status tdk_rescale(const double *image, int height, int width, double *out,
                        int out_height, int out_width);
+/* The same with the anti-aliasing prefilter skimage.transform.rescale applies by
+ * default (0.15+) when it shrinks an image: scipy.ndimage.gaussian_filter(image,
+ * sigma = (factor - 1) / 2 per axis, mode='mirror', truncate=4), then the
+ * bilinear warp.  Third-party behaviour restated from its published algorithm
+ * (skimage is not importable in the build container): "parity unpinned". */
+tdk_status tdk_rescale_anti_aliased(const double *image, int height, int width, double *out,
+                                    int out_height, int out_width);
 
 /* ---- DVO: device-resident batch of frame pairs (new, fused) ---------------
  * Replaces, for all pairs at once, the per-iteration body of
@@ -102,6 +109,9 @@ tdk_status tdk_dvo_fill_synthetic(tdk_dvo *h, const double *camera, const double
 tdk_status tdk_dvo_build_pyramid(tdk_dvo *h);
 /* Device -> host copy of one array of one pair/level: which = 0 I0, 1 D0, 2 I1, 3 W0. */
 tdk_status tdk_dvo_download(tdk_dvo *h, int pair, int level, int which, double *out);
+/* Pyramid levels with (1) or without (0, the default: SURVEY cfg2's plain
+ * bilinear rescale) the anti-aliasing prefilter of tdk_rescale_anti_aliased. */
+tdk_status tdk_dvo_set_anti_aliasing(tdk_dvo *h, int enabled);
 tdk_status tdk_dvo_level_shape(tdk_dvo *h, int level, int *height, int *width);
 
 /* One evaluation per pair at `level`:

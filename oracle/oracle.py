@@ -202,12 +202,33 @@ def rescale_shape(shape, scale):
     return (int(np.round(shape[0] * scale)), int(np.round(shape[1] * scale)))
 
 
-def rescale(image, scale):
+def rescale(image, scale, anti_aliasing=False):
     image, p = _d(image)
     Ho, Wo = rescale_shape(image.shape, scale)
     out = np.empty((Ho, Wo))
-    lib().orc_rescale_bilinear(p, C.c_int(image.shape[0]), C.c_int(image.shape[1]),
-                               out.ctypes.data_as(_dp), C.c_int(Ho), C.c_int(Wo))
+    fn = lib().orc_rescale_anti_aliased if anti_aliasing else lib().orc_rescale_bilinear
+    fn(p, C.c_int(image.shape[0]), C.c_int(image.shape[1]), out.ctypes.data_as(_dp), C.c_int(Ho), C.c_int(Wo))
+    return out
+
+
+def gaussian_weights(sigma, radius=None):
+    radius = lib().orc_gaussian_radius(C.c_double(sigma)) if radius is None else radius
+    w = np.empty(2 * radius + 1)
+    lib().orc_gaussian_weights(C.c_double(sigma), C.c_int(radius), w.ctypes.data_as(_dp))
+    return w
+
+
+def gaussian_filter_mirror(image, weights_rows, weights_cols):
+    """scipy.ndimage.gaussian_filter(image, sigma, mode='mirror') for given 1-D kernels (None: skip the axis)."""
+    image, p = _d(image)
+    out = np.empty_like(image)
+    wr = None if weights_rows is None else np.ascontiguousarray(weights_rows, dtype=np.float64)
+    wc = None if weights_cols is None else np.ascontiguousarray(weights_cols, dtype=np.float64)
+    lib().orc_gaussian_filter_mirror(
+        p, C.c_int(image.shape[0]), C.c_int(image.shape[1]),
+        None if wr is None else wr.ctypes.data_as(_dp), C.c_int(0 if wr is None else len(wr) // 2),
+        None if wc is None else wc.ctypes.data_as(_dp), C.c_int(0 if wc is None else len(wc) // 2),
+        out.ctypes.data_as(_dp))
     return out
 
 

@@ -14,8 +14,10 @@
  * orchestration and from its sympy-generated Cython transform_project.
  * NOT pinned by any reference output (no Rust toolchain, missing dataset
  * depth maps): the numeric results of semi-dense estimate/update_depth beyond
- * the Rust unit-test literals, and the skimage pyramid -- "parity unpinned"
- * for those two, see DESIGN.md.
+ * the Rust unit-test literals, and the skimage pyramid (restated twice: plain
+ * bilinear and with skimage's default anti-aliasing prefilter, whose Gaussian
+ * half IS pinned, against scipy.ndimage) -- "parity unpinned" for those two,
+ * see DESIGN.md.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off so that +,-,*,/ and
  * sqrt are evaluated exactly as written, one IEEE rounding each).
@@ -406,6 +408,90 @@ void orc_rescale_bilinear(const double *src, int H, int W, double *dst, int Ho,
             dst[(int64_t)oy * Wo + ox] = top * (1.0 - wy) + bot * wy;
         }
     }
+}
+
+/* ------------------------------------------------------------------------
+ * Anti-aliased rescale: what skimage.transform.rescale (== 0.16.2, setup.py:117)
+ * does with its defaults when it shrinks an image (tadataka/vo/dvo/__init__.py:
+ * 144-148 calls it as rescale(image, scale)).  Third-party code that is not
+ * under /root/reference and not importable here, restated from its published
+ * algorithm (skimage/transform/_warps.py: resize()):
+ *     factors = input_shape / output_shape            (per axis)
+ *     sigma   = max(0, (factors - 1) / 2)
+ *     image   = scipy.ndimage.gaussian_filter(image, sigma, mode='mirror')
+ *               (skimage mode 'reflect' -> ndimage 'mirror'; truncate = 4)
+ *     out     = bilinear warp with dst -> src: (i + 0.5) * factor - 0.5
+ * The Gaussian part is pinned against scipy.ndimage itself (which IS
+ * importable) in tests/test_oracle_golden.py; whether 0.16.2 really defaults to
+ * anti_aliasing=True is from memory of that release -- "parity unpinned".
+ * --------------------------------------------------------------------- */
+
+/* scipy.ndimage._filters._gaussian_kernel1d, order 0: exp(-0.5 / sigma^2 * x^2) / sum */
+void orc_gaussian_weights(double sigma, int radius, double *w) {
+    double sigma2 = sigma * sigma, sum = 0.0;
+    for (int i = -radius; i <= radius; i++) {
+        w[i + radius] = exp(-0.5 / sigma2 * (double)(i * i));
+        sum += w[i + radius];
+    }
+    for (int i = 0; i <= 2 * radius; i++) w[i] = w[i] / sum;
+}
+
+/* int(truncate * sigma + 0.5), truncate = 4 (gaussian_filter1d) */
+int orc_gaussian_radius(double sigma) { return (int)(4.0 * sigma + 0.5); }
+
+/* ndimage 'mirror': d c b | a b c d | c b a */
+static int mirror_idx(int64_t i, int n) {
+    if (n == 1) return 0;
+    int64_t p = 2 * ((int64_t)n - 1);
+    i %= p;
+    if (i < 0) i += p;
+    if (i >= n) i = p - i;
+    return (int)i;
+}
+
+/* One axis of scipy.ndimage.correlate1d with a symmetric kernel (ni_filters.c,
+ * the `symmetric > 0` branch): centre tap first, then the pairs from the
+ * outermost inwards, (x[-j] + x[+j]) * w[j].  w has 2 * radius + 1 entries. */
+static double symmetric_tap(const double *line, int n, int64_t stride, int i, const double *w, int radius) {
+    double tmp = line[(int64_t)i * stride] * w[radius];
+    for (int j = -radius; j < 0; j++)
+        tmp += (line[(int64_t)mirror_idx((int64_t)i + j, n) * stride] +
+                line[(int64_t)mirror_idx((int64_t)i - j, n) * stride]) * w[radius + j];
+    return tmp;
+}
+
+/* gaussian_filter(src, (sigma_r, sigma_c), mode='mirror'): axis 0 first, then
+ * axis 1; an axis with sigma <= 1e-15 is skipped (scipy does the same). */
+void orc_gaussian_filter_mirror(const double *src, int H, int W, const double *wr, int Rr,
+                                const double *wc, int Rc, double *dst) {
+    double *tmp = (double *)malloc(sizeof(double) * (size_t)H * W);
+    if (wr) {
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) tmp[(int64_t)y * W + x] = symmetric_tap(src + x, H, W, y, wr, Rr);
+    } else {
+        memcpy(tmp, src, sizeof(double) * (size_t)H * W);
+    }
+    if (wc) {
+        for (int y = 0; y < H; y++)
+            for (int x = 0; x < W; x++) dst[(int64_t)y * W + x] = symmetric_tap(tmp + (int64_t)y * W, W, 1, x, wc, Rc);
+    } else {
+        memcpy(dst, tmp, sizeof(double) * (size_t)H * W);
+    }
+    free(tmp);
+}
+
+void orc_rescale_anti_aliased(const double *src, int H, int W, double *dst, int Ho, int Wo) {
+    double sr = ((double)H / (double)Ho - 1.0) / 2.0, sc = ((double)W / (double)Wo - 1.0) / 2.0;
+    if (sr < 0.0) sr = 0.0;
+    if (sc < 0.0) sc = 0.0;
+    int Rr = orc_gaussian_radius(sr), Rc = orc_gaussian_radius(sc);
+    double *wr = NULL, *wc = NULL;
+    if (sr > 1e-15) { wr = (double *)malloc(sizeof(double) * (2 * Rr + 1)); orc_gaussian_weights(sr, Rr, wr); }
+    if (sc > 1e-15) { wc = (double *)malloc(sizeof(double) * (2 * Rc + 1)); orc_gaussian_weights(sc, Rc, wc); }
+    double *f = (double *)malloc(sizeof(double) * (size_t)H * W);
+    orc_gaussian_filter_mirror(src, H, W, wr, Rr, wc, Rc, f);
+    orc_rescale_bilinear(f, H, W, dst, Ho, Wo);
+    free(f); free(wr); free(wc);
 }
 
 /* ========================================================================

@@ -67,6 +67,13 @@ int64_t orc_photometric_error(const double *I0, const double *D0,
 /* Pyramid level (the build's stand-in for skimage.transform.rescale, parity
  * unpinned -- see DESIGN.md).  Output shape is (Ho, Wo). */
 void orc_rescale_bilinear(const double *src, int H, int W, double *dst, int Ho, int Wo);
+/* skimage.transform.rescale with anti_aliasing=True (its 0.15+ default): Gaussian
+ * prefilter (scipy.ndimage.gaussian_filter, mode 'mirror') + the bilinear warp */
+void orc_gaussian_weights(double sigma, int radius, double *w);
+int orc_gaussian_radius(double sigma);
+void orc_gaussian_filter_mirror(const double *src, int H, int W, const double *wr, int Rr,
+                                const double *wc, int Rc, double *dst);
+void orc_rescale_anti_aliased(const double *src, int H, int W, double *dst, int Ho, int Wo);
 
 /* ---- semi-dense ---------------------------------------------------------- */
 typedef struct {

@@ -96,6 +96,17 @@ def _pose12(pose):
     return ops.pose12(pose.R, pose.t)[None]
 
 
+# The reference builds its pyramid with skimage.transform.rescale(image, scale)
+# (:144-148; scikit-image pinned to 0.16.2, setup.py:117).  Since 0.15 that call
+# anti-aliases by default when it shrinks: a Gaussian prefilter with
+# sigma = (1 / scale - 1) / 2 before the bilinear resampling.  scikit-image cannot
+# be imported where this package was built, so the behaviour is restated from its
+# published algorithm (Gaussian part checked against scipy.ndimage bit for bit) and
+# the default of that old release is from memory -- set this to False for the plain
+# bilinear pyramid (what SURVEY.md assumed and what bench.py measures).
+ANTI_ALIASING = True
+
+
 # Device batches are kept between calls (one per shape / pyramid / weight-map
 # configuration, most recent two): creating one costs ~4 ms of allocations and a
 # stream, an estimation of one 640x480 pair ~0.5 ms.  Not thread-safe, like the
@@ -108,6 +119,7 @@ def _batch_for(shape, n_levels, ratio, with_weight_map):
     batch = _BATCHES.pop(key, None)
     if batch is None:
         batch = ops.DvoBatch(1, key[0], key[1], n_levels=key[2], ratio=key[3], with_weight_map=key[4])
+    batch.set_anti_aliasing(ANTI_ALIASING)
     _BATCHES[key] = batch          # most recently used last
     while len(_BATCHES) > 2:
         _BATCHES.pop(next(iter(_BATCHES))).close()

@@ -1092,6 +1092,8 @@ struct tdk_dvo {
     double prof_ms;
     int64_t prof_launches, prof_pixels;
     std::vector<double> cams;   // cameras currently on the device: [cam0 (n x 4) | cam1 (n x 4)]
+    bool anti_aliasing;         // pyramid levels get skimage's Gaussian prefilter (tdk_dvo_set_anti_aliasing)
+    double *d_aa_weights;       // its 1-D kernels, per level and axis (allocated on first use)
     int *h_flag;   // "pairs still running", written by k_dvo_reduce (mapped pinned host memory)
 };
 
@@ -1433,6 +1435,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     }
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
+    if (h->d_aa_weights) (void)hipFree(h->d_aa_weights);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return TDK_OK;
@@ -1480,6 +1483,19 @@ tdk_status tdk_dvo_build_pyramid(tdk_dvo *h) {
     // re-reads of level 0 stay on die.  TDK_PYRAMID=lds stages level-0 tiles in
     // LDS (one read, slower as measured), TDK_PYRAMID=levels runs one k_rescale
     // per (array, level).  All three are bit-identical.
+    if (h->anti_aliasing && h->n_levels > 1) {
+        const double *srcs[4] = {S.I0, S.D0, S.I1, S.W0};
+        tdk::PyramidLevelDesc lv[kMaxLevels];
+        for (int l = 1; l < h->n_levels; l++) {
+            const tdk_dvo::Level &L = h->lv[l];
+            lv[l - 1].dst[0] = L.I0; lv[l - 1].dst[1] = L.D0; lv[l - 1].dst[2] = L.I1; lv[l - 1].dst[3] = L.W0;
+            lv[l - 1].stride = L.stride; lv[l - 1].H = L.H; lv[l - 1].W = L.W;
+        }
+        if (!h->d_aa_weights)
+            TDK_HIP(hipMalloc(&h->d_aa_weights, tdk::pyramid_aa_weight_doubles(h->n_levels - 1) * sizeof(double)));
+        return tdk::launch_pyramid_aa(srcs, h->with_w ? 4 : 3, S.H, S.W, S.stride, h->n_levels - 1, lv, h->n_pairs,
+                                      h->d_aa_weights, h->stream);
+    }
     static const int mode = [] {
         const char *v = getenv("TDK_PYRAMID");
         if (v && !strcmp(v, "lds")) return 1;
@@ -1599,6 +1615,12 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
     TDK_HIP(hipMemcpyAsync(poses12, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, h->stream));
     TDK_HIP(hipStreamSynchronize(h->stream));
     if (h->profiling) TDK_TRY(collect_profile(h));
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_set_anti_aliasing(tdk_dvo *h, int enabled) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    h->anti_aliasing = enabled != 0;
     return TDK_OK;
 }
 

@@ -37,6 +37,10 @@ struct PyramidLevelDesc {
 };
 tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride,
                           int n_out, const PyramidLevelDesc *levels, int batch, int mode, hipStream_t stream);
+// the same levels with skimage's anti-aliasing prefilter (Gaussian, sigma = (factor - 1) / 2 per axis)
+tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride, int n_out,
+                             const PyramidLevelDesc *levels, int batch, double *weights, hipStream_t stream);
+size_t pyramid_aa_weight_doubles(int n_out);
 
 }  // namespace tdk
 

@@ -118,11 +118,14 @@ def rescale_shape(shape, scale):
     return (max(1, int(np.round(shape[0] * scale))), max(1, int(np.round(shape[1] * scale))))
 
 
-def rescale(image, scale):
+def rescale(image, scale, anti_aliasing=False):
+    """Bilinear rescale by `scale`; anti_aliasing=True adds the Gaussian prefilter
+    skimage.transform.rescale applies by default when shrinking."""
     image = _f64(image)
     Ho, Wo = rescale_shape(image.shape, scale)
     out = np.empty((Ho, Wo))
-    call("tdk_rescale", _p(image), image.shape[0], image.shape[1], _p(out), Ho, Wo)
+    call("tdk_rescale_anti_aliased" if anti_aliasing else "tdk_rescale", _p(image), image.shape[0],
+         image.shape[1], _p(out), Ho, Wo)
     return out
 
 
@@ -162,6 +165,9 @@ class DvoBatch(object):
         cam = camera_vec(camera)
         P = _f64(poses12, (self.n_pairs, 12))
         call("tdk_dvo_fill_synthetic", self._h, _p(cam), _p(P), C.c_uint64(seed0), float(noise))
+
+    def set_anti_aliasing(self, enabled):
+        call("tdk_dvo_set_anti_aliasing", self._h, int(bool(enabled)))
 
     def build_pyramid(self):
         call("tdk_dvo_build_pyramid", self._h)

@@ -63,6 +63,9 @@ def _load_ref_bilinear():
     return interpolation
 
 
+ANTI_ALIASING = [False]
+
+
 def install_stubs():
     def mod(name, **attrs):
         m = types.ModuleType(name)
@@ -71,7 +74,8 @@ def install_stubs():
         return m
 
     def rescale(image, scale, **kw):
-        return orc.rescale(image, scale)
+        # ANTI_ALIASING[0]: the oracle's restatement of skimage's default Gaussian prefilter
+        return orc.rescale(image, scale, anti_aliasing=ANTI_ALIASING[0])
 
     mod("skimage")
     mod("skimage.transform", rescale=rescale, resize=None,
@@ -237,11 +241,15 @@ def capture_pyramid(h, w, seed):
     cm = CameraModel(CameraParameters(cam[0:2], cam[2:4]), distortion_model=None)
     out = dict(I0=pair["I0"], D0=pair["D0"], I1=pair["I1"], cam=cam,
                omega_true=pair["omega"], t_true=pair["t"])
-    for wname in (None, "huber"):
-        est = dvo.PoseChangeEstimator(cm, cm, n_coarse_to_fine=3, max_iter=20)
-        pose = est(pair["I0"], pair["D0"], pair["I1"], wname)
-        out[f"pyr_{wname}_rotvec"] = pose.rotation.as_rotvec()
-        out[f"pyr_{wname}_t"] = pose.t
+    # plain bilinear pyramid ("pyr_") and the anti-aliased one skimage builds by default ("pyr_aa_")
+    for tag, aa in (("pyr", False), ("pyr_aa", True)):
+        ANTI_ALIASING[0] = aa
+        for wname in (None, "huber"):
+            est = dvo.PoseChangeEstimator(cm, cm, n_coarse_to_fine=3, max_iter=20)
+            pose = est(pair["I0"], pair["D0"], pair["I1"], wname)
+            out[f"{tag}_{wname}_rotvec"] = pose.rotation.as_rotvec()
+            out[f"{tag}_{wname}_t"] = pose.t
+    ANTI_ALIASING[0] = False
     return out
 
 
@@ -318,6 +326,12 @@ def capture_ba(tp):
 def main():
     install_stubs()
     os.makedirs(HERE, exist_ok=True)
+    if "--only-pyramid" in sys.argv:
+        pyr = capture_pyramid(120, 160, seed=4)
+        for k in ("I0", "D0", "I1"):
+            pyr.pop(k)
+        np.savez_compressed(os.path.join(HERE, "dvo_pyramid.npz"), **pyr)
+        return
 
     small = capture_dvo(48, 64, seed=3, weights_list=[None, "huber", "student-t", "tukey", "map"],
                         tag="s", keep_rows=True)

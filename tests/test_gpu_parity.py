@@ -166,12 +166,15 @@ def test_dvo_pyramid_vs_golden(ops, orc, golden):
         scale = 1 / 1.5 ** level
         for name in ("I0", "D0", "I1"):
             assert np.array_equal(batch.download(0, level, name), orc.rescale(pair[name], scale))
-    for wname in (None, "huber"):
-        P, px = batch.estimate(pair["cam"], pair["cam"], _pose12(np.eye(4))[None], ops.WEIGHT_MODES[wname], 20)
-        R = Rotation.from_rotvec(p[f"pyr_{wname}_rotvec"]).as_matrix()
-        assert np.max(np.abs(P[0, :9].reshape(3, 3) - R)) < POSE_ATOL
-        assert np.max(np.abs(P[0, 9:] - p[f"pyr_{wname}_t"])) < POSE_ATOL
-        assert px > 0
+    for tag, aa in (("pyr", False), ("pyr_aa", True)):
+        batch.set_anti_aliasing(aa)
+        batch.build_pyramid()
+        for wname in (None, "huber"):
+            P, px = batch.estimate(pair["cam"], pair["cam"], _pose12(np.eye(4))[None], ops.WEIGHT_MODES[wname], 20)
+            R = Rotation.from_rotvec(p[f"{tag}_{wname}_rotvec"]).as_matrix()
+            assert np.max(np.abs(P[0, :9].reshape(3, 3) - R)) < POSE_ATOL
+            assert np.max(np.abs(P[0, 9:] - p[f"{tag}_{wname}_t"])) < POSE_ATOL
+            assert px > 0
     batch.close()
 
 
@@ -217,6 +220,37 @@ def test_dvo_pyramid_modes_bit_identical(ops, orc):
         out = subprocess.run([sys.executable, "-c", _PYRAMID_SCRIPT], env=env, cwd=root, check=True,
                              capture_output=True, text=True, timeout=300)
         assert out.stdout.strip().splitlines()[-1] == h.hexdigest(), mode
+
+
+def test_anti_aliased_rescale_and_pyramid_bit_exact(ops, orc):
+    """The anti-aliased rescale (Gaussian prefilter + bilinear, skimage's default when
+    shrinking) equals the oracle bit for bit -- stateless operator and the pyramid of
+    a device batch (several pairs, weight map, four levels, odd shapes, a frame
+    smaller than the deepest level's kernel)."""
+    from tadataka_amd import synthetic
+    rng = np.random.default_rng(1)
+    for shape, scale in (((61, 83), 1 / 1.5), ((61, 83), 1 / 1.5 ** 3), ((5, 4), 0.4), ((48, 64), 1.0), ((20, 30), 1.7)):
+        img = rng.uniform(0, 1, shape)
+        assert np.array_equal(ops.rescale(img, scale, anti_aliasing=True), orc.rescale(img, scale, anti_aliasing=True))
+    H, W, B = 61, 83, 3
+    batch = ops.DvoBatch(B, H, W, n_levels=4, ratio=1.5, with_weight_map=True)
+    batch.set_anti_aliasing(True)
+    pairs = []
+    for i in range(B):
+        pr = synthetic.make_pair(H, W, seed=30 + i)
+        pr["W0"] = np.full((H, W), 0.5 + 0.1 * i) + 0.01 * rng.standard_normal((H, W))
+        batch.upload(i, pr["I0"], pr["D0"], pr["I1"], pr["W0"])
+        pairs.append(pr)
+    batch.build_pyramid()
+    for i, pr in enumerate(pairs):
+        for level in (1, 2, 3):
+            for name in ("I0", "D0", "I1", "W0"):
+                assert np.array_equal(batch.download(i, level, name),
+                                      orc.rescale(pr[name], 1 / 1.5 ** level, anti_aliasing=True)), (i, level, name)
+    batch.set_anti_aliasing(False)
+    batch.build_pyramid()
+    assert np.array_equal(batch.download(1, 2, "I1"), orc.rescale(pairs[1]["I1"], 1 / 1.5 ** 2))
+    batch.close()
 
 
 def test_dvo_batch_ragged_shapes_and_independence(ops, orc):

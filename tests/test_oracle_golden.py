@@ -143,3 +143,39 @@ def test_ba_matches_cython_reference(golden):
     assert np.max(np.abs(A - g["A"]) / scale(g["A"])) < 1e-8
     R = np.array([orc.exp_so3(p[:3]) for p in poses])
     assert np.max(np.abs(R - g["R"])) < 1e-12
+
+
+@pytest.mark.parametrize("shape, sigma", [((37, 53), (0.25, 0.2494)), ((48, 64), (0.625, 0.625)),
+                                          ((9, 7), (2.03, 1.3)), ((2, 2), (0.625, 0.625)), ((5, 1), (0.625, 0.0))])
+def test_gaussian_prefilter_is_scipy_ndimage(shape, sigma):
+    """The anti-aliasing prefilter of skimage.transform.rescale is
+    scipy.ndimage.gaussian_filter(image, sigma, mode='mirror'); scipy is importable,
+    so the oracle's restatement is pinned against the real thing, bit for bit
+    (same kernel weights in), down to frames smaller than the kernel."""
+    from scipy import ndimage as ndi
+    from scipy.ndimage._filters import _gaussian_kernel1d
+    rng = np.random.default_rng(shape[0])
+    img = rng.uniform(0, 1, shape)
+    ref = ndi.gaussian_filter(img, sigma, mode="mirror")
+    weights = [None if s <= 1e-15 else _gaussian_kernel1d(s, 0, int(4 * s + 0.5)) for s in sigma]
+    assert np.array_equal(orc.gaussian_filter_mirror(img, weights[0], weights[1]), ref)
+    for s in sigma:
+        if s > 1e-15:                    # the C kernel weights: exp / sum as numpy computes them, to an ulp
+            assert np.allclose(orc.gaussian_weights(s), _gaussian_kernel1d(s, 0, int(4 * s + 0.5)), rtol=0, atol=2e-16)
+
+
+def test_anti_aliased_rescale_is_prefilter_plus_bilinear():
+    """skimage/transform/_warps.py resize(): sigma = max(0, (factor - 1) / 2) per
+    axis, ndimage 'mirror' Gaussian, then the order-1 warp."""
+    from scipy import ndimage as ndi
+    rng = np.random.default_rng(3)
+    img = rng.uniform(0, 1, (61, 83))
+    for level in (1, 2, 3):
+        scale = 1 / 1.5 ** level
+        Ho, Wo = orc.rescale_shape(img.shape, scale)
+        sigma = (max(0.0, (61 / Ho - 1) / 2), max(0.0, (83 / Wo - 1) / 2))
+        expected = orc.rescale(ndi.gaussian_filter(img, sigma, mode="mirror"), scale)
+        got = orc.rescale(img, scale, anti_aliasing=True)
+        assert got.shape == (Ho, Wo)
+        assert np.allclose(got, expected, rtol=0, atol=4e-16)     # kernel weights differ by <= 1 ulp
+    assert np.array_equal(orc.rescale(img, 1.0, anti_aliasing=True), img)
