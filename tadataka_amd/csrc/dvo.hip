@@ -1491,10 +1491,11 @@ tdk_status tdk_dvo_build_pyramid(tdk_dvo *h) {
             lv[l - 1].dst[0] = L.I0; lv[l - 1].dst[1] = L.D0; lv[l - 1].dst[2] = L.I1; lv[l - 1].dst[3] = L.W0;
             lv[l - 1].stride = L.stride; lv[l - 1].H = L.H; lv[l - 1].W = L.W;
         }
-        if (!h->d_aa_weights)
+        const bool first = h->d_aa_weights == nullptr;
+        if (first)
             TDK_HIP(hipMalloc(&h->d_aa_weights, tdk::pyramid_aa_weight_doubles(h->n_levels - 1) * sizeof(double)));
         return tdk::launch_pyramid_aa(srcs, h->with_w ? 4 : 3, S.H, S.W, S.stride, h->n_levels - 1, lv, h->n_pairs,
-                                      h->d_aa_weights, h->stream);
+                                      h->d_aa_weights, first, h->stream);
     }
     static const int mode = [] {
         const char *v = getenv("TDK_PYRAMID");

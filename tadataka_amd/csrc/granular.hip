@@ -344,27 +344,24 @@ __global__ __launch_bounds__(256) void k_rescale_levels_aa(RescaleAaArgs args) {
     const PyrLevel &L = a.lv[l];
     const AaLevel &aa = args.aa[l];
     const int arr = blockIdx.y, pair = blockIdx.z;
-    const int oy = (((int)blockIdx.x - (l ? a.blk_end[l - 1] : 0)) << 2) + (int)(threadIdx.x >> 6);
-    if (oy >= L.Ho) return;
+    // one thread per output pixel: each one is hundreds of dependent-address loads,
+    // so a single frame wants all the parallelism it can get
+    const int i = ((int)blockIdx.x - (l ? a.blk_end[l - 1] : 0)) * 256 + (int)threadIdx.x;
+    if (i >= L.Ho * L.Wo) return;
+    const int oy = i / L.Wo, ox = i - oy * L.Wo;
     const int H = a.H, W = a.W;
     const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
     const double sy = (double)H / (double)L.Ho, sx = (double)W / (double)L.Wo;
     double cy = ((double)oy + 0.5) * sy - 0.5;
-    double fy0 = floor(cy);
-    double wy = cy - fy0;
-    const int iy = (int)fy0;
+    double cx = ((double)ox + 0.5) * sx - 0.5;
+    double fy0 = floor(cy), fx0 = floor(cx);
+    double wy = cy - fy0, wx = cx - fx0;
+    const int iy = (int)fy0, ix = (int)fx0;
     const int y0 = reflect_fast(iy, H), y1 = reflect_fast(iy + 1, H);
-    double *d = L.dst[arr] + (int64_t)pair * L.stride + (int64_t)oy * L.Wo;
-    for (int ox = threadIdx.x & 63; ox < L.Wo; ox += 64) {
-        double cx = ((double)ox + 0.5) * sx - 0.5;
-        double fx0 = floor(cx);
-        double wx = cx - fx0;
-        const int ix = (int)fx0;
-        const int x0 = reflect_fast(ix, W), x1 = reflect_fast(ix + 1, W);
-        double top = filtered_tap(s, H, W, y0, x0, aa) * (1.0 - wx) + filtered_tap(s, H, W, y0, x1, aa) * wx;
-        double bot = filtered_tap(s, H, W, y1, x0, aa) * (1.0 - wx) + filtered_tap(s, H, W, y1, x1, aa) * wx;
-        d[ox] = top * (1.0 - wy) + bot * wy;
-    }
+    const int x0 = reflect_fast(ix, W), x1 = reflect_fast(ix + 1, W);
+    double top = filtered_tap(s, H, W, y0, x0, aa) * (1.0 - wx) + filtered_tap(s, H, W, y0, x1, aa) * wx;
+    double bot = filtered_tap(s, H, W, y1, x0, aa) * (1.0 - wx) + filtered_tap(s, H, W, y1, x1, aa) * wx;
+    L.dst[arr][(int64_t)pair * L.stride + i] = top * (1.0 - wy) + bot * wy;
 }
 
 // scipy.ndimage._filters._gaussian_kernel1d (order 0), radius int(4 sigma + 0.5)
@@ -386,7 +383,8 @@ namespace tdk {
 // buffer of n_out * 2 * (2 kMaxGaussRadius + 1) doubles owned by the caller; the
 // kernels of every level are computed here and copied into it.
 tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride, int n_out,
-                             const PyramidLevelDesc *levels, int batch, double *weights, hipStream_t stream) {
+                             const PyramidLevelDesc *levels, int batch, double *weights, bool upload_weights,
+                             hipStream_t stream) {
     if (n_out <= 0) return TDK_OK;
     if (n_out > 15 || n_arrays > 4) {
         set_error("pyramid too deep");
@@ -402,7 +400,7 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
     for (int l = 0; l < n_out; l++) {
         for (int i = 0; i < 4; i++) r.lv[l].dst[i] = i < n_arrays ? levels[l].dst[i] : nullptr;
         r.lv[l].stride = levels[l].stride; r.lv[l].Ho = levels[l].H; r.lv[l].Wo = levels[l].W;
-        blocks += (levels[l].H + 3) / 4;
+        blocks += (int)(((int64_t)levels[l].H * levels[l].W + 255) / 256);   // one thread per output pixel
         r.blk_end[l] = blocks;
         // sigma = max(0, (factor - 1) / 2) per axis; sigma 0 = the one-tap kernel {1} (x * 1.0 is exact)
         double sg[2] = {((double)H / (double)levels[l].H - 1.0) / 2.0, ((double)W / (double)levels[l].W - 1.0) / 2.0};
@@ -426,8 +424,10 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
         args.aa[l].Rr = R[0];
         args.aa[l].Rc = R[1];
     }
-    TDK_HIP(hipMemcpyAsync(weights, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-    TDK_HIP(hipStreamSynchronize(stream));   // `host` goes out of scope
+    if (upload_weights) {   // they depend on the shapes only: a batch uploads them once
+        TDK_HIP(hipMemcpyAsync(weights, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        TDK_HIP(hipStreamSynchronize(stream));   // `host` goes out of scope
+    }
     dim3 grid(blocks, n_arrays, batch);
     k_rescale_levels_aa<<<grid, 256, 0, stream>>>(args);
     TDK_LAUNCH_CHECK();
@@ -650,7 +650,7 @@ tdk_status tdk_rescale_anti_aliased(const double *image, int H, int W, double *o
     tdk::PyramidLevelDesc lv;
     lv.dst[0] = (double *)d_out; lv.dst[1] = lv.dst[2] = lv.dst[3] = nullptr;
     lv.stride = 0; lv.H = Ho; lv.W = Wo;
-    TDK_TRY(tdk::launch_pyramid_aa(srcs, 1, H, W, 0, 1, &lv, 1, (double *)d_w, tdk::stream()));
+    TDK_TRY(tdk::launch_pyramid_aa(srcs, 1, H, W, 0, 1, &lv, 1, (double *)d_w, true, tdk::stream()));
     return to_host(out, d_out, (size_t)Ho * Wo * 8);
 }
 

@@ -39,7 +39,8 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
                           int n_out, const PyramidLevelDesc *levels, int batch, int mode, hipStream_t stream);
 // the same levels with skimage's anti-aliasing prefilter (Gaussian, sigma = (factor - 1) / 2 per axis)
 tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride, int n_out,
-                             const PyramidLevelDesc *levels, int batch, double *weights, hipStream_t stream);
+                             const PyramidLevelDesc *levels, int batch, double *weights, bool upload_weights,
+                             hipStream_t stream);
 size_t pyramid_aa_weight_doubles(int n_out);
 
 }  // namespace tdk
