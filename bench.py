@@ -51,6 +51,8 @@ def parse_args():
     ap.add_argument("--weights", default="huber", choices=["none", "huber", "student-t", "tukey"])
     ap.add_argument("--double-buffer", action="store_true",
                     help="two batches: the next batch's pyramid is built under the current estimation")
+    ap.add_argument("--anti-aliasing", action="store_true",
+                    help="pyramid with skimage's Gaussian prefilter instead of SURVEY cfg2's plain bilinear rescale")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -133,6 +135,7 @@ def main():
     for seed0 in seeds:
         bt = ops.DvoBatch(B, H, W, n_levels=args.levels, ratio=1.5)
         bt.fill_synthetic(cam, true_poses(B, seed0), seed0=seed0, noise=0.02)
+        bt.set_anti_aliasing(args.anti_aliasing)
         batches.append(bt)
     batch = batches[0]
     ident = np.tile(ops.pose12(np.eye(3), np.zeros(3)), (B, 1))
@@ -224,6 +227,7 @@ def main():
                                    f"{W}x{H} frame pairs, {args.levels}-level pyramid ratio 1.5, "
                                    f"weights={args.weights}, max_iter={args.max_iter}",
                        "pairs_per_gpu": B, "batches_in_flight": n_batches,
+                       "pyramid": "anti-aliased (gaussian prefilter + bilinear)" if args.anti_aliasing else "bilinear",
                        "height": H, "width": W, "levels": args.levels,
                        "weights": args.weights, "max_iter": args.max_iter,
                        "parallelism": f"pair-shard x{world}" if world > 1 else "single GPU"},

@@ -364,6 +364,99 @@ __global__ __launch_bounds__(256) void k_rescale_levels_aa(RescaleAaArgs args) {
     L.dst[arr][(int64_t)pair * L.stride + i] = top * (1.0 - wy) + bot * wy;
 }
 
+// Tiled form of the same arithmetic for one level, used whenever the level shrinks both
+// axes and its tiles fit in LDS: a block produces kAaRows x kAaCols output pixels.
+//   1. the source rows / columns its taps and their filter support touch go to LDS
+//      (mirror boundary applied while loading),
+//   2. the vertical Gaussian is evaluated once per needed (row, column) into a second
+//      LDS tile V -- ndimage filters axis 0 first, so V is rounded exactly like its
+//      intermediate image,
+//   3. every thread evaluates the horizontal Gaussian of V at its four taps and blends.
+// Same operations in the same order as filtered_tap(), so the results are bit-identical
+// to k_rescale_levels_aa; ~70 LDS reads per output instead of ~200 global loads.
+constexpr int kAaRows = 4, kAaCols = 64;
+
+struct AaTileArgs {
+    const double *src[4];
+    double *dst[4];
+    int64_t src_stride, dst_stride;
+    int H, W, Ho, Wo;
+    AaLevel aa;
+    int max_v_rows, max_cols;   // LDS tile bounds (host: ceil(rows * factor) + 2, ceil(cols * factor) + 2 + 2 Rc)
+};
+
+// R > 0: both radii are the compile-time R (loops unrolled, the LDS reads of a tap issue
+// together); R == 0: radii from the arguments.
+template <int R>
+__global__ __launch_bounds__(256) void k_rescale_aa_tiled(AaTileArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
+    const int Rr = R > 0 ? R : a.aa.Rr, Rc = R > 0 ? R : a.aa.Rc;
+    const int SC = a.max_cols;
+    double *S = reinterpret_cast<double *>(aa_smem);           // [max_v_rows + 2 Rr][SC] source
+    double *V = S + (size_t)(a.max_v_rows + 2 * Rr) * SC;       // [max_v_rows][SC] vertically filtered
+    double *wr = V + (size_t)a.max_v_rows * SC;                 // [2 Rr + 1] kernel weights, LDS copies:
+    double *wc = wr + 2 * Rr + 1;                               // [2 Rc + 1] broadcast reads in the inner loops
+    for (int k = threadIdx.x; k < 2 * Rr + 1; k += 256) wr[k] = a.aa.wr[k];
+    for (int k = threadIdx.x; k < 2 * Rc + 1; k += 256) wc[k] = a.aa.wc[k];
+    const int tiles_x = (a.Wo + kAaCols - 1) / kAaCols;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int arr = blockIdx.y, pair = blockIdx.z;
+    const int H = a.H, W = a.W;
+    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    const double sy = (double)H / (double)a.Ho, sx = (double)W / (double)a.Wo;
+    const int oy0 = ty * kAaRows, oy1 = min(oy0 + kAaRows, a.Ho);
+    const int ox0 = tx * kAaCols, ox1 = min(ox0 + kAaCols, a.Wo);
+    // first / last lower tap of the tile (a shrinking level: all taps lie inside the image)
+    const int yv0 = (int)floor(((double)oy0 + 0.5) * sy - 0.5);
+    const int yv1 = min((int)floor(((double)(oy1 - 1) + 0.5) * sy - 0.5) + 1, H - 1);
+    const int xv0 = (int)floor(((double)ox0 + 0.5) * sx - 0.5);
+    const int xv1 = min((int)floor(((double)(ox1 - 1) + 0.5) * sx - 0.5) + 1, W - 1);
+    const int nv = yv1 - yv0 + 1, ns = nv + 2 * Rr;             // V rows, source rows
+    const int nc = xv1 - xv0 + 1 + 2 * Rc;                       // columns incl. the horizontal support
+    const int xs0 = xv0 - Rc, ys0 = yv0 - Rr;
+    // a wave per tile row, lanes along it: no division, coalesced rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < ns; r += 4) {
+        const double *row = s + (int64_t)mirror_idx(ys0 + r, H) * W;
+        for (int c = lane; c < nc; c += 64) S[r * SC + c] = row[mirror_idx(xs0 + c, W)];
+    }
+    __syncthreads();
+    for (int r = wave; r < nv; r += 4) {
+        for (int c = lane; c < nc; c += 64) {
+            const double *col = S + (r + Rr) * SC + c;           // centre row of this V row
+            double tmp = col[0] * wr[Rr];
+#pragma unroll
+            for (int j = -Rr; j < 0; j++) tmp += (col[j * SC] + col[-j * SC]) * wr[Rr + j];
+            V[r * SC + c] = tmp;
+        }
+    }
+    __syncthreads();
+    const int oy = oy0 + (int)(threadIdx.x >> 6), ox = ox0 + (int)(threadIdx.x & 63);
+    if (oy >= oy1 || ox >= ox1) return;
+    double cy = ((double)oy + 0.5) * sy - 0.5;
+    double cx = ((double)ox + 0.5) * sx - 0.5;
+    double fy0 = floor(cy), fx0 = floor(cx);
+    double wy = cy - fy0, wx = cx - fx0;
+    const int iy = (int)fy0, ix = (int)fx0;
+    const int y0 = reflect_fast(iy, H), y1 = reflect_fast(iy + 1, H);
+    const int x0 = reflect_fast(ix, W), x1 = reflect_fast(ix + 1, W);
+    double f[2][2];
+#pragma unroll
+    for (int ry = 0; ry < 2; ry++) {
+#pragma unroll
+        for (int rx = 0; rx < 2; rx++) {
+            const double *row = V + ((ry ? y1 : y0) - yv0) * SC + ((rx ? x1 : x0) - xs0);
+            double tmp = row[0] * wc[Rc];
+#pragma unroll
+            for (int j = -Rc; j < 0; j++) tmp += (row[j] + row[-j]) * wc[Rc + j];
+            f[ry][rx] = tmp;
+        }
+    }
+    double top = f[0][0] * (1.0 - wx) + f[0][1] * wx;
+    double bot = f[1][0] * (1.0 - wx) + f[1][1] * wx;
+    a.dst[arr][(int64_t)pair * a.dst_stride + (int64_t)oy * a.Wo + ox] = top * (1.0 - wy) + bot * wy;
+}
+
 // scipy.ndimage._filters._gaussian_kernel1d (order 0), radius int(4 sigma + 0.5)
 void gaussian_weights(double sigma, int radius, double *w) {
     const double sigma2 = sigma * sigma;
@@ -428,9 +521,51 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
         TDK_HIP(hipMemcpyAsync(weights, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         TDK_HIP(hipStreamSynchronize(stream));   // `host` goes out of scope
     }
-    dim3 grid(blocks, n_arrays, batch);
-    k_rescale_levels_aa<<<grid, 256, 0, stream>>>(args);
-    TDK_LAUNCH_CHECK();
+    // levels that shrink both axes and whose tiles fit in LDS take the tiled kernel, one
+    // launch each; whatever is left (an enlarged axis, very deep levels) the general one
+    bool general = false;
+    for (int l = 0; l < n_out; l++) {
+        const PyrLevel &L = r.lv[l];
+        const double fy = (double)H / (double)L.Ho, fx = (double)W / (double)L.Wo;
+        AaTileArgs t;
+        t.max_v_rows = (int)ceil(kAaRows * fy) + 2;
+        t.max_cols = (int)ceil(kAaCols * fx) + 2 + 2 * args.aa[l].Rc;
+        const size_t lds = sizeof(double) * ((size_t)(2 * t.max_v_rows + 2 * args.aa[l].Rr) * t.max_cols +
+                                             2 * args.aa[l].Rr + 2 * args.aa[l].Rc + 2);
+        if (L.Ho > H || L.Wo > W || lds > 64 * 1024) {
+            general = true;
+            continue;
+        }
+        for (int i = 0; i < 4; i++) { t.src[i] = r.src[i]; t.dst[i] = L.dst[i]; }
+        t.src_stride = src_stride; t.dst_stride = L.stride;
+        t.H = H; t.W = W; t.Ho = L.Ho; t.Wo = L.Wo;
+        t.aa = args.aa[l];
+        const int tiles = ((L.Ho + kAaRows - 1) / kAaRows) * ((L.Wo + kAaCols - 1) / kAaCols);
+        dim3 tgrid(tiles, n_arrays, batch);
+        const int R = t.aa.Rr == t.aa.Rc ? t.aa.Rr : 0;
+        if (R == 1) k_rescale_aa_tiled<1><<<tgrid, 256, lds, stream>>>(t);          // ratio 1.5, level 1
+        else if (R == 3) k_rescale_aa_tiled<3><<<tgrid, 256, lds, stream>>>(t);     // level 2
+        else if (R == 5) k_rescale_aa_tiled<5><<<tgrid, 256, lds, stream>>>(t);     // level 3
+        else k_rescale_aa_tiled<0><<<tgrid, 256, lds, stream>>>(t);
+        TDK_LAUNCH_CHECK();
+    }
+    if (general) {
+        // recompute the cumulative block counts over the levels that are left
+        int total = 0;
+        for (int l = 0; l < n_out; l++) {
+            const PyrLevel &L = r.lv[l];
+            const double fy = (double)H / (double)L.Ho, fx = (double)W / (double)L.Wo;
+            const size_t lds = sizeof(double) * ((size_t)(2 * ((int)ceil(kAaRows * fy) + 2) + 2 * args.aa[l].Rr) *
+                                                     ((int)ceil(kAaCols * fx) + 2 + 2 * args.aa[l].Rc) +
+                                                 2 * args.aa[l].Rr + 2 * args.aa[l].Rc + 2);
+            const bool tiled = !(L.Ho > H || L.Wo > W || lds > 64 * 1024);
+            if (!tiled) total += (int)(((int64_t)L.Ho * L.Wo + 255) / 256);
+            r.blk_end[l] = total;
+        }
+        dim3 grid(total, n_arrays, batch);
+        k_rescale_levels_aa<<<grid, 256, 0, stream>>>(args);
+        TDK_LAUNCH_CHECK();
+    }
     return TDK_OK;
 }
 
