@@ -366,12 +366,10 @@ __global__ __launch_bounds__(256) void k_rescale_levels_aa(RescaleAaArgs args) {
 
 // Tiled form of the same arithmetic for one level, used whenever the level shrinks both
 // axes and its tiles fit in LDS: a block produces kAaRows x kAaCols output pixels.
-//   1. the source rows / columns its taps and their filter support touch go to LDS
-//      (mirror boundary applied while loading),
-//   2. the vertical Gaussian is evaluated once per needed (row, column) into a second
-//      LDS tile V -- ndimage filters axis 0 first, so V is rounded exactly like its
-//      intermediate image,
-//   3. every thread evaluates the horizontal Gaussian of V at its four taps and blends.
+//   1. the vertical Gaussian is evaluated once per (row, column) its taps and their
+//      horizontal support touch (mirror boundary), from global memory into an LDS tile
+//      V -- ndimage filters axis 0 first, so V is rounded exactly like its intermediate image,
+//   2. every thread evaluates the horizontal Gaussian of V at its four taps and blends.
 // Same operations in the same order as filtered_tap(), so the results are bit-identical
 // to k_rescale_levels_aa; ~70 LDS reads per output instead of ~200 global loads.
 constexpr int kAaRows = 4, kAaCols = 64;
@@ -391,9 +389,9 @@ template <int R>
 __global__ __launch_bounds__(256) void k_rescale_aa_tiled(AaTileArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
     const int Rr = R > 0 ? R : a.aa.Rr, Rc = R > 0 ? R : a.aa.Rc;
+    constexpr int kUnroll = R > 0 ? R : 1;
     const int SC = a.max_cols;
-    double *S = reinterpret_cast<double *>(aa_smem);           // [max_v_rows + 2 Rr][SC] source
-    double *V = S + (size_t)(a.max_v_rows + 2 * Rr) * SC;       // [max_v_rows][SC] vertically filtered
+    double *V = reinterpret_cast<double *>(aa_smem);           // [max_v_rows][SC] vertically filtered
     double *wr = V + (size_t)a.max_v_rows * SC;                 // [2 Rr + 1] kernel weights, LDS copies:
     double *wc = wr + 2 * Rr + 1;                               // [2 Rc + 1] broadcast reads in the inner loops
     for (int k = threadIdx.x; k < 2 * Rr + 1; k += 256) wr[k] = a.aa.wr[k];
@@ -411,22 +409,21 @@ __global__ __launch_bounds__(256) void k_rescale_aa_tiled(AaTileArgs a) {
     const int yv1 = min((int)floor(((double)(oy1 - 1) + 0.5) * sy - 0.5) + 1, H - 1);
     const int xv0 = (int)floor(((double)ox0 + 0.5) * sx - 0.5);
     const int xv1 = min((int)floor(((double)(ox1 - 1) + 0.5) * sx - 0.5) + 1, W - 1);
-    const int nv = yv1 - yv0 + 1, ns = nv + 2 * Rr;             // V rows, source rows
+    const int nv = yv1 - yv0 + 1;                                // V rows
     const int nc = xv1 - xv0 + 1 + 2 * Rc;                       // columns incl. the horizontal support
-    const int xs0 = xv0 - Rc, ys0 = yv0 - Rr;
-    // a wave per tile row, lanes along it: no division, coalesced rows
+    const int xs0 = xv0 - Rc;
+    __syncthreads();                                             // weights in place
+    // vertical Gaussian straight from global memory (a source texel is re-read 2 Rr + 1
+    // times by the block: L1 hits); a wave per V row, lanes along it: coalesced, no division
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < ns; r += 4) {
-        const double *row = s + (int64_t)mirror_idx(ys0 + r, H) * W;
-        for (int c = lane; c < nc; c += 64) S[r * SC + c] = row[mirror_idx(xs0 + c, W)];
-    }
-    __syncthreads();
     for (int r = wave; r < nv; r += 4) {
+        const int y = yv0 + r;
         for (int c = lane; c < nc; c += 64) {
-            const double *col = S + (r + Rr) * SC + c;           // centre row of this V row
-            double tmp = col[0] * wr[Rr];
-#pragma unroll
-            for (int j = -Rr; j < 0; j++) tmp += (col[j * SC] + col[-j * SC]) * wr[Rr + j];
+            const double *col = s + mirror_idx(xs0 + c, W);
+            double tmp = col[(int64_t)y * W] * wr[Rr];
+#pragma unroll kUnroll
+            for (int j = -Rr; j < 0; j++)
+                tmp += (col[(int64_t)mirror_idx(y + j, H) * W] + col[(int64_t)mirror_idx(y - j, H) * W]) * wr[Rr + j];
             V[r * SC + c] = tmp;
         }
     }
@@ -447,7 +444,7 @@ __global__ __launch_bounds__(256) void k_rescale_aa_tiled(AaTileArgs a) {
         for (int rx = 0; rx < 2; rx++) {
             const double *row = V + ((ry ? y1 : y0) - yv0) * SC + ((rx ? x1 : x0) - xs0);
             double tmp = row[0] * wc[Rc];
-#pragma unroll
+#pragma unroll kUnroll
             for (int j = -Rc; j < 0; j++) tmp += (row[j] + row[-j]) * wc[Rc + j];
             f[ry][rx] = tmp;
         }
@@ -530,8 +527,8 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
         AaTileArgs t;
         t.max_v_rows = (int)ceil(kAaRows * fy) + 2;
         t.max_cols = (int)ceil(kAaCols * fx) + 2 + 2 * args.aa[l].Rc;
-        const size_t lds = sizeof(double) * ((size_t)(2 * t.max_v_rows + 2 * args.aa[l].Rr) * t.max_cols +
-                                             2 * args.aa[l].Rr + 2 * args.aa[l].Rc + 2);
+        const size_t lds = sizeof(double) * ((size_t)t.max_v_rows * t.max_cols + 2 * args.aa[l].Rr +
+                                             2 * args.aa[l].Rc + 2);
         if (L.Ho > H || L.Wo > W || lds > 64 * 1024) {
             general = true;
             continue;
@@ -555,7 +552,7 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
         for (int l = 0; l < n_out; l++) {
             const PyrLevel &L = r.lv[l];
             const double fy = (double)H / (double)L.Ho, fx = (double)W / (double)L.Wo;
-            const size_t lds = sizeof(double) * ((size_t)(2 * ((int)ceil(kAaRows * fy) + 2) + 2 * args.aa[l].Rr) *
+            const size_t lds = sizeof(double) * ((size_t)((int)ceil(kAaRows * fy) + 2) *
                                                      ((int)ceil(kAaCols * fx) + 2 + 2 * args.aa[l].Rc) +
                                                  2 * args.aa[l].Rr + 2 * args.aa[l].Rc + 2);
             const bool tiled = !(L.Ho > H || L.Wo > W || lds > 64 * 1024);
