@@ -193,6 +193,79 @@ tdk_status tdk_estimate_one(const int64_t *u_key, double prior_depth, double pri
 /* Sobel maps of ImageGradient::new (src/semi_dense/gradient.rs:11-15) */
 tdk_status tdk_sobel(const double *image, int height, int width, double *gx, double *gy);
 
+/* Semi-dense post-steps.  Disabled in the reference's Python surface
+ * (src/semi_dense/mod.rs:13, src/py/semi_dense.rs:220-233) but called by
+ * examples/semi_dense_vo.py:82-88.
+ * regularize (src/semi_dense/regularization.rs:29-64): 3x3 inverse-variance
+ * weighted mean of the inverse depths of the Success (flag == 0) neighbours,
+ * returned as a depth; pixels without a contributing neighbour keep their depth. */
+tdk_status tdk_regularize(const double *depth, const double *variance, const int64_t *flag,
+                          int height, int width, double *regularized);
+/* fusion_arrays (src/semi_dense/fusion.rs:13-42): elementwise Gaussian fusion
+ * mu = (mu1 var2 + mu2 var1) / (var1 + var2), var = var1 var2 / (var1 + var2). */
+tdk_status tdk_fusion_arrays(const double *mu1, const double *mu2, const double *var1,
+                             const double *var2, int64_t n, double *mu, double *var);
+/* skimage.color.rgb2gray as the examples call it (examples/dvo_pose_change.py:22-31,
+ * examples/semi_dense_vo.py:62-66): 0.2125 R + 0.7154 G + 0.0721 B of the first
+ * three of `channels` interleaved channels; rgb is float64 [height][width][channels]
+ * (tdk_rgb2gray) or uint8 scaled by 1/255 first, as img_as_float does (tdk_rgb2gray_u8). */
+tdk_status tdk_rgb2gray(const double *rgb, int height, int width, int channels, double *gray);
+tdk_status tdk_rgb2gray_u8(const uint8_t *rgb, int height, int width, int channels, double *gray);
+
+/* ---- semi-dense: device-resident session over a batch of tracks (new, fused) ----
+ * One step of the mapping loop of examples/semi_dense_vo.py:182-199 for n_tracks
+ * independent sequences at once, with every map and frame resident in HBM:
+ *     age1            = increment_age(age0, cam0, cam1, T10, depth0)
+ *     depth1, var1    = propagate(T10, cam0, cam1, depth0, var0, defaults...)
+ *     depth, var, flag = update_depth(newest frame, earlier frames, age1, depth1, var1, params)
+ * Frames live in a per-track ring of max_refframes + 1 images; the newest pushed
+ * frame is the key frame of the step, the one before it is "frame 0" of the warp
+ * and the frame `age` steps back is the reference frame of a pixel
+ * (refframes[len - age], src/semi_dense/semi_dense.rs:207). */
+typedef struct tdk_sd tdk_sd;
+tdk_status tdk_sd_create(int n_tracks, int height, int width, int max_refframes, tdk_sd **out);
+tdk_status tdk_sd_destroy(tdk_sd *h);
+/* Params.new (src/py/semi_dense.rs:93-108) + the three scalars of propagate */
+tdk_status tdk_sd_set_params(tdk_sd *h, const tdk_semi_dense_params *params, double default_depth,
+                             double default_variance, double uncertaintity_bias);
+/* Host -> device / device -> host copies of one track's maps; any pointer may be NULL. */
+tdk_status tdk_sd_set_maps(tdk_sd *h, int track, const double *depth, const double *variance,
+                           const uint64_t *age);
+tdk_status tdk_sd_get_maps(tdk_sd *h, int track, double *depth, double *variance, uint64_t *age,
+                           int64_t *flag);
+/* Frame.new (src/py/semi_dense.rs:53-66): appends a frame to the track's ring
+ * (the oldest one is dropped when the ring is full).  transform_wf may be NULL and
+ * supplied by the step that makes this frame its key frame. */
+tdk_status tdk_sd_push_frame(tdk_sd *h, int track, const double *camera, const double *image,
+                             const double *transform_wf);
+/* The step described above for every track.  transforms10 [n_tracks][16] maps the
+ * previous frame to the newest one; key_transforms_wf [n_tracks][16] (may be NULL
+ * if given to tdk_sd_push_frame) is the pose of the newest frame.  commit = 0
+ * leaves the session's maps untouched (the results can still be read with
+ * tdk_sd_get_results); flag_histogram (optional) receives, per track, the number of
+ * pixels with flag 0, -1, ..., -9.  TDK_ERR_AGE_EXCEEDS_REFFRAMES (nothing is
+ * committed) where the reference exits the process. */
+tdk_status tdk_sd_step(tdk_sd *h, const double *transforms10, const double *key_transforms_wf,
+                       int commit, int64_t *flag_histogram);
+/* The two halves of the step on their own, on the session's current maps:
+ * tdk_sd_propagate = increment_age + propagate (results: age, depth, variance);
+ * tdk_sd_update_depth = update_depth with the current (age, depth, variance) as
+ * (age_map, prior_depth, prior_variance) and the newest frame as key frame. */
+tdk_status tdk_sd_propagate(tdk_sd *h, const double *transforms10, int commit);
+tdk_status tdk_sd_update_depth(tdk_sd *h, const double *key_transforms_wf, int commit,
+                               int64_t *flag_histogram);
+/* Outputs of the last step / propagate / update_depth call whether committed or not. */
+tdk_status tdk_sd_get_results(tdk_sd *h, int track, double *depth, double *variance,
+                              uint64_t *age, int64_t *flag);
+/* Feeds the DVO batch of the same step on the device (examples/semi_dense_vo.py:44-53):
+ * pair t gets I0 = the track's previous frame, D0 = its depth map, I1 = its newest
+ * frame and, if the batch has a weight map, W0 = safe_invert(variance). */
+tdk_status tdk_sd_export_dvo(tdk_sd *h, tdk_dvo *batch);
+/* Kernel times of the last step, measured with HIP events on the session's stream:
+ * ms[0] scatter + fold (increment_age + propagate), ms[1] update_depth (classify +
+ * estimate), ms[2] the whole step. */
+tdk_status tdk_sd_get_timing(tdk_sd *h, double *ms3);
+
 /* ---- bundle adjustment (tadataka.transform_project, tadataka/local_ba.py) -- */
 /* Projection.compute / .jacobians over n observations (local_ba.py:23-39);
  * x_pred [n][2], A [n][2][6], B [n][2][3]; any output may be NULL. */

@@ -398,6 +398,57 @@ def update_depth(key, refs, age, prior_depth, prior_variance, params):
     return depth, var, flag
 
 
+# ---- semi-dense post-steps, colour conversion ------------------------
+def regularize_patch(inv_depth, inv_variance, flag):
+    """regularize_patch (regularization.rs:5-27) on 3x3 arrays; None if nothing contributes."""
+    a, pa = _d(np.asarray(inv_depth, dtype=np.float64).reshape(9))
+    b, pb = _d(np.asarray(inv_variance, dtype=np.float64).reshape(9))
+    f = np.ascontiguousarray(flag, dtype=np.int64).reshape(9)
+    out = C.c_double()
+    ok = lib().orc_regularize_patch(pa, pb, f.ctypes.data_as(_i64p), C.byref(out))
+    return float(out.value) if ok else None
+
+
+def regularize(depth, variance, flag):
+    depth, pd = _d(depth); variance, pv = _d(variance)
+    flag = np.ascontiguousarray(flag, dtype=np.int64)
+    out = np.empty_like(depth)
+    lib().orc_regularize(pd, pv, flag.ctypes.data_as(_i64p), C.c_int(depth.shape[0]),
+                         C.c_int(depth.shape[1]), out.ctypes.data_as(_dp))
+    return out
+
+
+def fusion_arrays(mu1, mu2, var1, var2):
+    mu1, p1 = _d(mu1); mu2, p2 = _d(mu2); var1, q1 = _d(var1); var2, q2 = _d(var2)
+    mu = np.empty_like(mu1); var = np.empty_like(mu1)
+    lib().orc_fusion_arrays(p1, p2, q1, q2, C.c_int64(mu1.size), mu.ctypes.data_as(_dp),
+                            var.ctypes.data_as(_dp))
+    return mu, var
+
+
+def rgb2gray(rgb):
+    rgb = np.asarray(rgb)
+    if rgb.dtype == np.uint8:
+        rgb = rgb / 255.0
+    rgb, p = _d(rgb)
+    H, W, ch = rgb.shape
+    out = np.empty((H, W))
+    lib().orc_rgb2gray(p, C.c_int64(H * W), C.c_int(ch), out.ctypes.data_as(_dp))
+    return out
+
+
+def semi_dense_step(key, prev_cam, refs, T10, age0, depth0, var0, params, default_depth,
+                    default_variance, uncertaintity_bias):
+    """One mapping step of examples/semi_dense_vo.py:182-199: increment_age ->
+    propagate -> update_depth.  key = (cam, image, T_wf) of the newest frame,
+    refs = earlier frames, oldest first.  Returns (depth, variance, age, flag)."""
+    age1 = increment_age(age0, prev_cam, key[0], T10, depth0)
+    d1, v1 = propagate(T10, prev_cam, key[0], depth0, var0, default_depth, default_variance,
+                       uncertaintity_bias)
+    d, v, f = update_depth(key, refs, age1, d1, v1, params)
+    return d, v, age1, f
+
+
 # ---- bundle adjustment -------------------------------------------------------
 def exp_so3(rotvec):
     r, p = _d(rotvec)

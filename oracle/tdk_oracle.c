@@ -1030,6 +1030,76 @@ int orc_update_depth(const double *key_cam, const double *key_image,
 }
 
 /* ========================================================================
+ * Semi-dense post-steps and colour conversion
+ * ======================================================================== */
+
+/* regularize_patch (src/semi_dense/regularization.rs:5-27): inverse-variance
+ * weighted mean of the inverse depths of the Success pixels of a 3x3 patch,
+ * accumulated in raster order.  Returns 0 and leaves *out alone if no pixel
+ * contributes (`None`). */
+int orc_regularize_patch(const double *inv_depth, const double *inv_variance,
+                         const int64_t *flag, double *out) {
+    double numerator = 0.0, denominator = 0.0;
+    for (int k = 0; k < 9; k++) {
+        if (flag[k] == 0) { /* Flag::Success, src/semi_dense/flag.rs:4 */
+            numerator = numerator + inv_depth[k] * inv_variance[k];
+            denominator = denominator + inv_variance[k];
+        }
+    }
+    if (denominator == 0.0) return 0;
+    *out = numerator / denominator;
+    return 1;
+}
+
+/* regularize (src/semi_dense/regularization.rs:29-64): the maps are padded by
+ * one pixel with (0, 0, NotProcessed); out = inv(patch mean) or the input depth. */
+void orc_regularize(const double *depth, const double *variance,
+                    const int64_t *flag, int H, int W, double *out) {
+    for (int y = 0; y < H; y++) {
+        for (int x = 0; x < W; x++) {
+            double id[9], iv[9];
+            int64_t f[9];
+            for (int dy = 0; dy < 3; dy++) {
+                for (int dx = 0; dx < 3; dx++) {
+                    int yy = y + dy - 1, xx = x + dx - 1, k = 3 * dy + dx;
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) {
+                        id[k] = 0.0; iv[k] = 0.0; f[k] = -9;
+                    } else {
+                        id[k] = safe_inv(depth[(int64_t)yy * W + xx]);
+                        iv[k] = safe_inv(variance[(int64_t)yy * W + xx]);
+                        f[k] = flag[(int64_t)yy * W + xx];
+                    }
+                }
+            }
+            double r;
+            if (orc_regularize_patch(id, iv, f, &r)) out[(int64_t)y * W + x] = safe_inv(r);
+            else out[(int64_t)y * W + x] = depth[(int64_t)y * W + x];
+        }
+    }
+}
+
+/* fusion_arrays (src/semi_dense/fusion.rs:3-42), elementwise */
+void orc_fusion_arrays(const double *mu1, const double *mu2, const double *var1,
+                       const double *var2, int64_t n, double *mu, double *var) {
+    for (int64_t i = 0; i < n; i++) {
+        double v = var1[i] + var2[i];
+        mu[i] = (mu1[i] * var2[i] + mu2[i] * var1[i]) / v;
+        var[i] = (var1[i] * var2[i]) / v;
+    }
+}
+
+/* skimage.color.rgb2gray (0.16.2; examples/dvo_pose_change.py:22-31): luma
+ * 0.2125 R + 0.7154 G + 0.0721 B of the first three channels of a float image.
+ * Third-party, restated from its published definition: parity unpinned in the
+ * last ulp (the library sums through a BLAS dot whose order is unspecified). */
+void orc_rgb2gray(const double *rgb, int64_t n, int channels, double *out) {
+    for (int64_t i = 0; i < n; i++) {
+        const double *p = rgb + i * channels;
+        out[i] = (0.2125 * p[0] + 0.7154 * p[1]) + 0.0721 * p[2];
+    }
+}
+
+/* ========================================================================
  * Bundle adjustment per observation (tadataka/so3_codegen.py:48-87,
  * tadataka/transform_project.pyx:22-50, tadataka/local_ba.py:14-39)
  *

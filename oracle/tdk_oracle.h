@@ -115,6 +115,15 @@ int orc_update_depth(const double *key_cam, const double *key_image,
                      const orc_params *params, double *out_depth,
                      double *out_variance, int64_t *out_flag);
 
+/* ---- semi-dense post-steps and colour conversion ---------------- */
+int orc_regularize_patch(const double *inv_depth, const double *inv_variance,
+                         const int64_t *flag, double *out);
+void orc_regularize(const double *depth, const double *variance,
+                    const int64_t *flag, int H, int W, double *out);
+void orc_fusion_arrays(const double *mu1, const double *mu2, const double *var1,
+                       const double *var2, int64_t n, double *mu, double *var);
+void orc_rgb2gray(const double *rgb, int64_t n, int channels, double *out);
+
 /* ---- bundle adjustment ---------------------------------------------------- */
 void orc_exp_so3(const double *rotvec, double *R);
 void orc_ba_transform_project(const double *pose, const double *point, double *out);

@@ -83,6 +83,22 @@ PROTOTYPES = {
     "tdk_estimate_one": [c_int64_p, C.c_double, C.c_double, _d, _d, _d, _d, _d, _d, _i, _i,
                          C.POINTER(SemiDenseParams), _d, _d, c_int64_p],
     "tdk_sobel": [_d, _i, _i, _d, _d],
+    "tdk_regularize": [_d, _d, c_int64_p, _i, _i, _d],
+    "tdk_fusion_arrays": [_d, _d, _d, _d, _i64, _d, _d],
+    "tdk_rgb2gray": [_d, _i, _i, _i, _d],
+    "tdk_rgb2gray_u8": [C.POINTER(C.c_uint8), _i, _i, _i, _d],
+    "tdk_sd_create": [_i, _i, _i, _i, C.POINTER(_vp)],
+    "tdk_sd_destroy": [_vp],
+    "tdk_sd_set_params": [_vp, C.POINTER(SemiDenseParams), C.c_double, C.c_double, C.c_double],
+    "tdk_sd_set_maps": [_vp, _i, _d, _d, c_uint64_p],
+    "tdk_sd_get_maps": [_vp, _i, _d, _d, c_uint64_p, c_int64_p],
+    "tdk_sd_get_results": [_vp, _i, _d, _d, c_uint64_p, c_int64_p],
+    "tdk_sd_push_frame": [_vp, _i, _d, _d, _d],
+    "tdk_sd_step": [_vp, _d, _d, _i, c_int64_p],
+    "tdk_sd_propagate": [_vp, _d, _i],
+    "tdk_sd_update_depth": [_vp, _d, _i, c_int64_p],
+    "tdk_sd_export_dvo": [_vp, _vp],
+    "tdk_sd_get_timing": [_vp, _d],
     "tdk_ba_projection": [_d, _i64, _d, _i64, c_int64_p, c_int64_p, _i64, _d, _d, _d],
     "tdk_ba_exp_so3": [_d, _i64, _d],
     "tdk_ba_block_reduce": [_d, _i64, _d, _i64, _d, c_int64_p, c_int64_p, _i64, _d, _d, _d, _d, _d],

@@ -1357,6 +1357,19 @@ tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64
 
 }  // namespace
 
+namespace tdk {
+
+tdk_status dvo_level0(tdk_dvo *h, DvoLevel0 *out) {
+    TDK_REQUIRE(h != nullptr && out != nullptr, "null pointer");
+    const tdk_dvo::Level &L = h->lv[0];
+    out->I0 = L.I0; out->D0 = L.D0; out->I1 = L.I1; out->W0 = L.W0;
+    out->stride = L.stride; out->H = L.H; out->W = L.W; out->n_pairs = h->n_pairs;
+    out->stream = h->stream;
+    return TDK_OK;
+}
+
+}  // namespace tdk
+
 extern "C" {
 
 tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, double ratio,

@@ -652,6 +652,21 @@ tdk_status normalize_impl(const double *kp, int64_t n, const double *camera, dou
     return to_host(out, d_out, (size_t)n * 16);
 }
 
+// skimage.color.rgb2gray as the examples use it (examples/dvo_pose_change.py:22-31):
+// luma of the first three interleaved channels; uint8 input is scaled by 1/255 first
+// (img_as_float).  -ffp-contract=off keeps the two products and two sums as written.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_rgb2gray(const T *__restrict__ rgb, int64_t n, int channels,
+                                                     double *__restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const T *p = rgb + i * channels;
+        double r, g, b;
+        if (sizeof(T) == 1) { r = (double)p[0] / 255.0; g = (double)p[1] / 255.0; b = (double)p[2] / 255.0; }
+        else { r = (double)p[0]; g = (double)p[1]; b = (double)p[2]; }
+        out[i] = (0.2125 * r + 0.7154 * g) + 0.0721 * b;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -784,6 +799,28 @@ tdk_status tdk_rescale_anti_aliased(const double *image, int H, int W, double *o
     lv.stride = 0; lv.H = Ho; lv.W = Wo;
     TDK_TRY(tdk::launch_pyramid_aa(srcs, 1, H, W, 0, 1, &lv, 1, (double *)d_w, true, tdk::stream()));
     return to_host(out, d_out, (size_t)Ho * Wo * 8);
+}
+
+tdk_status tdk_rgb2gray(const double *rgb, int H, int W, int channels, double *gray) {
+    TDK_REQUIRE(H > 0 && W > 0 && channels >= 3 && channels <= 4 && rgb && gray, "bad argument");
+    const int64_t n = (int64_t)H * W;
+    void *d_rgb, *d_out;
+    TDK_TRY(to_device(0, rgb, (size_t)n * channels * 8, &d_rgb));
+    TDK_TRY(tdk::scratch(1, (size_t)n * 8, &d_out));
+    k_rgb2gray<double><<<grid_for(n), kBlock, 0, tdk::stream()>>>((const double *)d_rgb, n, channels, (double *)d_out);
+    TDK_LAUNCH_CHECK();
+    return to_host(gray, d_out, (size_t)n * 8);
+}
+
+tdk_status tdk_rgb2gray_u8(const uint8_t *rgb, int H, int W, int channels, double *gray) {
+    TDK_REQUIRE(H > 0 && W > 0 && channels >= 3 && channels <= 4 && rgb && gray, "bad argument");
+    const int64_t n = (int64_t)H * W;
+    void *d_rgb, *d_out;
+    TDK_TRY(to_device(0, rgb, (size_t)n * channels, &d_rgb));
+    TDK_TRY(tdk::scratch(1, (size_t)n * 8, &d_out));
+    k_rgb2gray<uint8_t><<<grid_for(n), kBlock, 0, tdk::stream()>>>((const uint8_t *)d_rgb, n, channels, (double *)d_out);
+    TDK_LAUNCH_CHECK();
+    return to_host(gray, d_out, (size_t)n * 8);
 }
 
 }  // extern "C"

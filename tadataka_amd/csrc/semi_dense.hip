@@ -1,5 +1,8 @@
 // semi_dense.hip -- rust_bindings.semi_dense on the MI355X: increment_age,
-// propagate, update_depth / estimate_debug_ and the Sobel maps they use.
+// propagate, update_depth / estimate_debug_, the Sobel maps they use, the
+// post-steps regularize / fusion -- as 1:1 host-pointer entries and
+// as a device-resident session (tdk_sd) that runs the mapping step of
+// examples/semi_dense_vo.py:182-199 for a batch of independent tracks per launch.
 //
 // Compiled with -ffp-contract=off: the warped target pixel is an *index* and the
 // per-pixel result a discrete flag, so every + - * / sqrt is kept as one IEEE
@@ -8,12 +11,21 @@
 // The two forward-warp scatters are order dependent in the reference (a raster
 // loop): increment_age keeps the LAST raster writer (src/semi_dense/age.rs:18-29)
 // and propagate folds colliding sources SEQUENTIALLY in raster order with a
-// non-associative rule (src/semi_dense/propagation.rs:21-46,59-82).  Both are
-// reproduced deterministically:
-//   * age:       atomicMax of the source raster index per target, then a gather;
-//   * propagate: sources are threaded onto a per-target linked list with
-//                atomicExch; one thread per target then folds its list in
-//                increasing source index (selection over the short list).
+// non-associative rule (src/semi_dense/propagation.rs:21-46,59-82).  Both warp
+// the same source pixel with the same transform to the same target, so ONE
+// scatter serves both: sources are threaded onto a per-target linked list with
+// atomicExch; one thread per target then walks its list in increasing source
+// index -- the largest index is the age winner, the fold in that order is the
+// propagated hypothesis.  The warp of a source is recomputed in the fold from
+// depth0 (a 16 B gather) instead of being written out and read back (32 B).
+//
+// update_depth is split so that the heavy per-pixel search only runs on full
+// waves: k_ud_classify streams age / prior maps, settles NotProcessed and
+// check_args pixels and compacts the rest (wave ballot + block prefix, one
+// atomic per block and track); k_ud_estimate runs `estimate` with one lane per
+// live pixel.  The key frame's Sobel value is computed in place from its 3x3
+// neighbourhood (ImageGradient::get is only ever asked at the integer key
+// pixel, src/semi_dense/variance.rs:30-52) -- no Sobel maps in HBM.
 #include "tdk_math.h"
 #include "tdk_runtime.h"
 
@@ -35,59 +47,43 @@ inline int grid_for(int64_t n) {
     return (int)g;
 }
 
-struct Mat4 {
-    double m[16];
-};
-
 // ---- Sobel (src/gradient.rs:4-26, src/convolution.rs:29-52) -----------------
-__global__ __launch_bounds__(kBlock) void k_sobel(const double *__restrict__ img, int H, int W,
-                                                  double *__restrict__ gx, double *__restrict__ gy) {
+__device__ __forceinline__ void sobel_at(const double *__restrict__ img, int H, int W, int x, int y, double &sx,
+                                         double &sy) {
     const double kx[9] = {1., 0., -1., 2., 0., -2., 1., 0., -1.};
     const double ky[9] = {1., 2., 1., 0., 0., 0., -1., -2., -1.};
+    sx = 0.0;
+    sy = 0.0;
+    if (y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2) {
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                double v = img[(int64_t)(y - 1 + a) * W + (x - 1 + b)];
+                sx += kx[3 * a + b] * v;
+                sy += ky[3 * a + b] * v;
+            }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sobel(const double *__restrict__ img, int H, int W,
+                                                  double *__restrict__ gx, double *__restrict__ gy) {
     int64_t N = (int64_t)H * W;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < N; i += (int64_t)gridDim.x * kBlock) {
         int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
-        double sx = 0.0, sy = 0.0;
-        if (y >= 1 && y <= H - 2 && x >= 1 && x <= W - 2) {
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int b = 0; b < 3; b++) {
-                    double v = img[(int64_t)(y - 1 + a) * W + (x - 1 + b)];
-                    sx += kx[3 * a + b] * v;
-                    sy += ky[3 * a + b] * v;
-                }
-        }
+        double sx, sy;
+        sobel_at(img, H, W, x, y, sx, sy);
         gx[i] = sx;
         gy[i] = sy;
     }
 }
 
-// ---- increment_age (src/semi_dense/age.rs:6-32) -------------------------------
-__global__ __launch_bounds__(kBlock) void k_age_scatter(int H, int W, Cam c0, Cam c1, Mat4 T,
-                                                        const double *__restrict__ depth0,
-                                                        int *__restrict__ winner) {
-    int N = H * W;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
-        int y0 = i / W, x0 = i - y0 * W;
-        double px, py, d1;
-        tdk::perspective_warp(T.m, c0, c1, (double)x0, (double)y0, depth0[i], px, py, d1);
-        if (!tdk::in_range(px, py, H, W)) continue;
-        int x1 = (int)px, y1 = (int)py;  // `as usize`: truncation
-        atomicMax(&winner[y1 * W + x1], i + 1);
-    }
-}
+// ---- increment_age (src/semi_dense/age.rs:6-32) + propagate (propagation.rs) ----
+struct TrackWarp {   // per track and step
+    double T10[16];
+    double cam0[4], cam1[4];
+};
 
-__global__ __launch_bounds__(kBlock) void k_age_gather(int N, const uint64_t *__restrict__ age0,
-                                                       const int *__restrict__ winner,
-                                                       uint64_t *__restrict__ age1) {
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
-        int w = winner[i];
-        age1[i] = w > 0 ? age0[w - 1] + 1 : 0;
-    }
-}
-
-// ---- propagate (src/semi_dense/propagation.rs) ----------------------------------
 __device__ __forceinline__ double propagate_variance(double depth0, double depth1, double variance0,
                                                      double uncertaintity) {
     double ratio = tdk::safe_inv(depth1) / tdk::safe_inv(depth0);  // :16-18
@@ -117,55 +113,75 @@ __device__ __forceinline__ void handle_collision(double depth_a, double depth_b,
     else { d = depth_b; v = var_b; }
 }
 
-__global__ __launch_bounds__(kBlock) void k_propagate_scatter(int H, int W, Cam c0, Cam c1, Mat4 T,
-                                                              const double *__restrict__ depth0,
-                                                              const double *__restrict__ var0, double bias,
-                                                              double *__restrict__ d1a,
-                                                              double *__restrict__ v1a,
-                                                              int *__restrict__ head,
-                                                              int *__restrict__ next) {
-    int N = H * W;
+// Forward warp of every source pixel of every track; in-range sources are pushed
+// onto their target's list: next[i] = previous head, -1 ends a list, -2 marks a
+// source that left the image.  grid = (blocks, n_tracks).
+__global__ __launch_bounds__(kBlock) void k_sd_scatter(int H, int W, const TrackWarp *__restrict__ tw,
+                                                       const double *__restrict__ depth0, int64_t stride,
+                                                       int *__restrict__ head, int *__restrict__ next) {
+    const int track = blockIdx.y;
+    const TrackWarp &t = tw[track];
+    const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
+    const int N = H * W;
+    const double *__restrict__ d0 = depth0 + (int64_t)track * stride;
+    int *__restrict__ hd = head + (int64_t)track * stride;
+    int *__restrict__ nx = next + (int64_t)track * stride;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
         int y0 = i / W, x0 = i - y0 * W;
-        double d0 = depth0[i];
         double ux, uy, d1;
-        tdk::perspective_warp(T.m, c0, c1, (double)x0, (double)y0, d0, ux, uy, d1);
-        if (!tdk::in_range(ux, uy, H, W)) { next[i] = -2; continue; }
-        d1a[i] = d1;
-        v1a[i] = propagate_variance(d0, d1, var0[i], bias);
-        int t = (int)uy * W + (int)ux;
-        next[i] = atomicExch(&head[t], i);
+        tdk::perspective_warp(t.T10, c0, c1, (double)x0, (double)y0, d0[i], ux, uy, d1);
+        if (!tdk::in_range(ux, uy, H, W)) { nx[i] = -2; continue; }
+        int tg = (int)uy * W + (int)ux;  // `as usize`: truncation
+        nx[i] = atomicExch(&hd[tg], i);
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_propagate_fold(int N, const int *__restrict__ head,
-                                                           const int *__restrict__ next,
-                                                           const double *__restrict__ d1a,
-                                                           const double *__restrict__ v1a,
-                                                           double default_depth, double default_variance,
-                                                           double *__restrict__ depth1,
-                                                           double *__restrict__ var1) {
-    for (int t = blockIdx.x * kBlock + threadIdx.x; t < N; t += gridDim.x * kBlock) {
-        int h = head[t];
+// One thread per target pixel: walk its list in increasing source index.
+//   AGE : age1 = age0[last raster writer] + 1, untouched = 0            (age.rs:18-31)
+//   PROP: sequential fold of (depth1, variance1) with handle_collision,
+//         misses get the defaults                                         (propagation.rs:59-89)
+template <bool AGE, bool PROP>
+__global__ __launch_bounds__(kBlock) void k_sd_fold(int H, int W, const TrackWarp *__restrict__ tw,
+                                                    const int *__restrict__ head, const int *__restrict__ next,
+                                                    const uint64_t *__restrict__ age0,
+                                                    const double *__restrict__ depth0,
+                                                    const double *__restrict__ var0, int64_t stride,
+                                                    double default_depth, double default_variance, double bias,
+                                                    uint64_t *__restrict__ age1, double *__restrict__ depth1,
+                                                    double *__restrict__ var1) {
+    const int track = blockIdx.y;
+    const TrackWarp &t = tw[track];
+    const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
+    const int N = H * W;
+    const int64_t base = (int64_t)track * stride;
+    const int *__restrict__ nx = next + base;
+    for (int tg = blockIdx.x * kBlock + threadIdx.x; tg < N; tg += gridDim.x * kBlock) {
+        const int h = head[base + tg];
         double d = default_depth, v = default_variance;
         int last = -1;
         bool have = false;
-        while (true) {
+        while (h >= 0) {
             // next source in raster order: smallest list entry greater than `last`
             int best = 0x7fffffff;
-            for (int j = h; j >= 0; j = next[j])
+            for (int j = h; j >= 0; j = nx[j])
                 if (j > last && j < best) best = j;
             if (best == 0x7fffffff) break;
-            if (!have) { d = d1a[best]; v = v1a[best]; have = true; }
-            else {
-                double nd, nv;
-                handle_collision(d1a[best], d, v1a[best], v, nd, nv);
-                d = nd; v = nv;
+            if (PROP) {
+                int y0 = best / W, x0 = best - y0 * W;
+                double sd0 = depth0[base + best], ux, uy, sd1;
+                tdk::perspective_warp(t.T10, c0, c1, (double)x0, (double)y0, sd0, ux, uy, sd1);
+                double sv1 = propagate_variance(sd0, sd1, var0[base + best], bias);
+                if (!have) { d = sd1; v = sv1; have = true; }
+                else {
+                    double nd, nv;
+                    handle_collision(sd1, d, sv1, v, nd, nv);
+                    d = nd; v = nv;
+                }
             }
             last = best;
         }
-        depth1[t] = d;
-        var1[t] = v;
+        if (AGE) age1[base + tg] = last >= 0 ? age0[base + last] + 1 : 0;
+        if (PROP) { depth1[base + tg] = d; var1[base + tg] = v; }
     }
 }
 
@@ -215,7 +231,6 @@ __device__ __forceinline__ double sample(const double *img, int H, int W, double
 // estimate (:91-158).  Returns the Flag (0 = Success) and writes (inv_depth, variance).
 __device__ int estimate(double ukx, double uky, double prior_id, double prior_var, const Cam &kc,
                         const double *__restrict__ key_image, const RefConst &rf, int H, int W,
-                        const double *__restrict__ gx, const double *__restrict__ gy,
                         const EstParams &pr, double &out_id, double &out_var) {
     const double *T = rf.T_rk;
     const Cam rc{rf.cam[0], rf.cam[1], rf.cam[2], rf.cam[3]};
@@ -338,7 +353,10 @@ __device__ int estimate(double ukx, double uky, double prior_id, double prior_va
     // geo_var (variance.rs:30-52) with ImageGradient::get (gradient.rs:17-25)
     double edx = xk - rf.pt_rk[0], edy = yk - rf.pt_rk[1];
     vnormalize2(edx, edy);
-    double igx = sample(gx, H, W, ukx, uky), igy = sample(gy, H, W, ukx, uky);
+    // the key coordinate is an integer pixel: the bilinear sample of the Sobel map there is the
+    // map value itself (interpolation.rs:9-43 short-circuits integer coordinates), computed in place
+    double igx, igy;
+    sobel_at(key_image, H, W, (int)ukx, (int)uky, igx, igy);
     vnormalize2(igx, igy);
     double p = edx * igx + edy * igy;
     double geo = (p == 0.) ? 1. / tdk::kEps16 : 1. / (p * p);
@@ -355,50 +373,186 @@ __device__ int estimate(double ukx, double uky, double prior_id, double prior_va
     return 0;
 }
 
-// update_depth raster loop (:186-229), one thread per pixel.
-__global__ __launch_bounds__(kBlock) void k_update_depth(Cam kc, const double *__restrict__ key_image,
-                                                         const double *__restrict__ gx,
-                                                         const double *__restrict__ gy, int n_ref,
-                                                         const RefConst *__restrict__ refs,
-                                                         const uint64_t *__restrict__ age,
-                                                         const double *__restrict__ prior_depth,
-                                                         const double *__restrict__ prior_var, int H, int W,
-                                                         EstParams pr, double *__restrict__ out_depth,
-                                                         double *__restrict__ out_var,
-                                                         int64_t *__restrict__ out_flag) {
-    int N = H * W;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
-        uint64_t a = age[i];
-        double d = prior_depth[i], v = prior_var[i];
-        if (a == 0) {
-            out_depth[i] = d; out_var[i] = v; out_flag[i] = -9;  // NotProcessed
-            continue;
+// ---- update_depth (:160-234), split into classify + estimate ---------------------
+struct TrackKey {   // per track and step: the key frame of update_depth
+    double cam[4];
+    const double *image;
+    int n_ref, pad;
+};
+
+enum { SD_ERR_AGE = 1 };
+
+// Streams age / prior maps.  NotProcessed (age == 0, :196-200) and check_args
+// failures (:208-214) are final here; everything else is appended to the track's
+// list of live pixels.  One pixel per thread, 4 sweeps per block.
+constexpr int kClassifySweeps = 4;
+__global__ __launch_bounds__(kBlock) void k_ud_classify(int N, const TrackKey *__restrict__ keys,
+                                                        const uint64_t *__restrict__ age,
+                                                        const double *__restrict__ prior_depth,
+                                                        const double *__restrict__ prior_var, int64_t stride,
+                                                        double vmin, double vmax, double *__restrict__ out_depth,
+                                                        double *__restrict__ out_var,
+                                                        int64_t *__restrict__ out_flag, int *__restrict__ list,
+                                                        int *__restrict__ count, int *__restrict__ err) {
+    const int track = blockIdx.y;
+    const int64_t base = (int64_t)track * stride;
+    const int n_ref = keys[track].n_ref;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int wave_total[kBlock / 64];
+    __shared__ int block_base;
+    for (int s = 0; s < kClassifySweeps; s++) {
+        const int i = (blockIdx.x * kClassifySweeps + s) * kBlock + (int)threadIdx.x;
+        bool live = false;
+        if (i < N) {
+            const uint64_t a = age[base + i];
+            const double d = prior_depth[base + i], v = prior_var[base + i];
+            int f = -9;  // NotProcessed
+            if (a != 0) {
+                if (a > (uint64_t)n_ref) atomicOr(err, SD_ERR_AGE);  // the reference exits here (:202-205)
+                else f = check_args(tdk::safe_inv(d), v, vmin, vmax);
+            }
+            live = f == 0;
+            if (!live) {
+                out_depth[base + i] = d;
+                out_var[base + i] = v;
+                out_flag[base + i] = f;
+            }
         }
-        double pid = tdk::safe_inv(d);
-        int f = check_args(pid, v, pr.vmin, pr.vmax);
-        if (f) {
-            out_depth[i] = d; out_var[i] = v; out_flag[i] = f;
-            continue;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(live);
+        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (lane == 0) wave_total[wave] = __builtin_popcountll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; w++) { int c = wave_total[w]; wave_total[w] = tot; tot += c; }
+            block_base = tot ? atomicAdd(&count[track], tot) : 0;
         }
-        int y = i / W, x = i - y * W;
-        const RefConst &rf = refs[n_ref - (int)a];
-        double id = pid, var = v;
-        f = estimate((double)x, (double)y, pid, v, kc, key_image, rf, H, W, gx, gy, pr, id, var);
-        if (f) { id = pid; var = v; }  // Err(flag) => (prior, flag)
-        out_depth[i] = tdk::safe_inv(id);
-        out_var[i] = var;
-        out_flag[i] = f;
+        __syncthreads();
+        if (live) list[base + block_base + wave_total[wave] + before] = i;
+        __syncthreads();
     }
 }
 
-__global__ void k_estimate_one(Cam kc, const double *key_image, const double *gx, const double *gy,
-                               const RefConst *refs, double ukx, double uky, double pid, double pvar, int H,
-                               int W, EstParams pr, double *out /*[id, var, flag]*/) {
+// One lane per live pixel.
+__global__ __launch_bounds__(kBlock) void k_ud_estimate(int H, int W, const TrackKey *__restrict__ keys,
+                                                        const RefConst *__restrict__ refs, int refs_per_track,
+                                                        const uint64_t *__restrict__ age,
+                                                        const double *__restrict__ prior_depth,
+                                                        const double *__restrict__ prior_var, int64_t stride,
+                                                        EstParams pr, const int *__restrict__ list,
+                                                        const int *__restrict__ count,
+                                                        double *__restrict__ out_depth,
+                                                        double *__restrict__ out_var,
+                                                        int64_t *__restrict__ out_flag) {
+    const int track = blockIdx.y;
+    const int k = blockIdx.x * kBlock + (int)threadIdx.x;
+    if (k >= count[track]) return;
+    const int64_t base = (int64_t)track * stride;
+    const int i = list[base + k];
+    const TrackKey &key = keys[track];
+    const Cam kc{key.cam[0], key.cam[1], key.cam[2], key.cam[3]};
+    const int a = (int)age[base + i];
+    const double d = prior_depth[base + i], v = prior_var[base + i];
+    const double pid = tdk::safe_inv(d);
+    const int y = i / W, x = i - y * W;
+    // refframes[len - age] (:207): refs[track][age - 1] is the frame `age` steps before the key frame
+    const RefConst &rf = refs[(int64_t)track * refs_per_track + (a - 1)];
+    double id = pid, var = v;
+    int f = estimate((double)x, (double)y, pid, v, kc, key.image, rf, H, W, pr, id, var);
+    if (f) { id = pid; var = v; }  // Err(flag) => (prior, flag)
+    out_depth[base + i] = tdk::safe_inv(id);
+    out_var[base + i] = var;
+    out_flag[base + i] = f;
+}
+
+__global__ void k_estimate_one(Cam kc, const double *key_image, const RefConst *refs, double ukx, double uky,
+                               double pid, double pvar, int H, int W, EstParams pr,
+                               double *out /*[id, var, flag]*/) {
     double id = 0, var = 0;
-    int f = estimate(ukx, uky, pid, pvar, kc, key_image, refs[0], H, W, gx, gy, pr, id, var);
+    int f = estimate(ukx, uky, pid, pvar, kc, key_image, refs[0], H, W, pr, id, var);
     out[0] = id;
     out[1] = var;
     out[2] = (double)f;
+}
+
+// flag histogram per track: bins 0, -1, ..., -9
+__global__ __launch_bounds__(kBlock) void k_flag_hist(int N, const int64_t *__restrict__ flag, int64_t stride,
+                                                      unsigned long long *__restrict__ hist) {
+    const int track = blockIdx.y;
+    __shared__ unsigned int h[10];
+    if (threadIdx.x < 10) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+        const int f = (int)flag[(int64_t)track * stride + i];
+#pragma unroll
+        for (int b = 0; b < 10; b++) {
+            const uint64_t m = __builtin_amdgcn_ballot_w64(f == -b);
+            if (m && (threadIdx.x & 63) == 0) atomicAdd(&h[b], (unsigned int)__builtin_popcountll(m));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 10 && h[threadIdx.x]) atomicAdd(&hist[track * 10 + threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+// ---- post-steps ---------------------------------------------------------
+// regularize (src/semi_dense/regularization.rs:5-64): zero padding contributes
+// nothing (flag NotProcessed), so out-of-image neighbours are simply skipped; the
+// accumulation order is the raster order of the 3x3 patch.
+__global__ __launch_bounds__(kBlock) void k_regularize(const double *__restrict__ depth,
+                                                       const double *__restrict__ variance,
+                                                       const int64_t *__restrict__ flag, int H, int W,
+                                                       double *__restrict__ out) {
+    const int N = H * W;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+        const int y = i / W, x = i - y * W;
+        double numerator = 0.0, denominator = 0.0;
+#pragma unroll
+        for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+            for (int dx = -1; dx <= 1; dx++) {
+                const int yy = y + dy, xx = x + dx;
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                const int j = yy * W + xx;
+                if (flag[j] != 0) continue;   // Flag::Success
+                const double id = tdk::safe_inv(depth[j]), iv = tdk::safe_inv(variance[j]);
+                numerator = numerator + id * iv;
+                denominator = denominator + iv;
+            }
+        out[i] = denominator == 0.0 ? depth[i] : tdk::safe_inv(numerator / denominator);
+    }
+}
+
+// fusion_arrays (src/semi_dense/fusion.rs:3-42)
+__global__ __launch_bounds__(kBlock) void k_fusion(const double *__restrict__ mu1, const double *__restrict__ mu2,
+                                                   const double *__restrict__ var1,
+                                                   const double *__restrict__ var2, int64_t n,
+                                                   double *__restrict__ mu, double *__restrict__ var) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const double m1 = mu1[i], m2 = mu2[i], v1 = var1[i], v2 = var2[i];
+        const double v = v1 + v2;
+        mu[i] = (m1 * v2 + m2 * v1) / v;
+        var[i] = (v1 * v2) / v;
+    }
+}
+
+// tdk_sd_export_dvo: I0 = previous frame, D0 = depth map, I1 = newest frame, W0 = safe_invert(variance)
+__global__ __launch_bounds__(kBlock) void k_export_dvo(int N, const double *const *__restrict__ prev_image,
+                                                       const double *const *__restrict__ new_image,
+                                                       const double *__restrict__ depth,
+                                                       const double *__restrict__ variance, int64_t stride,
+                                                       double *__restrict__ I0, double *__restrict__ D0,
+                                                       double *__restrict__ I1, double *__restrict__ W0,
+                                                       int64_t dvo_stride) {
+    const int track = blockIdx.y;
+    const double *__restrict__ p = prev_image[track], *__restrict__ q = new_image[track];
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+        const int64_t o = (int64_t)track * dvo_stride + i, m = (int64_t)track * stride + i;
+        I0[o] = p[i];
+        I1[o] = q[i];
+        D0[o] = depth[m];
+        if (W0) W0[o] = tdk::safe_inv(variance[m]);
+    }
 }
 
 // ---- host helpers ---------------------------------------------------------------
@@ -464,12 +618,6 @@ EstParams est_params(const tdk_semi_dense_params *p) {
 
 Cam cam_of(const double *c) { return Cam{c[0], c[1], c[2], c[3]}; }
 
-Mat4 mat_of(const double *T) {
-    Mat4 m;
-    for (int i = 0; i < 16; i++) m.m[i] = T[i];
-    return m;
-}
-
 tdk_status h2d(int slot, const void *host, size_t bytes, void **dev) {
     TDK_TRY(tdk::scratch(slot, bytes, dev));
     if (bytes) TDK_HIP(hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, tdk::stream()));
@@ -478,6 +626,47 @@ tdk_status h2d(int slot, const void *host, size_t bytes, void **dev) {
 
 tdk_status check_image_dims(int H, int W) {
     TDK_REQUIRE(H >= 1 && W >= 1 && (int64_t)H * W < (1ll << 30), "bad image size");
+    return TDK_OK;
+}
+
+void fill_track_warp(TrackWarp *tw, const double *T10, const double *cam0, const double *cam1) {
+    memcpy(tw->T10, T10, sizeof(double) * 16);
+    memcpy(tw->cam0, cam0, sizeof(double) * 4);
+    memcpy(tw->cam1, cam1, sizeof(double) * 4);
+}
+
+// scatter + fold for n_tracks maps laid out [track][stride]
+template <bool AGE, bool PROP>
+tdk_status launch_warp_step(int n_tracks, int H, int W, const TrackWarp *d_tw, const uint64_t *age0,
+                            const double *depth0, const double *var0, int64_t stride, double default_depth,
+                            double default_variance, double bias, int *head, int *next, uint64_t *age1,
+                            double *depth1, double *var1, hipStream_t stream) {
+    const int N = H * W;
+    TDK_HIP(hipMemsetAsync(head, 0xff, sizeof(int) * (size_t)stride * n_tracks, stream));  // -1: empty list
+    dim3 grid(grid_for(N), n_tracks);
+    k_sd_scatter<<<grid, kBlock, 0, stream>>>(H, W, d_tw, depth0, stride, head, next);
+    TDK_LAUNCH_CHECK();
+    k_sd_fold<AGE, PROP><<<grid, kBlock, 0, stream>>>(H, W, d_tw, head, next, age0, depth0, var0, stride,
+                                                       default_depth, default_variance, bias, age1, depth1, var1);
+    TDK_LAUNCH_CHECK();
+    return TDK_OK;
+}
+
+tdk_status launch_update_depth(int n_tracks, int H, int W, const TrackKey *d_keys, const RefConst *d_refs,
+                               int refs_per_track, const uint64_t *age, const double *prior_depth,
+                               const double *prior_var, int64_t stride, const EstParams &pr, int *list,
+                               int *count, int *err, double *out_depth, double *out_var, int64_t *out_flag,
+                               hipStream_t stream) {
+    const int N = H * W;
+    TDK_HIP(hipMemsetAsync(count, 0, sizeof(int) * n_tracks, stream));
+    dim3 cgrid((N + kBlock * kClassifySweeps - 1) / (kBlock * kClassifySweeps), n_tracks);
+    k_ud_classify<<<cgrid, kBlock, 0, stream>>>(N, d_keys, age, prior_depth, prior_var, stride, pr.vmin, pr.vmax,
+                                                out_depth, out_var, out_flag, list, count, err);
+    TDK_LAUNCH_CHECK();
+    dim3 egrid((N + kBlock - 1) / kBlock, n_tracks);
+    k_ud_estimate<<<egrid, kBlock, 0, stream>>>(H, W, d_keys, d_refs, refs_per_track, age, prior_depth, prior_var,
+                                                stride, pr, list, count, out_depth, out_var, out_flag);
+    TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
 
@@ -506,21 +695,21 @@ tdk_status tdk_increment_age(const uint64_t *age0, int H, int W, const double *c
                              const double *T10, const double *depth0, uint64_t *age1) {
     TDK_REQUIRE(age0 && camera0 && camera1 && T10 && depth0 && age1, "null pointer");
     TDK_TRY(check_image_dims(H, W));
-    int N = H * W;
-    void *d_age0, *d_depth, *d_winner, *d_age1;
+    const int N = H * W;
+    void *d_age0, *d_depth, *d_head, *d_next, *d_age1, *d_tw;
     TDK_TRY(h2d(0, age0, (size_t)N * 8, &d_age0));
     TDK_TRY(h2d(1, depth0, (size_t)N * 8, &d_depth));
-    TDK_TRY(tdk::scratch(2, (size_t)N * 4, &d_winner));
-    TDK_TRY(tdk::scratch(3, (size_t)N * 8, &d_age1));
-    TDK_HIP(hipMemsetAsync(d_winner, 0, (size_t)N * 4, tdk::stream()));
-    k_age_scatter<<<grid_for(N), kBlock, 0, tdk::stream()>>>(H, W, cam_of(camera0), cam_of(camera1), mat_of(T10),
-                                                             (const double *)d_depth, (int *)d_winner);
-    TDK_LAUNCH_CHECK();
-    k_age_gather<<<grid_for(N), kBlock, 0, tdk::stream()>>>(N, (const uint64_t *)d_age0, (const int *)d_winner,
-                                                            (uint64_t *)d_age1);
-    TDK_LAUNCH_CHECK();
+    TDK_TRY(tdk::scratch(2, (size_t)N * 4, &d_head));
+    TDK_TRY(tdk::scratch(3, (size_t)N * 4, &d_next));
+    TDK_TRY(tdk::scratch(4, (size_t)N * 8, &d_age1));
+    TrackWarp tw;
+    fill_track_warp(&tw, T10, camera0, camera1);
+    TDK_TRY(h2d(10, &tw, sizeof(tw), &d_tw));
+    TDK_TRY((launch_warp_step<true, false>(1, H, W, (const TrackWarp *)d_tw, (const uint64_t *)d_age0,
+                                           (const double *)d_depth, nullptr, N, 0., 0., 0., (int *)d_head,
+                                           (int *)d_next, (uint64_t *)d_age1, nullptr, nullptr, tdk::stream())));
     TDK_HIP(hipMemcpyAsync(age1, d_age1, (size_t)N * 8, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));  // tw must outlive the H2D copy
     return TDK_OK;
 }
 
@@ -529,27 +718,22 @@ tdk_status tdk_propagate(const double *T10, const double *camera0, const double 
                          double uncertaintity_bias, double *depth1, double *variance1) {
     TDK_REQUIRE(T10 && camera0 && camera1 && depth0 && variance0 && depth1 && variance1, "null pointer");
     TDK_TRY(check_image_dims(H, W));
-    int N = H * W;
+    const int N = H * W;
     size_t b8 = (size_t)N * 8, b4 = (size_t)N * 4;
-    void *d_d0, *d_v0, *d_d1a, *d_v1a, *d_head, *d_next, *d_d1, *d_v1;
+    void *d_d0, *d_v0, *d_head, *d_next, *d_d1, *d_v1, *d_tw;
     TDK_TRY(h2d(0, depth0, b8, &d_d0));
     TDK_TRY(h2d(1, variance0, b8, &d_v0));
-    TDK_TRY(tdk::scratch(2, b8, &d_d1a));
-    TDK_TRY(tdk::scratch(3, b8, &d_v1a));
-    TDK_TRY(tdk::scratch(4, b4, &d_head));
-    TDK_TRY(tdk::scratch(5, b4, &d_next));
-    TDK_TRY(tdk::scratch(6, b8, &d_d1));
-    TDK_TRY(tdk::scratch(7, b8, &d_v1));
-    TDK_HIP(hipMemsetAsync(d_head, 0xff, b4, tdk::stream()));  // -1: empty list
-    k_propagate_scatter<<<grid_for(N), kBlock, 0, tdk::stream()>>>(
-        H, W, cam_of(camera0), cam_of(camera1), mat_of(T10), (const double *)d_d0, (const double *)d_v0,
-        uncertaintity_bias, (double *)d_d1a, (double *)d_v1a, (int *)d_head, (int *)d_next);
-    TDK_LAUNCH_CHECK();
-    k_propagate_fold<<<grid_for(N), kBlock, 0, tdk::stream()>>>(N, (const int *)d_head, (const int *)d_next,
-                                                                (const double *)d_d1a, (const double *)d_v1a,
-                                                                default_depth, default_variance, (double *)d_d1,
-                                                                (double *)d_v1);
-    TDK_LAUNCH_CHECK();
+    TDK_TRY(tdk::scratch(2, b4, &d_head));
+    TDK_TRY(tdk::scratch(3, b4, &d_next));
+    TDK_TRY(tdk::scratch(4, b8, &d_d1));
+    TDK_TRY(tdk::scratch(5, b8, &d_v1));
+    TrackWarp tw;
+    fill_track_warp(&tw, T10, camera0, camera1);
+    TDK_TRY(h2d(10, &tw, sizeof(tw), &d_tw));
+    TDK_TRY((launch_warp_step<false, true>(1, H, W, (const TrackWarp *)d_tw, nullptr, (const double *)d_d0,
+                                           (const double *)d_v0, N, default_depth, default_variance,
+                                           uncertaintity_bias, (int *)d_head, (int *)d_next, nullptr,
+                                           (double *)d_d1, (double *)d_v1, tdk::stream())));
     TDK_HIP(hipMemcpyAsync(depth1, d_d1, b8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(variance1, d_v1, b8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
@@ -566,18 +750,10 @@ tdk_status tdk_update_depth(const double *key_camera, const double *key_image, c
                 "bad argument");
     TDK_REQUIRE(n_ref == 0 || (ref_cameras && ref_images && ref_Ts), "null reference frames");
     TDK_TRY(check_image_dims(H, W));
-    int N = H * W;
-    // the reference exits the process if some age exceeds len(refframes) (:202-205)
-    for (int i = 0; i < N; i++)
-        if (age[i] > (uint64_t)n_ref) {
-            tdk::set_error("Age exceeds the refframe size");
-            return TDK_ERR_AGE_EXCEEDS_REFFRAMES;
-        }
+    const int N = H * W;
     size_t b8 = (size_t)N * 8;
-    void *d_key, *d_gx, *d_gy, *d_refs_img, *d_age, *d_pd, *d_pv, *d_od, *d_ov, *d_of, *d_rc;
+    void *d_key, *d_refs_img, *d_age, *d_pd, *d_pv, *d_od, *d_ov, *d_of, *d_rc, *d_keys, *d_list, *d_cnt;
     TDK_TRY(h2d(0, key_image, b8, &d_key));
-    TDK_TRY(tdk::scratch(1, b8, &d_gx));
-    TDK_TRY(tdk::scratch(2, b8, &d_gy));
     TDK_TRY(h2d(3, ref_images, b8 * (size_t)n_ref, &d_refs_img));
     TDK_TRY(h2d(4, age, b8, &d_age));
     TDK_TRY(h2d(5, prior_depth, b8, &d_pd));
@@ -585,22 +761,40 @@ tdk_status tdk_update_depth(const double *key_camera, const double *key_image, c
     TDK_TRY(tdk::scratch(7, b8, &d_od));
     TDK_TRY(tdk::scratch(8, b8, &d_ov));
     TDK_TRY(tdk::scratch(9, b8, &d_of));
+    TDK_TRY(tdk::scratch(1, (size_t)N * 4, &d_list));
+    TDK_TRY(tdk::scratch(2, 2 * sizeof(int), &d_cnt));
+    // indexed by age - 1: refframes[n_ref - age] (:207)
     std::vector<RefConst> rcs((size_t)(n_ref > 0 ? n_ref : 1));
-    for (int r = 0; r < n_ref; r++)
+    for (int a = 1; a <= n_ref; a++) {
+        const int r = n_ref - a;
         TDK_TRY(make_ref_const(key_T, ref_Ts + 16 * r, ref_cameras + 4 * r,
-                               (const double *)d_refs_img + (size_t)r * N, &rcs[r]));
+                               (const double *)d_refs_img + (size_t)r * N, &rcs[a - 1]));
+    }
     TDK_TRY(h2d(10, rcs.data(), sizeof(RefConst) * rcs.size(), &d_rc));
-    k_sobel<<<grid_for(N), kBlock, 0, tdk::stream()>>>((const double *)d_key, H, W, (double *)d_gx, (double *)d_gy);
-    TDK_LAUNCH_CHECK();
-    k_update_depth<<<grid_for(N), kBlock, 0, tdk::stream()>>>(
-        cam_of(key_camera), (const double *)d_key, (const double *)d_gx, (const double *)d_gy, n_ref,
-        (const RefConst *)d_rc, (const uint64_t *)d_age, (const double *)d_pd, (const double *)d_pv, H, W,
-        est_params(params), (double *)d_od, (double *)d_ov, (int64_t *)d_of);
-    TDK_LAUNCH_CHECK();
+    TrackKey key;
+    memcpy(key.cam, key_camera, sizeof(double) * 4);
+    key.image = (const double *)d_key;
+    key.n_ref = n_ref;
+    key.pad = 0;
+    TDK_TRY(h2d(11, &key, sizeof(key), &d_keys));
+    int *d_err = (int *)d_cnt + 1;
+    TDK_HIP(hipMemsetAsync(d_err, 0, sizeof(int), tdk::stream()));
+    TDK_TRY(launch_update_depth(1, H, W, (const TrackKey *)d_keys, (const RefConst *)d_rc, n_ref > 0 ? n_ref : 1,
+                                (const uint64_t *)d_age, (const double *)d_pd, (const double *)d_pv, N,
+                                est_params(params), (int *)d_list, (int *)d_cnt, d_err, (double *)d_od,
+                                (double *)d_ov, (int64_t *)d_of, tdk::stream()));
+    int err = 0;
+    TDK_HIP(hipMemcpyAsync(&err, d_err, sizeof(int), hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));  // rcs / key must outlive the H2D copies
+    if (err & SD_ERR_AGE) {
+        // the reference exits the process if some age exceeds len(refframes) (:202-205)
+        tdk::set_error("Age exceeds the refframe size");
+        return TDK_ERR_AGE_EXCEEDS_REFFRAMES;
+    }
     TDK_HIP(hipMemcpyAsync(depth, d_od, b8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(variance, d_ov, b8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(flag, d_of, b8, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));  // rcs must outlive the H2D copy
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
     return TDK_OK;
 }
 
@@ -612,6 +806,7 @@ tdk_status tdk_estimate_one(const int64_t *u_key, double prior_depth, double pri
                     depth && variance && flag,
                 "null pointer");
     TDK_TRY(check_image_dims(H, W));
+    TDK_REQUIRE(u_key[0] >= 0 && u_key[0] < W && u_key[1] >= 0 && u_key[1] < H, "u_key outside the image");
     EstParams pr = est_params(params);
     *depth = prior_depth;
     *variance = prior_variance;
@@ -623,21 +818,16 @@ tdk_status tdk_estimate_one(const int64_t *u_key, double prior_depth, double pri
         if (mx <= pr.vmin || pr.vmax <= mn) { *flag = -1; return TDK_OK; }
     }
     size_t b8 = (size_t)H * W * 8;
-    void *d_key, *d_gx, *d_gy, *d_ref, *d_rc, *d_out;
+    void *d_key, *d_ref, *d_rc, *d_out;
     TDK_TRY(h2d(0, key_image, b8, &d_key));
-    TDK_TRY(tdk::scratch(1, b8, &d_gx));
-    TDK_TRY(tdk::scratch(2, b8, &d_gy));
     TDK_TRY(h2d(3, ref_image, b8, &d_ref));
     RefConst rc;
     TDK_TRY(make_ref_const(key_T, ref_T, ref_camera, (const double *)d_ref, &rc));
     TDK_TRY(h2d(10, &rc, sizeof(RefConst), &d_rc));
     TDK_TRY(tdk::scratch(7, 3 * 8, &d_out));
-    k_sobel<<<grid_for((int64_t)H * W), kBlock, 0, tdk::stream()>>>((const double *)d_key, H, W, (double *)d_gx,
-                                                                    (double *)d_gy);
-    TDK_LAUNCH_CHECK();
-    k_estimate_one<<<1, 1, 0, tdk::stream()>>>(cam_of(key_camera), (const double *)d_key, (const double *)d_gx,
-                                               (const double *)d_gy, (const RefConst *)d_rc, (double)u_key[0],
-                                               (double)u_key[1], pid, prior_variance, H, W, pr, (double *)d_out);
+    k_estimate_one<<<1, 1, 0, tdk::stream()>>>(cam_of(key_camera), (const double *)d_key, (const RefConst *)d_rc,
+                                               (double)u_key[0], (double)u_key[1], pid, prior_variance, H, W, pr,
+                                               (double *)d_out);
     TDK_LAUNCH_CHECK();
     double out[3];
     TDK_HIP(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, tdk::stream()));
@@ -647,6 +837,442 @@ tdk_status tdk_estimate_one(const int64_t *u_key, double prior_depth, double pri
         *depth = tdk::safe_inv(out[0]);
         *variance = out[1];
     }
+    return TDK_OK;
+}
+
+tdk_status tdk_regularize(const double *depth, const double *variance, const int64_t *flag, int H, int W,
+                          double *regularized) {
+    TDK_REQUIRE(depth && variance && flag && regularized, "null pointer");
+    TDK_TRY(check_image_dims(H, W));
+    size_t b8 = (size_t)H * W * 8;
+    void *d_d, *d_v, *d_f, *d_o;
+    TDK_TRY(h2d(0, depth, b8, &d_d));
+    TDK_TRY(h2d(1, variance, b8, &d_v));
+    TDK_TRY(h2d(2, flag, b8, &d_f));
+    TDK_TRY(tdk::scratch(3, b8, &d_o));
+    k_regularize<<<grid_for((int64_t)H * W), kBlock, 0, tdk::stream()>>>(
+        (const double *)d_d, (const double *)d_v, (const int64_t *)d_f, H, W, (double *)d_o);
+    TDK_LAUNCH_CHECK();
+    TDK_HIP(hipMemcpyAsync(regularized, d_o, b8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    return TDK_OK;
+}
+
+tdk_status tdk_fusion_arrays(const double *mu1, const double *mu2, const double *var1, const double *var2,
+                             int64_t n, double *mu, double *var) {
+    TDK_REQUIRE(n >= 0 && (n == 0 || (mu1 && mu2 && var1 && var2 && mu && var)), "null pointer");
+    if (n == 0) return TDK_OK;
+    size_t b8 = (size_t)n * 8;
+    void *d_m1, *d_m2, *d_v1, *d_v2, *d_m, *d_v;
+    TDK_TRY(h2d(0, mu1, b8, &d_m1));
+    TDK_TRY(h2d(1, mu2, b8, &d_m2));
+    TDK_TRY(h2d(2, var1, b8, &d_v1));
+    TDK_TRY(h2d(3, var2, b8, &d_v2));
+    TDK_TRY(tdk::scratch(4, b8, &d_m));
+    TDK_TRY(tdk::scratch(5, b8, &d_v));
+    k_fusion<<<grid_for(n), kBlock, 0, tdk::stream()>>>((const double *)d_m1, (const double *)d_m2,
+                                                        (const double *)d_v1, (const double *)d_v2, n,
+                                                        (double *)d_m, (double *)d_v);
+    TDK_LAUNCH_CHECK();
+    TDK_HIP(hipMemcpyAsync(mu, d_m, b8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(var, d_v, b8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    return TDK_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// tdk_sd: device-resident session
+// ---------------------------------------------------------------------------
+struct tdk_sd {
+    hipStream_t stream;
+    int n, H, W, R;          // tracks, frame size, max reference frames; the ring holds R + 1 frames
+    int N;
+    int64_t stride;          // elements between consecutive tracks in every map
+    double *images;          // [n][R + 1][stride]
+    // maps: cur = state, out = results of the last step, prior = propagate output
+    uint64_t *age[2];
+    double *depth[2], *var[2];
+    double *prior_depth, *prior_var;
+    int64_t *flag;
+    int cur, result_buf;
+    int *head, *next, *list, *count, *err;
+    unsigned long long *hist;
+    TrackWarp *d_tw;
+    TrackKey *d_keys;
+    RefConst *d_refs;
+    const double **d_img_ptrs;   // [2][n]: previous / newest frame of every track
+    void *stage;                 // pinned staging for the per-step constants
+    size_t stage_bytes;
+    std::vector<int64_t> n_frames;             // frames pushed per track
+    std::vector<double> cams, Twf;             // [n][R + 1][4], [n][R + 1][16] by ring slot
+    std::vector<char> has_T;
+    tdk_semi_dense_params params;
+    double default_depth, default_variance, bias;
+    bool params_set, have_result, result_has_flag;
+    hipEvent_t ev[4];
+    double ms[3];
+};
+
+namespace {
+
+int sd_slot(const tdk_sd *h, int64_t frame_index) { return (int)(frame_index % (h->R + 1)); }
+
+double *sd_image(const tdk_sd *h, int track, int slot) {
+    return h->images + ((size_t)track * (h->R + 1) + slot) * (size_t)h->stride;
+}
+
+tdk_status sd_check_track(const tdk_sd *h, int track) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    TDK_REQUIRE(track >= 0 && track < h->n, "track out of range");
+    return TDK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+tdk_status tdk_sd_destroy(tdk_sd *h) {
+    if (!h) return TDK_OK;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->images);
+    for (int k = 0; k < 2; k++) { (void)hipFree(h->age[k]); (void)hipFree(h->depth[k]); (void)hipFree(h->var[k]); }
+    (void)hipFree(h->prior_depth); (void)hipFree(h->prior_var); (void)hipFree(h->flag);
+    (void)hipFree(h->head); (void)hipFree(h->next); (void)hipFree(h->list); (void)hipFree(h->count);
+    (void)hipFree(h->hist); (void)hipFree(h->d_tw); (void)hipFree(h->d_keys); (void)hipFree(h->d_refs);
+    (void)hipFree((void *)h->d_img_ptrs);
+    if (h->stage) (void)hipHostFree(h->stage);
+    for (hipEvent_t e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return TDK_OK;
+}
+
+tdk_status tdk_sd_create(int n_tracks, int height, int width, int max_refframes, tdk_sd **out) {
+    TDK_REQUIRE(out != nullptr, "out is NULL");
+    TDK_REQUIRE(n_tracks >= 1 && n_tracks <= 65535, "n_tracks must be in [1, 65535]");
+    TDK_REQUIRE(max_refframes >= 1 && max_refframes <= 1024, "max_refframes must be in [1, 1024]");
+    TDK_TRY(check_image_dims(height, width));
+    TDK_REQUIRE((int64_t)height * width < (1ll << 30), "frame too large");
+    TDK_TRY(tdk::ensure_device());
+    tdk_sd *h = new tdk_sd();   // value-initialised: every pointer is null until allocated
+    h->n = n_tracks; h->H = height; h->W = width; h->R = max_refframes;
+    h->N = height * width;
+    h->stride = ((int64_t)h->N + 1) & ~1ll;
+    h->cur = 0; h->result_buf = 0;
+    h->params_set = false; h->have_result = false; h->result_has_flag = false;
+    h->n_frames.assign((size_t)n_tracks, 0);
+    h->cams.assign((size_t)n_tracks * (h->R + 1) * 4, 0.0);
+    h->Twf.assign((size_t)n_tracks * (h->R + 1) * 16, 0.0);
+    h->has_T.assign((size_t)n_tracks * (h->R + 1), 0);
+    const size_t m = (size_t)h->stride * n_tracks;
+    h->stage_bytes = (sizeof(TrackWarp) + sizeof(TrackKey) + sizeof(RefConst) * h->R + 2 * sizeof(double *)) *
+                         (size_t)n_tracks + 64;
+#define SD_ALLOC(call)                          \
+    do {                                        \
+        hipError_t e_ = (call);                 \
+        if (e_ != hipSuccess) {                 \
+            tdk::set_error("%s failed: %s", #call, hipGetErrorString(e_)); \
+            tdk_sd_destroy(h);                  \
+            return TDK_ERR_HIP;                 \
+        }                                       \
+    } while (0)
+    SD_ALLOC(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    SD_ALLOC(hipMalloc(&h->images, sizeof(double) * m * (h->R + 1)));
+    for (int k = 0; k < 2; k++) {
+        SD_ALLOC(hipMalloc(&h->age[k], 8 * m));
+        SD_ALLOC(hipMalloc(&h->depth[k], 8 * m));
+        SD_ALLOC(hipMalloc(&h->var[k], 8 * m));
+    }
+    SD_ALLOC(hipMalloc(&h->prior_depth, 8 * m));
+    SD_ALLOC(hipMalloc(&h->prior_var, 8 * m));
+    SD_ALLOC(hipMalloc(&h->flag, 8 * m));
+    SD_ALLOC(hipMalloc(&h->head, 4 * m));
+    SD_ALLOC(hipMalloc(&h->next, 4 * m));
+    SD_ALLOC(hipMalloc(&h->list, 4 * m));
+    SD_ALLOC(hipMalloc(&h->count, sizeof(int) * (n_tracks + 1)));
+    h->err = h->count + n_tracks;
+    SD_ALLOC(hipMalloc(&h->hist, sizeof(unsigned long long) * 10 * n_tracks));
+    SD_ALLOC(hipMalloc(&h->d_tw, sizeof(TrackWarp) * n_tracks));
+    SD_ALLOC(hipMalloc(&h->d_keys, sizeof(TrackKey) * n_tracks));
+    SD_ALLOC(hipMalloc(&h->d_refs, sizeof(RefConst) * (size_t)h->R * n_tracks));
+    SD_ALLOC(hipMalloc((void **)&h->d_img_ptrs, sizeof(double *) * 2 * n_tracks));
+    SD_ALLOC(hipHostMalloc(&h->stage, h->stage_bytes, hipHostMallocDefault));
+    for (int k = 0; k < 4; k++) SD_ALLOC(hipEventCreate(&h->ev[k]));
+    // fresh maps: age 0 everywhere, depth / variance undefined until tdk_sd_set_maps
+    SD_ALLOC(hipMemsetAsync(h->age[0], 0, 8 * m, h->stream));
+    SD_ALLOC(hipMemsetAsync(h->depth[0], 0, 8 * m, h->stream));
+    SD_ALLOC(hipMemsetAsync(h->var[0], 0, 8 * m, h->stream));
+    SD_ALLOC(hipStreamSynchronize(h->stream));
+#undef SD_ALLOC
+    *out = h;
+    return TDK_OK;
+}
+
+tdk_status tdk_sd_set_params(tdk_sd *h, const tdk_semi_dense_params *params, double default_depth,
+                             double default_variance, double uncertaintity_bias) {
+    TDK_REQUIRE(h && params, "null pointer");
+    h->params = *params;
+    h->default_depth = default_depth;
+    h->default_variance = default_variance;
+    h->bias = uncertaintity_bias;
+    h->params_set = true;
+    return TDK_OK;
+}
+
+tdk_status tdk_sd_set_maps(tdk_sd *h, int track, const double *depth, const double *variance,
+                           const uint64_t *age) {
+    TDK_TRY(sd_check_track(h, track));
+    const size_t off = (size_t)track * h->stride, b8 = (size_t)h->N * 8;
+    if (depth) TDK_HIP(hipMemcpyAsync(h->depth[h->cur] + off, depth, b8, hipMemcpyHostToDevice, h->stream));
+    if (variance) TDK_HIP(hipMemcpyAsync(h->var[h->cur] + off, variance, b8, hipMemcpyHostToDevice, h->stream));
+    if (age) TDK_HIP(hipMemcpyAsync(h->age[h->cur] + off, age, b8, hipMemcpyHostToDevice, h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
+    return TDK_OK;
+}
+
+static tdk_status sd_read(tdk_sd *h, int which, int track, double *depth, double *variance, uint64_t *age,
+                          int64_t *flag) {
+    const size_t off = (size_t)track * h->stride, b8 = (size_t)h->N * 8;
+    if (depth) TDK_HIP(hipMemcpyAsync(depth, h->depth[which] + off, b8, hipMemcpyDeviceToHost, h->stream));
+    if (variance) TDK_HIP(hipMemcpyAsync(variance, h->var[which] + off, b8, hipMemcpyDeviceToHost, h->stream));
+    if (age) TDK_HIP(hipMemcpyAsync(age, h->age[which] + off, b8, hipMemcpyDeviceToHost, h->stream));
+    if (flag) TDK_HIP(hipMemcpyAsync(flag, h->flag + off, b8, hipMemcpyDeviceToHost, h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
+    return TDK_OK;
+}
+
+tdk_status tdk_sd_get_maps(tdk_sd *h, int track, double *depth, double *variance, uint64_t *age,
+                           int64_t *flag) {
+    TDK_TRY(sd_check_track(h, track));
+    TDK_REQUIRE(flag == nullptr || (h->have_result && h->result_has_flag), "no update_depth has run yet: there is no flag map");
+    return sd_read(h, h->cur, track, depth, variance, age, flag);
+}
+
+tdk_status tdk_sd_get_results(tdk_sd *h, int track, double *depth, double *variance, uint64_t *age,
+                              int64_t *flag) {
+    TDK_TRY(sd_check_track(h, track));
+    TDK_REQUIRE(h->have_result, "no step has run yet");
+    TDK_REQUIRE(flag == nullptr || h->result_has_flag, "the last call (tdk_sd_propagate) produced no flag map");
+    return sd_read(h, h->result_buf, track, depth, variance, age, flag);
+}
+
+tdk_status tdk_sd_push_frame(tdk_sd *h, int track, const double *camera, const double *image,
+                             const double *transform_wf) {
+    TDK_TRY(sd_check_track(h, track));
+    TDK_REQUIRE(camera && image, "null pointer");
+    const int64_t idx = h->n_frames[track];
+    const int slot = sd_slot(h, idx);
+    const size_t s = (size_t)track * (h->R + 1) + slot;
+    memcpy(&h->cams[4 * s], camera, sizeof(double) * 4);
+    h->has_T[s] = transform_wf != nullptr;
+    if (transform_wf) memcpy(&h->Twf[16 * s], transform_wf, sizeof(double) * 16);
+    TDK_HIP(hipMemcpyAsync(sd_image(h, track, slot), image, (size_t)h->N * 8, hipMemcpyHostToDevice, h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
+    h->n_frames[track] = idx + 1;
+    return TDK_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Per-step constants, assembled in pinned memory [TrackWarp n][TrackKey n][RefConst n R][ptrs 2 n][err]
+// and copied to the device on the session's stream.
+struct SdStage {
+    TrackWarp *tw;
+    TrackKey *keys;
+    RefConst *refs;
+    const double **ptrs;
+    int *err;
+};
+
+SdStage sd_stage(tdk_sd *h) {
+    SdStage st;
+    st.tw = (TrackWarp *)h->stage;
+    st.keys = (TrackKey *)(st.tw + h->n);
+    st.refs = (RefConst *)(st.keys + h->n);
+    st.ptrs = (const double **)(st.refs + (size_t)h->n * h->R);
+    st.err = (int *)(st.ptrs + 2 * (size_t)h->n);
+    return st;
+}
+
+tdk_status sd_require_frames(const tdk_sd *h, int64_t need) {
+    for (int t = 0; t < h->n; t++)
+        if (h->n_frames[t] < need) {
+            tdk::set_error("track %d holds %lld frame(s), this call needs %lld", t, (long long)h->n_frames[t],
+                           (long long)need);
+            return TDK_ERR_INVALID_ARGUMENT;
+        }
+    return TDK_OK;
+}
+
+// warp constants of every track: previous frame -> newest frame
+tdk_status sd_upload_warp(tdk_sd *h, const double *transforms10) {
+    TDK_TRY(sd_require_frames(h, 2));
+    SdStage st = sd_stage(h);
+    for (int t = 0; t < h->n; t++) {
+        const int64_t nf = h->n_frames[t];
+        const size_t kb = (size_t)t * (h->R + 1) + sd_slot(h, nf - 1), pb = (size_t)t * (h->R + 1) + sd_slot(h, nf - 2);
+        fill_track_warp(&st.tw[t], transforms10 + 16 * (size_t)t, &h->cams[4 * pb], &h->cams[4 * kb]);
+    }
+    TDK_HIP(hipMemcpyAsync(h->d_tw, st.tw, sizeof(TrackWarp) * h->n, hipMemcpyHostToDevice, h->stream));
+    return TDK_OK;
+}
+
+// key frame + reference frame constants of every track (update_depth)
+tdk_status sd_upload_keys(tdk_sd *h, const double *key_transforms_wf) {
+    TDK_TRY(sd_require_frames(h, 1));
+    SdStage st = sd_stage(h);
+    const int n = h->n, R = h->R;
+    for (int t = 0; t < n; t++) {
+        const int64_t nf = h->n_frames[t];
+        const int ks = sd_slot(h, nf - 1);
+        const size_t kb = (size_t)t * (R + 1) + ks;
+        if (key_transforms_wf) {
+            memcpy(&h->Twf[16 * kb], key_transforms_wf + 16 * (size_t)t, sizeof(double) * 16);
+            h->has_T[kb] = 1;
+        }
+        TDK_REQUIRE(h->has_T[kb], "the newest frame has no transform_wf");
+        memcpy(st.keys[t].cam, &h->cams[4 * kb], sizeof(double) * 4);
+        st.keys[t].image = sd_image(h, t, ks);
+        const int n_ref = (int)(nf - 1 < R ? nf - 1 : R);
+        st.keys[t].n_ref = n_ref;
+        st.keys[t].pad = 0;
+        for (int a = 1; a <= R; a++) {
+            RefConst *rc = &st.refs[(size_t)t * R + (a - 1)];
+            if (a > n_ref) { memset(rc, 0, sizeof(*rc)); continue; }
+            const int rs = sd_slot(h, nf - 1 - a);
+            const size_t rb = (size_t)t * (R + 1) + rs;
+            TDK_REQUIRE(h->has_T[rb], "a reference frame has no transform_wf");
+            TDK_TRY(make_ref_const(&h->Twf[16 * kb], &h->Twf[16 * rb], &h->cams[4 * rb], sd_image(h, t, rs), rc));
+        }
+    }
+    TDK_HIP(hipMemcpyAsync(h->d_keys, st.keys, sizeof(TrackKey) * n, hipMemcpyHostToDevice, h->stream));
+    TDK_HIP(hipMemcpyAsync(h->d_refs, st.refs, sizeof(RefConst) * (size_t)n * R, hipMemcpyHostToDevice, h->stream));
+    return TDK_OK;
+}
+
+// closes a session call: optional flag histogram, error word, sync, timing
+tdk_status sd_finish(tdk_sd *h, bool with_flags, int64_t *flag_histogram, int result_buf, int commit) {
+    hipStream_t s = h->stream;
+    SdStage st = sd_stage(h);
+    if (flag_histogram && with_flags) {
+        TDK_HIP(hipMemsetAsync(h->hist, 0, sizeof(unsigned long long) * 10 * h->n, s));
+        dim3 grid(64, h->n);
+        k_flag_hist<<<grid, kBlock, 0, s>>>(h->N, h->flag, h->stride, h->hist);
+        TDK_LAUNCH_CHECK();
+        TDK_HIP(hipMemcpyAsync(flag_histogram, h->hist, sizeof(int64_t) * 10 * h->n, hipMemcpyDeviceToHost, s));
+    }
+    TDK_HIP(hipMemcpyAsync(st.err, h->err, sizeof(int), hipMemcpyDeviceToHost, s));
+    TDK_HIP(hipStreamSynchronize(s));
+    float ms01 = 0.f, ms12 = 0.f, ms02 = 0.f;
+    TDK_HIP(hipEventElapsedTime(&ms01, h->ev[0], h->ev[1]));
+    TDK_HIP(hipEventElapsedTime(&ms12, h->ev[1], h->ev[2]));
+    TDK_HIP(hipEventElapsedTime(&ms02, h->ev[0], h->ev[2]));
+    h->ms[0] = ms01; h->ms[1] = ms12; h->ms[2] = ms02;
+    if (*st.err & SD_ERR_AGE) {
+        tdk::set_error("Age exceeds the refframe size");   // the reference exits the process (:202-205)
+        return TDK_ERR_AGE_EXCEEDS_REFFRAMES;
+    }
+    h->result_buf = result_buf;
+    h->have_result = true;
+    h->result_has_flag = with_flags;
+    if (commit) h->cur = result_buf;
+    return TDK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+tdk_status tdk_sd_step(tdk_sd *h, const double *transforms10, const double *key_transforms_wf, int commit,
+                       int64_t *flag_histogram) {
+    TDK_REQUIRE(h && transforms10, "null pointer");
+    TDK_REQUIRE(h->params_set, "tdk_sd_set_params has not been called");
+    TDK_TRY(sd_upload_warp(h, transforms10));
+    TDK_TRY(sd_upload_keys(h, key_transforms_wf));
+    hipStream_t s = h->stream;
+    TDK_HIP(hipMemsetAsync(h->err, 0, sizeof(int), s));
+    const int c = h->cur, o = c ^ 1;
+    TDK_HIP(hipEventRecord(h->ev[0], s));
+    TDK_TRY((launch_warp_step<true, true>(h->n, h->H, h->W, h->d_tw, h->age[c], h->depth[c], h->var[c], h->stride,
+                                          h->default_depth, h->default_variance, h->bias, h->head, h->next,
+                                          h->age[o], h->prior_depth, h->prior_var, s)));
+    TDK_HIP(hipEventRecord(h->ev[1], s));
+    TDK_TRY(launch_update_depth(h->n, h->H, h->W, h->d_keys, h->d_refs, h->R, h->age[o], h->prior_depth,
+                                h->prior_var, h->stride, est_params(&h->params), h->list, h->count, h->err,
+                                h->depth[o], h->var[o], h->flag, s));
+    TDK_HIP(hipEventRecord(h->ev[2], s));
+    return sd_finish(h, true, flag_histogram, o, commit);
+}
+
+tdk_status tdk_sd_propagate(tdk_sd *h, const double *transforms10, int commit) {
+    TDK_REQUIRE(h && transforms10, "null pointer");
+    TDK_REQUIRE(h->params_set, "tdk_sd_set_params has not been called");
+    TDK_TRY(sd_upload_warp(h, transforms10));
+    hipStream_t s = h->stream;
+    TDK_HIP(hipMemsetAsync(h->err, 0, sizeof(int), s));
+    const int c = h->cur, o = c ^ 1;
+    TDK_HIP(hipEventRecord(h->ev[0], s));
+    TDK_TRY((launch_warp_step<true, true>(h->n, h->H, h->W, h->d_tw, h->age[c], h->depth[c], h->var[c], h->stride,
+                                          h->default_depth, h->default_variance, h->bias, h->head, h->next,
+                                          h->age[o], h->depth[o], h->var[o], s)));
+    TDK_HIP(hipEventRecord(h->ev[1], s));
+    TDK_HIP(hipEventRecord(h->ev[2], s));
+    return sd_finish(h, false, nullptr, o, commit);
+}
+
+tdk_status tdk_sd_update_depth(tdk_sd *h, const double *key_transforms_wf, int commit,
+                               int64_t *flag_histogram) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    TDK_REQUIRE(h->params_set, "tdk_sd_set_params has not been called");
+    TDK_TRY(sd_upload_keys(h, key_transforms_wf));
+    hipStream_t s = h->stream;
+    TDK_HIP(hipMemsetAsync(h->err, 0, sizeof(int), s));
+    const int c = h->cur, o = c ^ 1;
+    TDK_HIP(hipEventRecord(h->ev[0], s));
+    TDK_HIP(hipEventRecord(h->ev[1], s));
+    TDK_TRY(launch_update_depth(h->n, h->H, h->W, h->d_keys, h->d_refs, h->R, h->age[c], h->depth[c], h->var[c],
+                                h->stride, est_params(&h->params), h->list, h->count, h->err, h->depth[o],
+                                h->var[o], h->flag, s));
+    TDK_HIP(hipEventRecord(h->ev[2], s));
+    // the age map is an input only: the result set carries it along (outside the timed region)
+    TDK_HIP(hipMemcpyAsync(h->age[o], h->age[c], 8 * (size_t)h->stride * h->n, hipMemcpyDeviceToDevice, s));
+    return sd_finish(h, true, flag_histogram, o, commit);
+}
+
+tdk_status tdk_sd_export_dvo(tdk_sd *h, tdk_dvo *batch) {
+    TDK_REQUIRE(h && batch, "null pointer");
+    tdk::DvoLevel0 L;
+    TDK_TRY(tdk::dvo_level0(batch, &L));
+    TDK_REQUIRE(L.n_pairs == h->n && L.H == h->H && L.W == h->W,
+                "the DVO batch must have one pair per track and the same frame size");
+    const int n = h->n;
+    const double **ptrs = (const double **)h->stage;
+    for (int t = 0; t < n; t++) {
+        const int64_t nf = h->n_frames[t];
+        TDK_REQUIRE(nf >= 2, "every track needs the previous and the newest frame");
+        ptrs[t] = sd_image(h, t, sd_slot(h, nf - 2));
+        ptrs[n + t] = sd_image(h, t, sd_slot(h, nf - 1));
+    }
+    TDK_HIP(hipMemcpyAsync((void *)h->d_img_ptrs, ptrs, sizeof(double *) * 2 * n, hipMemcpyHostToDevice, h->stream));
+    dim3 grid(grid_for(h->N), n);
+    k_export_dvo<<<grid, kBlock, 0, h->stream>>>(h->N, h->d_img_ptrs, h->d_img_ptrs + n, h->depth[h->cur],
+                                                 h->var[h->cur], h->stride, L.I0, L.D0, L.I1, L.W0, L.stride);
+    TDK_LAUNCH_CHECK();
+    // the batch's own stream continues after the export
+    TDK_HIP(hipEventRecord(h->ev[3], h->stream));
+    TDK_HIP(hipStreamWaitEvent(L.stream, h->ev[3], 0));
+    TDK_HIP(hipStreamSynchronize(h->stream));   // the staging buffer is reused by the next call
+    return TDK_OK;
+}
+
+tdk_status tdk_sd_get_timing(tdk_sd *h, double *ms3) {
+    TDK_REQUIRE(h && ms3, "null pointer");
+    TDK_REQUIRE(h->have_result, "no step has run yet");
+    for (int k = 0; k < 3; k++) ms3[k] = h->ms[k];
     return TDK_OK;
 }
 

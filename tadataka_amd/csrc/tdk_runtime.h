@@ -43,6 +43,15 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
                              hipStream_t stream);
 size_t pyramid_aa_weight_doubles(int n_out);
 
+// dvo.hip: level-0 arrays of a DVO batch, for producers that fill it on the device (tdk_sd_export_dvo)
+struct DvoLevel0 {
+    double *I0, *D0, *I1, *W0;   // [n_pairs][stride]; W0 is null without a weight map
+    int64_t stride;
+    int H, W, n_pairs;
+    hipStream_t stream;
+};
+tdk_status dvo_level0(tdk_dvo *h, DvoLevel0 *out);
+
 }  // namespace tdk
 
 #define TDK_HIP(call)                                                                   \

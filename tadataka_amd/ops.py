@@ -129,6 +129,16 @@ def rescale(image, scale, anti_aliasing=False):
     return out
 
 
+def resize(image, output_shape, anti_aliasing=False):
+    """Bilinear resize to an explicit (height, width)."""
+    image = _f64(image)
+    Ho, Wo = int(output_shape[0]), int(output_shape[1])
+    out = np.empty((Ho, Wo))
+    call("tdk_rescale_anti_aliased" if anti_aliasing else "tdk_rescale", _p(image), image.shape[0],
+         image.shape[1], _p(out), Ho, Wo)
+    return out
+
+
 # ---- DVO batch ----------------------------------------------------------------
 def pose12(R, t):
     return np.concatenate([_f64(R, (9,)), _f64(t, (3,))])
@@ -334,6 +344,135 @@ def estimate_one(u_key, prior_depth, prior_variance, key, ref, params):
          _p(kc), _p(ki), _p(kT), _p(rc), _p(ri), _p(rT), H, W, C.byref(params), C.byref(d), C.byref(v),
          C.byref(f))
     return float(d.value), float(v.value), int(f.value)
+
+
+def regularize(depth_map, variance_map, flag_map):
+    """regularize (src/semi_dense/regularization.rs:29-64): regularized DEPTH map."""
+    d = _f64(depth_map)
+    H, W = d.shape
+    v = _f64(variance_map, (H, W))
+    f = np.ascontiguousarray(flag_map, dtype=np.int64).reshape(H, W)
+    out = np.empty_like(d)
+    call("tdk_regularize", _p(d), _p(v), f.ctypes.data_as(c_int64_p), H, W, _p(out))
+    return out
+
+
+def fusion_arrays(mu1, mu2, var1, var2):
+    """fusion_arrays (src/semi_dense/fusion.rs:13-42): (mu, var), elementwise."""
+    m1 = _f64(mu1)
+    m2 = _f64(mu2, m1.shape); v1 = _f64(var1, m1.shape); v2 = _f64(var2, m1.shape)
+    mu = np.empty_like(m1); var = np.empty_like(m1)
+    call("tdk_fusion_arrays", _p(m1), _p(m2), _p(v1), _p(v2), m1.size, _p(mu), _p(var))
+    return mu, var
+
+
+def rgb2gray(image):
+    """skimage.color.rgb2gray as the examples call it: [H,W,3|4] float or uint8 -> [H,W] float64;
+    two-dimensional input is returned as float64 unchanged."""
+    a = np.asarray(image)
+    if a.ndim == 2:
+        return _f64(a / 255.0 if a.dtype == np.uint8 else a)
+    if a.ndim != 3 or a.shape[2] not in (3, 4):
+        raise ValueError("the input array must have a shape == (.., ..,[ ..,] 3)), got " + str(a.shape))
+    H, W, ch = a.shape
+    out = np.empty((H, W))
+    if a.dtype == np.uint8:
+        a = np.ascontiguousarray(a)
+        call("tdk_rgb2gray_u8", a.ctypes.data_as(C.POINTER(C.c_uint8)), H, W, ch, _p(out))
+    else:
+        a = _f64(a)
+        call("tdk_rgb2gray", _p(a), H, W, ch, _p(out))
+    return out
+
+
+class SemiDenseSession(object):
+    """Device-resident semi-dense mapping session over a batch of tracks (tdk_sd):
+    per step increment_age -> propagate -> update_depth for every track, the maps
+    and the frame rings staying in HBM (examples/semi_dense_vo.py:182-199)."""
+
+    def __init__(self, n_tracks, height, width, max_refframes=4):
+        self.n_tracks, self.height, self.width = int(n_tracks), int(height), int(width)
+        self.max_refframes = int(max_refframes)
+        self._h = C.c_void_p()
+        call("tdk_sd_create", self.n_tracks, self.height, self.width, self.max_refframes, C.byref(self._h))
+
+    def close(self):
+        if self._h:
+            call("tdk_sd_destroy", self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, params, default_depth, default_variance, uncertaintity_bias):
+        call("tdk_sd_set_params", self._h, C.byref(params), float(default_depth), float(default_variance),
+             float(uncertaintity_bias))
+
+    def set_maps(self, track, depth=None, variance=None, age=None):
+        shape = (self.height, self.width)
+        d = None if depth is None else _f64(depth, shape)
+        v = None if variance is None else _f64(variance, shape)
+        a = None if age is None else np.ascontiguousarray(age, dtype=np.uint64).reshape(shape)
+        call("tdk_sd_set_maps", self._h, track, None if d is None else _p(d), None if v is None else _p(v),
+             None if a is None else a.ctypes.data_as(c_uint64_p))
+
+    def _read(self, fn, track, with_flag):
+        shape = (self.height, self.width)
+        d = np.empty(shape); v = np.empty(shape); a = np.empty(shape, dtype=np.uint64)
+        f = np.empty(shape, dtype=np.int64) if with_flag else None
+        call(fn, self._h, track, _p(d), _p(v), a.ctypes.data_as(c_uint64_p),
+             None if f is None else f.ctypes.data_as(c_int64_p))
+        return (d, v, a, f) if with_flag else (d, v, a)
+
+    def get_maps(self, track, with_flag=False):
+        """(depth, variance, age[, flag]) of the session's current state."""
+        return self._read("tdk_sd_get_maps", track, with_flag)
+
+    def get_results(self, track, with_flag=True):
+        """(depth, variance, age[, flag]) of the last call, committed or not."""
+        return self._read("tdk_sd_get_results", track, with_flag)
+
+    def push_frame(self, track, camera, image, transform_wf=None):
+        cam = camera_vec(camera)
+        img = _f64(image, (self.height, self.width))
+        T = None if transform_wf is None else _f64(transform_wf, (4, 4))
+        call("tdk_sd_push_frame", self._h, track, _p(cam), _p(img), None if T is None else _p(T))
+
+    def step(self, transforms10, key_transforms_wf=None, commit=True, histogram=False):
+        """One mapping step for every track.  Returns the per-track flag histogram
+        [n_tracks, 10] (flags 0, -1, ..., -9) if asked for."""
+        T10 = _f64(transforms10, (self.n_tracks, 4, 4))
+        Tw = None if key_transforms_wf is None else _f64(key_transforms_wf, (self.n_tracks, 4, 4))
+        hist = np.zeros((self.n_tracks, 10), dtype=np.int64) if histogram else None
+        call("tdk_sd_step", self._h, _p(T10), None if Tw is None else _p(Tw), int(bool(commit)),
+             None if hist is None else hist.ctypes.data_as(c_int64_p))
+        return hist
+
+    def propagate(self, transforms10, commit=True):
+        """increment_age + propagate on the current maps."""
+        T10 = _f64(transforms10, (self.n_tracks, 4, 4))
+        call("tdk_sd_propagate", self._h, _p(T10), int(bool(commit)))
+
+    def update_depth(self, key_transforms_wf=None, commit=True, histogram=False):
+        """update_depth with the current maps as (age, prior depth, prior variance)."""
+        Tw = None if key_transforms_wf is None else _f64(key_transforms_wf, (self.n_tracks, 4, 4))
+        hist = np.zeros((self.n_tracks, 10), dtype=np.int64) if histogram else None
+        call("tdk_sd_update_depth", self._h, None if Tw is None else _p(Tw), int(bool(commit)),
+             None if hist is None else hist.ctypes.data_as(c_int64_p))
+        return hist
+
+    def export_dvo(self, batch):
+        """Fills `batch` (a DvoBatch with one pair per track) on the device."""
+        call("tdk_sd_export_dvo", self._h, batch._h)
+
+    def timing(self):
+        """dict(warp_ms, update_depth_ms, step_ms) of the last step (HIP events)."""
+        ms = np.empty(3)
+        call("tdk_sd_get_timing", self._h, _p(ms))
+        return dict(warp_ms=float(ms[0]), update_depth_ms=float(ms[1]), step_ms=float(ms[2]))
 
 
 # ---- bundle adjustment ------------------------------------------------------------------

@@ -253,6 +253,55 @@ def capture_pyramid(h, w, seed):
     return out
 
 
+def capture_vga_pyramid(seed=0):
+    """BASELINE configs[1] end to end: the reference's own PoseChangeEstimator
+    (tadataka/vo/dvo/__init__.py:114-150) at 640x480, n_coarse_to_fine=3,
+    layer_size_ratio=1.5, max_iter=20 on the seed-0 synthetic pair -- final pose,
+    the pose after every level and the number of PhotometricError evaluations per
+    level (= updates + 1).  Inputs are regenerated from the seed by the tests."""
+    import tadataka.vo.dvo as dvo
+    from tadataka.camera import CameraModel, CameraParameters
+    pair = synthetic.make_pair(480, 640, seed=seed)
+    cam = pair["cam"]
+    cm = CameraModel(CameraParameters(cam[0:2], cam[2:4]), distortion_model=None)
+    out = dict(cam=cam, omega_true=pair["omega"], t_true=pair["t"])
+    orig_err_cls = dvo.PhotometricError
+    orig_level = dvo._PoseChangeEstimator.__call__
+    for tag, aa in (("pyr", False), ("pyr_aa", True)):
+        ANTI_ALIASING[0] = aa
+        for wname in (None, "huber"):
+            counts, level_poses = [], []
+
+            class Err(orig_err_cls):
+                def __init__(self, *a, **k):
+                    super().__init__(*a, **k)
+                    counts.append(0)
+
+                def __call__(self, pose10):
+                    counts[-1] += 1
+                    return super().__call__(pose10)
+
+            def level_call(self, I0, D0, I1, pose10, weights=None):
+                pose = orig_level(self, I0, D0, I1, pose10, weights)
+                level_poses.append(np.concatenate([pose.rotation.as_rotvec(), pose.t]))
+                return pose
+
+            dvo.PhotometricError = Err
+            dvo._PoseChangeEstimator.__call__ = level_call
+            try:
+                est = dvo.PoseChangeEstimator(cm, cm, n_coarse_to_fine=3, max_iter=20)
+                pose = est(pair["I0"], pair["D0"], pair["I1"], wname)
+            finally:
+                dvo.PhotometricError = orig_err_cls
+                dvo._PoseChangeEstimator.__call__ = orig_level
+            out[f"{tag}_{wname}_rotvec"] = pose.rotation.as_rotvec()
+            out[f"{tag}_{wname}_t"] = pose.t
+            out[f"{tag}_{wname}_evals"] = np.array(counts, dtype=np.int64)        # coarse -> fine
+            out[f"{tag}_{wname}_level_poses"] = np.array(level_poses)             # coarse -> fine
+    ANTI_ALIASING[0] = False
+    return out
+
+
 def capture_pyref():
     """Outputs of the reference's pure-Python numerics on seeded inputs."""
     from tadataka.robust import weights as rw
@@ -326,6 +375,9 @@ def capture_ba(tp):
 def main():
     install_stubs()
     os.makedirs(HERE, exist_ok=True)
+    if "--only-vga-pyramid" in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "dvo_vga_pyramid.npz"), **capture_vga_pyramid())
+        return
     if "--only-pyramid" in sys.argv:
         pyr = capture_pyramid(120, 160, seed=4)
         for k in ("I0", "D0", "I1"):
@@ -348,6 +400,8 @@ def main():
     for k in ("I0", "D0", "I1"):
         pyr.pop(k)
     np.savez_compressed(os.path.join(HERE, "dvo_pyramid.npz"), **pyr)
+
+    np.savez_compressed(os.path.join(HERE, "dvo_vga_pyramid.npz"), **capture_vga_pyramid())
 
     np.savez_compressed(os.path.join(HERE, "pyref.npz"), **capture_pyref())
 
