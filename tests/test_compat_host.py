@@ -97,12 +97,20 @@ def test_out_of_scope_names_import_but_raise():
     from tadataka.dataset import NewTsukubaDataset
     from tadataka.feature import Matcher
     from tadataka.pose import estimate_pose_change
-    from tadataka.vo.semi_dense.regularization import regularize
+    from tadataka.vo.semi_dense.reference import make_reference_selector
     from tadataka.vo.semi_dense.flag import ResultFlag
-    for f in (lambda: NewTsukubaDataset("x"), Matcher, estimate_pose_change, regularize):
+    for f in (lambda: NewTsukubaDataset("x"), Matcher, estimate_pose_change, make_reference_selector):
         with pytest.raises(NotImplementedError):
             f()
     assert ResultFlag.NOT_PROCESSED == -9 and ResultFlag.SUCCESS == 0
+    # N4: fusion / regularize / HypothesisMap are real (they run on the device when called)
+    from tadataka.vo.semi_dense.fusion import fusion
+    from tadataka.vo.semi_dense.hypothesis import HypothesisMap
+    from tadataka.vo.semi_dense.regularization import regularize
+    h = HypothesisMap(np.full((2, 3), 0.5), np.ones((2, 3)))
+    assert h.shape == (2, 3) and np.allclose(h.depth_map, 2.0) and callable(fusion) and callable(regularize)
+    with pytest.raises(ValueError):
+        HypothesisMap(np.zeros((2, 3)), np.zeros((3, 2)))
 
 
 def test_rust_bindings_type_strictness():
