@@ -297,6 +297,15 @@ tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *viewp
                          tdk_ba **out);
 tdk_status tdk_ba_destroy(tdk_ba *h);
 tdk_status tdk_ba_error(tdk_ba *h, const double *poses, const double *points, double *sum_sq);
+/* The block sums of tdk_ba_block_reduce on the handle's graph, without atomics:
+ * bit-reproducible for any observation order.  Any output may be NULL. */
+tdk_status tdk_ba_block_sums(tdk_ba *h, const double *poses, const double *points, double *U,
+                             double *ea, double *V, double *eb, double *sum_sq);
+/* Per-kernel timing with HIP events on the library stream.  Index: 0 block reduce
+ * (Jacobians + per-pose sums), 1 error-only reduce, 2 per-point sums, 3 Schur
+ * complement, 4 back-substitution; launches[5] and total_ms[5] since enabling. */
+tdk_status tdk_ba_set_profiling(tdk_ba *h, int enabled);
+tdk_status tdk_ba_get_profile(tdk_ba *h, int64_t *launches, double *total_ms);
 tdk_status tdk_ba_step(tdk_ba *h, const double *poses, const double *points, double mu,
                        double *dposes, double *dpoints, double *sum_sq);
 /* The whole Levenberg-Marquardt loop of LocalBundleAdjustment.compute

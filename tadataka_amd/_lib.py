@@ -106,6 +106,9 @@ PROTOTYPES = {
     "tdk_ba_destroy": [_vp],
     "tdk_ba_error": [_vp, _d, _d, _d],
     "tdk_ba_step": [_vp, _d, _d, C.c_double, _d, _d, _d],
+    "tdk_ba_block_sums": [_vp, _d, _d, _d, _d, _d, _d, _d],
+    "tdk_ba_set_profiling": [_vp, _i],
+    "tdk_ba_get_profile": [_vp, c_int64_p, _d],
     "tdk_ba_solve": [_vp, _d, _d, _i, C.c_double, C.c_double, C.c_double, C.c_double, _d, C.POINTER(C.c_int)],
 }
 

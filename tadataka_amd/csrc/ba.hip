@@ -12,6 +12,7 @@
 // (d theta / d omega_k = (omega_k + 1e-16) / theta included).
 #include "tdk_math.h"
 #include "tdk_runtime.h"
+#include "tdk_wave.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -152,114 +153,133 @@ __global__ __launch_bounds__(kBlock) void k_ba_exp_so3(const double *__restrict_
     }
 }
 
-// Fused residual + Jacobians + block sums.  grid = (chunks, n_poses): block
-// (c, j) walks observation chunk c and accumulates, in registers, only the
-// observations of viewpoint j -- so the per-pose sums U_j / ea_j need no atomics
-// and are bit-reproducible for any observation order; a chunk that holds no
-// observation of j (the common case for the viewpoint-major order np.where
-// produces) is skipped after two index reads.  The per-point sums V_i / eb_i are
-// either scattered with f64 atomics (stateless entry point: no observation
-// lists) or, for a tdk_ba handle, left to k_ba_point_sums: this kernel then only
-// stores B_ij and the residual per observation (Bobs, structure of arrays
-// [8][n]) and W_ij = A^T B (Wobs, [18][n]).
-__global__ __launch_bounds__(kBlock) void k_ba_block_reduce(const double *__restrict__ poses,
-                                                            const double *__restrict__ points,
-                                                            const double *__restrict__ x_true,
-                                                            const int64_t *__restrict__ vp,
-                                                            const int64_t *__restrict__ pt, int64_t n,
-                                                            int64_t chunk, int sorted_by_viewpoint,
-                                                            double *__restrict__ V, double *__restrict__ eb,
-                                                            double *__restrict__ partials,
-                                                            double *__restrict__ Wobs,
-                                                            double *__restrict__ Bobs) {
-    const int64_t j = blockIdx.y;
-    const int64_t start = blockIdx.x * chunk;
-    const int64_t end = min(n, start + chunk);
+// Fused residual + Jacobians + block sums over per-pose SEGMENTS.  The
+// observations are listed by viewpoint once per graph (CSR: obs_sorted, or the
+// identity for the viewpoint-major order np.where produces); every block takes
+// one segment of at most `seg_len` observations of ONE pose, so every block
+// works, the pose lives in SGPRs and the per-pose sums U_j / ea_j need no
+// atomics and are bit-reproducible for any observation order: the 28
+// accumulators go through the transposed wave reduction, LDS across the four
+// waves, one partial per block; the last block of a pose to finish (ticket)
+// adds that pose's partials in segment order.
+//   MODE_ATOMIC_V : V_i / eb_i scattered with f64 atomics (stateless entry point)
+//   MODE_STORE_B  : B_ij and the residual stored per observation (Bobs, [8][n]) for
+//                   k_ba_point_sums
+//   MODE_STORE_BW : ... and W_ij = A^T B (Wobs, [18][n]) for the Schur complement
+//   MODE_ERROR    : sum ||x_true - x_pred||^2 only -- no Jacobians (the damping
+//                   trials of the Levenberg-Marquardt loop, tdk_ba_error)
+enum { MODE_ATOMIC_V = 0, MODE_STORE_B = 1, MODE_STORE_BW = 2, MODE_ERROR = 3 };
+
+struct BaSeg {
+    int pose, start, end, slot;   // [start, end) of the pose-sorted list; slot = index among the pose's segments
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_ba_reduce_seg(const double *__restrict__ poses,
+                                                          const double *__restrict__ points,
+                                                          const double *__restrict__ x_true,
+                                                          const int *__restrict__ obs_sorted,
+                                                          const int *__restrict__ pt32,
+                                                          const BaSeg *__restrict__ segs,
+                                                          const int *__restrict__ seg_ptr, int64_t n,
+                                                          double *__restrict__ V, double *__restrict__ eb,
+                                                          double *__restrict__ Wobs, double *__restrict__ Bobs,
+                                                          double *__restrict__ partials, int *__restrict__ ticket,
+                                                          double *__restrict__ U, double *__restrict__ ea,
+                                                          double *__restrict__ err_per_pose) {
+    const BaSeg sg = segs[blockIdx.x];
+    const int j = sg.pose;
     double acc[kPoseAcc];
 #pragma unroll
     for (int i = 0; i < kPoseAcc; i++) acc[i] = 0.0;
-
-    bool skip = false;
-    if (sorted_by_viewpoint) skip = (vp[start] > j) || (vp[end - 1] < j);
-    if (!skip) {
-        double pose[6];
+    double pose[6];
 #pragma unroll
-        for (int i = 0; i < 6; i++) pose[i] = poses[6 * j + i];
-        for (int64_t k = start + threadIdx.x; k < end; k += kBlock) {
-            if (vp[k] != j) continue;
-            int64_t ip = pt[k];
-            double p[3] = {points[3 * ip], points[3 * ip + 1], points[3 * ip + 2]};
-            double x[2], A[12], B[6];
-            project_observation<true>(pose, p, x, A, B);
-            double e0 = x_true[2 * k] - x[0], e1 = x_true[2 * k + 1] - x[1];
-            acc[27] += e0 * e0 + e1 * e1;
-            int m = 0;
+    for (int i = 0; i < 6; i++) pose[i] = poses[6 * j + i];
+    for (int q = sg.start + (int)threadIdx.x; q < sg.end; q += kBlock) {
+        const int k = obs_sorted ? obs_sorted[q] : q;
+        const int ip = pt32[k];
+        const double p[3] = {points[3 * (int64_t)ip], points[3 * (int64_t)ip + 1], points[3 * (int64_t)ip + 2]};
+        double x[2], A[12], B[6];
+        if (MODE == MODE_ERROR) project_observation<false>(pose, p, x, A, B);
+        else project_observation<true>(pose, p, x, A, B);
+        const double e0 = x_true[2 * (int64_t)k] - x[0], e1 = x_true[2 * (int64_t)k + 1] - x[1];
+        acc[27] += e0 * e0 + e1 * e1;
+        if (MODE == MODE_ERROR) continue;
+        int m = 0;
 #pragma unroll
-            for (int a = 0; a < 6; a++) {
+        for (int a = 0; a < 6; a++) {
 #pragma unroll
-                for (int b = a; b < 6; b++) acc[m++] += A[a] * A[b] + A[6 + a] * A[6 + b];
-                acc[21 + a] += A[a] * e0 + A[6 + a] * e1;
+            for (int b = a; b < 6; b++) acc[m++] += A[a] * A[b] + A[6 + a] * A[6 + b];
+            acc[21 + a] += A[a] * e0 + A[6 + a] * e1;
+        }
+        if (MODE == MODE_ATOMIC_V) {
+            m = 0;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+#pragma unroll
+                for (int b = a; b < 3; b++) atomicAdd(&V[6 * (int64_t)ip + m++], B[a] * B[b] + B[3 + a] * B[3 + b]);
+                atomicAdd(&eb[3 * (int64_t)ip + a], B[a] * e0 + B[3 + a] * e1);
             }
-            if (V != nullptr) {
-                m = 0;
+        }
+        if (MODE == MODE_STORE_B || MODE == MODE_STORE_BW) {
 #pragma unroll
-                for (int a = 0; a < 3; a++) {
+            for (int a = 0; a < 6; a++) Bobs[a * n + k] = B[a];
+            Bobs[6 * n + k] = e0;
+            Bobs[7 * n + k] = e1;
+        }
+        if (MODE == MODE_STORE_BW) {   // W_ij = A^T B (6x3), kept for the Schur complement
 #pragma unroll
-                    for (int b = a; b < 3; b++) atomicAdd(&V[6 * ip + m++], B[a] * B[b] + B[3 + a] * B[3 + b]);
-                    atomicAdd(&eb[3 * ip + a], B[a] * e0 + B[3 + a] * e1);
-                }
-            }
-            if (Bobs != nullptr) {
+            for (int a = 0; a < 6; a++)
 #pragma unroll
-                for (int a = 0; a < 6; a++) Bobs[a * n + k] = B[a];
-                Bobs[6 * n + k] = e0;
-                Bobs[7 * n + k] = e1;
-            }
-            if (Wobs != nullptr) {   // W_ij = A^T B (6x3), kept for the Schur complement
-#pragma unroll
-                for (int a = 0; a < 6; a++)
-#pragma unroll
-                    for (int b = 0; b < 3; b++) Wobs[(3 * a + b) * n + k] = A[a] * B[b] + A[6 + a] * B[3 + b];
-            }
+                for (int b = 0; b < 3; b++) Wobs[(3 * a + b) * n + k] = A[a] * B[b] + A[6 + a] * B[3 + b];
         }
     }
     __shared__ double red[kBlock / 64][kPoseAccPad];
+    __shared__ int is_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (MODE == MODE_ERROR) {
+        double v = acc[27];
 #pragma unroll
-    for (int i = 0; i < kPoseAcc; i++) {
-        double s = acc[i];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane == 0) red[wave][i] = s;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][27] = v;
+    } else {
+        const double v = tdk::wave_sum_transposed(acc);
+        if ((lane & 1) == 0) red[wave][lane >> 1] = v;
     }
     __syncthreads();
-    if (threadIdx.x < kPoseAcc) {
-        double s = 0.0;
+    const int first = seg_ptr[j], nseg = seg_ptr[j + 1] - first;
+    const int t0 = MODE == MODE_ERROR ? 27 : 0;
+    if ((int)threadIdx.x >= t0 && threadIdx.x < kPoseAcc) {
+        double v = 0.0;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; w++) s += red[w][threadIdx.x];
-        partials[((int64_t)j * gridDim.x + blockIdx.x) * kPoseAccPad + threadIdx.x] = s;
+        for (int w = 0; w < kBlock / 64; w++) v += red[w][threadIdx.x];
+        partials[(int64_t)(first + sg.slot) * kPoseAccPad + threadIdx.x] = v;
     }
-}
-
-__global__ __launch_bounds__(kBlock) void k_ba_finish(const double *__restrict__ partials, int nchunks,
-                                                      double *__restrict__ U, double *__restrict__ ea,
-                                                      double *__restrict__ err_per_pose) {
-    const int j = blockIdx.x;
-    __shared__ double red[kBlock / 32][kPoseAccPad];
-    const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
-    double s = 0.0;
-    if (k < kPoseAcc)
-        for (int b = g; b < nchunks; b += kBlock / 32) s += partials[((int64_t)j * nchunks + b) * kPoseAccPad + k];
-    red[g][k] = s;
+    // the last block of this pose adds the pose's partials in segment order
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(&ticket[j], 1) == nseg - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    const int kk = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double v = 0.0;
+    if (kk >= t0 && kk < kPoseAcc)
+        for (int b = g; b < nseg; b += kBlock / 32) v += __builtin_nontemporal_load(&partials[(int64_t)(first + b) * kPoseAccPad + kk]);
+    __shared__ double fin[kBlock / 32][kPoseAccPad];
+    fin[g][kk] = v;
     __syncthreads();
     if (threadIdx.x < kPoseAcc) {
         double t = 0.0;
 #pragma unroll
-        for (int i = 0; i < kBlock / 32; i++) t += red[i][threadIdx.x];
-        if (threadIdx.x < 21) U[21 * j + threadIdx.x] = t;
-        else if (threadIdx.x < 27) ea[6 * j + threadIdx.x - 21] = t;
-        else err_per_pose[j] = t;
+        for (int i = 0; i < kBlock / 32; i++) t += fin[i][threadIdx.x];
+        if (threadIdx.x == 27) err_per_pose[j] = t;
+        else if (MODE != MODE_ERROR) {
+            if (threadIdx.x < 21) U[21 * j + threadIdx.x] = t;
+            else ea[6 * j + threadIdx.x - 21] = t;
+        }
     }
+    if (threadIdx.x == 0) ticket[j] = 0;   // ready for the next launch
 }
 
 // ---------------------------------------------------------------------------
@@ -551,6 +571,55 @@ tdk_status check_indices(const int64_t *vp, const int64_t *pt, int64_t n, int64_
     return TDK_OK;
 }
 
+// Observation lists by viewpoint and their split into block-sized segments (see k_ba_reduce_seg).
+struct BaPlan {
+    std::vector<int> obs_sorted;   // empty: the observations already are viewpoint-major
+    std::vector<int> pt32;
+    std::vector<BaSeg> segs;
+    std::vector<int> seg_ptr;      // [n_poses + 1]
+};
+
+void ba_make_plan(const int64_t *vp, const int64_t *pt, int64_t n, int64_t n_poses, bool sorted, BaPlan *plan) {
+    plan->pt32.resize((size_t)n);
+    for (int64_t k = 0; k < n; k++) plan->pt32[(size_t)k] = (int)pt[k];
+    std::vector<int64_t> pose_ptr((size_t)n_poses + 1, 0);
+    for (int64_t k = 0; k < n; k++) pose_ptr[(size_t)vp[k] + 1]++;
+    for (int64_t j = 0; j < n_poses; j++) pose_ptr[(size_t)j + 1] += pose_ptr[(size_t)j];
+    plan->obs_sorted.clear();
+    if (!sorted) {   // counting sort by viewpoint, observation order kept inside a pose
+        plan->obs_sorted.resize((size_t)n);
+        std::vector<int64_t> cursor(pose_ptr.begin(), pose_ptr.end() - 1);
+        for (int64_t k = 0; k < n; k++) plan->obs_sorted[(size_t)cursor[(size_t)vp[k]]++] = (int)k;
+    }
+    // aim at >= ~1024 blocks (4 per CU) without going below one observation per thread
+    int64_t len = (n / 1024 + kBlock - 1) / kBlock * kBlock;
+    if (len < kBlock) len = kBlock;
+    if (len > 8 * kBlock) len = 8 * kBlock;
+    plan->segs.clear();
+    plan->seg_ptr.assign((size_t)n_poses + 1, 0);
+    for (int64_t j = 0; j < n_poses; j++) {
+        const int64_t b0 = pose_ptr[(size_t)j], b1 = pose_ptr[(size_t)j + 1];
+        int slot = 0;
+        // a pose without observations still gets one (empty) segment: its block writes the zeros
+        for (int64_t q = b0; q < b1 || slot == 0; q += len) {
+            BaSeg sg;
+            sg.pose = (int)j; sg.start = (int)q; sg.end = (int)(q + len < b1 ? q + len : b1); sg.slot = slot++;
+            plan->segs.push_back(sg);
+        }
+        plan->seg_ptr[(size_t)j + 1] = (int)plan->segs.size();
+    }
+}
+
+template <int MODE>
+void launch_reduce_seg(const double *d_poses, const double *d_points, const double *d_xt, const int *d_obs_sorted,
+                       const int *d_pt32, const BaSeg *d_segs, const int *d_seg_ptr, int n_segs, int64_t n,
+                       double *d_V, double *d_eb, double *d_W, double *d_Be, double *d_part, int *d_ticket,
+                       double *d_U, double *d_ea, double *d_err, hipStream_t stream) {
+    k_ba_reduce_seg<MODE><<<(unsigned)n_segs, kBlock, 0, stream>>>(d_poses, d_points, d_xt, d_obs_sorted, d_pt32, d_segs,
+                                                                   d_seg_ptr, n, d_V, d_eb, d_W, d_Be, d_part,
+                                                                   d_ticket, d_U, d_ea, d_err);
+}
+
 }  // namespace
 
 extern "C" {
@@ -598,41 +667,36 @@ tdk_status tdk_ba_block_reduce(const double *poses, int64_t n_poses, const doubl
                                const double *x_true, const int64_t *vp, const int64_t *pt, int64_t n, double *U,
                                double *ea, double *V, double *eb, double *err) {
     TDK_REQUIRE(n >= 0 && n_poses >= 1 && n_points >= 1 && n_poses <= 65535, "bad sizes");
+    TDK_REQUIRE(n < (1ll << 31) && n_points < (1ll << 31), "more than 2^31 observations or points");
     TDK_REQUIRE(poses && points && U && ea && V && eb && err && (n == 0 || (x_true && vp && pt)), "null pointer");
     int sorted = 0;
     TDK_TRY(check_indices(vp, pt, n, n_poses, n_points, &sorted));
-    void *d_poses, *d_points, *d_xt, *d_vp, *d_pt, *d_U, *d_ea, *d_V, *d_eb, *d_part, *d_err;
+    BaPlan plan;
+    ba_make_plan(vp, pt, n, n_poses, sorted != 0, &plan);
+    void *d_poses, *d_points, *d_xt, *d_pt, *d_U, *d_ea, *d_V, *d_eb, *d_part, *d_err, *d_segs, *d_sptr, *d_tick;
+    void *d_sorted = nullptr;
     TDK_TRY(h2d(0, poses, (size_t)n_poses * 48, &d_poses));
     TDK_TRY(h2d(1, points, (size_t)n_points * 24, &d_points));
     TDK_TRY(h2d(2, x_true, (size_t)n * 16, &d_xt));
-    TDK_TRY(h2d(3, vp, (size_t)n * 8, &d_vp));
-    TDK_TRY(h2d(4, pt, (size_t)n * 8, &d_pt));
+    TDK_TRY(h2d(3, plan.pt32.data(), (size_t)n * 4, &d_pt));
+    if (!plan.obs_sorted.empty()) TDK_TRY(h2d(4, plan.obs_sorted.data(), (size_t)n * 4, &d_sorted));
     TDK_TRY(tdk::scratch(5, (size_t)n_poses * 21 * 8, &d_U));
     TDK_TRY(tdk::scratch(6, (size_t)n_poses * 6 * 8, &d_ea));
     TDK_TRY(tdk::scratch(7, (size_t)n_points * 6 * 8, &d_V));
     TDK_TRY(tdk::scratch(8, (size_t)n_points * 3 * 8, &d_eb));
+    TDK_TRY(tdk::scratch(9, plan.segs.size() * kPoseAccPad * 8, &d_part));
     TDK_TRY(tdk::scratch(10, (size_t)n_poses * 8, &d_err));
-    int64_t chunk = 2048;
-    int64_t nchunks = n > 0 ? (n + chunk - 1) / chunk : 1;
-    if (nchunks > 4096) {
-        nchunks = 4096;
-        chunk = (n + nchunks - 1) / nchunks;
-        nchunks = (n + chunk - 1) / chunk;
-    }
-    TDK_TRY(tdk::scratch(9, (size_t)n_poses * nchunks * kPoseAccPad * 8, &d_part));
+    TDK_TRY(h2d(11, plan.segs.data(), plan.segs.size() * sizeof(BaSeg), &d_segs));
+    TDK_TRY(h2d(12, plan.seg_ptr.data(), plan.seg_ptr.size() * sizeof(int), &d_sptr));
+    TDK_TRY(tdk::scratch(13, (size_t)n_poses * sizeof(int), &d_tick));
+    TDK_HIP(hipMemsetAsync(d_tick, 0, (size_t)n_poses * sizeof(int), tdk::stream()));
     TDK_HIP(hipMemsetAsync(d_V, 0, (size_t)n_points * 6 * 8, tdk::stream()));
     TDK_HIP(hipMemsetAsync(d_eb, 0, (size_t)n_points * 3 * 8, tdk::stream()));
-    if (n > 0) {
-        dim3 grid((unsigned)nchunks, (unsigned)n_poses);
-        k_ba_block_reduce<<<grid, kBlock, 0, tdk::stream()>>>(
-            (const double *)d_poses, (const double *)d_points, (const double *)d_xt, (const int64_t *)d_vp,
-            (const int64_t *)d_pt, n, chunk, sorted, (double *)d_V, (double *)d_eb, (double *)d_part, nullptr, nullptr);
-        TDK_LAUNCH_CHECK();
-    } else {
-        TDK_HIP(hipMemsetAsync(d_part, 0, (size_t)n_poses * nchunks * kPoseAccPad * 8, tdk::stream()));
-    }
-    k_ba_finish<<<(unsigned)n_poses, kBlock, 0, tdk::stream()>>>((const double *)d_part, (int)nchunks, (double *)d_U,
-                                                                 (double *)d_ea, (double *)d_err);
+    launch_reduce_seg<MODE_ATOMIC_V>((const double *)d_poses, (const double *)d_points, (const double *)d_xt,
+                                     (const int *)d_sorted, (const int *)d_pt, (const BaSeg *)d_segs,
+                                     (const int *)d_sptr, (int)plan.segs.size(), n, (double *)d_V, (double *)d_eb,
+                                     nullptr, nullptr, (double *)d_part, (int *)d_tick, (double *)d_U,
+                                     (double *)d_ea, (double *)d_err, tdk::stream());
     TDK_LAUNCH_CHECK();
     TDK_HIP(hipMemcpyAsync(U, d_U, (size_t)n_poses * 21 * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(ea, d_ea, (size_t)n_poses * 6 * 8, hipMemcpyDeviceToHost, tdk::stream()));
@@ -641,7 +705,7 @@ tdk_status tdk_ba_block_reduce(const double *poses, int64_t n_poses, const doubl
     void *stage;
     TDK_TRY(tdk::pinned(3, (size_t)n_poses * 8, &stage));
     TDK_HIP(hipMemcpyAsync(stage, d_err, (size_t)n_poses * 8, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));   // `plan` must outlive the H2D copies
     double e = 0.0;
     for (int64_t j = 0; j < n_poses; j++) e += ((const double *)stage)[j];
     *err = e;
@@ -650,12 +714,23 @@ tdk_status tdk_ba_block_reduce(const double *poses, int64_t n_poses, const doubl
 
 }  // extern "C"
 
+enum { BA_K_REDUCE = 0, BA_K_ERROR = 1, BA_K_POINT_SUMS = 2, BA_K_SCHUR = 3, BA_K_BACKSUB = 4, BA_K_COUNT = 5 };
+
 struct tdk_ba {
     int64_t n_poses, n_points, n;
     int sorted;
-    int64_t chunk, nchunks;
+    int n_segs;
+    int *d_obs_sorted, *d_pt32, *d_seg_ptr, *d_ticket;   // pose-sorted observation list (NULL: identity), segments
+    BaSeg *d_segs;
     double *d_poses, *d_points, *d_xt;
     int64_t *d_vp, *d_pt, *d_row_ptr, *d_obs;
+    // per-kernel timing with HIP events (tdk_ba_set_profiling)
+    bool profiling;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<int> ev_kind;
+    size_t ev_used;
+    double prof_ms[BA_K_COUNT];
+    int64_t prof_launches[BA_K_COUNT];
     double *d_U, *d_ea, *d_V, *d_eb, *d_part, *d_err, *d_W, *d_Vinv, *d_S, *d_e, *d_da, *d_db;
     double *d_cposes, *d_cpoints;   // candidate parameters of tdk_ba_solve
     double *d_Be;       // [8][n]: B_ij (2x3) and the residual of every observation
@@ -667,39 +742,83 @@ struct tdk_ba {
 
 namespace {
 
-// residuals, per-pose block sums (and, for a step, B / W per observation and the
-// per-point sums) at parameters that are already on the device
-tdk_status ba_reduce_dev(tdk_ba *h, const double *d_poses, const double *d_points, bool for_step, double *err) {
-    dim3 grid((unsigned)h->nchunks, (unsigned)h->n_poses);
-    k_ba_block_reduce<<<grid, kBlock, 0, tdk::stream()>>>(d_poses, d_points, h->d_xt, h->d_vp, h->d_pt, h->n,
-                                                          h->chunk, h->sorted, nullptr, nullptr, h->d_part,
-                                                          for_step ? h->d_W : nullptr, for_step ? h->d_Be : nullptr);
-    TDK_LAUNCH_CHECK();
-    k_ba_finish<<<(unsigned)h->n_poses, kBlock, 0, tdk::stream()>>>(h->d_part, (int)h->nchunks, h->d_U, h->d_ea,
-                                                                    h->d_err);
-    TDK_LAUNCH_CHECK();
-    if (for_step) {
+// event pair around the launches of one kernel family, only when profiling is on
+struct BaTimer {
+    tdk_ba *h;
+    hipEvent_t e1;
+    BaTimer(tdk_ba *h_, int kind) : h(h_), e1(nullptr) {
+        if (!h->profiling) return;
+        while (h->ev_pool.size() < h->ev_used + 2) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            h->ev_pool.push_back(e);
+            h->ev_kind.push_back(0);
+        }
+        hipEvent_t e0 = h->ev_pool[h->ev_used];
+        e1 = h->ev_pool[h->ev_used + 1];
+        h->ev_kind[h->ev_used] = kind;
+        h->ev_used += 2;
+        (void)hipEventRecord(e0, tdk::stream());
+    }
+    ~BaTimer() {
+        if (e1) (void)hipEventRecord(e1, tdk::stream());
+    }
+};
+
+// after a stream synchronisation: fold the recorded event pairs into the per-kernel sums
+void ba_collect_profile(tdk_ba *h) {
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev_pool[i], h->ev_pool[i + 1]) != hipSuccess) continue;
+        h->prof_ms[h->ev_kind[i]] += ms;
+        h->prof_launches[h->ev_kind[i]] += 1;
+    }
+    h->ev_used = 0;
+}
+
+// what a reduce computes at parameters that are already on the device
+enum { REDUCE_ERROR = 0, REDUCE_SUMS = 1, REDUCE_STEP = 2 };
+//   REDUCE_ERROR: the residual sum only (damping trials)
+//   REDUCE_SUMS : per-pose and per-point block sums U, ea, V, eb
+//   REDUCE_STEP : ... and W_ij per observation for the Schur complement
+tdk_status ba_reduce_dev(tdk_ba *h, const double *d_poses, const double *d_points, int what, double *err) {
+    {
+        BaTimer t(h, what == REDUCE_ERROR ? BA_K_ERROR : BA_K_REDUCE);
+#define BA_LAUNCH(MODE)                                                                                          \
+    launch_reduce_seg<MODE>(d_poses, d_points, h->d_xt, h->d_obs_sorted, h->d_pt32, h->d_segs, h->d_seg_ptr,      \
+                            h->n_segs, h->n, nullptr, nullptr, h->d_W, h->d_Be, h->d_part, h->d_ticket, h->d_U, \
+                            h->d_ea, h->d_err, tdk::stream())
+        if (what == REDUCE_ERROR) BA_LAUNCH(MODE_ERROR);
+        else if (what == REDUCE_SUMS) BA_LAUNCH(MODE_STORE_B);
+        else BA_LAUNCH(MODE_STORE_BW);
+#undef BA_LAUNCH
+        TDK_LAUNCH_CHECK();
+    }
+    if (what != REDUCE_ERROR) {
+        BaTimer t(h, BA_K_POINT_SUMS);
         k_ba_point_sums<<<grid_for(h->n_points), kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_Be, h->n,
                                                                              h->n_points, h->d_V, h->d_eb);
         TDK_LAUNCH_CHECK();
     }
-    std::vector<double> e((size_t)h->n_poses);
-    TDK_HIP(hipMemcpyAsync(e.data(), h->d_err, (size_t)h->n_poses * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    void *stage;
+    TDK_TRY(tdk::pinned(3, (size_t)h->n_poses * 8, &stage));
+    TDK_HIP(hipMemcpyAsync(stage, h->d_err, (size_t)h->n_poses * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
-    double s = 0.0;
-    for (double v : e) s += v;
-    *err = s;
+    if (h->profiling) ba_collect_profile(h);
+    double sum = 0.0;
+    for (int64_t j = 0; j < h->n_poses; j++) sum += ((const double *)stage)[j];
+    *err = sum;
     return TDK_OK;
 }
 
-tdk_status ba_reduce(tdk_ba *h, const double *poses, const double *points, bool for_step, double *err) {
+tdk_status ba_reduce(tdk_ba *h, const double *poses, const double *points, int what, double *err) {
     TDK_HIP(hipMemcpyAsync(h->d_poses, poses, (size_t)h->n_poses * 48, hipMemcpyHostToDevice, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(h->d_points, points, (size_t)h->n_points * 24, hipMemcpyHostToDevice, tdk::stream()));
-    return ba_reduce_dev(h, h->d_poses, h->d_points, for_step, err);
+    return ba_reduce_dev(h, h->d_poses, h->d_points, what, err);
 }
 
 // Levenberg-Marquardt update for damping mu from the sums of the last
-// ba_reduce_dev(..., for_step = true): V*^-1, Schur complement, dense solve of the
+// ba_reduce_dev(..., REDUCE_STEP): V*^-1, Schur complement, dense solve of the
 // reduced camera system on the host, back-substitution.  U / ea are the host
 // copies of the per-pose sums of THAT reduce (an error evaluation at candidate
 // parameters in between overwrites the device ones).  Leaves dpoints in h->d_db.
@@ -711,6 +830,7 @@ tdk_status ba_update_dev(tdk_ba *h, double mu, const std::vector<double> &U, con
     TDK_LAUNCH_CHECK();
     TDK_HIP(hipMemsetAsync(h->d_S, 0, (size_t)dim * dim * 8, tdk::stream()));
     TDK_HIP(hipMemsetAsync(h->d_e, 0, (size_t)dim * 8, tdk::stream()));
+    BaTimer *schur_timer = new BaTimer(h, BA_K_SCHUR);
     if (h->d_obs_at != nullptr) {
         const int pairs = (int)(h->n_poses * (h->n_poses + 1) / 2);
         dim3 grid((unsigned)h->npchunks, (unsigned)pairs);
@@ -730,6 +850,7 @@ tdk_status ba_update_dev(tdk_ba *h, double mu, const std::vector<double> &U, con
                                                                 h->d_eb, h->n, h->n_points, dim, h->d_S, h->d_e);
         }
     }
+    delete schur_timer;
     TDK_LAUNCH_CHECK();
     std::vector<double> S((size_t)dim * dim), e((size_t)dim);
     TDK_HIP(hipMemcpyAsync(S.data(), h->d_S, S.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
@@ -757,8 +878,11 @@ tdk_status ba_update_dev(tdk_ba *h, double mu, const std::vector<double> &U, con
     }
     dposes = e;
     TDK_HIP(hipMemcpyAsync(h->d_da, dposes.data(), (size_t)dim * 8, hipMemcpyHostToDevice, tdk::stream()));
-    k_ba_backsub<<<gp, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv, h->d_eb,
-                                                   h->d_da, h->n, h->n_points, h->d_db);
+    {
+        BaTimer t(h, BA_K_BACKSUB);
+        k_ba_backsub<<<gp, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv, h->d_eb,
+                                                       h->d_da, h->n, h->n_points, h->d_db);
+    }
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
@@ -787,18 +911,17 @@ tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *vp, c
                          const double *x_true, int64_t n, tdk_ba **out) {
     TDK_REQUIRE(out && vp && pt && x_true, "null pointer");
     TDK_REQUIRE(n >= 1 && n_poses >= 1 && n_points >= 1 && n_poses <= 2048, "bad sizes");
+    TDK_REQUIRE(n < (1ll << 31) && n_points < (1ll << 31), "more than 2^31 observations or points");
     int sorted = 0;
     TDK_TRY(check_indices(vp, pt, n, n_poses, n_points, &sorted));
     TDK_TRY(tdk::ensure_device());
     tdk_ba *h = new tdk_ba();
     h->n_poses = n_poses; h->n_points = n_points; h->n = n; h->sorted = sorted;
-    h->chunk = 2048;   // (512 was measured slower: the per-block reduction dominates small chunks)
-    h->nchunks = (n + h->chunk - 1) / h->chunk;
-    if (h->nchunks > 4096) {
-        h->nchunks = 4096;
-        h->chunk = (n + h->nchunks - 1) / h->nchunks;
-        h->nchunks = (n + h->chunk - 1) / h->chunk;
-    }
+    h->profiling = false; h->ev_used = 0;
+    for (int k = 0; k < BA_K_COUNT; k++) { h->prof_ms[k] = 0.0; h->prof_launches[k] = 0; }
+    BaPlan plan;
+    ba_make_plan(vp, pt, n, n_poses, sorted != 0, &plan);
+    h->n_segs = (int)plan.segs.size();
     // observation lists per point (CSR), in increasing observation index
     std::vector<int64_t> row_ptr((size_t)n_points + 1, 0), obs((size_t)n);
     for (int64_t k = 0; k < n; k++) row_ptr[(size_t)pt[k] + 1]++;
@@ -819,7 +942,20 @@ tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *vp, c
     TDK_HIP(hipMalloc(&h->d_ea, (size_t)n_poses * 6 * 8));
     TDK_HIP(hipMalloc(&h->d_V, (size_t)n_points * 48));
     TDK_HIP(hipMalloc(&h->d_eb, (size_t)n_points * 24));
-    TDK_HIP(hipMalloc(&h->d_part, (size_t)n_poses * h->nchunks * kPoseAccPad * 8));
+    TDK_HIP(hipMalloc(&h->d_part, (size_t)h->n_segs * kPoseAccPad * 8));
+    TDK_HIP(hipMalloc(&h->d_pt32, (size_t)n * sizeof(int)));
+    TDK_HIP(hipMalloc(&h->d_segs, plan.segs.size() * sizeof(BaSeg)));
+    TDK_HIP(hipMalloc(&h->d_seg_ptr, plan.seg_ptr.size() * sizeof(int)));
+    TDK_HIP(hipMalloc(&h->d_ticket, (size_t)n_poses * sizeof(int)));
+    h->d_obs_sorted = nullptr;
+    if (!plan.obs_sorted.empty()) {
+        TDK_HIP(hipMalloc(&h->d_obs_sorted, (size_t)n * sizeof(int)));
+        TDK_HIP(hipMemcpy(h->d_obs_sorted, plan.obs_sorted.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    }
+    TDK_HIP(hipMemcpy(h->d_pt32, plan.pt32.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice));
+    TDK_HIP(hipMemcpy(h->d_segs, plan.segs.data(), plan.segs.size() * sizeof(BaSeg), hipMemcpyHostToDevice));
+    TDK_HIP(hipMemcpy(h->d_seg_ptr, plan.seg_ptr.data(), plan.seg_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    TDK_HIP(hipMemset(h->d_ticket, 0, (size_t)n_poses * sizeof(int)));
     TDK_HIP(hipMalloc(&h->d_err, (size_t)n_poses * 8));
     TDK_HIP(hipMalloc(&h->d_W, (size_t)n * 18 * 8));
     TDK_HIP(hipMalloc(&h->d_Vinv, (size_t)n_points * 48));
@@ -867,22 +1003,62 @@ tdk_status tdk_ba_destroy(tdk_ba *h) {
     (void)hipStreamSynchronize(tdk::stream());
     void *ptrs[] = {h->d_poses, h->d_points, h->d_xt, h->d_vp, h->d_pt, h->d_row_ptr, h->d_obs, h->d_U, h->d_ea,
                     h->d_V, h->d_eb, h->d_part, h->d_err, h->d_W, h->d_Vinv, h->d_S, h->d_e, h->d_da, h->d_db,
-                    h->d_Be, h->d_obs_at, h->d_spart, h->d_cposes, h->d_cpoints};
+                    h->d_Be, h->d_obs_at, h->d_spart, h->d_cposes, h->d_cpoints, h->d_obs_sorted, h->d_pt32,
+                    h->d_segs, h->d_seg_ptr, h->d_ticket};
     for (void *p : ptrs) (void)hipFree(p);
+    for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
     return TDK_OK;
 }
 
 tdk_status tdk_ba_error(tdk_ba *h, const double *poses, const double *points, double *sum_sq) {
     TDK_REQUIRE(h && poses && points && sum_sq, "null pointer");
-    return ba_reduce(h, poses, points, false, sum_sq);
+    return ba_reduce(h, poses, points, REDUCE_ERROR, sum_sq);
+}
+
+tdk_status tdk_ba_block_sums(tdk_ba *h, const double *poses, const double *points, double *U, double *ea,
+                             double *V, double *eb, double *sum_sq) {
+    TDK_REQUIRE(h && poses && points, "null pointer");
+    double err = 0.0;
+    TDK_TRY(ba_reduce(h, poses, points, REDUCE_SUMS, &err));
+    if (sum_sq) *sum_sq = err;
+    if (U) TDK_HIP(hipMemcpyAsync(U, h->d_U, (size_t)h->n_poses * 21 * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    if (ea) TDK_HIP(hipMemcpyAsync(ea, h->d_ea, (size_t)h->n_poses * 6 * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    // the per-point sums live as structure of arrays on the device ([6][Q], [3][Q])
+    if (V || eb) {
+        const size_t Q = (size_t)h->n_points;
+        std::vector<double> soa(Q * 9);
+        TDK_HIP(hipMemcpyAsync(soa.data(), h->d_V, Q * 48, hipMemcpyDeviceToHost, tdk::stream()));
+        TDK_HIP(hipMemcpyAsync(soa.data() + 6 * Q, h->d_eb, Q * 24, hipMemcpyDeviceToHost, tdk::stream()));
+        TDK_HIP(hipStreamSynchronize(tdk::stream()));
+        for (size_t i = 0; i < Q; i++) {
+            if (V) for (int m = 0; m < 6; m++) V[6 * i + m] = soa[(size_t)m * Q + i];
+            if (eb) for (int a = 0; a < 3; a++) eb[3 * i + a] = soa[(6 + (size_t)a) * Q + i];
+        }
+    }
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    return TDK_OK;
+}
+
+tdk_status tdk_ba_set_profiling(tdk_ba *h, int enabled) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    h->profiling = enabled != 0;
+    h->ev_used = 0;
+    for (int k = 0; k < BA_K_COUNT; k++) { h->prof_ms[k] = 0.0; h->prof_launches[k] = 0; }
+    return TDK_OK;
+}
+
+tdk_status tdk_ba_get_profile(tdk_ba *h, int64_t *launches, double *total_ms) {
+    TDK_REQUIRE(h && launches && total_ms, "null pointer");
+    for (int k = 0; k < BA_K_COUNT; k++) { launches[k] = h->prof_launches[k]; total_ms[k] = h->prof_ms[k]; }
+    return TDK_OK;
 }
 
 tdk_status tdk_ba_step(tdk_ba *h, const double *poses, const double *points, double mu, double *dposes,
                        double *dpoints, double *sum_sq) {
     TDK_REQUIRE(h && poses && points && dposes && dpoints && sum_sq, "null pointer");
     TDK_REQUIRE(mu >= 0.0, "mu must be non-negative");
-    TDK_TRY(ba_reduce(h, poses, points, true, sum_sq));
+    TDK_TRY(ba_reduce(h, poses, points, REDUCE_STEP, sum_sq));
     std::vector<double> U, ea, da;
     TDK_TRY(ba_fetch_pose_sums(h, U, ea));
     TDK_TRY(ba_update_dev(h, mu, U, ea, da));
@@ -906,7 +1082,7 @@ tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, 
     const double inv_n = 1.0 / (double)h->n;                    // calc_error is the MEAN squared error (:51-56)
     std::vector<double> cur(poses, poses + np6), cand(np6), da, U, ea;
     double sum_sq = 0.0;
-    TDK_TRY(ba_reduce(h, poses, points, true, &sum_sq));        // uploads the parameters as well
+    TDK_TRY(ba_reduce(h, poses, points, REDUCE_STEP, &sum_sq)); // uploads the parameters as well
     TDK_TRY(ba_fetch_pose_sums(h, U, ea));
     double current_error = sum_sq * inv_n, mu = initial_mu;
     if (error_history) error_history[0] = current_error;
@@ -923,7 +1099,7 @@ tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, 
             k_ba_add<<<grid_for((int64_t)nq3), kBlock, 0, tdk::stream()>>>(h->d_points, h->d_db, (int64_t)nq3,
                                                                            h->d_cpoints);
             TDK_LAUNCH_CHECK();
-            TDK_TRY(ba_reduce_dev(h, h->d_cposes, h->d_cpoints, false, &sum_sq));
+            TDK_TRY(ba_reduce_dev(h, h->d_cposes, h->d_cpoints, REDUCE_ERROR, &sum_sq));
             new_error = sum_sq * inv_n;
             if (trial < 2 ? new_error < error0 : !(new_error > error0)) break;
             if (trial > 400) {                                   // mu overflowed to inf long ago
@@ -944,7 +1120,7 @@ tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, 
         }
         current_error = new_error;
         if (it + 1 < max_iter) {                                 // sums for the next step at the accepted parameters
-            TDK_TRY(ba_reduce_dev(h, h->d_poses, h->d_points, true, &sum_sq));
+            TDK_TRY(ba_reduce_dev(h, h->d_poses, h->d_points, REDUCE_STEP, &sum_sq));
             TDK_TRY(ba_fetch_pose_sums(h, U, ea));
         }
     }

@@ -541,6 +541,27 @@ class BundleAdjustment(object):
         call("tdk_ba_error", self._h, _p(poses), _p(points), C.byref(err))
         return float(err.value)
 
+    def block_sums(self, poses, points):
+        """(U [P,21], ea [P,6], V [Q,6], eb [Q,3], sum ||e||^2): the sums of ba_block_reduce on
+        this graph, atomics-free (bit-reproducible)."""
+        poses = _f64(poses, (self.n_poses, 6)); points = _f64(points, (self.n_points, 3))
+        U = np.empty((self.n_poses, 21)); ea = np.empty((self.n_poses, 6))
+        V = np.empty((self.n_points, 6)); eb = np.empty((self.n_points, 3))
+        err = C.c_double()
+        call("tdk_ba_block_sums", self._h, _p(poses), _p(points), _p(U), _p(ea), _p(V), _p(eb), C.byref(err))
+        return U, ea, V, eb, float(err.value)
+
+    KERNELS = ("block_reduce", "error_reduce", "point_sums", "schur", "backsub")
+
+    def set_profiling(self, enabled):
+        call("tdk_ba_set_profiling", self._h, int(bool(enabled)))
+
+    def get_profile(self):
+        """{kernel: (launches, total_ms)} since set_profiling(True)."""
+        n = np.zeros(5, dtype=np.int64); ms = np.zeros(5)
+        call("tdk_ba_get_profile", self._h, n.ctypes.data_as(c_int64_p), _p(ms))
+        return {k: (int(n[i]), float(ms[i])) for i, k in enumerate(self.KERNELS)}
+
     def solve(self, poses, points, max_iter=200, initial_mu=1.0, nu=100.0,
               absolute_error_threshold=1e-8, relative_error_threshold=1e-6):
         """Levenberg-Marquardt loop on the device.  Returns (poses [P,6], points [Q,3],

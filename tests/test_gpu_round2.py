@@ -351,3 +351,42 @@ def test_rgb2gray_bit_exact(ops, orc):
     assert np.array_equal(ops.rgb2gray(gray), gray)
     with pytest.raises(ValueError):
         ops.rgb2gray(np.zeros((4, 4, 2)))
+
+
+# ---------------------------------------------------------------------------
+# bundle adjustment: per-pose segment reduce, atomics-free block sums
+# ---------------------------------------------------------------------------
+def test_ba_block_sums_handle_vs_oracle_and_reproducible(ops, orc):
+    from tadataka_amd import synthetic
+    c = synthetic.make_ba_case(n_poses=6, n_points=3000, seed=4)
+    x_true = orc.ba_projection(c["poses"], c["points"], c["vp_idx"], c["pt_idx"], jacobians=False)
+    rng = np.random.default_rng(2)
+    keep = rng.uniform(size=len(c["vp_idx"])) < 0.7            # ragged visibility
+    keep[c["vp_idx"] == 3] = False                              # one pose sees nothing
+    for order in ("viewpoint-major", "shuffled"):
+        vp, pt, xt = c["vp_idx"][keep], c["pt_idx"][keep], x_true[keep]
+        if order == "shuffled":
+            perm = rng.permutation(len(vp))
+            vp, pt, xt = vp[perm], pt[perm], xt[perm]
+        ba = ops.BundleAdjustment(6, 3000, vp, pt, xt)
+        U, ea, V, eb, err = ba.block_sums(c["poses_noisy"], c["points_noisy"])
+        oU, oea, oV, oeb, oerr = orc.ba_block_reduce(c["poses_noisy"], c["points_noisy"], xt, vp, pt)
+        scale = lambda a: np.maximum(np.abs(a).max(axis=1, keepdims=True), 1e-300)
+        assert np.max(np.abs(U - oU) / np.maximum(scale(oU), 1e-30)) < 1e-9
+        assert np.max(np.abs(V - oV) / scale(oV + 1e-300)) < 1e-9
+        assert np.max(np.abs(ea - oea)) <= 1e-8 * np.max(np.abs(oea))
+        assert np.max(np.abs(eb - oeb)) <= 1e-8 * np.max(np.abs(oeb))
+        assert abs(err - oerr) <= 1e-9 * oerr
+        assert np.all(U[3] == 0) and np.all(ea[3] == 0)
+        again = ba.block_sums(c["poses_noisy"], c["points_noisy"])           # no atomics: bit-reproducible
+        assert all(np.array_equal(a, b) for a, b in zip((U, ea, V, eb), again[:4])) and again[4] == err
+        assert ba.sum_squared_error(c["poses_noisy"], c["points_noisy"]) == pytest.approx(oerr, rel=1e-9)
+        # the stateless entry (atomics for the per-point sums) agrees
+        sU, sea, sV, seb, serr = ops.ba_block_reduce(c["poses_noisy"], c["points_noisy"], xt, vp, pt)
+        assert np.array_equal(sU, U) and np.array_equal(sea, ea) and serr == err
+        assert np.max(np.abs(sV - V) / scale(oV + 1e-300)) < 1e-12
+        ba.set_profiling(True)
+        ba.step(c["poses_noisy"], c["points_noisy"], 1e-3)
+        prof = ba.get_profile()
+        assert prof["block_reduce"][0] == 1 and prof["schur"][0] == 1 and prof["block_reduce"][1] > 0
+        ba.close()
