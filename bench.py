@@ -1,30 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- the headline measurement (BASELINE.json: "warp+residual+J^T J
-Mpixels/sec per DVO iter; frame-pairs/sec at 1/2/4/8 GPUs").
+Mpixels/sec per DVO iter; frame-pairs/sec at 1/2/4/8 GPUs") and, on one GPU, every
+other BASELINE config as an entry of `workloads` in the same JSON line.
 
-A *step* is one full DVO pose estimation (PoseChangeEstimator: 3-level pyramid,
-ratio 1.5, max_iter 20, weights="huber" -- BASELINE configs[1]) over one batch of
-independent synthetic 640x480 frame pairs resident in HBM: build the pyramids,
-then per level the fused evaluate/solve Gauss-Newton loop, all pairs in lock
-step on the device.  With `--double-buffer` two batches alternate: every step
-builds the pyramid of the batch the NEXT step will estimate -- queued on that
-batch's own stream, underneath the estimation of the current batch -- and
-estimates the current one (one build + one estimation per step either way;
-measured +3 %, the estimation already saturates the chip's FP64 issue/power).  `value` counts every source pixel pushed through one DVO
-iteration (= one calc_pose_update + one photometric_error at one pose, which
-the fused kernel does in a single pass): sum over levels, iterations and still
-running pairs of the level's pixel count, divided by wall time.
+Headline.  A *step* is one full DVO pose estimation (PoseChangeEstimator: 3-level
+pyramid, ratio 1.5, max_iter 20, weights="huber" -- BASELINE configs[1]) over one
+batch of independent synthetic 640x480 frame pairs resident in HBM: build the
+pyramids (anti-aliased, as skimage.rescale does by default -- the same constant
+the drop-in tadataka.vo.dvo uses), then per level the fused evaluate/solve
+Gauss-Newton loop, all pairs in lock step on the device.  `value` counts every
+source pixel pushed through one DVO iteration (= one calc_pose_update + one
+photometric_error at one pose, which the fused kernel does in a single pass):
+sum over levels, iterations and still running pairs of the level's pixel count,
+divided by wall time.  `frame_pairs_per_s` is the unambiguous companion.  Pair 0
+of the batch is the seed-0 pair of tests/golden/dvo_vga_pyramid.npz: its pose is
+checked against what the REFERENCE's own PoseChangeEstimator returned.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns
-its own shard of `--pairs` pairs (weak scaling; no data-path collective inside
-the estimation) and the recovered poses are all-gathered over RCCL at the end
-of each step.
+N > 1: one process per GPU (launched by torch.distributed.run as the driver does,
+or by this script itself when WORLD_SIZE is unset), every rank owns its own shard
+of `--pairs` pairs (weak scaling; no data-path collective inside the estimation)
+and the recovered poses are all-gathered with RCCL through the C ABI
+(tdk_comm_*) at the end of each step.  No PyTorch in any process.
+
+Timing: W warm-up steps, then blocks of exactly K steps, each bracketed by a
+barrier + device synchronisation on both sides and reduced with MAX over ranks;
+blocks repeat until --min-seconds of timed work have run (so that a GPU-busy
+sampler sees the run) and ms_per_step is the mean over all timed steps.
 
 One JSON line on stdout (rank 0).
 """
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
@@ -35,10 +44,16 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-BYTES_PER_PX_EVAL = 24.0  # fused evaluation reads D0, I0, I1 once (f64); see DESIGN.md
+# Algorithmic bytes per unit
+BYTES_PER_PX_EVAL = 24.0      # fused evaluation reads D0, I0, I1 once (f64)
+BYTES_PER_PX_WARP = 56.0      # increment_age 24 + propagate 32
+BYTES_PER_OBS_BA = 56.0       # point 24 + x_true 16 + two int64 indices 16
+SD_PARAMS = (0.5, 10.0, 0.01, 0.01, 0.002, 0.02)
+SD_DEFAULTS = (1.0, 10.0, 0.01)
 
 
 def parse_args():
+    import tadataka_amd
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -51,10 +66,14 @@ def parse_args():
     ap.add_argument("--weights", default="huber", choices=["none", "huber", "student-t", "tukey"])
     ap.add_argument("--double-buffer", action="store_true",
                     help="two batches: the next batch's pyramid is built under the current estimation")
-    ap.add_argument("--anti-aliasing", action="store_true",
-                    help="pyramid with skimage's Gaussian prefilter instead of SURVEY cfg2's plain bilinear rescale")
+    ap.add_argument("--pyramid", choices=["anti-aliased", "bilinear"],
+                    default="anti-aliased" if tadataka_amd.PYRAMID_ANTI_ALIASING else "bilinear",
+                    help="anti-aliased = what skimage.rescale builds by default (the reference-equivalent one)")
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="repeat the timed block of --steps steps until this much timed work has run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-workloads", action="store_true", help="headline only")
     return ap.parse_args()
 
 
@@ -69,30 +88,6 @@ def true_poses(n, seed0):
     return out
 
 
-def cpu_baseline(batch, cam, seconds):
-    """The CPU oracle (plain-C restatement, 1 thread) timed on this box's host
-    cores on a bounded sample of the same workload: one 640x480 pair taken from
-    the device batch, repeated DVO iterations (calc_pose_update with Huber
-    weights + photometric_error) at full resolution."""
-    from oracle import oracle as orc
-    I0 = batch.download(0, 0, "I0"); D0 = batch.download(0, 0, "D0"); I1 = batch.download(0, 0, "I1")
-    GX, GY = orc.image_gradient(I1)
-    R, t, T = np.eye(3), np.zeros(3), np.eye(4)
-    orc.dvo_normal_equations(I0, D0, I1, GX, GY, cam, cam, R, t, "huber")   # warm-up
-    n_iter, t0 = 0, time.perf_counter()
-    while True:
-        orc.dvo_normal_equations(I0, D0, I1, GX, GY, cam, cam, R, t, "huber")
-        orc.photometric_error_sums(I0, D0, I1, cam, cam, T)
-        n_iter += 1
-        if time.perf_counter() - t0 >= seconds:
-            break
-    dt = time.perf_counter() - t0
-    return {"value": I0.size * n_iter / dt / 1e6, "unit": "Mpx/s", "cores": 1, "kind": "port",
-            "sample": f"1 pair {I0.shape[1]}x{I0.shape[0]}, {n_iter} DVO iterations "
-                      f"(calc_pose_update huber + photometric_error) in {dt:.1f} s, oracle/tdk_oracle.c -O2",
-            "host_cpu": _cpu_model(), "host_cores_total": os.cpu_count()}
-
-
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -103,31 +98,295 @@ def _cpu_model():
     return "unknown"
 
 
+def _timed_loop(fn, seconds, min_iter=2):
+    fn()                                            # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fn()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds and n >= min_iter:
+            return n, dt
+
+
+def roofline(bytes_per_launch, kernel_ms, **extra):
+    achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel_ms": kernel_ms}
+    out.update(extra)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# CPU baselines (the oracle as the thing that is TIMED, on this box's host cores)
+# ---------------------------------------------------------------------------
+def dvo_cpu_baselines(I0, D0, I1, cam, seconds):
+    """One 640x480 pair, repeated DVO iterations (calc_pose_update with Huber weights +
+    photometric_error) at full resolution, single thread, three ways."""
+    from oracle import numpy_port as npp
+    from oracle import oracle as orc
+    out = {}
+    common = {"unit": "Mpx/s", "cores": 1, "host_cpu": _cpu_model(), "host_cores_total": os.cpu_count()}
+    R, t, T = np.eye(3), np.zeros(3), np.eye(4)
+
+    def c_iter():
+        orc.dvo_normal_equations(I0, D0, I1, GX, GY, cam, cam, R, t, "huber")
+        orc.photometric_error_sums(I0, D0, I1, cam, cam, T)
+
+    for name, native, share in (("c_port_O3_native", True, 0.4), ("c_port_O2_exact", False, 0.25)):
+        try:
+            orc.use_library(orc.build_native() if native else None)
+            GX, GY = orc.image_gradient(I1)
+            n, dt = _timed_loop(c_iter, seconds * share)
+            out[name] = dict(common, value=I0.size * n / dt / 1e6, kind="port",
+                             sample=f"1 pair {I0.shape[1]}x{I0.shape[0]}, {n} DVO iterations (calc_pose_update "
+                                    f"huber + photometric_error, full resolution, no pyramid work) in {dt:.1f} s; "
+                                    "oracle/tdk_oracle.c " +
+                                    ("gcc -O3 -march=native" if native else "gcc -O2 -ffp-contract=off (the exact checker build)"))
+        except Exception as e:                      # noqa: BLE001  (a missing compiler must not kill the bench)
+            out[name] = {"error": repr(e)}
+        finally:
+            orc.use_library(None)
+    level = npp.Level(I0, D0, I1, cam, cam)
+    n, dt = _timed_loop(lambda: npp.one_iteration(level, T, "huber"), seconds * 0.35)
+    out["numpy_structured"] = dict(common, value=I0.size * n / dt / 1e6, kind="port",
+                                   sample=f"1 pair {I0.shape[1]}x{I0.shape[0]}, {n} DVO iterations in {dt:.1f} s; "
+                                          "oracle/numpy_port.py: the reference's own Python/NumPy structure (every "
+                                          "intermediate materialised, lstsq on the masked M x 6 Jacobian)")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# the other BASELINE configs (one GPU)
+# ---------------------------------------------------------------------------
+def workload_dvo_single_pair(args, golden):
+    """The drop-in path the examples drive: tadataka.vo.dvo.PoseChangeEstimator on host
+    arrays, one 640x480 pair per call -- H2D, pyramid, 3 levels, D2H of the pose."""
+    import tadataka_amd  # noqa: F401
+    from tadataka.camera import CameraModel, CameraParameters
+    from tadataka.vo import dvo
+    from tadataka_amd import synthetic
+    pair = synthetic.make_pair(480, 640, seed=0)
+    cam = pair["cam"]
+    cm = CameraModel(CameraParameters(cam[0:2], cam[2:4]), distortion_model=None)
+    est = dvo.PoseChangeEstimator(cm, cm, n_coarse_to_fine=3, max_iter=20)
+    weights = None if args.weights == "none" else args.weights
+    pose = est(pair["I0"], pair["D0"], pair["I1"], weights)          # creates the device batch
+    batch = dvo._batch_for((480, 640), 3, 1.5, False)
+    batch.set_profiling(True)
+    n_calls = 100
+    t0 = time.perf_counter()
+    for _ in range(n_calls):
+        pose = est(pair["I0"], pair["D0"], pair["I1"], weights)
+    dt = time.perf_counter() - t0
+    prof = batch.get_profile()
+    batch.set_profiling(False)
+    out = {"config": "BASELINE configs[1] through the drop-in API: tadataka.vo.dvo.PoseChangeEstimator, one "
+                     "640x480 pair per call, host arrays in, Pose out (PCIe and launch latency included)",
+           "ms_per_call": dt / n_calls * 1e3, "frame_pairs_per_s": n_calls / dt,
+           "h2d_bytes_per_call": 3 * 480 * 640 * 8}
+    tag = ("pyr_aa_" if dvo.ANTI_ALIASING else "pyr_") + str(weights)
+    if golden is not None and f"{tag}_t" in golden:
+        from scipy.spatial.transform import Rotation
+        err = max(float(np.max(np.abs(pose.R - Rotation.from_rotvec(golden[f"{tag}_rotvec"]).as_matrix()))),
+                  float(np.max(np.abs(pose.t - golden[f"{tag}_t"]))))
+        evals = golden[f"{tag}_evals"]
+        shapes = [(213, 284), (320, 427), (480, 640)]
+        px = sum(int(e) * h * w for e, (h, w) in zip(evals, shapes))
+        out["pose_error_vs_reference_loop"] = err
+        out["value"] = px * n_calls / dt / 1e6
+        out["unit"] = "Mpx/s per DVO iter"
+        assert err < 1e-6, f"single-pair pose differs from the reference loop by {err}"
+    if prof["launches"]:
+        kernel_ms = prof["total_ms"] / prof["launches"]
+        out["roofline"] = roofline(BYTES_PER_PX_EVAL * prof["pixels"] / prof["launches"], kernel_ms,
+                                   kernel="k_dvo_eval (full-resolution level, one pair: 300 blocks on 256 CUs)",
+                                   bytes_per_px=BYTES_PER_PX_EVAL, launches=prof["launches"])
+    return out
+
+
+def workload_dvo_720p(args):
+    """BASELINE configs[3], one GPU's shard: 64 pairs of 1280x720, 1 level, 2 iterations."""
+    from tadataka_amd import ops, synthetic
+    B, H, W = 64, 720, 1280
+    cam = synthetic.camera_for(W, H)
+    truth = true_poses(B, 0)
+    batch = ops.DvoBatch(B, H, W, n_levels=1)
+    batch.fill_synthetic(cam, truth, seed0=0, noise=0.02)
+    ident = np.tile(ops.pose12(np.eye(3), np.zeros(3)), (B, 1))
+    mode = ops.WEIGHT_MODES[None if args.weights == "none" else args.weights]
+    for _ in range(2):
+        batch.estimate(cam, cam, ident, mode, 2)
+    batch.set_profiling(True)
+    steps, px = 10, 0
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        P, p = batch.estimate(cam, cam, ident, mode, 2)
+        px += p
+    dt = time.perf_counter() - t0
+    prof = batch.get_profile()
+    batch.close()
+    err0 = np.linalg.norm(truth[:, 9:], axis=1)
+    err1 = np.linalg.norm(P[:, 9:] - truth[:, 9:], axis=1)
+    kernel_ms = prof["total_ms"] / max(prof["launches"], 1)
+    return {"config": "BASELINE configs[3], one GPU's shard: 64 pairs of 1280x720, 1 level, max_iter 2, "
+                      f"weights={args.weights}, inputs generated on the device",
+            "value": px / dt / 1e6, "unit": "Mpx/s per DVO iter", "ms_per_step": dt / steps * 1e3,
+            "frame_pairs_per_s": B * steps / dt,
+            "median_translation_error_ratio": float(np.median(err1 / err0)),
+            "roofline": roofline(BYTES_PER_PX_EVAL * prof["pixels"] / max(prof["launches"], 1), kernel_ms,
+                                 kernel="k_dvo_eval (1280x720)", bytes_per_px=BYTES_PER_PX_EVAL,
+                                 launches=prof["launches"])}
+
+
+def workload_semi_dense(args, fixture):
+    """BASELINE configs[2]: increment_age + propagate + update_depth on 640x480 maps with
+    ~30 % valid pixels, B tracks per launch, everything resident in HBM."""
+    from oracle import oracle as orc
+    from tadataka_amd import ops, synthetic
+    B, H, W = 64, 480, 640
+    N = H * W
+    sd = ops.SemiDenseSession(B, H, W, max_refframes=2)
+    pg = ops.make_params(*SD_PARAMS)
+    sd.set_params(pg, *SD_DEFAULTS)
+    base = synthetic.make_semi_dense_case(H, W, seed=1)
+    T10 = np.linalg.inv(base["T_wk"]) @ base["T_wr"]
+    p_valid = 0.0
+    for t in range(B):
+        sd.push_frame(t, base["cam"], base["ref_image"], base["T_wr"])
+        sd.push_frame(t, base["cam"], base["key_image"], base["T_wk"])
+        if t == 0:
+            age, pd_ = base["age"], base["prior_depth"]
+        else:                      # same frames, another draw of the age map and of the prior noise
+            rng = np.random.default_rng(1000 + t)
+            age = (rng.uniform(0, 1, (H, W)) < 0.3).astype(np.uint64)
+            pd_ = base["depth_gt"] * rng.uniform(0.9, 1.1, (H, W))
+        p_valid += float((age > 0).mean()) / B
+        sd.set_maps(t, pd_, base["prior_variance"], age)
+    T10s = np.tile(T10, (B, 1, 1))
+    sd.propagate(T10s, commit=False)
+    hist = sd.update_depth(commit=False, histogram=True)
+    if fixture is not None:
+        assert np.array_equal(hist[0], fixture["flag_histogram"]), "track 0 does not reproduce the cfg3 fixture"
+    reps, warp_ms, ud_ms = 10, 0.0, 0.0
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sd.propagate(T10s, commit=False)
+        warp_ms += sd.timing()["warp_ms"]
+        sd.update_depth(commit=False)
+        ud_ms += sd.timing()["update_depth_ms"]
+    dt = time.perf_counter() - t0
+    sd.close()
+    warp_ms /= reps
+    ud_ms /= reps
+    bytes_ud = 48.0 + 32.0 * p_valid
+    out = {"config": "BASELINE configs[2]: increment_age + propagate + update_depth, 640x480, ~30 % valid pixels, "
+                     f"{B} tracks per launch, device-resident session (tdk_sd)",
+           "value": B * N * reps / dt / 1e6, "unit": "Mpx/s (map pixels through the three operators)",
+           "frames_per_s": B * reps / dt, "ms_per_frame_host_api": dt / reps / B * 1e3,
+           "valid_fraction": p_valid, "flag_histogram_track0": [int(v) for v in hist[0]],
+           "roofline": roofline(bytes_ud * N * B, ud_ms, kernel="k_ud_classify + k_ud_estimate (update_depth)",
+                                bytes_per_px=bytes_ud, tracks=B),
+           "roofline_warp": roofline(BYTES_PER_PX_WARP * N * B, warp_ms,
+                                     kernel="k_sd_scatter + k_sd_fold (increment_age + propagate)",
+                                     bytes_per_px=BYTES_PER_PX_WARP, tracks=B)}
+    if not args.no_cpu_baseline:
+        po = orc.make_params(*SD_PARAMS)
+        key = (base["cam"], base["key_image"], base["T_wk"]); ref = (base["cam"], base["ref_image"], base["T_wr"])
+
+        def one():
+            orc.increment_age(base["age"], base["cam"], base["cam"], T10, base["prior_depth"])
+            orc.propagate(T10, base["cam"], base["cam"], base["prior_depth"], base["prior_variance"], *SD_DEFAULTS)
+            orc.update_depth(key, [ref], base["age"], base["prior_depth"], base["prior_variance"], po)
+        n, cdt = _timed_loop(one, 2.0)
+        out["cpu_baseline"] = {"value": N * n / cdt / 1e6, "unit": out["unit"], "cores": 1, "kind": "port",
+                               "sample": f"{n} frames (the three operators on the track-0 maps) in {cdt:.1f} s, "
+                                         "oracle/tdk_oracle.c -O2"}
+    return out
+
+
+def workload_ba(args):
+    """BASELINE configs[4]: 8 poses x 50 000 points, every point seen by every pose."""
+    from oracle import oracle as orc
+    from tadataka_amd import ops, synthetic
+    b = synthetic.make_ba_case()
+    n = len(b["vp_idx"])
+    x_obs = ops.ba_projection(b["poses"], b["points"], b["vp_idx"], b["pt_idx"], jacobians=False)
+    ba = ops.BundleAdjustment(len(b["poses"]), len(b["points"]), b["vp_idx"], b["pt_idx"], x_obs)
+    ba.block_sums(b["poses_noisy"], b["points_noisy"])
+    ba.set_profiling(True)
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ba.block_sums(b["poses_noisy"], b["points_noisy"])
+    dt_sums = (time.perf_counter() - t0) / reps
+    prof = ba.get_profile()
+    red_ms = prof["block_reduce"][1] / max(prof["block_reduce"][0], 1)
+    pts_ms = prof["point_sums"][1] / max(prof["point_sums"][0], 1)
+    ba.set_profiling(True)                               # reset the sums
+    t0 = time.perf_counter()
+    poses, points, errors = ba.solve(b["poses_noisy"], b["points_noisy"], max_iter=20)
+    dt_solve = time.perf_counter() - t0
+    lm = ba.get_profile()
+    ba.close()
+    iters = max(len(errors) - 1, 1)
+    out = {"config": "BASELINE configs[4]: local BA window, 8 poses x 50 000 points, 400 000 observations",
+           "value": n / (dt_sums) / 1e6, "unit": "Mobs/s (block sums U, ea, V, eb through the host API, parameters uploaded)",
+           "block_sums_ms_host_api": dt_sums * 1e3,
+           "lm_iterations": iters, "lm_ms_per_iteration": dt_solve / iters * 1e3,
+           "lm_final_mean_squared_error": float(errors[-1]),
+           "lm_kernel_ms": {k: (v[1] / v[0] if v[0] else 0.0) for k, v in lm.items()},
+           "roofline": roofline(BYTES_PER_OBS_BA * n, red_ms + pts_ms,
+                                kernel="k_ba_reduce_seg<STORE_B> + k_ba_point_sums (U, ea | V, eb; no atomics)",
+                                bytes_per_obs=BYTES_PER_OBS_BA, block_reduce_ms=red_ms, point_sums_ms=pts_ms)}
+    if not args.no_cpu_baseline:
+        def one():
+            orc.ba_block_reduce(b["poses_noisy"], b["points_noisy"], x_obs, b["vp_idx"], b["pt_idx"])
+        k, cdt = _timed_loop(one, 2.0)
+        out["cpu_baseline"] = {"value": n * k / cdt / 1e6, "unit": "Mobs/s", "cores": 1, "kind": "port",
+                               "sample": f"{k} block reduces of the same graph in {cdt:.1f} s, oracle/tdk_oracle.c -O2"}
+    return out
+
+
+# ---------------------------------------------------------------------------
+def spawn_ranks(n):
+    """`python bench.py --gpus N` by itself: one worker process per GPU with the
+    environment torch.distributed.run would export; rank 0's JSON line is relayed."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]                   # only a rendezvous key: nothing listens on it
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit("bench worker exit codes: %s" % rcs)
+
+
 def main():
     args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = args.gpus > 1 or world > 1
-
-    # torch (only needed for torch.distributed / RCCL when N > 1) bundles its own
-    # libamdhip64 with the same soname as /opt/rocm's: whichever is loaded first
-    # serves the whole process, so bring torch up BEFORE libtadataka_hip.so.
-    dist = torch = None
-    if distributed:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        world, rank = dist.get_world_size(), dist.get_rank()
 
     from tadataka_amd import _lib, ops, sharding, synthetic
     _lib.require_gpu()
     _lib.call("tdk_set_device", local_rank)
+    comm = sharding.connect()                       # RCCL through the C ABI when WORLD_SIZE > 1
+    world, rank = comm.world, comm.rank
 
     B, H, W = args.pairs, args.height, args.width
     cam = synthetic.camera_for(W, H)
-    mode = ops.WEIGHT_MODES[None if args.weights == "none" else args.weights]
+    weights = None if args.weights == "none" else args.weights
+    mode = ops.WEIGHT_MODES[weights]
+    anti_aliasing = args.pyramid == "anti-aliased"
     n_batches = 2 if args.double_buffer else 1
     # this rank's shard of the pair ids: n_batches consecutive blocks of B pairs
     seeds = [int(sharding.pair_seeds(rank, n_batches * B)[0]) + k * B for k in range(n_batches)]
@@ -135,13 +394,19 @@ def main():
     for seed0 in seeds:
         bt = ops.DvoBatch(B, H, W, n_levels=args.levels, ratio=1.5)
         bt.fill_synthetic(cam, true_poses(B, seed0), seed0=seed0, noise=0.02)
-        bt.set_anti_aliasing(args.anti_aliasing)
+        bt.set_anti_aliasing(anti_aliasing)
         batches.append(bt)
     batch = batches[0]
+    # pair 0 of the whole job = the pair the reference's own PoseChangeEstimator was run on
+    golden, host_pair = None, None
+    gpath = os.path.join(REPO, "tests", "golden", "dvo_vga_pyramid.npz")
+    if rank == 0 and (H, W, args.levels, args.max_iter) == (480, 640, 3, 20) and os.path.exists(gpath):
+        golden = np.load(gpath)
+        host_pair = synthetic.make_pair(H, W, seed=0)
+        batch.upload(0, host_pair["I0"], host_pair["D0"], host_pair["I1"])
     ident = np.tile(ops.pose12(np.eye(3), np.zeros(3)), (B, 1))
-    device = torch.device("cuda", local_rank) if distributed else None
     counter = [0]
-    gather = sharding.PoseGather(B, dist, device)
+    gather = sharding.PoseGather(B, comm)
     batches[0].build_pyramid()
 
     def step():
@@ -153,56 +418,62 @@ def main():
         else:
             batches[(k + 1) % n_batches].build_pyramid()   # asynchronous, on that batch's stream
         poses, px = cur.estimate(cam, cam, ident, mode, args.max_iter)
-        # the only exchange: the recovered poses, all-gathered (RCCL over xGMI).  The gather of
-        # this step is queued now and collected after the next step's estimation (flush() below
-        # collects the last one inside the timed region).
+        # the only exchange: the recovered poses, all-gathered (RCCL over xGMI) from where the
+        # device loop left them.  The gather of this step is queued now and collected after the
+        # next step's estimation (flush() collects the last one inside the timed region).
         previous = gather.finish() if gather.pending else None
-        gather.start(poses)
-        return previous, px, seeds[k % n_batches]
-
-    def flush():
-        return gather.finish()
+        gather.start(poses, cur)
+        return previous, px, k % n_batches
 
     def fence():
         _lib.call("tdk_sync")
-        if distributed:
-            torch.cuda.synchronize()
-            dist.barrier()
-            torch.cuda.synchronize()
+        comm.barrier()
+        _lib.call("tdk_sync")
 
     for _ in range(args.warmup):
         step()
     if gather.pending:
-        flush()
+        gather.finish()
     for bt in batches:
         bt.set_profiling(True)
-    fence()
-    t0 = time.perf_counter()
-    pixels = 0
-    for _ in range(args.steps):
-        _, px, last_seed = step()
+
+    def timed_block():
+        fence()
+        t0 = time.perf_counter()
+        pixels, last = 0, 0
+        for _ in range(args.steps):
+            _, px, last = step()
+            pixels += px
+        poses = gather.finish() if gather.pending else None   # all-gathered poses of the last step
+        fence()
+        dt = time.perf_counter() - t0
+        dt = float(sharding.reduce_scalars([dt], "max", comm)[0])
+        return dt, pixels, poses, last
+
+    elapsed, pixels, poses, last_batch = timed_block()
+    blocks = 1
+    n_more = max(0, int(math.ceil(args.min_seconds / max(elapsed, 1e-6))) - 1)
+    n_more = int(sharding.reduce_scalars([float(n_more)], "max", comm)[0])     # every rank repeats alike
+    for _ in range(n_more):
+        dt, px, poses, last_batch = timed_block()
+        elapsed += dt
         pixels += px
-    poses = flush() if gather.pending else None   # all-gathered poses of the last step
-    fence()
-    elapsed = time.perf_counter() - t0
+        blocks += 1
+    total_steps = blocks * args.steps
     prof = {"launches": 0, "total_ms": 0.0, "pixels": 0}
     for bt in batches:
         for key, val in bt.get_profile().items():
             prof[key] += val
         bt.set_profiling(False)
-
-    elapsed = float(sharding.reduce_scalars([elapsed], "max", dist, device)[0])
-    pixels_all = float(sharding.reduce_scalars([float(pixels)], "sum", dist, device)[0])
+    pixels_all = float(sharding.reduce_scalars([float(pixels)], "sum", comm)[0])
 
     if rank == 0:
         # rank r's batch of the last step holds pairs [r * n_batches * B + offset, ... + B)
-        offset = last_seed - seeds[0]
+        offset = seeds[last_batch] - seeds[0]
         truth = np.concatenate([true_poses(B, r * n_batches * B + offset) for r in range(world)])
         assert poses.shape == truth.shape
         t_err = float(np.max(np.linalg.norm(poses[:, 9:] - truth[:, 9:], axis=1)))
         kernel_ms = prof["total_ms"] / max(prof["launches"], 1)
-        bytes_per_launch = BYTES_PER_PX_EVAL * prof["pixels"] / max(prof["launches"], 1)
-        achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
         pmc_file = os.path.join(REPO, "profiles", "pmc_dvo_eval.json")
         if os.path.exists(pmc_file):
@@ -210,6 +481,11 @@ def main():
                 traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
             except (ValueError, OSError):
                 traffic = None
+        rl = roofline(BYTES_PER_PX_EVAL * prof["pixels"] / max(prof["launches"], 1), kernel_ms,
+                      kernel=f"k_dvo_eval<{args.weights}> (full-resolution level)", bytes_per_px=BYTES_PER_PX_EVAL,
+                      px_per_launch=prof["pixels"] / max(prof["launches"], 1), launches=prof["launches"],
+                      limiter="FP64 issue at the package power cap (DESIGN.md 5.1), not HBM")
+        rl["traffic"] = traffic
         out = {
             "metric": "warp+residual+JtJ Mpixels/sec per DVO iter",
             "value": pixels_all / elapsed / 1e6,
@@ -217,7 +493,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": elapsed / total_steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -227,30 +503,63 @@ def main():
                                    f"{W}x{H} frame pairs, {args.levels}-level pyramid ratio 1.5, "
                                    f"weights={args.weights}, max_iter={args.max_iter}",
                        "pairs_per_gpu": B, "batches_in_flight": n_batches,
-                       "pyramid": "anti-aliased (gaussian prefilter + bilinear)" if args.anti_aliasing else "bilinear",
+                       "pyramid": "anti-aliased (gaussian prefilter + bilinear, skimage.rescale's default)"
+                                  if anti_aliasing else "bilinear",
                        "height": H, "width": W, "levels": args.levels,
                        "weights": args.weights, "max_iter": args.max_iter,
-                       "parallelism": f"pair-shard x{world}" if world > 1 else "single GPU"},
-            "frame_pairs_per_s": B * world * args.steps / elapsed,
-            "dvo_iterations_per_pair_per_step": pixels / args.steps / B / (H * W),
+                       "parallelism": f"pair-shard x{world}, RCCL all-gather of poses" if world > 1 else "single GPU"},
+            "timed_blocks": blocks, "timed_seconds": elapsed,
+            "frame_pairs_per_s": B * world * total_steps / elapsed,
+            "dvo_iterations_per_pair_per_step": pixels / total_steps / B / (H * W),
             "max_translation_error": t_err,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": f"k_dvo_eval<{args.weights}> (full-resolution level)",
-                         "bytes_per_px": BYTES_PER_PX_EVAL,
-                         "px_per_launch": prof["pixels"] / max(prof["launches"], 1),
-                         "kernel_ms": kernel_ms, "launches": prof["launches"],
-                         "limiter": "FP64 issue at the 1400 W package power cap (DESIGN.md 5.1), not HBM"},
+            "rccl_ranks": world if world > 1 else 0,
+            "roofline": rl,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(batch, cam, args.cpu_seconds)
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        if golden is not None and last_batch == 0:
+            from scipy.spatial.transform import Rotation
+            tag = ("pyr_aa_" if anti_aliasing else "pyr_") + str(weights)
+            if f"{tag}_t" in golden:
+                err = max(float(np.max(np.abs(poses[0, :9].reshape(3, 3) -
+                                              Rotation.from_rotvec(golden[f"{tag}_rotvec"]).as_matrix()))),
+                          float(np.max(np.abs(poses[0, 9:] - golden[f"{tag}_t"]))))
+                out["pair0_pose_error_vs_reference_loop"] = err
+                assert err < 1e-6, f"pair 0 differs from the reference's PoseChangeEstimator by {err}"
+        if world == 1 and not args.no_cpu_baseline:
+            if host_pair is None:
+                host_pair = {k: batch.download(0, 0, k) for k in ("I0", "D0", "I1")}
+            cb = dvo_cpu_baselines(host_pair["I0"], host_pair["D0"], host_pair["I1"], cam, args.cpu_seconds)
+            out["cpu_baselines"] = cb
+            best = cb.get("c_port_O3_native")
+            if not best or "value" not in best:
+                best = cb["c_port_O2_exact"]
+            out["cpu_baseline"] = best
+            out["speedup_vs_cpu_baseline"] = out["value"] / best["value"]
+            out["speedup_vs_numpy_structured_reference_path"] = out["value"] / cb["numpy_structured"]["value"]
+        for bt in batches:
+            bt.close()
+        batches = []
+        if world == 1 and not args.no_workloads:
+            fixture = None
+            fpath = os.path.join(REPO, "tests", "golden", "semi_dense_cfg3.npz")
+            if os.path.exists(fpath):
+                fixture = np.load(fpath)
+            wl = {}
+            for name, fn in (("dvo_single_pair_vga", lambda: workload_dvo_single_pair(args, golden)),
+                             ("dvo_720p_x64", lambda: workload_dvo_720p(args)),
+                             ("semi_dense_vga", lambda: workload_semi_dense(args, fixture)),
+                             ("ba_8x50k", lambda: workload_ba(args))):
+                try:
+                    wl[name] = fn()
+                except AssertionError:
+                    raise
+                except Exception as e:              # noqa: BLE001
+                    wl[name] = {"error": repr(e)}
+            out["workloads"] = wl
         print(json.dumps(out))
     for bt in batches:
         bt.close()
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
 if __name__ == "__main__":

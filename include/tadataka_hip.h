@@ -319,6 +319,30 @@ tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, 
                         double nu, double absolute_error_threshold,
                         double relative_error_threshold, double *error_history, int *n_iter);
 
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------
+ * The reference has no distributed code; independent frame pairs shard across
+ * ranks with no data-path collective and the recovered poses are all-gathered
+ * (SURVEY section 8(e)).  librccl.so is opened on the first call.  Rank 0 creates
+ * a 128-byte unique id (ncclGetUniqueId) and hands it to the other ranks out of
+ * band (tadataka_amd/sharding.py uses a file next to the rendezvous port);
+ * tdk_comm_create is collective (ncclCommInitRank) on the current device. */
+typedef struct tdk_comm tdk_comm;
+tdk_status tdk_comm_unique_id(uint8_t *id128);
+tdk_status tdk_comm_create(const uint8_t *id128, int rank, int world, tdk_comm **out);
+tdk_status tdk_comm_destroy(tdk_comm *c);
+tdk_status tdk_comm_rank(tdk_comm *c, int *rank, int *world);
+/* Host-buffer collectives on float64 (staged through the device; blocking):
+ * recv holds world * count doubles in rank order; op: 0 sum, 1 max. */
+tdk_status tdk_comm_all_gather(tdk_comm *c, const double *send, int64_t count, double *recv);
+tdk_status tdk_comm_all_reduce(tdk_comm *c, double *values, int64_t count, int op);
+tdk_status tdk_comm_barrier(tdk_comm *c);
+/* ncclAllGather of the batch's device-resident poses [n_pairs][12] (the result of the
+ * last tdk_dvo_estimate / _estimate_level), queued on the batch's own stream right
+ * behind the estimation; _finish waits for it and copies [world * n_pairs][12] out.
+ * One gather in flight per communicator. */
+tdk_status tdk_dvo_gather_poses_start(tdk_dvo *h, tdk_comm *c);
+tdk_status tdk_dvo_gather_poses_finish(tdk_comm *c, double *poses_all);
+
 #ifdef __cplusplus
 }
 #endif

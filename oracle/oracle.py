@@ -46,15 +46,42 @@ def build(force=False):
     return so
 
 
+def build_native(out_dir=None):
+    """The same C restatement compiled `-O3 -march=native` (contraction allowed) on
+    the box it is timed on -- SURVEY section 8(d)'s stronger CPU baseline (ii).  Not
+    bit-identical to the exact build; it is only ever TIMED (bench.py)."""
+    import tempfile
+    out_dir = out_dir or tempfile.gettempdir()
+    so = os.path.join(out_dir, "liboracle_native_%d.so" % os.getuid())
+    src = os.path.join(_HERE, "tdk_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=c11", "-shared", "-o", so, src,
+                               "-lm"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def use_library(path=None):
+    """Switch the loaded shared object (None: the exact -O2 build)."""
+    global _LIB
+    _LIB = None
+    if path is not None:
+        _LIB = _load(path)
+
+
+def _load(path):
+    L = C.CDLL(path)
+    L.orc_calc_depth0.restype = C.c_double
+    L.orc_ba_block_reduce.restype = C.c_double
+    for name in ("orc_dvo_rows", "orc_dvo_normal_equations",
+                 "orc_photometric_error", "orc_estimate_debug"):
+        getattr(L, name).restype = C.c_int64
+    return L
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
-        _LIB.orc_calc_depth0.restype = C.c_double
-        _LIB.orc_ba_block_reduce.restype = C.c_double
-        for name in ("orc_dvo_rows", "orc_dvo_normal_equations",
-                     "orc_photometric_error", "orc_estimate_debug"):
-            getattr(_LIB, name).restype = C.c_int64
+        _LIB = _load(build())
     return _LIB
 
 

@@ -109,6 +109,15 @@ PROTOTYPES = {
     "tdk_ba_block_sums": [_vp, _d, _d, _d, _d, _d, _d, _d],
     "tdk_ba_set_profiling": [_vp, _i],
     "tdk_ba_get_profile": [_vp, c_int64_p, _d],
+    "tdk_comm_unique_id": [C.POINTER(C.c_uint8)],
+    "tdk_comm_create": [C.POINTER(C.c_uint8), _i, _i, C.POINTER(_vp)],
+    "tdk_comm_destroy": [_vp],
+    "tdk_comm_rank": [_vp, c_int_p, c_int_p],
+    "tdk_comm_all_gather": [_vp, _d, _i64, _d],
+    "tdk_comm_all_reduce": [_vp, _d, _i64, _i],
+    "tdk_comm_barrier": [_vp],
+    "tdk_dvo_gather_poses_start": [_vp, _vp],
+    "tdk_dvo_gather_poses_finish": [_vp, _d],
     "tdk_ba_solve": [_vp, _d, _d, _i, C.c_double, C.c_double, C.c_double, C.c_double, _d, C.POINTER(C.c_int)],
 }
 

@@ -101,10 +101,11 @@ def _pose12(pose):
 # anti-aliases by default when it shrinks: a Gaussian prefilter with
 # sigma = (1 / scale - 1) / 2 before the bilinear resampling.  scikit-image cannot
 # be imported where this package was built, so the behaviour is restated from its
-# published algorithm (Gaussian part checked against scipy.ndimage bit for bit) and
-# the default of that old release is from memory -- set this to False for the plain
-# bilinear pyramid (what SURVEY.md assumed and what bench.py measures).
-ANTI_ALIASING = True
+# published algorithm (Gaussian part checked against scipy.ndimage bit for bit);
+# set this to False for the plain bilinear pyramid.  The default is the package-wide
+# constant bench.py measures with as well.
+import tadataka_amd
+ANTI_ALIASING = tadataka_amd.PYRAMID_ANTI_ALIASING
 
 
 # Device batches are kept between calls (one per shape / pyramid / weight-map

@@ -1065,6 +1065,7 @@ tdk_status tdk_ba_step(tdk_ba *h, const double *poses, const double *points, dou
     memcpy(dposes, da.data(), da.size() * 8);
     TDK_HIP(hipMemcpyAsync(dpoints, h->d_db, (size_t)h->n_points * 24, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    if (h->profiling) ba_collect_profile(h);
     return TDK_OK;
 }
 
@@ -1128,6 +1129,7 @@ tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, 
     memcpy(poses, cur.data(), np6 * 8);
     TDK_HIP(hipMemcpyAsync(points, h->d_points, nq3 * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    if (h->profiling) ba_collect_profile(h);
     return TDK_OK;
 }
 

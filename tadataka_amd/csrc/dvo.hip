@@ -1304,6 +1304,7 @@ tdk_status dvo_level0(tdk_dvo *h, DvoLevel0 *out) {
     out->I0 = L.I0; out->D0 = L.D0; out->I1 = L.I1; out->W0 = L.W0;
     out->stride = L.stride; out->H = L.H; out->W = L.W; out->n_pairs = h->n_pairs;
     out->stream = h->stream;
+    out->poses = h->ls.pose;
     return TDK_OK;
 }
 

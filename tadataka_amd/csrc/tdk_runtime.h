@@ -46,6 +46,7 @@ size_t pyramid_aa_weight_doubles(int n_out);
 // dvo.hip: level-0 arrays of a DVO batch, for producers that fill it on the device (tdk_sd_export_dvo)
 struct DvoLevel0 {
     double *I0, *D0, *I1, *W0;   // [n_pairs][stride]; W0 is null without a weight map
+    double *poses;               // [n_pairs][12] last accepted poses of the device loop
     int64_t stride;
     int H, W, n_pairs;
     hipStream_t stream;

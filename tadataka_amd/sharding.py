@@ -1,9 +1,16 @@
-"""Pair sharding across GPUs: independent frame pairs are dealt to
-ranks in contiguous blocks, every rank estimates its own block with no data-path
-collective, and the recovered poses are all-gathered at the end (RCCL over xGMI
-when the process group is `nccl`; `gloo` in the CPU tests).
+"""Pair sharding across GPUs: independent frame pairs are dealt
+to ranks in contiguous blocks, every rank estimates its own block with no
+data-path collective, and the recovered poses are all-gathered at the end --
+ncclAllGather from RCCL over xGMI through the C ABI (tdk_comm_*,
+include/tadataka_hip.h), one process per GPU.  No PyTorch anywhere.
 
-torch is imported lazily: the single-GPU path never needs it."""
+A communicator is anything with `rank`, `world`, `all_gather(array)`,
+`all_reduce(values, op)` and `barrier()`: LocalComm (one process), RcclComm (the
+product path) or the gloo adapter the CPU tests bring along."""
+import ctypes as C
+import os
+import time
+
 import numpy as np
 
 
@@ -21,81 +28,170 @@ def pair_seeds(rank, pairs_per_rank):
     return np.arange(rank * pairs_per_rank, (rank + 1) * pairs_per_rank)
 
 
-def _tensor(array, device):
-    import torch
-    t = torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64))
-    return t.to(device) if device is not None else t
+class LocalComm(object):
+    """World of one: every collective is the identity."""
+    rank, world = 0, 1
+
+    def all_gather(self, array):
+        return np.array(array, dtype=np.float64)
+
+    def all_reduce(self, values, op):
+        return np.array(values, dtype=np.float64)
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass
 
 
-def all_gather_poses(local_poses, dist=None, device=None):
+class RcclComm(object):
+    """RCCL communicator of this process (tdk_comm).  The device must have been
+    selected (tdk_set_device) before; creation is collective."""
+
+    def __init__(self, rank, world, unique_id):
+        from tadataka_amd import _lib
+        self._lib = _lib
+        self.rank, self.world = int(rank), int(world)
+        self._h = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        _lib.call("tdk_comm_create", buf, self.rank, self.world, C.byref(self._h))
+
+    @staticmethod
+    def unique_id():
+        from tadataka_amd import _lib
+        buf = (C.c_uint8 * 128)()
+        _lib.call("tdk_comm_unique_id", buf)
+        return bytes(buf)
+
+    def all_gather(self, array):
+        a = np.ascontiguousarray(array, dtype=np.float64)
+        out = np.empty((self.world,) + a.shape)
+        self._lib.call("tdk_comm_all_gather", self._h, a.ctypes.data_as(self._lib.c_double_p), a.size,
+                       out.ctypes.data_as(self._lib.c_double_p))
+        return out.reshape((self.world * a.shape[0],) + a.shape[1:]) if a.ndim else out
+
+    def all_reduce(self, values, op):
+        v = np.array(values, dtype=np.float64)
+        self._lib.call("tdk_comm_all_reduce", self._h, v.ctypes.data_as(self._lib.c_double_p), v.size,
+                       {"sum": 0, "max": 1}[op])
+        return v
+
+    def barrier(self):
+        self._lib.call("tdk_comm_barrier", self._h)
+
+    # device-resident pose gather, asynchronous on the batch's stream
+    def gather_poses_start(self, batch):
+        self._lib.call("tdk_dvo_gather_poses_start", batch._h, self._h)
+        self._pending_shape = (self.world * batch.n_pairs, 12)
+
+    def gather_poses_finish(self):
+        out = np.empty(self._pending_shape)
+        self._lib.call("tdk_dvo_gather_poses_finish", self._h, out.ctypes.data_as(self._lib.c_double_p))
+        return out
+
+    def close(self):
+        if self._h:
+            self._lib.call("tdk_comm_destroy", self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _rendezvous_path():
+    # all ranks of one launch share the launcher as parent and the rendezvous port
+    key = os.environ.get("TDK_RENDEZVOUS_KEY") or "%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "tdk_rccl_%s.id" % key)
+
+
+def connect(rank=None, world=None, timeout=300.0):
+    """The communicator of this process from the launcher's environment (RANK,
+    WORLD_SIZE -- what torch.distributed.run and bench.py's own spawner export).
+    Rank 0 publishes the RCCL unique id in a file keyed by the rendezvous port and
+    the launcher's pid; the others wait for it.  One process: LocalComm."""
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+    if world <= 1:
+        return LocalComm()
+    path = _rendezvous_path()
+    if rank == 0:
+        uid = RcclComm.unique_id()
+        tmp = path + ".%d.tmp" % os.getpid()
+        with open(tmp, "wb") as f:
+            f.write(uid)
+        os.replace(tmp, path)           # atomic: readers see nothing or all 128 bytes
+    else:
+        t0 = time.time()
+        while True:
+            try:
+                with open(path, "rb") as f:
+                    uid = f.read()
+                if len(uid) == 128:
+                    break
+            except OSError:
+                pass
+            if time.time() - t0 > timeout:
+                raise RuntimeError("rank %d: no RCCL unique id at %s after %.0f s" % (rank, path, timeout))
+            time.sleep(0.02)
+    comm = RcclComm(rank, world, uid)   # collective: returns once every rank has joined
+    if rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    return comm
+
+
+def all_gather_poses(local_poses, comm=None):
     """[B, 12] poses of this rank -> [world * B, 12] in rank order on every rank.
     Every rank must contribute the same B (weak scaling)."""
     local_poses = np.ascontiguousarray(local_poses, dtype=np.float64)
-    if dist is None or not dist.is_initialized():
+    if comm is None or comm.world == 1:
         return local_poses.copy()
-    import torch
-    mine = _tensor(local_poses, device)
-    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
-    dist.all_gather(parts, mine)
-    return torch.cat(parts, dim=0).cpu().numpy()
+    return comm.all_gather(local_poses)
 
 
 class PoseGather(object):
     """All-gather of the per-rank [B, 12] poses that does not stall the rank:
-    start() queues the collective (async_op) and returns at once, finish() waits
-    for the oldest one.  bench.py starts the gather of step k and collects it
-    after the estimation of step k + 1, so the RCCL launch and the two small
-    copies hide under the next batch's kernels.  Buffers are allocated once."""
+    start() queues the collective and returns at once, finish() waits for the
+    oldest one.  bench.py starts the gather of step k and collects it after the
+    estimation of step k + 1, so the RCCL launch and the copy hide under the next
+    batch's kernels.  With an RcclComm and a DvoBatch the gather reads the poses
+    where the device loop left them (ncclAllGather on the batch's stream)."""
 
-    def __init__(self, pairs_per_rank, dist=None, device=None):
-        self.dist = dist if (dist is not None and dist.is_initialized()) else None
-        self.device = device
+    def __init__(self, pairs_per_rank, comm=None):
+        self.comm = comm if (comm is not None and comm.world > 1) else None
+        self.pairs_per_rank = pairs_per_rank
         self.pending = []
-        if self.dist is not None:
-            import torch
-            self.world = self.dist.get_world_size()
-            on_gpu = device is not None
-            self.mine = torch.empty((pairs_per_rank, 12), dtype=torch.float64, device=device)
-            self.out = torch.empty((self.world * pairs_per_rank, 12), dtype=torch.float64, device=device)
-            # pinned staging on the GPU path: both copies are asynchronous, one event wait in finish()
-            self.mine_host = torch.empty((pairs_per_rank, 12), dtype=torch.float64, pin_memory=on_gpu)
-            self.out_host = torch.empty_like(self.out, device="cpu", pin_memory=on_gpu)
-            self.done = torch.cuda.Event() if on_gpu else None
 
-    def start(self, local_poses):
+    def start(self, local_poses, batch=None):
         local_poses = np.ascontiguousarray(local_poses, dtype=np.float64)
-        if self.dist is None:
+        if self.comm is None:
             self.pending.append(local_poses.copy())
             return
-        import torch
-        if self.pending:               # one set of buffers: at most one gather in flight
+        if self.pending:                       # one set of buffers: at most one gather in flight
             raise RuntimeError("finish() the previous gather first")
-        self.mine_host.copy_(torch.from_numpy(local_poses))
-        self.mine.copy_(self.mine_host, non_blocking=True)
-        work = self.dist.all_gather_into_tensor(self.out, self.mine, async_op=True)
-        if self.done is not None:
-            work.wait()                # orders the current torch stream after the collective; does not block the host
-            self.out_host.copy_(self.out, non_blocking=True)
-            self.done.record()
-        self.pending.append(work)
+        if batch is not None and hasattr(self.comm, "gather_poses_start"):
+            self.comm.gather_poses_start(batch)
+            self.pending.append(None)          # collected in finish()
+        else:
+            self.pending.append(self.comm.all_gather(local_poses))
 
     def finish(self):
         """Poses of all ranks, [world * B, 12] in rank order, of the oldest start()."""
         item = self.pending.pop(0)
-        if self.dist is None:
-            return item
-        if self.done is not None:
-            self.done.synchronize()
-            return self.out_host.numpy().copy()
-        item.wait()
-        return self.out.numpy().copy()
+        if item is None:
+            return self.comm.gather_poses_finish()
+        return item
 
 
-def reduce_scalars(values, op, dist=None, device=None):
+def reduce_scalars(values, op, comm=None):
     """Element-wise MAX or SUM of a few float64 scalars over all ranks."""
     values = np.asarray(values, dtype=np.float64)
-    if dist is None or not dist.is_initialized():
+    if comm is None or comm.world == 1:
         return values.copy()
-    t = _tensor(values, device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
-    return t.cpu().numpy()
+    return comm.all_reduce(values, op)

@@ -21,25 +21,51 @@ def estimate_pair(seed, h=32, w=40):
     return np.concatenate([rot.as_matrix().ravel(), t])
 
 
+class GlooComm(object):
+    """The communicator interface of tadataka_amd.sharding on torch.distributed/gloo:
+    stands in for RCCL where there is no GPU (test infrastructure only)."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def all_gather(self, array):
+        import torch
+        mine = torch.from_numpy(np.ascontiguousarray(array, dtype=np.float64))
+        parts = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine)
+        return torch.cat(parts, dim=0).numpy()
+
+    def all_reduce(self, values, op):
+        import torch
+        t = torch.from_numpy(np.array(values, dtype=np.float64))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX if op == "max" else self.dist.ReduceOp.SUM)
+        return t.numpy()
+
+    def barrier(self):
+        self.dist.barrier()
+
+
 def main():
     import torch.distributed as dist
     from tadataka_amd import sharding
     out_path, pairs_per_rank = sys.argv[1], int(sys.argv[2])
     dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    comm = GlooComm(dist)
+    rank, world = comm.rank, comm.world
     seeds = sharding.pair_seeds(rank, pairs_per_rank)
     local = np.array([estimate_pair(s) for s in seeds])
-    gathered = sharding.all_gather_poses(local, dist)
+    gathered = sharding.all_gather_poses(local, comm)
     # the pipelined form bench.py uses: queue the gather of "step k", collect it after "step k + 1"
-    pg = sharding.PoseGather(pairs_per_rank, dist)
+    pg = sharding.PoseGather(pairs_per_rank, comm)
     pg.start(local)
     first = pg.finish()
     pg.start(local + 1.0)
     second = pg.finish()
     assert np.array_equal(first, gathered) and np.array_equal(second, gathered + 1.0)
-    stats = sharding.reduce_scalars([float(rank + 1), float(len(seeds))], "max", dist)
-    total = sharding.reduce_scalars([float(len(seeds))], "sum", dist)
-    dist.barrier()
+    stats = sharding.reduce_scalars([float(rank + 1), float(len(seeds))], "max", comm)
+    total = sharding.reduce_scalars([float(len(seeds))], "sum", comm)
+    comm.barrier()
     if rank == 0:
         np.savez(out_path, gathered=gathered, stats=stats, total=total, world=world)
     dist.destroy_process_group()

