@@ -59,10 +59,8 @@ __device__ __forceinline__ void cross3(const double *a, const double *b, double 
 
 // x (2), optionally A = dx/dpose (2x6 row-major) and B = dx/dpoint (2x3 row-major)
 template <bool JAC>
-__device__ __forceinline__ void project_observation(const double *pose, const double *p, double *x, double *A,
-                                                    double *B) {
-    Rod c;
-    rodrigues_coeffs(pose, c);
+__device__ __forceinline__ void project_observation(const double *pose, const Rod &c, const double *p, double *x,
+                                                    double *A, double *B) {
     const double *w = pose;
     double wxp[3], wwxp[3], q[3];
     cross3(w, p, wxp);
@@ -106,6 +104,14 @@ __device__ __forceinline__ void project_observation(const double *pose, const do
 #pragma unroll
         for (int r = 0; r < 2; r++) B[3 * r + k] = dxq[r][0] * col[0] + dxq[r][1] * col[1] + dxq[r][2] * col[2];
     }
+}
+
+template <bool JAC>
+__device__ __forceinline__ void project_observation(const double *pose, const double *p, double *x, double *A,
+                                                    double *B) {
+    Rod c;
+    rodrigues_coeffs(pose, c);
+    project_observation<JAC>(pose, c, p, x, A, B);
 }
 
 __global__ __launch_bounds__(kBlock) void k_ba_projection(const double *__restrict__ poses,
@@ -160,8 +166,8 @@ __global__ __launch_bounds__(kBlock) void k_ba_exp_so3(const double *__restrict_
 // works, the pose lives in SGPRs and the per-pose sums U_j / ea_j need no
 // atomics and are bit-reproducible for any observation order: the 28
 // accumulators go through the transposed wave reduction, LDS across the four
-// waves, one partial per block; the last block of a pose to finish (ticket)
-// adds that pose's partials in segment order.
+// waves, one partial per block; k_ba_finish_seg adds a pose's partials in segment
+// order.
 //   MODE_ATOMIC_V : V_i / eb_i scattered with f64 atomics (stateless entry point)
 //   MODE_STORE_B  : B_ij and the residual stored per observation (Bobs, [8][n]) for
 //                   k_ba_point_sums
@@ -195,13 +201,15 @@ __global__ __launch_bounds__(kBlock) void k_ba_reduce_seg(const double *__restri
     double pose[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) pose[i] = poses[6 * j + i];
+    Rod rod;   // depends on the pose only: once per block, not per observation
+    rodrigues_coeffs(pose, rod);
     for (int q = sg.start + (int)threadIdx.x; q < sg.end; q += kBlock) {
         const int k = obs_sorted ? obs_sorted[q] : q;
         const int ip = pt32[k];
         const double p[3] = {points[3 * (int64_t)ip], points[3 * (int64_t)ip + 1], points[3 * (int64_t)ip + 2]};
         double x[2], A[12], B[6];
-        if (MODE == MODE_ERROR) project_observation<false>(pose, p, x, A, B);
-        else project_observation<true>(pose, p, x, A, B);
+        if (MODE == MODE_ERROR) project_observation<false>(pose, rod, p, x, A, B);
+        else project_observation<true>(pose, rod, p, x, A, B);
         const double e0 = x_true[2 * (int64_t)k] - x[0], e1 = x_true[2 * (int64_t)k + 1] - x[1];
         acc[27] += e0 * e0 + e1 * e1;
         if (MODE == MODE_ERROR) continue;
@@ -235,7 +243,6 @@ __global__ __launch_bounds__(kBlock) void k_ba_reduce_seg(const double *__restri
         }
     }
     __shared__ double red[kBlock / 64][kPoseAccPad];
-    __shared__ int is_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (MODE == MODE_ERROR) {
         double v = acc[27];
@@ -255,17 +262,25 @@ __global__ __launch_bounds__(kBlock) void k_ba_reduce_seg(const double *__restri
         for (int w = 0; w < kBlock / 64; w++) v += red[w][threadIdx.x];
         partials[(int64_t)(first + sg.slot) * kPoseAccPad + threadIdx.x] = v;
     }
-    // the last block of this pose adds the pose's partials in segment order
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(&ticket[j], 1) == nseg - 1;
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
+}
+
+// Fixed-order sum of a pose's segment partials (bit-reproducible).  A separate launch
+// on the same stream, not a "last block done" tail inside k_ba_reduce_seg: a device-scope
+// release fence per block writes the XCD's L2 back (buffer_wbl2) and, at ~1000 blocks
+// that each stored a share of B / W, that cost more than the whole reduction
+// (measured 214 us at 1563 blocks against 45 us at 196).
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_ba_finish_seg(const double *__restrict__ partials,
+                                                          const int *__restrict__ seg_ptr, double *__restrict__ U,
+                                                          double *__restrict__ ea,
+                                                          double *__restrict__ err_per_pose) {
+    const int j = blockIdx.x;
+    const int first = seg_ptr[j], nseg = seg_ptr[j + 1] - first;
+    const int t0 = MODE == MODE_ERROR ? 27 : 0;
     const int kk = threadIdx.x & 31, g = threadIdx.x >> 5;
     double v = 0.0;
     if (kk >= t0 && kk < kPoseAcc)
-        for (int b = g; b < nseg; b += kBlock / 32) v += __builtin_nontemporal_load(&partials[(int64_t)(first + b) * kPoseAccPad + kk]);
+        for (int b = g; b < nseg; b += kBlock / 32) v += partials[(int64_t)(first + b) * kPoseAccPad + kk];
     __shared__ double fin[kBlock / 32][kPoseAccPad];
     fin[g][kk] = v;
     __syncthreads();
@@ -279,7 +294,6 @@ __global__ __launch_bounds__(kBlock) void k_ba_reduce_seg(const double *__restri
             else ea[6 * j + threadIdx.x - 21] = t;
         }
     }
-    if (threadIdx.x == 0) ticket[j] = 0;   // ready for the next launch
 }
 
 // ---------------------------------------------------------------------------
@@ -595,6 +609,7 @@ void ba_make_plan(const int64_t *vp, const int64_t *pt, int64_t n, int64_t n_pos
     int64_t len = (n / 1024 + kBlock - 1) / kBlock * kBlock;
     if (len < kBlock) len = kBlock;
     if (len > 8 * kBlock) len = 8 * kBlock;
+    if (const char *v = getenv("TDK_BA_SEGLEN")) len = atoll(v) > 0 ? atoll(v) : len;   // tuning knob
     plan->segs.clear();
     plan->seg_ptr.assign((size_t)n_poses + 1, 0);
     for (int64_t j = 0; j < n_poses; j++) {
@@ -612,12 +627,13 @@ void ba_make_plan(const int64_t *vp, const int64_t *pt, int64_t n, int64_t n_pos
 
 template <int MODE>
 void launch_reduce_seg(const double *d_poses, const double *d_points, const double *d_xt, const int *d_obs_sorted,
-                       const int *d_pt32, const BaSeg *d_segs, const int *d_seg_ptr, int n_segs, int64_t n,
+                       const int *d_pt32, const BaSeg *d_segs, const int *d_seg_ptr, int n_segs, int n_poses, int64_t n,
                        double *d_V, double *d_eb, double *d_W, double *d_Be, double *d_part, int *d_ticket,
                        double *d_U, double *d_ea, double *d_err, hipStream_t stream) {
     k_ba_reduce_seg<MODE><<<(unsigned)n_segs, kBlock, 0, stream>>>(d_poses, d_points, d_xt, d_obs_sorted, d_pt32, d_segs,
                                                                    d_seg_ptr, n, d_V, d_eb, d_W, d_Be, d_part,
                                                                    d_ticket, d_U, d_ea, d_err);
+    k_ba_finish_seg<MODE><<<(unsigned)n_poses, kBlock, 0, stream>>>(d_part, d_seg_ptr, d_U, d_ea, d_err);
 }
 
 }  // namespace
@@ -694,7 +710,7 @@ tdk_status tdk_ba_block_reduce(const double *poses, int64_t n_poses, const doubl
     TDK_HIP(hipMemsetAsync(d_eb, 0, (size_t)n_points * 3 * 8, tdk::stream()));
     launch_reduce_seg<MODE_ATOMIC_V>((const double *)d_poses, (const double *)d_points, (const double *)d_xt,
                                      (const int *)d_sorted, (const int *)d_pt, (const BaSeg *)d_segs,
-                                     (const int *)d_sptr, (int)plan.segs.size(), n, (double *)d_V, (double *)d_eb,
+                                     (const int *)d_sptr, (int)plan.segs.size(), (int)n_poses, n, (double *)d_V, (double *)d_eb,
                                      nullptr, nullptr, (double *)d_part, (int *)d_tick, (double *)d_U,
                                      (double *)d_ea, (double *)d_err, tdk::stream());
     TDK_LAUNCH_CHECK();
@@ -786,7 +802,7 @@ tdk_status ba_reduce_dev(tdk_ba *h, const double *d_poses, const double *d_point
         BaTimer t(h, what == REDUCE_ERROR ? BA_K_ERROR : BA_K_REDUCE);
 #define BA_LAUNCH(MODE)                                                                                          \
     launch_reduce_seg<MODE>(d_poses, d_points, h->d_xt, h->d_obs_sorted, h->d_pt32, h->d_segs, h->d_seg_ptr,      \
-                            h->n_segs, h->n, nullptr, nullptr, h->d_W, h->d_Be, h->d_part, h->d_ticket, h->d_U, \
+                            h->n_segs, (int)h->n_poses, h->n, nullptr, nullptr, h->d_W, h->d_Be, h->d_part, h->d_ticket, h->d_U, \
                             h->d_ea, h->d_err, tdk::stream())
         if (what == REDUCE_ERROR) BA_LAUNCH(MODE_ERROR);
         else if (what == REDUCE_SUMS) BA_LAUNCH(MODE_STORE_B);

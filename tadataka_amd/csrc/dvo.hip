@@ -522,7 +522,8 @@ struct LoopState {   // device arrays, one entry per pair
     int *n_evals;      // [n]
     int *active;       // [1] number of pairs still running
     int *ticket;       // [1] blocks of the current k_dvo_reduce launch that are through
-    int *host_flag;    // [1] mapped host memory: `active` as left by the last launch
+    unsigned long long *evals;   // [1] evaluations executed at this level, summed over the pairs
+    int *host_flag;    // mapped host memory: [0] `active` as left by the last launch, [2..3] `evals` (64 bit)
 };
 
 // Fixed-order reduction of the per-block partials of one pair; in loop mode the
@@ -552,6 +553,7 @@ __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials,
     double err = R[27] / R[29];  // mean over the error mask; 0/0 = NaN like np.mean([])
     double *pose = ls.pose + 12 * pair, *cand = ls.cand + 12 * pair;
     ls.n_evals[pair] += 1;
+    atomicAdd(ls.evals, 1ull);
     bool finished = false;
     if (iter > 0) {
         if (err > ls.prev_err[pair]) {
@@ -590,12 +592,13 @@ __global__ __launch_bounds__(kBlock) void k_dvo_reduce(const double *__restrict_
     __threadfence();
     if (atomicAdd(ls.ticket, 1) == (int)gridDim.x - 1) {
         *ls.ticket = 0;
+        *reinterpret_cast<volatile unsigned long long *>(ls.host_flag + 2) = atomicAdd(ls.evals, 0ull);
         *ls.host_flag = atomicAdd(ls.active, 0);
         __threadfence_system();
     }
 }
 
-__global__ void k_loop_init(LoopState ls, const double *__restrict__ poses_in, int n) {
+__global__ void k_loop_init(LoopState ls, const double *poses_in, int n) {   // poses_in may be ls.pose itself
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     for (int k = 0; k < 12; k++) {
@@ -609,6 +612,7 @@ __global__ void k_loop_init(LoopState ls, const double *__restrict__ poses_in, i
     if (i == 0) {
         *ls.active = n;
         *ls.ticket = 0;
+        *ls.evals = 0ull;
     }
 }
 
@@ -1054,7 +1058,8 @@ void plan_blocks(const tdk_dvo *h, const tdk_dvo::Level &L, int *nblk, int64_t *
     // -- unless the batch is so small that this would leave CUs without a block
     // (a single pair): then down to 4 pixels per thread, aiming at >= 512 blocks
     int64_t px_per_thread = L.N * h->n_pairs / (512 * (int64_t)kBlock);
-    px_per_thread = px_per_thread < 4 ? 4 : (px_per_thread > 16 ? 16 : px_per_thread);
+    static const int64_t min_px = [] { const char *v = getenv("TDK_DVO_MIN_PX"); return v ? atoll(v) : 4ll; }();
+    px_per_thread = px_per_thread < min_px ? min_px : (px_per_thread > 16 ? 16 : px_per_thread);
     int64_t per_block = (int64_t)kBlock * px_per_thread;
     int64_t nb = (L.N + per_block - 1) / per_block;
     int64_t cap = 8192 / h->n_pairs;
@@ -1277,20 +1282,28 @@ tdk_status collect_profile(tdk_dvo *h) {
 
 // One pyramid level for the whole batch; poses live in h->ls.pose on entry and exit.
 // The host only needs to know when every pair has finished: one 4-byte read per
-// iteration.  (Queueing iteration i+1 before looking at the count of iteration i
-// was tried: no gain -- the round trip is ~1 % of an iteration -- and occasional
-// millisecond stalls in the event wait, so the read is a plain blocking one.)
+// round trip.  Large batches take one iteration per round trip (the wait is ~1 % of
+// an iteration).  Small ones (a single pair: the drop-in PoseChangeEstimator) are
+// latency-bound, so two iterations are queued per round trip -- the second one
+// returns at once for pairs that finished in the first (state != RUNNING) -- which
+// halves the host waits of the typical 2-3 evaluation level.  Evaluations are
+// counted on the device (LoopState::evals), so the pixel bookkeeping stays exact.
 tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64_t *pixel_evals) {
-    int running = h->n_pairs;
-    for (int iter = 0; iter <= max_iter; iter++) {
-        if (h->profiling && level == 0) h->prof_pixels += h->lv[0].N * (int64_t)running;
-        if (pixel_evals) *pixel_evals += h->lv[level].N * (int64_t)running;
-        TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, weight_mode));
-        TDK_TRY(launch_reduce(h, level, 1, iter, max_iter));
+    const bool small = (int64_t)h->n_pairs * h->lv[level].N <= (1ll << 22) && !h->profiling;
+    const int burst = small ? 2 : 1;
+    for (int iter = 0; iter <= max_iter;) {
+        const int nb = max_iter + 1 - iter < burst ? max_iter + 1 - iter : burst;
+        for (int b = 0; b < nb; b++) {
+            TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, weight_mode));
+            TDK_TRY(launch_reduce(h, level, 1, iter + b, max_iter));
+        }
         TDK_HIP(hipStreamSynchronize(h->stream));   // k_dvo_reduce left the count in h_flag
-        running = *(volatile int *)h->h_flag;
-        if (running <= 0) break;
+        iter += nb;
+        if (*(volatile int *)h->h_flag <= 0) break;
     }
+    const int64_t evals = (int64_t)*(volatile unsigned long long *)(h->h_flag + 2);
+    if (h->profiling && level == 0) h->prof_pixels += h->lv[0].N * evals;
+    if (pixel_evals) *pixel_evals += h->lv[level].N * evals;
     return TDK_OK;
 }
 
@@ -1363,7 +1376,8 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
     TDK_HIP(hipMalloc(&h->ls.n_evals, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.active, sizeof(int)));
     TDK_HIP(hipMalloc(&h->ls.ticket, sizeof(int)));
-    TDK_HIP(hipHostMalloc(&h->h_flag, sizeof(int), hipHostMallocMapped));
+    TDK_HIP(hipMalloc(&h->ls.evals, sizeof(unsigned long long)));
+    TDK_HIP(hipHostMalloc(&h->h_flag, 4 * sizeof(int), hipHostMallocMapped));
     TDK_HIP(hipHostGetDevicePointer((void **)&h->ls.host_flag, h->h_flag, 0));
     *out = h;
     return TDK_OK;
@@ -1380,7 +1394,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     (void)hipFree(h->d_params); (void)hipFree(h->d_poses_in); (void)hipFree(h->d_partials);
     (void)hipFree(h->d_results); (void)hipFree(h->ls.pose); (void)hipFree(h->ls.cand);
     (void)hipFree(h->ls.prev_err); (void)hipFree(h->ls.state); (void)hipFree(h->ls.n_evals);
-    (void)hipFree(h->ls.active); (void)hipFree(h->ls.ticket);
+    (void)hipFree(h->ls.active); (void)hipFree(h->ls.ticket); (void)hipFree(h->ls.evals);
     if (h->d_rm) {
         (void)hipFree(h->d_rm); (void)hipFree(h->d_wscale); (void)hipFree(h->d_stat);
         (void)hipFree(h->d_spartial); (void)hipFree(h->d_count); (void)hipFree(h->d_select);
@@ -1557,12 +1571,8 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
                            h->stream));
     if (pixel_evals) *pixel_evals = 0;
     for (int level = h->n_levels - 1; level >= 0; level--) {
-        // the prior of a level is the result of the coarser one (:131-134)
-        if (level != h->n_levels - 1) {
-            TDK_HIP(hipMemcpyAsync(h->d_poses_in, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToDevice,
-                                   h->stream));
-        }
-        k_loop_init<<<(n + 255) / 256, 256, 0, h->stream>>>(h->ls, h->d_poses_in, n);
+        // the prior of a level is the result of the coarser one (:131-134), already in ls.pose
+        k_loop_init<<<(n + 255) / 256, 256, 0, h->stream>>>(h->ls, level == h->n_levels - 1 ? h->d_poses_in : h->ls.pose, n);
         TDK_LAUNCH_CHECK();
         TDK_TRY(run_level(h, level, weight_mode, max_iter, pixel_evals));
     }

@@ -384,8 +384,12 @@ enum { SD_ERR_AGE = 1 };
 
 // Streams age / prior maps.  NotProcessed (age == 0, :196-200) and check_args
 // failures (:208-214) are final here; everything else is appended to the track's
-// list of live pixels.  One pixel per thread, 4 sweeps per block.
+// list of live pixels.  kClassifySweeps pixels per thread; the block reserves its
+// slice of the list with ONE atomic on the track's counter -- counters of different
+// tracks sit kCountStride ints apart (own cache lines: atomics on one line
+// serialise in its L2 channel).
 constexpr int kClassifySweeps = 4;
+constexpr int kCountStride = 64;
 __global__ __launch_bounds__(kBlock) void k_ud_classify(int N, const TrackKey *__restrict__ keys,
                                                         const uint64_t *__restrict__ age,
                                                         const double *__restrict__ prior_depth,
@@ -398,11 +402,14 @@ __global__ __launch_bounds__(kBlock) void k_ud_classify(int N, const TrackKey *_
     const int64_t base = (int64_t)track * stride;
     const int n_ref = keys[track].n_ref;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ int wave_total[kBlock / 64];
+    __shared__ int wave_total[kClassifySweeps][kBlock / 64];
     __shared__ int block_base;
+    bool live[kClassifySweeps];
+    int before[kClassifySweeps];
+#pragma unroll
     for (int s = 0; s < kClassifySweeps; s++) {
         const int i = (blockIdx.x * kClassifySweeps + s) * kBlock + (int)threadIdx.x;
-        bool live = false;
+        live[s] = false;
         if (i < N) {
             const uint64_t a = age[base + i];
             const double d = prior_depth[base + i], v = prior_var[base + i];
@@ -411,26 +418,31 @@ __global__ __launch_bounds__(kBlock) void k_ud_classify(int N, const TrackKey *_
                 if (a > (uint64_t)n_ref) atomicOr(err, SD_ERR_AGE);  // the reference exits here (:202-205)
                 else f = check_args(tdk::safe_inv(d), v, vmin, vmax);
             }
-            live = f == 0;
-            if (!live) {
+            live[s] = f == 0;
+            if (!live[s]) {
                 out_depth[base + i] = d;
                 out_var[base + i] = v;
                 out_flag[base + i] = f;
             }
         }
-        const uint64_t m = __builtin_amdgcn_ballot_w64(live);
-        const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-        if (lane == 0) wave_total[wave] = __builtin_popcountll(m);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int tot = 0;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(live[s]);
+        before[s] = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+        if (lane == 0) wave_total[s][wave] = __builtin_popcountll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
 #pragma unroll
-            for (int w = 0; w < kBlock / 64; w++) { int c = wave_total[w]; wave_total[w] = tot; tot += c; }
-            block_base = tot ? atomicAdd(&count[track], tot) : 0;
-        }
-        __syncthreads();
-        if (live) list[base + block_base + wave_total[wave] + before] = i;
-        __syncthreads();
+        for (int s = 0; s < kClassifySweeps; s++)
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; w++) { int c = wave_total[s][w]; wave_total[s][w] = tot; tot += c; }
+        block_base = tot ? atomicAdd(&count[track * kCountStride], tot) : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kClassifySweeps; s++) {
+        const int i = (blockIdx.x * kClassifySweeps + s) * kBlock + (int)threadIdx.x;
+        if (live[s]) list[base + block_base + wave_total[s][wave] + before[s]] = i;
     }
 }
 
@@ -447,7 +459,7 @@ __global__ __launch_bounds__(kBlock) void k_ud_estimate(int H, int W, const Trac
                                                         int64_t *__restrict__ out_flag) {
     const int track = blockIdx.y;
     const int k = blockIdx.x * kBlock + (int)threadIdx.x;
-    if (k >= count[track]) return;
+    if (k >= count[track * kCountStride]) return;
     const int64_t base = (int64_t)track * stride;
     const int i = list[base + k];
     const TrackKey &key = keys[track];
@@ -658,7 +670,7 @@ tdk_status launch_update_depth(int n_tracks, int H, int W, const TrackKey *d_key
                                int *count, int *err, double *out_depth, double *out_var, int64_t *out_flag,
                                hipStream_t stream) {
     const int N = H * W;
-    TDK_HIP(hipMemsetAsync(count, 0, sizeof(int) * n_tracks, stream));
+    TDK_HIP(hipMemsetAsync(count, 0, sizeof(int) * kCountStride * n_tracks, stream));
     dim3 cgrid((N + kBlock * kClassifySweeps - 1) / (kBlock * kClassifySweeps), n_tracks);
     k_ud_classify<<<cgrid, kBlock, 0, stream>>>(N, d_keys, age, prior_depth, prior_var, stride, pr.vmin, pr.vmax,
                                                 out_depth, out_var, out_flag, list, count, err);
@@ -762,7 +774,7 @@ tdk_status tdk_update_depth(const double *key_camera, const double *key_image, c
     TDK_TRY(tdk::scratch(8, b8, &d_ov));
     TDK_TRY(tdk::scratch(9, b8, &d_of));
     TDK_TRY(tdk::scratch(1, (size_t)N * 4, &d_list));
-    TDK_TRY(tdk::scratch(2, 2 * sizeof(int), &d_cnt));
+    TDK_TRY(tdk::scratch(2, (kCountStride + 1) * sizeof(int), &d_cnt));
     // indexed by age - 1: refframes[n_ref - age] (:207)
     std::vector<RefConst> rcs((size_t)(n_ref > 0 ? n_ref : 1));
     for (int a = 1; a <= n_ref; a++) {
@@ -777,7 +789,7 @@ tdk_status tdk_update_depth(const double *key_camera, const double *key_image, c
     key.n_ref = n_ref;
     key.pad = 0;
     TDK_TRY(h2d(11, &key, sizeof(key), &d_keys));
-    int *d_err = (int *)d_cnt + 1;
+    int *d_err = (int *)d_cnt + kCountStride;
     TDK_HIP(hipMemsetAsync(d_err, 0, sizeof(int), tdk::stream()));
     TDK_TRY(launch_update_depth(1, H, W, (const TrackKey *)d_keys, (const RefConst *)d_rc, n_ref > 0 ? n_ref : 1,
                                 (const uint64_t *)d_age, (const double *)d_pd, (const double *)d_pv, N,
@@ -991,8 +1003,8 @@ tdk_status tdk_sd_create(int n_tracks, int height, int width, int max_refframes,
     SD_ALLOC(hipMalloc(&h->head, 4 * m));
     SD_ALLOC(hipMalloc(&h->next, 4 * m));
     SD_ALLOC(hipMalloc(&h->list, 4 * m));
-    SD_ALLOC(hipMalloc(&h->count, sizeof(int) * (n_tracks + 1)));
-    h->err = h->count + n_tracks;
+    SD_ALLOC(hipMalloc(&h->count, sizeof(int) * ((size_t)kCountStride * n_tracks + 1)));
+    h->err = h->count + (size_t)kCountStride * n_tracks;
     SD_ALLOC(hipMalloc(&h->hist, sizeof(unsigned long long) * 10 * n_tracks));
     SD_ALLOC(hipMalloc(&h->d_tw, sizeof(TrackWarp) * n_tracks));
     SD_ALLOC(hipMalloc(&h->d_keys, sizeof(TrackKey) * n_tracks));

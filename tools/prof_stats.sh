@@ -1,0 +1,22 @@
+#!/bin/bash
+# usage: bash tools/prof_stats.sh <tag> <command...>   -> kernel stats of the command (rocprofv3 --kernel-trace --stats)
+TAG=$1; shift
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o p -- "$@" > "$OUT/stdout.log" 2>&1
+cd "$ROOT"
+f=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
+python - "$f" <<'PY' | tee "$OUT/summary.txt"
+import csv, re, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+print("%-48s %7s %10s %10s %10s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
+for r in rows:
+    m = re.search(r'(k_\w+(<[^>]*>)?)', r["Name"])
+    name = m.group(1) if m else r["Name"][:48]
+    print("%-48s %7s %10.1f %10.1f %10.1f %7s" % (name, r["Calls"], float(r["AverageNs"]) / 1e3,
+          float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
+PY
+grep -v "^[EWI]20" "$OUT/stdout.log" | tail -8
