@@ -372,7 +372,10 @@ __global__ __launch_bounds__(256) void k_rescale_levels_aa(RescaleAaArgs args) {
 //   2. every thread evaluates the horizontal Gaussian of V at its four taps and blends.
 // Same operations in the same order as filtered_tap(), so the results are bit-identical
 // to k_rescale_levels_aa; ~70 LDS reads per output instead of ~200 global loads.
-constexpr int kAaRows = 4, kAaCols = 64;
+// 16 x 64 outputs per block (4 per thread): with 4 x 64 a VGA batch was 430 000 blocks of
+// two barriers and ~5 us of dependent latency each -- block-turnover bound at 1.6 TB/s;
+// the taller tile also cuts the vertical halo from (6 + 2 R + 1) / 6 to (24 + 2 R + 1) / 24.
+constexpr int kAaRows = 16, kAaCols = 64;
 
 struct AaTileArgs {
     const double *src[4];
@@ -380,14 +383,14 @@ struct AaTileArgs {
     int64_t src_stride, dst_stride;
     int H, W, Ho, Wo;
     AaLevel aa;
+    int tile_rows;              // output rows per block (kAaRows, or the per-radius choice of the host)
     int max_v_rows, max_cols;   // LDS tile bounds (host: ceil(rows * factor) + 2, ceil(cols * factor) + 2 + 2 Rc)
 };
 
 // R > 0: both radii are the compile-time R (loops unrolled, the LDS reads of a tap issue
 // together); R == 0: radii from the arguments.
 template <int R>
-__global__ __launch_bounds__(256) void k_rescale_aa_tiled(AaTileArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
+__device__ __forceinline__ void aa_tile(const AaTileArgs &a, int tile, int arr, int pair, unsigned char *aa_smem) {
     const int Rr = R > 0 ? R : a.aa.Rr, Rc = R > 0 ? R : a.aa.Rc;
     constexpr int kUnroll = R > 0 ? R : 1;
     const int SC = a.max_cols;
@@ -397,12 +400,11 @@ __global__ __launch_bounds__(256) void k_rescale_aa_tiled(AaTileArgs a) {
     for (int k = threadIdx.x; k < 2 * Rr + 1; k += 256) wr[k] = a.aa.wr[k];
     for (int k = threadIdx.x; k < 2 * Rc + 1; k += 256) wc[k] = a.aa.wc[k];
     const int tiles_x = (a.Wo + kAaCols - 1) / kAaCols;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-    const int arr = blockIdx.y, pair = blockIdx.z;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int H = a.H, W = a.W;
     const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
     const double sy = (double)H / (double)a.Ho, sx = (double)W / (double)a.Wo;
-    const int oy0 = ty * kAaRows, oy1 = min(oy0 + kAaRows, a.Ho);
+    const int oy0 = ty * a.tile_rows, oy1 = min(oy0 + a.tile_rows, a.Ho);
     const int ox0 = tx * kAaCols, ox1 = min(ox0 + kAaCols, a.Wo);
     // first / last lower tap of the tile (a shrinking level: all taps lie inside the image)
     const int yv0 = (int)floor(((double)oy0 + 0.5) * sy - 0.5);
@@ -416,42 +418,139 @@ __global__ __launch_bounds__(256) void k_rescale_aa_tiled(AaTileArgs a) {
     // vertical Gaussian straight from global memory (a source texel is re-read 2 Rr + 1
     // times by the block: L1 hits); a wave per V row, lanes along it: coalesced, no division
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < nv; r += 4) {
-        const int y = yv0 + r;
-        for (int c = lane; c < nc; c += 64) {
-            const double *col = s + mirror_idx(xs0 + c, W);
-            double tmp = col[(int64_t)y * W] * wr[Rr];
-#pragma unroll kUnroll
-            for (int j = -Rr; j < 0; j++)
-                tmp += (col[(int64_t)mirror_idx(y + j, H) * W] + col[(int64_t)mirror_idx(y - j, H) * W]) * wr[Rr + j];
-            V[r * SC + c] = tmp;
+    if (R > 0) {
+        // Compile-time radius: every wave takes a quarter of the V rows and walks down its
+        // columns with the source texels of the whole walk in registers: (rows + 2 R) loads
+        // per column walk instead of (2 R + 1) per V element (7x the L1 traffic at R = 3), ALL
+        // issued before the first one is used (one memory latency per walk, not one per row),
+        // and one boundary reflection per loaded texel instead of per tap.  Same products
+        // and sums in the same order as the generic loop below: bit-identical.
+        constexpr int RR = R > 0 ? R : 1;
+        constexpr int CH = 8;                       // V rows per wave held in registers
+        const int chunk = (nv + 3) / 4;
+        const int r0 = wave * chunk, r1 = min(r0 + chunk, nv);
+        const int rows = r1 - r0;                   // wave-uniform
+        const bool inside = yv0 + r0 - RR >= 0 && yv0 + r1 - 1 + RR <= H - 1;   // no reflection needed
+        double wk[RR + 1];
+#pragma unroll
+        for (int k = 0; k <= RR; k++) wk[k] = wr[k];
+        if (rows > 0 && rows <= CH) {
+            for (int c = lane; c < nc; c += 64) {
+                const double *col = s + mirror_idx(xs0 + c, W);
+                double v[CH + 2 * RR];
+#pragma unroll
+                for (int k = 0; k < CH + 2 * RR; k++) {
+                    const int y = yv0 + r0 - RR + k;
+                    v[k] = k < rows + 2 * RR ? col[(int64_t)(inside ? y : mirror_idx(y, H)) * W] : 0.0;
+                }
+#pragma unroll
+                for (int i = 0; i < CH; i++) {
+                    if (i < rows) {
+                        double tmp = v[i + RR] * wk[RR];
+#pragma unroll
+                        for (int j = -RR; j < 0; j++) tmp += (v[i + RR + j] + v[i + RR - j]) * wk[RR + j];
+                        V[(r0 + i) * SC + c] = tmp;
+                    }
+                }
+            }
+        } else {
+            for (int c = lane; c < nc && rows > 0; c += 64) {
+                const double *col = s + mirror_idx(xs0 + c, W);
+                double win[2 * RR + 1];
+#pragma unroll
+                for (int k = 0; k < 2 * RR; k++) {
+                    const int y = yv0 + r0 - RR + k;
+                    win[k + 1] = col[(int64_t)(inside ? y : mirror_idx(y, H)) * W];
+                }
+                for (int r = r0; r < r1; r++) {
+#pragma unroll
+                    for (int k = 0; k < 2 * RR; k++) win[k] = win[k + 1];
+                    const int y = yv0 + r + RR;
+                    win[2 * RR] = col[(int64_t)(inside ? y : mirror_idx(y, H)) * W];
+                    double tmp = win[RR] * wk[RR];
+#pragma unroll
+                    for (int j = -RR; j < 0; j++) tmp += (win[RR + j] + win[RR - j]) * wk[RR + j];
+                    V[r * SC + c] = tmp;
+                }
+            }
+        }
+    } else {
+        for (int r = wave; r < nv; r += 4) {
+            const int y = yv0 + r;
+            for (int c = lane; c < nc; c += 64) {
+                const double *col = s + mirror_idx(xs0 + c, W);
+                double tmp = col[(int64_t)y * W] * wr[Rr];
+                for (int j = -Rr; j < 0; j++)
+                    tmp += (col[(int64_t)mirror_idx(y + j, H) * W] + col[(int64_t)mirror_idx(y - j, H) * W]) * wr[Rr + j];
+                V[r * SC + c] = tmp;
+            }
         }
     }
     __syncthreads();
-    const int oy = oy0 + (int)(threadIdx.x >> 6), ox = ox0 + (int)(threadIdx.x & 63);
-    if (oy >= oy1 || ox >= ox1) return;
-    double cy = ((double)oy + 0.5) * sy - 0.5;
-    double cx = ((double)ox + 0.5) * sx - 0.5;
-    double fy0 = floor(cy), fx0 = floor(cx);
-    double wy = cy - fy0, wx = cx - fx0;
-    const int iy = (int)fy0, ix = (int)fx0;
-    const int y0 = reflect_fast(iy, H), y1 = reflect_fast(iy + 1, H);
+    const int ox = ox0 + (int)(threadIdx.x & 63);
+    if (ox >= ox1) return;
+    double wck[kUnroll + 1];                        // horizontal weights in registers (compile-time radius)
+#pragma unroll
+    for (int k = 0; k <= kUnroll; k++) wck[k] = k <= Rc ? wc[k] : 0.0;
+    const double cx = ((double)ox + 0.5) * sx - 0.5;
+    const double fx0 = floor(cx);
+    const double wx = cx - fx0;
+    const int ix = (int)fx0;
     const int x0 = reflect_fast(ix, W), x1 = reflect_fast(ix + 1, W);
-    double f[2][2];
+    for (int oy = oy0 + (int)(threadIdx.x >> 6); oy < oy1; oy += 4) {
+        const double cy = ((double)oy + 0.5) * sy - 0.5;
+        const double fy0 = floor(cy);
+        const double wy = cy - fy0;
+        const int iy = (int)fy0;
+        const int y0 = reflect_fast(iy, H), y1 = reflect_fast(iy + 1, H);
+        double f[2][2];
 #pragma unroll
-    for (int ry = 0; ry < 2; ry++) {
+        for (int ry = 0; ry < 2; ry++) {
 #pragma unroll
-        for (int rx = 0; rx < 2; rx++) {
-            const double *row = V + ((ry ? y1 : y0) - yv0) * SC + ((rx ? x1 : x0) - xs0);
-            double tmp = row[0] * wc[Rc];
-#pragma unroll kUnroll
-            for (int j = -Rc; j < 0; j++) tmp += (row[j] + row[-j]) * wc[Rc + j];
-            f[ry][rx] = tmp;
+            for (int rx = 0; rx < 2; rx++) {
+                const double *row = V + ((ry ? y1 : y0) - yv0) * SC + ((rx ? x1 : x0) - xs0);
+                double tmp;
+                if (R > 0) {
+                    tmp = row[0] * wck[kUnroll];
+#pragma unroll
+                    for (int j = -kUnroll; j < 0; j++) tmp += (row[j] + row[-j]) * wck[kUnroll + j];
+                } else {
+                    tmp = row[0] * wc[Rc];
+                    for (int j = -Rc; j < 0; j++) tmp += (row[j] + row[-j]) * wc[Rc + j];
+                }
+                f[ry][rx] = tmp;
+            }
         }
+        double top = f[0][0] * (1.0 - wx) + f[0][1] * wx;
+        double bot = f[1][0] * (1.0 - wx) + f[1][1] * wx;
+        a.dst[arr][(int64_t)pair * a.dst_stride + (int64_t)oy * a.Wo + ox] = top * (1.0 - wy) + bot * wy;
     }
-    double top = f[0][0] * (1.0 - wx) + f[0][1] * wx;
-    double bot = f[1][0] * (1.0 - wx) + f[1][1] * wx;
-    a.dst[arr][(int64_t)pair * a.dst_stride + (int64_t)oy * a.Wo + ox] = top * (1.0 - wy) + bot * wy;
+}
+
+// Every tiled level of the pyramid in ONE launch.  blockIdx.x enumerates the tiles of
+// level 1, then level 2, ... of one (array, pair); x runs fastest in dispatch order, so
+// the coarser levels of an image are produced right after the finer ones and find the
+// full-resolution source (2.4 MB per array) in the L2 / Infinity Cache instead of HBM.
+constexpr int kAaMaxFused = 4;
+struct AaMultiArgs {
+    int n;
+    int tile_end[kAaMaxFused];
+    AaTileArgs lv[kAaMaxFused];
+};
+
+__global__ __launch_bounds__(256) void k_rescale_aa_multi(AaMultiArgs m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
+    int l = 0;
+    while (l + 1 < m.n && (int)blockIdx.x >= m.tile_end[l]) l++;
+    const int tile = (int)blockIdx.x - (l ? m.tile_end[l - 1] : 0);
+    const AaTileArgs &a = m.lv[l];
+    const int R = a.aa.Rr == a.aa.Rc ? a.aa.Rr : 0;
+    switch (R) {      // block-uniform
+        case 1: aa_tile<1>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // ratio 1.5, level 1
+        case 3: aa_tile<3>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // level 2
+        case 5: aa_tile<5>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // level 3
+        default: aa_tile<0>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;
+    }
 }
 
 // scipy.ndimage._filters._gaussian_kernel1d (order 0), radius int(4 sigma + 0.5)
@@ -518,18 +617,35 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
         TDK_HIP(hipMemcpyAsync(weights, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         TDK_HIP(hipStreamSynchronize(stream));   // `host` goes out of scope
     }
-    // levels that shrink both axes and whose tiles fit in LDS take the tiled kernel, one
-    // launch each; whatever is left (an enlarged axis, very deep levels) the general one
+    // levels that shrink both axes and whose tiles fit in LDS take the tiled kernel -- all of
+    // them in one launch (k_rescale_aa_multi); whatever is left (an enlarged axis, very deep
+    // levels) the general one
     bool general = false;
+    bool is_tiled[15] = {};
+    AaMultiArgs m;
+    m.n = 0;
+    size_t lds_max = 0;
+    int tiles_total = 0;
     for (int l = 0; l < n_out; l++) {
         const PyrLevel &L = r.lv[l];
         const double fy = (double)H / (double)L.Ho, fx = (double)W / (double)L.Wo;
         AaTileArgs t;
-        t.max_v_rows = (int)ceil(kAaRows * fy) + 2;
+        const int Rk = args.aa[l].Rr == args.aa[l].Rc ? args.aa[l].Rr : 0;
+        // output rows per block: 20 for the 3-tap level, 12 from R = 3 on -- the tallest tiles whose
+        // V rows still fit the 8-rows-per-wave register walk of aa_tile (measured on the VGA bench
+        // batch, pyramid time: 4/4 rows 2.56 ms, 16/8 1.61, 20/12 1.45, 20/16 1.88)
+        t.tile_rows = Rk == 1 ? 20 : 12;
+        {   // tuning knobs (experiments): TDK_AA_ROWS_R1 / _R3 / _R5 / _R0
+            char name[32];
+            snprintf(name, sizeof(name), "TDK_AA_ROWS_R%d", Rk);
+            const char *v = getenv(name);
+            if (v && atoi(v) > 0) t.tile_rows = atoi(v);
+        }
+        t.max_v_rows = (int)ceil(t.tile_rows * fy) + 2;
         t.max_cols = (int)ceil(kAaCols * fx) + 2 + 2 * args.aa[l].Rc;
         const size_t lds = sizeof(double) * ((size_t)t.max_v_rows * t.max_cols + 2 * args.aa[l].Rr +
                                              2 * args.aa[l].Rc + 2);
-        if (L.Ho > H || L.Wo > W || lds > 64 * 1024) {
+        if (L.Ho > H || L.Wo > W || lds > 64 * 1024 || m.n == kAaMaxFused) {
             general = true;
             continue;
         }
@@ -537,13 +653,16 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
         t.src_stride = src_stride; t.dst_stride = L.stride;
         t.H = H; t.W = W; t.Ho = L.Ho; t.Wo = L.Wo;
         t.aa = args.aa[l];
-        const int tiles = ((L.Ho + kAaRows - 1) / kAaRows) * ((L.Wo + kAaCols - 1) / kAaCols);
-        dim3 tgrid(tiles, n_arrays, batch);
-        const int R = t.aa.Rr == t.aa.Rc ? t.aa.Rr : 0;
-        if (R == 1) k_rescale_aa_tiled<1><<<tgrid, 256, lds, stream>>>(t);          // ratio 1.5, level 1
-        else if (R == 3) k_rescale_aa_tiled<3><<<tgrid, 256, lds, stream>>>(t);     // level 2
-        else if (R == 5) k_rescale_aa_tiled<5><<<tgrid, 256, lds, stream>>>(t);     // level 3
-        else k_rescale_aa_tiled<0><<<tgrid, 256, lds, stream>>>(t);
+        tiles_total += ((L.Ho + t.tile_rows - 1) / t.tile_rows) * ((L.Wo + kAaCols - 1) / kAaCols);
+        m.lv[m.n] = t;
+        m.tile_end[m.n] = tiles_total;
+        m.n++;
+        is_tiled[l] = true;
+        if (lds > lds_max) lds_max = lds;
+    }
+    if (m.n > 0) {
+        dim3 tgrid(tiles_total, n_arrays, batch);
+        k_rescale_aa_multi<<<tgrid, 256, lds_max, stream>>>(m);
         TDK_LAUNCH_CHECK();
     }
     if (general) {
@@ -551,12 +670,7 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
         int total = 0;
         for (int l = 0; l < n_out; l++) {
             const PyrLevel &L = r.lv[l];
-            const double fy = (double)H / (double)L.Ho, fx = (double)W / (double)L.Wo;
-            const size_t lds = sizeof(double) * ((size_t)((int)ceil(kAaRows * fy) + 2) *
-                                                     ((int)ceil(kAaCols * fx) + 2 + 2 * args.aa[l].Rc) +
-                                                 2 * args.aa[l].Rr + 2 * args.aa[l].Rc + 2);
-            const bool tiled = !(L.Ho > H || L.Wo > W || lds > 64 * 1024);
-            if (!tiled) total += (int)(((int64_t)L.Ho * L.Wo + 255) / 256);
+            if (!is_tiled[l]) total += (int)(((int64_t)L.Ho * L.Wo + 255) / 256);
             r.blk_end[l] = total;
         }
         dim3 grid(total, n_arrays, batch);
