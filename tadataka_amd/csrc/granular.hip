@@ -365,17 +365,17 @@ __global__ __launch_bounds__(256) void k_rescale_levels_aa(RescaleAaArgs args) {
 }
 
 // Tiled form of the same arithmetic for one level, used whenever the level shrinks both
-// axes and its tiles fit in LDS: a block produces kAaRows x kAaCols output pixels.
+// axes and its tiles fit in LDS: a block produces tile_rows x kAaCols output pixels.
 //   1. the vertical Gaussian is evaluated once per (row, column) its taps and their
 //      horizontal support touch (mirror boundary), from global memory into an LDS tile
 //      V -- ndimage filters axis 0 first, so V is rounded exactly like its intermediate image,
 //   2. every thread evaluates the horizontal Gaussian of V at its four taps and blends.
 // Same operations in the same order as filtered_tap(), so the results are bit-identical
 // to k_rescale_levels_aa; ~70 LDS reads per output instead of ~200 global loads.
-// 16 x 64 outputs per block (4 per thread): with 4 x 64 a VGA batch was 430 000 blocks of
-// two barriers and ~5 us of dependent latency each -- block-turnover bound at 1.6 TB/s;
-// the taller tile also cuts the vertical halo from (6 + 2 R + 1) / 6 to (24 + 2 R + 1) / 24.
-constexpr int kAaRows = 16, kAaCols = 64;
+// tile_rows x 64 outputs per block (several per thread): with 4 x 64 a VGA batch was
+// 430 000 blocks of two barriers and ~5 us of dependent latency each -- block-turnover
+// bound at 1.6 TB/s; taller tiles also cut the vertical halo ((rows f + 2 R + 1) / (rows f)).
+constexpr int kAaCols = 64;
 
 struct AaTileArgs {
     const double *src[4];
