@@ -420,3 +420,16 @@ def test_rccl_single_rank_smoke(ops):
     assert np.array_equal(comm.gather_poses_finish(), P)
     batch.close()
     comm.close()
+
+
+def test_update_depth_unusual_intensity_ranges(ops, orc):
+    """Reference frames with negative, denormal-range or all-zero texels: same bits as the oracle."""
+    from tadataka_amd import synthetic
+    c = synthetic.make_semi_dense_case(96, 128, seed=5)
+    pg, po = ops.make_params(0.5, 10.0, 0.01, 0.01, 0.004, 0.01), orc.make_params(0.5, 10.0, 0.01, 0.01, 0.004, 0.01)
+    age = np.ones((96, 128), dtype=np.uint64)
+    for ref_image in (c["ref_image"], c["ref_image"] - 0.5, c["ref_image"] * 1e-300, np.zeros((96, 128))):
+        key = (c["cam"], c["key_image"], c["T_wk"]); ref = (c["cam"], np.ascontiguousarray(ref_image), c["T_wr"])
+        d, v, f = ops.update_depth(key, [ref], age, c["prior_depth"], c["prior_variance"], pg)
+        od, ov, of = orc.update_depth(key, [ref], age, c["prior_depth"], c["prior_variance"], po)
+        assert np.array_equal(f, of) and np.array_equal(d, od) and np.array_equal(v, ov)
