@@ -19,6 +19,11 @@
  *   - pointers are HOST pointers unless the name ends in `_dev`.
  *   - calls are serialised on one HIP stream per process; they block until the
  *     result is in the output buffers unless stated otherwise.
+ *   - NOT thread-safe: the stateless entry points share grow-only device / pinned
+ *     scratch pools and that stream, and a handle (tdk_dvo, tdk_sd, tdk_ba, tdk_comm)
+ *     must not be used from two threads at once.  The reference's extension modules
+ *     hold the GIL for the whole call (single-threaded by construction); a binding
+ *     that releases the GIL (ctypes does) must serialise calls into this library.
  */
 #ifndef TADATAKA_HIP_H
 #define TADATAKA_HIP_H
@@ -131,6 +136,11 @@ tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0,
 /* Coarse-to-fine over all levels (PoseChangeEstimator.__call__, :125-150). */
 tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *camera1,
                             double *poses12, int weight_mode, int max_iter, int64_t *pixel_evals);
+/* too_large[pair] = 1 if some evaluation of the last tdk_dvo_estimate /
+ * tdk_dvo_estimate_level call found an empty update mask for that pair -- where the
+ * reference warns "Camera pose change is too large." and returns the pose it had
+ * (vo/dvo/__init__.py:97-100), at any iteration and any pyramid level. */
+tdk_status tdk_dvo_get_warnings(tdk_dvo *h, int *too_large);
 /* The hipStream_t every launch and copy of this batch is queued on.  Each batch
  * owns its stream: calls on different batches overlap on the device (e.g. the
  * HBM-bound pyramid of one batch under the FP64-bound estimation of another). */
@@ -159,6 +169,10 @@ tdk_status tdk_dvo_pose_update(const double *camera1, const double *residuals, c
 /* compute_weights_{huber,student_t,tukey} (tadataka/robust/weights.py:4-43) of a
  * residual vector: mode = TDK_W_HUBER / TDK_W_STUDENT_T / TDK_W_TUKEY. */
 tdk_status tdk_robust_weights(const double *residuals, int64_t m, int mode, double *weights);
+/* The same with the reference's keyword parameters: huber (p0 = k), student-t
+ * (p0 = nu, p1 = n_iter), tukey (p0 = beta, p1 = c). */
+tdk_status tdk_robust_weights_ex(const double *residuals, int64_t m, int mode, double p0, double p1,
+                                 double *weights);
 
 /* ---- semi-dense (rust_bindings.semi_dense) --------------------------------- */
 typedef struct {

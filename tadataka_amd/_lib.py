@@ -71,11 +71,13 @@ PROTOTYPES = {
     "tdk_dvo_estimate_level": [_vp, _i, _d, _d, _d, _i, _i, c_int_p],
     "tdk_dvo_estimate": [_vp, _d, _d, _d, _i, _i, c_int64_p],
     "tdk_dvo_get_stream": [_vp, C.POINTER(_vp)],
+    "tdk_dvo_get_warnings": [_vp, c_int_p],
     "tdk_dvo_set_profiling": [_vp, _i],
     "tdk_dvo_get_profile": [_vp, c_int64_p, _d, c_int64_p],
     "tdk_weighted_normal_equations": [_d, _d, _d, _i64, _i, _d, _d],
     "tdk_dvo_pose_update": [_d, _d, _d, _d, _i, _i, _d, _i64, _i, _d, _d, _d, c_int64_p],
     "tdk_robust_weights": [_d, _i64, _i, _d],
+    "tdk_robust_weights_ex": [_d, _i64, _i, C.c_double, C.c_double, _d],
     "tdk_increment_age": [c_uint64_p, _i, _i, _d, _d, _d, _d, c_uint64_p],
     "tdk_propagate": [_d, _d, _d, _d, _d, _i, _i, C.c_double, C.c_double, C.c_double, _d, _d],
     "tdk_update_depth": [_d, _d, _d, _i, _d, _d, _d, c_uint64_p, _d, _d, _i, _i,

@@ -13,25 +13,19 @@ def _as_vector(r):
 
 
 def compute_weights_huber(r, k=1.345):
-    if k != 1.345:
-        raise NotImplementedError("the device kernel fixes k = 1.345 (the reference default)")
     r, flat = _as_vector(r)
-    return ops.robust_weights(flat, ops.W_HUBER).reshape(r.shape)
+    return ops.robust_weights(flat, ops.W_HUBER, k).reshape(r.shape)
 
 
 def compute_weights_student_t(r, nu=5, n_iter=10):
     """NB: returns the square ROOT of the Student-t weight, as the reference does."""
-    if nu != 5 or n_iter != 10:
-        raise NotImplementedError("the device kernel fixes nu = 5, n_iter = 10 (the reference defaults)")
     r, flat = _as_vector(r)
-    return ops.robust_weights(flat, ops.W_STUDENT_T).reshape(r.shape)
+    return ops.robust_weights(flat, ops.W_STUDENT_T, nu, n_iter).reshape(r.shape)
 
 
 def compute_weights_tukey(r, beta=4.6851, c=1.4826):
-    if beta != 4.6851 or c != 1.4826:
-        raise NotImplementedError("the device kernel fixes beta = 4.6851, c = 1.4826")
     r, flat = _as_vector(r)
-    return ops.robust_weights(flat, ops.W_TUKEY).reshape(r.shape)
+    return ops.robust_weights(flat, ops.W_TUKEY, beta, c).reshape(r.shape)
 
 
 def tukey(x, beta):

@@ -147,12 +147,15 @@ def _estimate_level(batch, level, camera_model0, camera_model1, pose10, weights,
     cam0, cam1 = ops.camera_vec(camera_model0), ops.camera_vec(camera_model1)
     mode = _fused_mode(weights)
     P, n_evals = batch.estimate_level(level, cam0, cam1, _pose12(pose10), mode, max_iter)
-    # one evaluation only and no step taken = the update mask was empty
-    if n_evals[0] == 1 and max_iter > 0 and np.array_equal(P[0], _pose12(pose10)[0]):
-        ev = batch.evaluate(level, cam0, cam1, P, ops.W_NONE)
-        if ev["n_update"][0] == 0:
-            warnings.warn("Camera pose change is too large.", RuntimeWarning)
+    _warn_if_too_large(batch)
     return Pose.from_matrix(P[0])
+
+
+def _warn_if_too_large(batch):
+    # the reference warns whenever calc_pose_update returns None (:97-100): at any iteration, at
+    # every pyramid level.  The device loop records that per pair.
+    if batch.warnings().any():
+        warnings.warn("Camera pose change is too large.", RuntimeWarning)
 
 
 class PoseChangeEstimator(object):
@@ -180,4 +183,5 @@ class PoseChangeEstimator(object):
         cam0 = ops.camera_vec(self.camera_model0)
         cam1 = ops.camera_vec(self.camera_model1)
         P, _ = batch.estimate(cam0, cam1, _pose12(pose10), _fused_mode(weights), self.max_iter)
+        _warn_if_too_large(batch)
         return Pose.from_matrix(P[0])

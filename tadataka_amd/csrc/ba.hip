@@ -254,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void k_ba_reduce_seg(const double *__restri
         if ((lane & 1) == 0) red[wave][lane >> 1] = v;
     }
     __syncthreads();
-    const int first = seg_ptr[j], nseg = seg_ptr[j + 1] - first;
+    const int first = seg_ptr[j];
     const int t0 = MODE == MODE_ERROR ? 27 : 0;
     if ((int)threadIdx.x >= t0 && threadIdx.x < kPoseAcc) {
         double v = 0.0;
@@ -921,6 +921,9 @@ __global__ void k_ba_add(const double *__restrict__ a, const double *__restrict_
 
 }  // namespace
 
+static tdk_status ba_allocate(tdk_ba *h, int64_t n_poses, int64_t n_points, const int64_t *vp, const int64_t *pt,
+                              const double *x_true, int64_t n, int sorted);
+
 extern "C" {
 
 tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *vp, const int64_t *pt,
@@ -931,7 +934,18 @@ tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *vp, c
     int sorted = 0;
     TDK_TRY(check_indices(vp, pt, n, n_poses, n_points, &sorted));
     TDK_TRY(tdk::ensure_device());
-    tdk_ba *h = new tdk_ba();
+    tdk_ba *h = new tdk_ba();   // value-initialised: every pointer is null until allocated
+    const tdk_status st = ba_allocate(h, n_poses, n_points, vp, pt, x_true, n, sorted);
+    if (st != TDK_OK) {
+        tdk_ba_destroy(h);      // nothing leaks when an allocation in the middle fails
+        return st;
+    }
+    *out = h;
+    return TDK_OK;
+}
+
+static tdk_status ba_allocate(tdk_ba *h, int64_t n_poses, int64_t n_points, const int64_t *vp, const int64_t *pt,
+                              const double *x_true, int64_t n, int sorted) {
     h->n_poses = n_poses; h->n_points = n_points; h->n = n; h->sorted = sorted;
     h->profiling = false; h->ev_used = 0;
     for (int k = 0; k < BA_K_COUNT; k++) { h->prof_ms[k] = 0.0; h->prof_launches[k] = 0; }
@@ -1010,7 +1024,6 @@ tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *vp, c
     TDK_HIP(hipMemcpyAsync(h->d_row_ptr, row_ptr.data(), row_ptr.size() * 8, hipMemcpyHostToDevice, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(h->d_obs, obs.data(), obs.size() * 8, hipMemcpyHostToDevice, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));   // the host vectors go out of scope
-    *out = h;
     return TDK_OK;
 }
 

@@ -523,6 +523,7 @@ struct LoopState {   // device arrays, one entry per pair
     int *active;       // [1] number of pairs still running
     int *ticket;       // [1] blocks of the current k_dvo_reduce launch that are through
     unsigned long long *evals;   // [1] evaluations executed at this level, summed over the pairs
+    int *warn;         // [n] an evaluation of the current estimate found an EMPTY update mask ("pose change is too large")
     int *host_flag;    // mapped host memory: [0] `active` as left by the last launch, [2..3] `evals` (64 bit)
 };
 
@@ -567,6 +568,7 @@ __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials,
         ls.prev_err[pair] = err;
         if (R[28] == 0.0) {
             finished = true;  // empty update mask: "pose change is too large" (:98-100)
+            ls.warn[pair] = 1;
         } else {
             double xi[6];
             tdk::solve6(R, R + 21, xi);
@@ -1038,6 +1040,7 @@ struct tdk_dvo {
     bool anti_aliasing;         // pyramid levels get skimage's Gaussian prefilter (tdk_dvo_set_anti_aliasing)
     double *d_aa_weights;       // its 1-D kernels, per level and axis (allocated on first use)
     int *h_flag;   // "pairs still running", written by k_dvo_reduce (mapped pinned host memory)
+    std::vector<int> host_warn;   // ls.warn of the last estimate call
 };
 
 namespace {
@@ -1112,7 +1115,7 @@ tdk_status upload_params(tdk_dvo *h, const double *cam0, const double *cam1) {
 }
 
 tdk_status ensure_robust_buffers(tdk_dvo *h) {
-    if (h->d_rm) return TDK_OK;
+    if (h->d_hist) return TDK_OK;   // the last buffer allocated below: all or nothing
     const size_t n = (size_t)h->n_pairs;
     TDK_HIP(hipMalloc(&h->d_rm, sizeof(double) * (size_t)h->lv[0].stride * n));
     TDK_HIP(hipMalloc(&h->d_wscale, sizeof(double) * n));
@@ -1323,6 +1326,9 @@ tdk_status dvo_level0(tdk_dvo *h, DvoLevel0 *out) {
 
 }  // namespace tdk
 
+static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, int n_levels, double ratio,
+                               int with_weight_map);
+
 extern "C" {
 
 tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, double ratio,
@@ -1336,7 +1342,18 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
     TDK_REQUIRE(n_levels >= 1 && n_levels <= kMaxLevels, "n_levels must be in [1, 16]");
     TDK_REQUIRE(ratio > 1.0 || n_levels == 1, "layer_size_ratio must be > 1");
     TDK_TRY(tdk::ensure_device());
-    tdk_dvo *h = new tdk_dvo();
+    tdk_dvo *h = new tdk_dvo();   // value-initialised: every pointer is null until allocated
+    const tdk_status st = dvo_allocate(h, n_pairs, height, width, n_levels, ratio, with_weight_map);
+    if (st != TDK_OK) {
+        tdk_dvo_destroy(h);       // a failed hipMalloc of a large batch must not leak what came before it
+        return st;
+    }
+    *out = h;
+    return TDK_OK;
+}
+
+static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, int n_levels, double ratio,
+                               int with_weight_map) {
     TDK_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->n_pairs = n_pairs; h->H = height; h->W = width; h->n_levels = n_levels;
     h->ratio = ratio; h->with_w = with_weight_map != 0;
@@ -1351,7 +1368,6 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
         L.W = l == 0 ? width : level_dim(width, L.scale);
         if (L.H < 2 || L.W < 2) {
             tdk::set_error("pyramid level %d would be %dx%d", l, L.H, L.W);
-            delete h;
             return TDK_ERR_INVALID_ARGUMENT;
         }
         L.N = (int64_t)L.H * L.W;
@@ -1377,16 +1393,17 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
     TDK_HIP(hipMalloc(&h->ls.active, sizeof(int)));
     TDK_HIP(hipMalloc(&h->ls.ticket, sizeof(int)));
     TDK_HIP(hipMalloc(&h->ls.evals, sizeof(unsigned long long)));
+    TDK_HIP(hipMalloc(&h->ls.warn, sizeof(int) * n_pairs));
+    h->host_warn.assign((size_t)n_pairs, 0);
     TDK_HIP(hipHostMalloc(&h->h_flag, 4 * sizeof(int), hipHostMallocMapped));
     TDK_HIP(hipHostGetDevicePointer((void **)&h->ls.host_flag, h->h_flag, 0));
-    *out = h;
     return TDK_OK;
 }
 
 tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     if (!h) return TDK_OK;
-    (void)hipStreamSynchronize(h->stream);
-    for (int l = 0; l < h->n_levels; l++) {
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int l = 0; l < h->n_levels; l++) {   // hipFree(nullptr) is a no-op: a partially built handle is fine
         (void)hipFree(h->lv[l].I0); (void)hipFree(h->lv[l].D0); (void)hipFree(h->lv[l].I1);
         if (h->lv[l].W0) (void)hipFree(h->lv[l].W0);
         (void)hipFree(h->lv[l].tab);
@@ -1394,16 +1411,14 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     (void)hipFree(h->d_params); (void)hipFree(h->d_poses_in); (void)hipFree(h->d_partials);
     (void)hipFree(h->d_results); (void)hipFree(h->ls.pose); (void)hipFree(h->ls.cand);
     (void)hipFree(h->ls.prev_err); (void)hipFree(h->ls.state); (void)hipFree(h->ls.n_evals);
-    (void)hipFree(h->ls.active); (void)hipFree(h->ls.ticket); (void)hipFree(h->ls.evals);
-    if (h->d_rm) {
-        (void)hipFree(h->d_rm); (void)hipFree(h->d_wscale); (void)hipFree(h->d_stat);
-        (void)hipFree(h->d_spartial); (void)hipFree(h->d_count); (void)hipFree(h->d_select);
-        (void)hipFree(h->d_hist); (void)hipFree(h->d_cand);
-    }
+    (void)hipFree(h->ls.active); (void)hipFree(h->ls.ticket); (void)hipFree(h->ls.evals); (void)hipFree(h->ls.warn);
+    (void)hipFree(h->d_rm); (void)hipFree(h->d_wscale); (void)hipFree(h->d_stat);
+    (void)hipFree(h->d_spartial); (void)hipFree(h->d_count); (void)hipFree(h->d_select);
+    (void)hipFree(h->d_hist); (void)hipFree(h->d_cand);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
     if (h->d_aa_weights) (void)hipFree(h->d_aa_weights);
-    (void)hipStreamDestroy(h->stream);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return TDK_OK;
 }
@@ -1550,10 +1565,12 @@ tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0, 
     TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * h->n_pairs, hipMemcpyHostToDevice,
                            h->stream));
     int n = h->n_pairs;
+    TDK_HIP(hipMemsetAsync(h->ls.warn, 0, sizeof(int) * n, h->stream));
     k_loop_init<<<(n + 255) / 256, 256, 0, h->stream>>>(h->ls, h->d_poses_in, n);
     TDK_LAUNCH_CHECK();
     TDK_TRY(run_level(h, level, weight_mode, max_iter, nullptr));
     TDK_HIP(hipMemcpyAsync(poses12, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, h->stream));
+    TDK_HIP(hipMemcpyAsync(h->host_warn.data(), h->ls.warn, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
     if (n_evals)
         TDK_HIP(hipMemcpyAsync(n_evals, h->ls.n_evals, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
     TDK_HIP(hipStreamSynchronize(h->stream));
@@ -1570,6 +1587,7 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
     TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * n, hipMemcpyHostToDevice,
                            h->stream));
     if (pixel_evals) *pixel_evals = 0;
+    TDK_HIP(hipMemsetAsync(h->ls.warn, 0, sizeof(int) * n, h->stream));
     for (int level = h->n_levels - 1; level >= 0; level--) {
         // the prior of a level is the result of the coarser one (:131-134), already in ls.pose
         k_loop_init<<<(n + 255) / 256, 256, 0, h->stream>>>(h->ls, level == h->n_levels - 1 ? h->d_poses_in : h->ls.pose, n);
@@ -1577,8 +1595,15 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
         TDK_TRY(run_level(h, level, weight_mode, max_iter, pixel_evals));
     }
     TDK_HIP(hipMemcpyAsync(poses12, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, h->stream));
+    TDK_HIP(hipMemcpyAsync(h->host_warn.data(), h->ls.warn, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
     TDK_HIP(hipStreamSynchronize(h->stream));
     if (h->profiling) TDK_TRY(collect_profile(h));
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_get_warnings(tdk_dvo *h, int *too_large) {
+    TDK_REQUIRE(h && too_large, "null pointer");
+    memcpy(too_large, h->host_warn.data(), sizeof(int) * (size_t)h->n_pairs);
     return TDK_OK;
 }
 

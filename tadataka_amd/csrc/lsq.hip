@@ -150,19 +150,19 @@ __global__ __launch_bounds__(kBlock) void k_pose_update(Cam c1, const double *__
 }
 
 // ---- robust weights ------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_huber(const double *__restrict__ r, int64_t m,
+__global__ __launch_bounds__(kBlock) void k_huber(const double *__restrict__ r, int64_t m, double k,
                                                   double *__restrict__ w) {
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
         double a = fabs(r[i]);
-        w[i] = a > kHuberK ? kHuberK / a : 1.0;
+        w[i] = a > k ? k / a : 1.0;
     }
 }
 
 // one fixed-point step of compute_weights_student_t: sum s (nu+1)/(nu + s/var)
 __global__ __launch_bounds__(kBlock) void k_student_t_step(const double *__restrict__ r, int64_t m,
-                                                           const double *__restrict__ variance,
+                                                           const double *__restrict__ variance, double nu,
                                                            double *__restrict__ partials) {
-    const double nu = 5.0, var = *variance;
+    const double var = *variance;
     double acc[1] = {0.0};
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
         double s = r[i] * r[i];
@@ -176,9 +176,9 @@ __global__ void k_student_t_update(const double *__restrict__ sum, int64_t m, do
 }
 
 __global__ __launch_bounds__(kBlock) void k_student_t_weights(const double *__restrict__ r, int64_t m,
-                                                              const double *__restrict__ variance,
+                                                              const double *__restrict__ variance, double nu,
                                                               double *__restrict__ w) {
-    const double nu = 5.0, var = *variance;
+    const double var = *variance;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
         double s = r[i] * r[i];
         w[i] = sqrt((nu + 1.0) / (nu + s / var));   // note: sqrt of the weight (weights.py:18)
@@ -253,9 +253,9 @@ __global__ void k_median_combine(const double *lo, const double *hi, double *out
 __global__ void k_scale(const double *in, double factor, double *out) { *out = factor * *in; }
 
 __global__ __launch_bounds__(kBlock) void k_tukey_weights(const double *__restrict__ r, int64_t m,
-                                                          const double *__restrict__ sigma,
+                                                          const double *__restrict__ sigma, double beta,
                                                           double *__restrict__ w) {
-    const double beta = 4.6851, s = *sigma;
+    const double s = *sigma;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < m; i += (int64_t)gridDim.x * kBlock) {
         double x = r[i] / s;
         double q = x / beta, u = 1.0 - q * q;
@@ -380,9 +380,18 @@ tdk_status tdk_dvo_pose_update(const double *camera1, const double *residuals, c
 }
 
 tdk_status tdk_robust_weights(const double *residuals, int64_t m, int mode, double *weights) {
+    // the reference defaults: k = 1.345 | nu = 5, n_iter = 10 | beta = 4.6851, c = 1.4826
+    const double p0 = mode == TDK_W_HUBER ? kHuberK : (mode == TDK_W_STUDENT_T ? 5.0 : 4.6851);
+    const double p1 = mode == TDK_W_STUDENT_T ? 10.0 : 1.4826;
+    return tdk_robust_weights_ex(residuals, m, mode, p0, p1, weights);
+}
+
+tdk_status tdk_robust_weights_ex(const double *residuals, int64_t m, int mode, double p0, double p1,
+                                 double *weights) {
     TDK_REQUIRE(m >= 0 && (m == 0 || (residuals && weights)), "bad argument");
     TDK_REQUIRE(mode == TDK_W_HUBER || mode == TDK_W_STUDENT_T || mode == TDK_W_TUKEY,
                 "mode must be huber, student-t or tukey");
+    TDK_REQUIRE(mode != TDK_W_STUDENT_T || (p1 >= 0.0 && p1 <= 1e6 && p1 == floor(p1)), "n_iter must be a non-negative integer");
     if (m == 0) return tdk::ensure_device();
     void *d_r, *d_w, *d_part, *d_s;
     TDK_TRY(h2d(0, residuals, (size_t)m * 8, &d_r));
@@ -397,28 +406,28 @@ tdk_status tdk_robust_weights(const double *residuals, int64_t m, int mode, doub
     const double *r = (const double *)d_r;
     double *w = (double *)d_w;
     if (mode == TDK_W_HUBER) {
-        k_huber<<<grid_for(m, 4), kBlock, 0, tdk::stream()>>>(r, m, w);
+        k_huber<<<grid_for(m, 4), kBlock, 0, tdk::stream()>>>(r, m, p0, w);
         TDK_LAUNCH_CHECK();
     } else if (mode == TDK_W_STUDENT_T) {
         double one = 1.0;
         TDK_HIP(hipMemcpyAsync(s, &one, 8, hipMemcpyHostToDevice, tdk::stream()));
-        for (int it = 0; it < 10; it++) {
-            k_student_t_step<<<nblk, kBlock, 0, tdk::stream()>>>(r, m, s, (double *)d_part);
+        for (int it = 0; it < (int)p1; it++) {
+            k_student_t_step<<<nblk, kBlock, 0, tdk::stream()>>>(r, m, s, p0, (double *)d_part);
             TDK_LAUNCH_CHECK();
             k_finish<<<1, kBlock, 0, tdk::stream()>>>((const double *)d_part, nblk, 1, s + 1);
             TDK_LAUNCH_CHECK();
             k_student_t_update<<<1, 1, 0, tdk::stream()>>>(s + 1, m, s);
             TDK_LAUNCH_CHECK();
         }
-        k_student_t_weights<<<grid_for(m, 4), kBlock, 0, tdk::stream()>>>(r, m, s, w);
+        k_student_t_weights<<<grid_for(m, 4), kBlock, 0, tdk::stream()>>>(r, m, s, p0, w);
         TDK_LAUNCH_CHECK();
     } else {
         TDK_HIP(hipMemsetAsync(hist, 0, 256 * 8, tdk::stream()));
         TDK_TRY(device_median(r, m, 0, nullptr, st, hist, s + 2, s + 4));   // median(r)
         TDK_TRY(device_median(r, m, 1, s + 4, st, hist, s + 2, s + 5));     // median(|r - median|)
-        k_scale<<<1, 1, 0, tdk::stream()>>>(s + 5, 1.4826, s);                // sigma_mad
+        k_scale<<<1, 1, 0, tdk::stream()>>>(s + 5, p1, s);                    // sigma_mad = c * MAD
         TDK_LAUNCH_CHECK();
-        k_tukey_weights<<<grid_for(m, 4), kBlock, 0, tdk::stream()>>>(r, m, s, w);
+        k_tukey_weights<<<grid_for(m, 4), kBlock, 0, tdk::stream()>>>(r, m, s, p0, w);
         TDK_LAUNCH_CHECK();
     }
     TDK_HIP(hipMemcpyAsync(weights, d_w, (size_t)m * 8, hipMemcpyDeviceToHost, tdk::stream()));

@@ -227,6 +227,13 @@ class DvoBatch(object):
         call("tdk_dvo_estimate", self._h, _p(c0), _p(c1), _p(P), weight_mode, max_iter, C.byref(px))
         return P, int(px.value)
 
+    def warnings(self):
+        """bool[n_pairs]: the last estimate() / estimate_level() met an empty update mask
+        ("Camera pose change is too large" in the reference)."""
+        f = np.zeros(self.n_pairs, dtype=np.int32)
+        call("tdk_dvo_get_warnings", self._h, f.ctypes.data_as(c_int_p))
+        return f != 0
+
     def set_profiling(self, enabled):
         call("tdk_dvo_set_profiling", self._h, int(bool(enabled)))
 
@@ -272,10 +279,17 @@ def dvo_pose_update(camera1, residuals, GX1, GY1, P1, weight_mode=W_NONE, weight
     return upper21_to_matrix(H21), b, int(nv.value)
 
 
-def robust_weights(residuals, mode):
+def robust_weights(residuals, mode, p0=None, p1=None):
+    """compute_weights_{huber,student_t,tukey}; (p0, p1) = (k, -) | (nu, n_iter) | (beta, c),
+    None = the reference defaults."""
     r = _f64(residuals).reshape(-1)
     w = np.empty_like(r)
-    call("tdk_robust_weights", _p(r), r.shape[0], mode, _p(w))
+    if p0 is None and p1 is None:
+        call("tdk_robust_weights", _p(r), r.shape[0], mode, _p(w))
+    else:
+        d0, d1 = {W_HUBER: (1.345, 0.0), W_STUDENT_T: (5.0, 10.0), W_TUKEY: (4.6851, 1.4826)}[mode]
+        call("tdk_robust_weights_ex", _p(r), r.shape[0], mode, float(d0 if p0 is None else p0),
+             float(d1 if p1 is None else p1), _p(w))
     return w
 
 

@@ -517,3 +517,50 @@ def test_local_ba_device_loop_matches_host_loop(capsys, initial_mu, noise, seed)
         assert errors[-1] < 1e-3 * host.calc_error(poses0, points0)
     assert np.allclose(np.hstack((rot, trans)), p, rtol=1e-7, atol=1e-9)
     assert np.allclose(points, q, rtol=1e-7, atol=1e-9)
+
+
+def test_pose_change_too_large_warns_in_the_pyramid_too():
+    """The reference warns wherever calc_pose_update returns None -- PoseChangeEstimator
+    (coarse-to-fine) included -- and stays silent on a normal pair."""
+    from tadataka.pose import Pose
+    from tadataka.vo.dvo import PoseChangeEstimator
+    from tadataka_amd import synthetic
+    pair = synthetic.make_pair(60, 80, seed=3)
+    cm = _camera_model(pair["cam"])
+    est = PoseChangeEstimator(cm, cm, n_coarse_to_fine=2, max_iter=5)
+    far = Pose(Rotation.from_rotvec(np.zeros(3)), np.array([1e3, 0., 0.]))
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        out = est(pair["I0"], pair["D0"], pair["I1"], "huber", far)
+    assert any(issubclass(w.category, RuntimeWarning) and "too large" in str(w.message) for w in rec)
+    assert out == far
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        est(pair["I0"], pair["D0"], pair["I1"], "huber")
+    assert not any("too large" in str(w.message) for w in rec)
+
+
+def test_robust_weight_parameters_and_cg():
+    """The keyword parameters of the reference's weight functions (weights.py:4,21,38) reach the
+    kernels; method='cg' solves the device-reduced system."""
+    from tadataka.math import solve_linear_equation
+    from tadataka.robust.weights import (compute_weights_huber, compute_weights_student_t,
+                                         compute_weights_tukey)
+    rng = np.random.default_rng(3)
+    r = rng.normal(0, 1.0, 4001); r[::40] *= 6
+    a = np.abs(r)
+    assert np.array_equal(compute_weights_huber(r, k=0.8), np.where(a > 0.8, 0.8 / a, 1.0))
+    nu, var = 3.0, 1.0
+    for _ in range(4):
+        s = r * r
+        var = np.mean(s * (nu + 1) / (nu + s / var))
+    assert np.allclose(compute_weights_student_t(r, nu=3, n_iter=4), np.sqrt((nu + 1) / (nu + r * r / var)), rtol=1e-12)
+    sigma = 1.2 * np.median(np.abs(r - np.median(r)))
+    x = r / sigma
+    ref = np.where(np.abs(x) <= 3.0, (1 - (x / 3.0) ** 2) ** 2, 0.0)
+    assert np.allclose(compute_weights_tukey(r, beta=3.0, c=1.2), ref, rtol=1e-12, atol=1e-15)
+    A = rng.normal(size=(500, 6)); b = rng.normal(size=500); w = rng.uniform(0.2, 2, 500)
+    x_cg = solve_linear_equation(A, b, w, method="cg", rtol=1e-13, atol=0.0)
+    assert np.allclose(x_cg, solve_linear_equation(A, b, w), rtol=1e-6, atol=1e-9)
+    with pytest.raises(ValueError):
+        solve_linear_equation(A, b, method="qr")
