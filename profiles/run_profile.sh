@@ -9,7 +9,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 2"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-workloads --min-seconds 0.2 --steps 10 --warmup 2"
 cd /tmp
 # 1) per-kernel time
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace_stdout.log" 2>&1

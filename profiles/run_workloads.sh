@@ -14,11 +14,13 @@ cd "$ROOT"
 f=$(find "$OUT/trace" -name "*kernel_stats.csv" | head -1)
 echo "== $f"
 python - "$f" <<'PY' | tee "$OUT/summary.txt"
-import csv, sys
+import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-print("%-60s %6s %10s %8s" % ("kernel", "calls", "avg_us", "pct"))
+print("%-48s %7s %10s %10s %10s %7s" % ("kernel", "calls", "avg_us", "min_us", "max_us", "pct"))
 for r in rows:
-    name = r["Name"].split("(")[0][:60]
-    print("%-60s %6s %10.1f %8s" % (name, r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    m = re.search(r'(k_\w+(<[^>]*>)?)', r["Name"])
+    name = m.group(1) if m else r["Name"][:48]
+    print("%-48s %7s %10.1f %10.1f %10.1f %7s" % (name, r["Calls"], float(r["AverageNs"]) / 1e3,
+          float(r["MinNs"]) / 1e3, float(r["MaxNs"]) / 1e3, r["Percentage"]))
 PY
 tail -3 "$OUT/stdout.log"

@@ -439,6 +439,165 @@ __global__ void k_ba_schur_finish(const double *__restrict__ partials, int nchun
     else if (ja == jb) evec[6 * ja + t - 36] = -v;
 }
 
+// ---------------------------------------------------------------------------
+// Schur complement as a symmetric rank-k update on the FP64 matrix cores.
+//
+// S - blockdiag(U*) = -sum_i W_i V*_i^-1 W_i^T with W_i the (6 P) x 3 stack of the W_ij
+// of point i.  With the Cholesky factor V*_i^-1 = L_i L_i^T this is -Z Z^T,
+// Z = [W_1 L_1 | W_2 L_2 | ...] of shape (6 P) x (3 Q): one dense contraction over
+// 150 000 columns for the 8 x 50 000 window -- GEMM-shaped, unlike anything on the DVO
+// path, so it goes to v_mfma_f64_16x16x4_f64.  (The FP64 MFMA rate equals the vector
+// rate on this part; the gain is that every W_ij is read from memory ONCE and then
+// served from LDS to all pose pairs, where the pair-wise kernel re-reads it P times
+// through L2: 99-113 us -> measured below.)
+//
+// A block stages a chunk of kSchurPC points: thread (pose j, point i) loads W_ij
+// (18 coalesced plane reads), factors V*_i^-1 and writes the three columns of
+// W_ij L_i into the LDS tile Z[16 RB][3 kSchurPC]; rows beyond 6 P and points beyond
+// Q are zero.  Each wave then takes every fourth K-step of 4 columns: ONE LDS read
+// per 16-row block gives the operand for that block both as A (rows) and as B
+// (columns: the update is symmetric), and the RB (RB + 1) / 2 upper tiles are
+// accumulated in 4 registers each.  Blocks loop over chunks with the accumulators
+// live (persistent grid), the four waves are added in wave order and one partial
+// per block goes out; k_ba_schur_mfma_finish adds the partials in block order -- no
+// atomics, bit-reproducible.  e_j -= sum_i W_ij (V*_i^-1 e_b,i) rides along: 6
+// values per thread, reduced over the chunk in LDS in a fixed order.
+// ---------------------------------------------------------------------------
+constexpr int kSchurPC = 32;                   // points per chunk
+constexpr int kSchurK = 3 * kSchurPC;          // columns of Z per chunk
+constexpr int kSchurPitch = kSchurK + 4;       // 100 doubles: the 64 operand lanes spread over all banks, 2 per bank
+typedef double schur_acc_t __attribute__((ext_vector_type(4)));
+
+template <int RB>
+__global__ __launch_bounds__(kBlock) void k_ba_schur_mfma(const int *__restrict__ obs_at,
+                                                          const double *__restrict__ Wobs,
+                                                          const double *__restrict__ Vinv,
+                                                          const double *__restrict__ eb, int64_t n,
+                                                          int64_t n_points, int n_poses, int n_chunks,
+                                                          double *__restrict__ partials) {
+    constexpr int kTiles = RB * (RB + 1) / 2;
+    constexpr int kRows = 16 * RB;
+    __shared__ double Zs[kRows * kSchurPitch];
+    __shared__ double Es[kRows * kSchurPC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t Q = n_points;
+    const int j = threadIdx.x / kSchurPC, il = threadIdx.x - j * kSchurPC;   // fill role: (pose, point of the chunk)
+    schur_acc_t acc[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; t++) acc[t] = (schur_acc_t){0.0, 0.0, 0.0, 0.0};
+    double e_acc = 0.0;                            // threads 0 .. 6 P - 1: row threadIdx.x of e
+    for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+        __syncthreads();                           // the previous chunk's tile has been consumed
+        for (int k = threadIdx.x; k < kRows * kSchurPitch; k += kBlock) Zs[k] = 0.0;
+        for (int k = threadIdx.x; k < kRows * kSchurPC; k += kBlock) Es[k] = 0.0;
+        __syncthreads();
+        const int64_t i = (int64_t)chunk * kSchurPC + il;
+        if (j < n_poses && i < Q) {
+            const int ko = obs_at[(int64_t)j * Q + i];
+            if (ko >= 0) {
+                const double v00 = Vinv[i], v01 = Vinv[Q + i], v02 = Vinv[2 * Q + i];
+                const double v11 = Vinv[3 * Q + i], v12 = Vinv[4 * Q + i], v22 = Vinv[5 * Q + i];
+                // V*^-1 = L L^T (3x3 Cholesky)
+                const double l00 = sqrt(v00), l10 = v01 / l00, l20 = v02 / l00;
+                const double l11 = sqrt(v11 - l10 * l10), l21 = (v12 - l20 * l10) / l11;
+                const double l22 = sqrt(v22 - l20 * l20 - l21 * l21);
+                const double b0 = eb[i], b1 = eb[Q + i], b2 = eb[2 * Q + i];
+                const double u0 = v00 * b0 + v01 * b1 + v02 * b2;   // V*^-1 e_b
+                const double u1 = v01 * b0 + v11 * b1 + v12 * b2;
+                const double u2 = v02 * b0 + v12 * b1 + v22 * b2;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+                    const double w0 = Wobs[(3 * a) * n + ko], w1 = Wobs[(3 * a + 1) * n + ko], w2 = Wobs[(3 * a + 2) * n + ko];
+                    double *z = &Zs[(6 * j + a) * kSchurPitch + 3 * il];
+                    z[0] = w0 * l00 + w1 * l10 + w2 * l20;
+                    z[1] = w1 * l11 + w2 * l21;
+                    z[2] = w2 * l22;
+                    Es[(6 * j + a) * kSchurPC + il] = w0 * u0 + w1 * u1 + w2 * u2;
+                }
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < 6 * n_poses) {      // e: the chunk's points in order
+            double v = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < kSchurPC; k++) v += Es[threadIdx.x * kSchurPC + k];
+            e_acc += v;
+        }
+        for (int ks = wave; ks < kSchurK / 4; ks += kBlock / 64) {
+            double op[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; rb++) op[rb] = Zs[(16 * rb + (lane & 15)) * kSchurPitch + 4 * ks + (lane >> 4)];
+            int t = 0;
+#pragma unroll
+            for (int r = 0; r < RB; r++)
+#pragma unroll
+                for (int c = r; c < RB; c++) {
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[r], op[c], acc[t], 0, 0, 0);
+                    t++;
+                }
+        }
+    }
+    // the four waves' accumulators, added in wave order through LDS (reuses the Z tile)
+    __syncthreads();
+    double *sum = Zs;                              // [kTiles][4][64]
+    for (int w = 0; w < kBlock / 64; w++) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < kTiles; t++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    double *p = &sum[(t * 4 + r) * 64 + lane];
+                    *p = (w == 0 ? 0.0 : *p) + acc[t][r];
+                }
+        }
+        __syncthreads();
+    }
+    double *out = partials + (size_t)blockIdx.x * (kTiles * 256 + 64);
+    for (int k = threadIdx.x; k < kTiles * 256; k += kBlock) out[k] = sum[k];
+    if (threadIdx.x < 64) out[kTiles * 256 + threadIdx.x] = (int)threadIdx.x < 6 * n_poses ? e_acc : 0.0;
+}
+
+// S(row, col) = -(sum of the block partials, in block order), written symmetrically;
+// e(row) likewise.  Tile t = (r, c), r <= c; register reg of lane l holds
+// D[row = (l >> 4) + 4 reg][col = l & 15] (the f64 MFMA C/D layout).
+template <int RB>
+__global__ __launch_bounds__(kBlock) void k_ba_schur_mfma_finish(const double *__restrict__ partials, int n_blocks,
+                                                                 int dim, double *__restrict__ S,
+                                                                 double *__restrict__ evec) {
+    constexpr int kTiles = RB * (RB + 1) / 2;
+    constexpr int kPer = kTiles * 256 + 64;
+    // 32 values per block of 256 threads: slice s of 8 adds blocks s, s + 8, ... (its loads are
+    // independent: several in flight), then the 8 slices are added in slice order
+    __shared__ double part[8][32];
+    const int kk = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + kk;
+    double v = 0.0;
+    if (k < kPer) {
+#pragma unroll 8
+        for (int b = sl; b < n_blocks; b += 8) v += partials[(size_t)b * kPer + k];
+    }
+    part[sl][kk] = v;
+    __syncthreads();
+    if (sl != 0 || k >= kPer) return;
+    v = part[0][kk];
+#pragma unroll
+    for (int q = 1; q < 8; q++) v += part[q][kk];
+    if (k >= kTiles * 256) {
+        const int row = k - kTiles * 256;
+        if (row < dim) evec[row] = -v;
+        return;
+    }
+    const int t = k >> 8, reg = (k >> 6) & 3, l = k & 63;
+    int r = 0, rem = t;
+    while (rem >= RB - r) { rem -= RB - r; r++; }
+    const int c = r + rem;
+    const int row = 16 * r + (l >> 4) + 4 * reg, col = 16 * c + (l & 15);
+    if (row >= dim || col >= dim) return;
+    if (r == c && row > col) return;               // the diagonal tiles hold both triangles: keep the upper one
+    S[(size_t)row * dim + col] = -v;
+    S[(size_t)col * dim + row] = -v;
+}
+
 // General fallback (too many poses x points for the dense observation table, or
 // duplicate observations): one thread per point walks the point's observation
 // list (CSR) and subtracts Y_ij W_ik^T from the (j, k) block of S for every
@@ -753,6 +912,8 @@ struct tdk_ba {
     // Schur complement by pose pair (k_ba_schur_pairs): dense observation table
     int *d_obs_at;      // [n_poses][n_points] observation index or -1; NULL -> atomics fallback
     double *d_spart;    // [pairs][point chunks][kSchurAccPad]
+    double *d_mpart;    // [mfma_blocks][tiles * 256 + 64] partials of k_ba_schur_mfma (NULL: more than 8 poses)
+    int mfma_blocks;
     int64_t pchunk, npchunks;
 };
 
@@ -844,10 +1005,31 @@ tdk_status ba_update_dev(tdk_ba *h, double mu, const std::vector<double> &U, con
     const int gp = grid_for(h->n_points);
     k_ba_invert_V<<<gp, kBlock, 0, tdk::stream()>>>(h->d_V, mu, h->n_points, h->d_Vinv);
     TDK_LAUNCH_CHECK();
-    TDK_HIP(hipMemsetAsync(h->d_S, 0, (size_t)dim * dim * 8, tdk::stream()));
-    TDK_HIP(hipMemsetAsync(h->d_e, 0, (size_t)dim * 8, tdk::stream()));
+    static const bool no_mfma = [] { const char *v = getenv("TDK_BA_SCHUR"); return v && !strcmp(v, "pairs"); }();
+    const bool mfma = h->d_obs_at != nullptr && h->d_mpart != nullptr && !no_mfma;
+    if (!mfma) {   // the other kernels accumulate into S and e; the MFMA finish writes every entry
+        TDK_HIP(hipMemsetAsync(h->d_S, 0, (size_t)dim * dim * 8, tdk::stream()));
+        TDK_HIP(hipMemsetAsync(h->d_e, 0, (size_t)dim * 8, tdk::stream()));
+    }
     BaTimer *schur_timer = new BaTimer(h, BA_K_SCHUR);
-    if (h->d_obs_at != nullptr) {
+    if (mfma) {
+        // dense contraction on the FP64 matrix cores (windows of up to 8 poses)
+        const int RB = (int)((6 * h->n_poses + 15) / 16);
+        const int n_chunks = (int)((h->n_points + kSchurPC - 1) / kSchurPC);
+        const int nb = n_chunks < h->mfma_blocks ? n_chunks : h->mfma_blocks;
+#define BA_SCHUR_MFMA(RBV)                                                                                         \
+    do {                                                                                                           \
+        k_ba_schur_mfma<RBV><<<nb, kBlock, 0, tdk::stream()>>>(h->d_obs_at, h->d_W, h->d_Vinv, h->d_eb, h->n,       \
+                                                               h->n_points, (int)h->n_poses, n_chunks, h->d_mpart); \
+        constexpr int per = RBV * (RBV + 1) / 2 * 256 + 64;                                                        \
+        k_ba_schur_mfma_finish<RBV><<<(per + 31) / 32, kBlock, 0, tdk::stream()>>>(h->d_mpart, nb, dim,           \
+                                                                                              h->d_S, h->d_e);    \
+    } while (0)
+        if (RB == 1) BA_SCHUR_MFMA(1);
+        else if (RB == 2) BA_SCHUR_MFMA(2);
+        else BA_SCHUR_MFMA(3);
+#undef BA_SCHUR_MFMA
+    } else if (h->d_obs_at != nullptr) {
         const int pairs = (int)(h->n_poses * (h->n_poses + 1) / 2);
         dim3 grid((unsigned)h->npchunks, (unsigned)pairs);
         k_ba_schur_pairs<<<grid, kBlock, 0, tdk::stream()>>>(h->d_obs_at, h->d_W, h->d_Vinv, h->d_eb, h->n,
@@ -998,7 +1180,7 @@ static tdk_status ba_allocate(tdk_ba *h, int64_t n_poses, int64_t n_points, cons
     TDK_HIP(hipMalloc(&h->d_cpoints, (size_t)n_points * 24));
     // dense (pose, point) -> observation table for the pair-wise Schur kernel:
     // only when it is small (local BA windows) and no observation is repeated
-    h->d_obs_at = nullptr; h->d_spart = nullptr;
+    h->d_obs_at = nullptr; h->d_spart = nullptr; h->d_mpart = nullptr; h->mfma_blocks = 0;
     h->pchunk = 2048;
     h->npchunks = (n_points + h->pchunk - 1) / h->pchunk;
     const char *force = getenv("TDK_BA_SCHUR");   // "atomics": always take the general kernel (tests)
@@ -1015,6 +1197,10 @@ static tdk_status ba_allocate(tdk_ba *h, int64_t n_poses, int64_t n_points, cons
             const int64_t pairs = n_poses * (n_poses + 1) / 2;
             TDK_HIP(hipMalloc(&h->d_obs_at, table.size() * sizeof(int)));
             TDK_HIP(hipMalloc(&h->d_spart, (size_t)(pairs * h->npchunks) * kSchurAccPad * 8));
+            if (n_poses <= 8) {   // 6 P <= 48 rows = three 16-row blocks of the FP64 MFMA tile
+                h->mfma_blocks = 768;   // 3 resident blocks per CU (50 KB of LDS each), ~2 chunks of 32 points per block at 50 000 points
+                TDK_HIP(hipMalloc(&h->d_mpart, (size_t)h->mfma_blocks * (6 * 256 + 64) * 8));
+            }
             TDK_HIP(hipMemcpy(h->d_obs_at, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice));
         }
     }
@@ -1032,7 +1218,7 @@ tdk_status tdk_ba_destroy(tdk_ba *h) {
     (void)hipStreamSynchronize(tdk::stream());
     void *ptrs[] = {h->d_poses, h->d_points, h->d_xt, h->d_vp, h->d_pt, h->d_row_ptr, h->d_obs, h->d_U, h->d_ea,
                     h->d_V, h->d_eb, h->d_part, h->d_err, h->d_W, h->d_Vinv, h->d_S, h->d_e, h->d_da, h->d_db,
-                    h->d_Be, h->d_obs_at, h->d_spart, h->d_cposes, h->d_cpoints, h->d_obs_sorted, h->d_pt32,
+                    h->d_Be, h->d_obs_at, h->d_spart, h->d_mpart, h->d_cposes, h->d_cpoints, h->d_obs_sorted, h->d_pt32,
                     h->d_segs, h->d_seg_ptr, h->d_ticket};
     for (void *p : ptrs) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
