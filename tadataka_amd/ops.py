@@ -555,14 +555,17 @@ class BundleAdjustment(object):
         call("tdk_ba_error", self._h, _p(poses), _p(points), C.byref(err))
         return float(err.value)
 
-    def block_sums(self, poses, points):
+    def block_sums(self, poses, points, per_point=True):
         """(U [P,21], ea [P,6], V [Q,6], eb [Q,3], sum ||e||^2): the sums of ba_block_reduce on
-        this graph, atomics-free (bit-reproducible)."""
+        this graph, atomics-free (bit-reproducible).  per_point=False leaves V and eb on the
+        device (returned as None): only the per-pose sums cross the bus."""
         poses = _f64(poses, (self.n_poses, 6)); points = _f64(points, (self.n_points, 3))
         U = np.empty((self.n_poses, 21)); ea = np.empty((self.n_poses, 6))
-        V = np.empty((self.n_points, 6)); eb = np.empty((self.n_points, 3))
+        V = np.empty((self.n_points, 6)) if per_point else None
+        eb = np.empty((self.n_points, 3)) if per_point else None
         err = C.c_double()
-        call("tdk_ba_block_sums", self._h, _p(poses), _p(points), _p(U), _p(ea), _p(V), _p(eb), C.byref(err))
+        call("tdk_ba_block_sums", self._h, _p(poses), _p(points), _p(U), _p(ea),
+             None if V is None else _p(V), None if eb is None else _p(eb), C.byref(err))
         return U, ea, V, eb, float(err.value)
 
     KERNELS = ("block_reduce", "error_reduce", "point_sums", "schur", "backsub")
