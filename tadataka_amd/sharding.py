@@ -137,7 +137,8 @@ def connect(rank=None, world=None, timeout=300.0):
             if time.time() - t0 > timeout:
                 raise RuntimeError("rank %d: no RCCL unique id at %s after %.0f s" % (rank, path, timeout))
             time.sleep(0.02)
-    comm = RcclComm(rank, world, uid)   # collective: returns once every rank has joined
+    comm = RcclComm(rank, world, uid)   # collective (ncclCommInitRank): returns once every rank has joined
+    comm.barrier()                      # ... and every rank has therefore read the id
     if rank == 0:
         try:
             os.unlink(path)

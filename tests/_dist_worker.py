@@ -71,5 +71,41 @@ def main():
     dist.destroy_process_group()
 
 
+
+
+def rendezvous_main():
+    """`python _dist_worker.py --rendezvous out.npy`: sharding.connect() with the RCCL communicator
+    replaced by a recorder -- exercises the unique-id exchange (file keyed by MASTER_PORT and the
+    launcher's pid) without a GPU."""
+    from tadataka_amd import sharding
+
+    class FakeComm(object):
+        def __init__(self, rank, world, unique_id):
+            self.rank, self.world, self.uid = rank, world, bytes(unique_id)
+
+        @staticmethod
+        def unique_id():
+            return bytes(((np.arange(128) * 7 + os.getpid()) % 256).astype(np.uint8))
+
+        def barrier(self):              # every rank drops a marker, then waits for all of them
+            import time
+            d = os.environ["TMPDIR"]
+            open(os.path.join(d, "arrived_%d" % self.rank), "w").close()
+            t0 = time.time()
+            while not all(os.path.exists(os.path.join(d, "arrived_%d" % r)) for r in range(self.world)):
+                assert time.time() - t0 < 60.0
+                time.sleep(0.01)
+
+    sharding.RcclComm = FakeComm
+    comm = sharding.connect(timeout=60.0)
+    np.save(sys.argv[2], np.frombuffer(comm.uid, dtype=np.uint8))
+    assert comm.world == int(os.environ["WORLD_SIZE"]) and comm.rank == int(os.environ["RANK"])
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--rendezvous":
+    rendezvous_main()
+    sys.exit(0)
+
+
 if __name__ == "__main__":
     main()

@@ -44,3 +44,28 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     assert got["gathered"].shape == (6, 12)
     assert np.array_equal(got["gathered"], expected)               # rank order, nothing lost
     assert np.array_equal(got["stats"], [2., 3.]) and got["total"][0] == 6.
+
+
+def test_unique_id_rendezvous_without_gpu(tmp_path):
+    """sharding.connect(): rank 0 publishes the 128-byte id in a file keyed by MASTER_PORT and the
+    launcher's pid, the other ranks wait for it, rank 0 removes it -- with a recording stand-in for
+    the RCCL communicator (three ranks, started out of order)."""
+    import glob
+    import time
+    worker = os.path.join(REPO, "tests", "_dist_worker.py")
+    procs, outs = [], []
+    for rank in (2, 1, 0):                                        # rank 0 last: the others must wait
+        out = str(tmp_path / f"uid{rank}.npy")
+        outs.append(out)
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29714", TMPDIR=str(tmp_path))
+        procs.append(subprocess.Popen([sys.executable, worker, "--rendezvous", out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        if rank != 0:
+            time.sleep(0.2)
+    for p in procs:
+        stdout, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, stdout[-2000:]
+    uids = [np.load(o) for o in outs]
+    assert uids[0].shape == (128,) and all(np.array_equal(u, uids[0]) for u in uids)
+    assert glob.glob(str(tmp_path / "tdk_rccl_*")) == []          # rank 0 cleaned up
