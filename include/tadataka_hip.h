@@ -273,7 +273,8 @@ tdk_status tdk_sd_get_results(tdk_sd *h, int track, double *depth, double *varia
                               uint64_t *age, int64_t *flag);
 /* Feeds the DVO batch of the same step on the device (examples/semi_dense_vo.py:44-53):
  * pair t gets I0 = the track's previous frame, D0 = its depth map, I1 = its newest
- * frame and, if the batch has a weight map, W0 = safe_invert(variance). */
+ * frame and, if the batch has a weight map, W0 = tadataka.numeric.safe_invert(variance)
+ * = 1 / (variance + 1e-16). */
 tdk_status tdk_sd_export_dvo(tdk_sd *h, tdk_dvo *batch);
 /* Kernel times of the last step, measured with HIP events on the session's stream:
  * ms[0] scatter + fold (increment_age + propagate), ms[1] update_depth (classify +

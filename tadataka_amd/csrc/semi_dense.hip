@@ -549,6 +549,7 @@ __global__ __launch_bounds__(kBlock) void k_fusion(const double *__restrict__ mu
 }
 
 // tdk_sd_export_dvo: I0 = previous frame, D0 = depth map, I1 = newest frame, W0 = safe_invert(variance)
+// (examples/semi_dense_vo.py:44-53; the Python safe_invert with epsilon 1e-16, not the Rust one)
 __global__ __launch_bounds__(kBlock) void k_export_dvo(int N, const double *const *__restrict__ prev_image,
                                                        const double *const *__restrict__ new_image,
                                                        const double *__restrict__ depth,
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(kBlock) void k_export_dvo(int N, const double *cons
         I0[o] = p[i];
         I1[o] = q[i];
         D0[o] = depth[m];
-        if (W0) W0[o] = tdk::safe_inv(variance[m]);
+        if (W0) W0[o] = 1.0 / (variance[m] + tdk::kEps16);   // tadataka.numeric.safe_invert (numeric.py:1-2), as the example calls it
     }
 }
 

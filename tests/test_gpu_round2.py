@@ -302,7 +302,7 @@ def test_sd_export_feeds_dvo_batch(ops):
         assert np.array_equal(batch.download(t, 0, "I0"), c["ref_image"])
         assert np.array_equal(batch.download(t, 0, "I1"), c["key_image"])
         assert np.array_equal(batch.download(t, 0, "D0"), c["prior_depth"])
-        assert np.array_equal(batch.download(t, 0, "W0"), 1.0 / (c["prior_variance"] * (1 + t) + 2.220446049250313e-16))
+        assert np.array_equal(batch.download(t, 0, "W0"), 1.0 / (c["prior_variance"] * (1 + t) + 1e-16))   # tadataka.numeric.safe_invert
     # and the batch is usable: the weight-map DVO runs on what the session exported
     cam = cases[0]["cam"]
     P, n_evals = batch.estimate_level(0, cam, cam, np.tile(_pose12(np.eye(4)), (n, 1)), ops.W_MAP, 5)
@@ -468,3 +468,67 @@ np.save(sys.argv[1], np.concatenate([dp.ravel(), dq.ravel(), [err]]))
     assert np.array_equal(outs[0], outs[1])                                   # run to run
     scale = np.max(np.abs(outs[2]))
     assert np.max(np.abs(outs[0] - outs[2])) < 1e-9 * scale                   # against the pair kernel
+
+
+# ---------------------------------------------------------------------------
+# the loop of examples/semi_dense_vo.py:160-199, device-resident end to end
+# ---------------------------------------------------------------------------
+def test_semi_dense_vo_loop_on_device(ops, orc):
+    """track (PoseChangeEstimator on image0, depth_map0, image1, weights = safe_invert(variance_map0))
+    -> increment_age -> propagate -> update_depth, three frames after the first, with only the new
+    image crossing PCIe per step.  Tracking against the oracle's coarse-to-fine loop (1e-6); mapping
+    against the oracle fed with the SAME transform (bit-exact)."""
+    from tadataka_amd import synthetic
+    H, W, n_frames = 96, 128, 4
+    cam = synthetic.camera_for(W, H)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    depth_gt0 = synthetic.depth_map(xs, ys)
+    # a camera sliding along x and slightly forward, looking at the textured surface of frame 0
+    T_w = []
+    for k in range(n_frames):
+        T = np.eye(4); T[:3, 3] = [0.03 * k, 0.005 * k, 0.01 * k]
+        T_w.append(T)
+    xn, yn = (xs - cam[2]) / cam[0], (ys - cam[3]) / cam[1]
+
+    def render(T_wk):        # first-order consistent views: texture attached to frame 0's surface
+        P = np.stack([xn * depth_gt0, yn * depth_gt0, depth_gt0], axis=-1) + T_wk[:3, 3]
+        return np.ascontiguousarray(synthetic.texture(P[..., 0] / P[..., 2] * cam[0] + cam[2],
+                                                      P[..., 1] / P[..., 2] * cam[1] + cam[3]))
+    images = [render(T) for T in T_w]
+    rng = np.random.default_rng(0)
+    depth = depth_gt0 * rng.uniform(0.95, 1.05, (H, W))
+    var = np.full((H, W), 0.05)
+    age = np.zeros((H, W), dtype=np.uint64)
+    pargs = (0.5, 10.0, 0.01, 0.01, 0.004, 0.01)
+    pg, po = ops.make_params(*pargs), orc.make_params(*pargs)
+    n_levels = 2
+    sd = ops.SemiDenseSession(1, H, W, max_refframes=n_frames)
+    sd.set_params(pg, *SD_DEFAULTS)
+    dvo = ops.DvoBatch(1, H, W, n_levels=n_levels, ratio=1.5, with_weight_map=True)
+    dvo.set_anti_aliasing(False)
+    sd.push_frame(0, cam, images[0], T_w[0])
+    sd.set_maps(0, depth, var, age)
+    T_w_est = [T_w[0]]
+    frames = [(cam, images[0], T_w[0])]
+    for k in range(1, n_frames):
+        sd.push_frame(0, cam, images[k])                               # the only upload of the step
+        sd.export_dvo(dvo)
+        dvo.build_pyramid()
+        P, _ = dvo.estimate(cam, cam, _pose12(np.eye(4))[None], ops.W_MAP, 20)
+        # tracking parity: the oracle's PoseChangeEstimator with the same weight map
+        rot, t = orc.dvo_estimate(images[k - 1], depth, images[k], cam, cam, weights=1.0 / (var + 1e-16),
+                                  n_coarse_to_fine=n_levels, max_iter=20)
+        assert np.max(np.abs(P[0, :9].reshape(3, 3) - rot.as_matrix())) < POSE_ATOL
+        assert np.max(np.abs(P[0, 9:] - t)) < POSE_ATOL
+        T10 = np.eye(4); T10[:3, :3] = P[0, :9].reshape(3, 3); T10[:3, 3] = P[0, 9:]
+        T_w1 = T_w_est[-1] @ np.linalg.inv(T10)                        # calc_pose_w1 (:127-130)
+        sd.step(T10[None], T_w1[None], commit=True)
+        key = (cam, images[k], T_w1)
+        depth, var, age, flag = orc.semi_dense_step(key, cam, frames, T10, age, depth, var, po, *SD_DEFAULTS)
+        gd, gv, ga, gf = sd.get_maps(0, with_flag=True)
+        assert np.array_equal(ga, age) and np.array_equal(gf, flag)
+        assert np.array_equal(gd, depth) and np.array_equal(gv, var)
+        frames.append(key)
+        T_w_est.append(T_w1)
+    assert int(age.max()) == n_frames - 1 and int((flag == 0).sum()) > 500
+    dvo.close(); sd.close()
