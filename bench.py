@@ -382,8 +382,13 @@ def main():
 
     from tadataka_amd import _lib, ops, sharding, synthetic
     _lib.require_gpu()
-    _lib.call("tdk_set_device", local_rank)
-    comm = sharding.connect()                       # RCCL through the C ABI when WORLD_SIZE > 1
+    # one GPU per rank; on a box with fewer GPUs than ranks (only ever a smoke test) ranks share devices
+    _lib.call("tdk_set_device", local_rank % _lib.device_count())
+    # RCCL through the C ABI when WORLD_SIZE > 1.  If RCCL cannot be brought up on this node the few
+    # bytes of poses and scalars go through files instead and the JSON line says so ("exchange").
+    comm, comm_error = sharding.connect_or_fallback()
+    if comm_error:
+        sys.stderr.write("bench.py: RCCL unavailable (%s); exchanging poses through files\n" % comm_error)
     world, rank = comm.world, comm.rank
 
     B, H, W = args.pairs, args.height, args.width
@@ -516,7 +521,10 @@ def main():
             "frame_pairs_per_s": B * world * total_steps / elapsed,
             "dvo_iterations_per_pair_per_step": pixels / total_steps / B / (H * W),
             "max_translation_error": t_err,
-            "rccl_ranks": world if world > 1 else 0,
+            "rccl_ranks": world if (world > 1 and comm.kind == "rccl") else 0,
+            "exchange": {"rccl": "ncclAllGather of the device-resident poses (tdk_comm, C ABI)",
+                         "file": "files in TMPDIR -- RCCL could not be initialised: %s" % comm_error,
+                         "local": "none (one process)"}[comm.kind],
             "roofline": rl,
         }
         if golden is not None and last_batch == 0:

@@ -31,6 +31,7 @@ def pair_seeds(rank, pairs_per_rank):
 class LocalComm(object):
     """World of one: every collective is the identity."""
     rank, world = 0, 1
+    kind = "local"
 
     def all_gather(self, array):
         return np.array(array, dtype=np.float64)
@@ -48,6 +49,7 @@ class LocalComm(object):
 class RcclComm(object):
     """RCCL communicator of this process (tdk_comm).  The device must have been
     selected (tdk_set_device) before; creation is collective."""
+    kind = "rccl"
 
     def __init__(self, rank, world, unique_id):
         from tadataka_amd import _lib
@@ -102,10 +104,70 @@ class RcclComm(object):
             pass
 
 
+class FileComm(object):
+    """Last-resort exchange through files in TMPDIR for the FEW BYTES this path ever moves
+    between ranks (poses, a handful of scalars): used only when RCCL cannot be brought up, so that
+    a multi-GPU measurement still completes -- and says so (`kind`).  The estimation itself never
+    goes through here; there is no data-path collective to fall back from."""
+    kind = "file"
+
+    def __init__(self, rank, world, key):
+        self.rank, self.world = int(rank), int(world)
+        self._dir = os.path.join(os.environ.get("TMPDIR", "/tmp"), "tdk_filecomm_%s" % key)
+        os.makedirs(self._dir, exist_ok=True)
+        self._seq = 0
+
+    def _exchange(self, array):
+        a = np.ascontiguousarray(array, dtype=np.float64)
+        self._seq += 1
+        mine = os.path.join(self._dir, "%d_%d.npy" % (self._seq, self.rank))
+        np.save(mine + ".tmp.npy", a)
+        os.replace(mine + ".tmp.npy", mine)
+        parts, t0 = [], time.time()
+        for r in range(self.world):
+            path = os.path.join(self._dir, "%d_%d.npy" % (self._seq, r))
+            while not os.path.exists(path):
+                if time.time() - t0 > 600.0:
+                    raise RuntimeError("file exchange: rank %d never arrived" % r)
+                time.sleep(0.0005)
+            parts.append(np.load(path))
+        if self._seq > 2:                           # everybody has passed exchange seq - 2 by now
+            try:
+                os.unlink(os.path.join(self._dir, "%d_%d.npy" % (self._seq - 2, self.rank)))
+            except OSError:
+                pass
+        return parts
+
+    def all_gather(self, array):
+        parts = self._exchange(array)
+        return np.concatenate([p.reshape((-1,) + p.shape[1:]) if p.ndim else p.reshape(1) for p in parts], axis=0)
+
+    def all_reduce(self, values, op):
+        parts = np.array(self._exchange(np.asarray(values, dtype=np.float64).reshape(-1)))
+        return parts.max(axis=0) if op == "max" else parts.sum(axis=0)
+
+    def barrier(self):
+        self._exchange(np.zeros(1))
+
+    def close(self):
+        pass
+
+
 def _rendezvous_path():
     # all ranks of one launch share the launcher as parent and the rendezvous port
     key = os.environ.get("TDK_RENDEZVOUS_KEY") or "%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
     return os.path.join(os.environ.get("TMPDIR", "/tmp"), "tdk_rccl_%s.id" % key)
+
+
+def connect_or_fallback(rank=None, world=None):
+    """connect(); if RCCL cannot be initialised, a FileComm and the reason -- (comm, error or None)."""
+    try:
+        return connect(rank, world), None
+    except Exception as e:                          # noqa: BLE001  (library missing, bootstrap failure, ...)
+        rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+        key = "%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+        return FileComm(rank, world, key), repr(e)
 
 
 def connect(rank=None, world=None, timeout=300.0):

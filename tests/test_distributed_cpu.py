@@ -69,3 +69,29 @@ def test_unique_id_rendezvous_without_gpu(tmp_path):
     uids = [np.load(o) for o in outs]
     assert uids[0].shape == (128,) and all(np.array_equal(u, uids[0]) for u in uids)
     assert glob.glob(str(tmp_path / "tdk_rccl_*")) == []          # rank 0 cleaned up
+
+
+def test_file_comm_fallback_three_ranks(tmp_path):
+    """FileComm (what bench.py falls back to when RCCL cannot be initialised): gather / reduce /
+    barrier across three processes."""
+    code = r'''
+import os, sys, numpy as np
+sys.path.insert(0, %r)
+from tadataka_amd import sharding
+rank = int(os.environ["RANK"])
+c = sharding.FileComm(rank, 3, "t")
+g = c.all_gather(np.full((2, 12), float(rank)))
+assert g.shape == (6, 12) and np.array_equal(g[:, 0], [0, 0, 1, 1, 2, 2])
+assert np.array_equal(c.all_reduce([rank, 1.0], "sum"), [3.0, 3.0])
+assert np.array_equal(c.all_reduce([rank, 1.0], "max"), [2.0, 1.0])
+for _ in range(5):
+    c.barrier()
+pg = sharding.PoseGather(2, c)
+pg.start(np.full((2, 12), 10.0 + rank))
+assert np.array_equal(pg.finish()[:, 0], [10, 10, 11, 11, 12, 12])
+''' % REPO
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(os.environ, RANK=str(r), TMPDIR=str(tmp_path)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(3)]
+    for p in procs:
+        out, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, out[-2000:]
