@@ -46,6 +46,27 @@ class LocalComm(object):
         pass
 
 
+class _StdoutToStderr(object):
+    """RCCL prints a version banner on the C-level stdout when a communicator comes up; bench.py
+    owes its caller exactly one JSON line there.  While the communicator is created, file
+    descriptor 1 points at stderr (C stdio flushed on both sides of the switch)."""
+
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._libc = C.CDLL(None)
+        self._libc.fflush(None)
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        self._libc.fflush(None)
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 class RcclComm(object):
     """RCCL communicator of this process (tdk_comm).  The device must have been
     selected (tdk_set_device) before; creation is collective."""
@@ -57,13 +78,15 @@ class RcclComm(object):
         self.rank, self.world = int(rank), int(world)
         self._h = C.c_void_p()
         buf = (C.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
-        _lib.call("tdk_comm_create", buf, self.rank, self.world, C.byref(self._h))
+        with _StdoutToStderr():
+            _lib.call("tdk_comm_create", buf, self.rank, self.world, C.byref(self._h))
 
     @staticmethod
     def unique_id():
         from tadataka_amd import _lib
         buf = (C.c_uint8 * 128)()
-        _lib.call("tdk_comm_unique_id", buf)
+        with _StdoutToStderr():
+            _lib.call("tdk_comm_unique_id", buf)
         return bytes(buf)
 
     def all_gather(self, array):
