@@ -229,9 +229,21 @@ __device__ __forceinline__ double sample(const double *img, int H, int W, double
 }
 
 // estimate (:91-158).  Returns the Flag (0 = Success) and writes (inv_depth, variance).
-__device__ int estimate(double ukx, double uky, double prior_id, double prior_var, const Cam &kc,
-                        const double *__restrict__ key_image, const RefConst &rf, int H, int W,
-                        const EstParams &pr, double &out_id, double &out_var) {
+// What the search needs of the geometry computed before the last early exit.
+struct SearchState {
+    double xk, yk;              // normalised key coordinate
+    double key_step, key_gradient;
+    double xmin_x, xmin_y;      // near end of the epipolar segment in the reference frame
+    double dirx, diry;          // its direction
+    double rdx, rdy;            // far end - near end
+    double key_I[5];            // the five key intensities
+    int n;                      // search positions
+};
+
+// First half of estimate (:91-158): everything up to the last early exit.  Returns the Flag, 0 = search on.
+__device__ int estimate_gate(double ukx, double uky, double prior_id, double prior_var, const Cam &kc,
+                             const double *__restrict__ key_image, const RefConst &rf, int H, int W,
+                             const EstParams &pr, SearchState &st) {
     const double *T = rf.T_rk;
     const Cam rc{rf.cam[0], rf.cam[1], rf.cam[2], rf.cam[3]};
     // prior.range() (hypothesis.rs:54-61) -> depth_search_range (depth.rs:25-30)
@@ -299,6 +311,26 @@ __device__ int estimate(double ukx, double uky, double prior_id, double prior_va
         tdk::unnormalize(rc, xmin_x + s * dirx, xmin_y + s * diry, ux, uy);
         if (!tdk::in_range(ux, uy, H, W)) return -4;
     }
+    st.xk = xk; st.yk = yk; st.key_step = key_step; st.key_gradient = key_gradient;
+    st.xmin_x = xmin_x; st.xmin_y = xmin_y; st.dirx = dirx; st.diry = diry; st.rdx = rdx; st.rdy = rdy;
+#pragma unroll
+    for (int i = 0; i < 5; i++) st.key_I[i] = key_I[i];
+    st.n = n;
+    return 0;
+}
+
+// Second half: the search along the epipolar line, depth and variance of the best match, final range check.
+__device__ int estimate_search(const SearchState &st, double ukx, double uky, const Cam &kc,
+                               const double *__restrict__ key_image, const RefConst &rf, int H, int W,
+                               const EstParams &pr, double &out_id, double &out_var) {
+    const double *T = rf.T_rk;
+    const Cam rc{rf.cam[0], rf.cam[1], rf.cam[2], rf.cam[3]};
+    const double xk = st.xk, yk = st.yk, key_step = st.key_step, key_gradient = st.key_gradient;
+    const double xmin_x = st.xmin_x, xmin_y = st.xmin_y, dirx = st.dirx, diry = st.diry, rdx = st.rdx, rdy = st.rdy;
+    const int n = st.n;
+    double key_I[5], dtmp;
+#pragma unroll
+    for (int i = 0; i < 5; i++) key_I[i] = st.key_I[i];
 
     // intensities::search (intensities.rs:6-36): sliding 5-window, first minimum
     double kn[5];
@@ -371,6 +403,16 @@ __device__ int estimate(double ukx, double uky, double prior_id, double prior_va
     out_id = id;
     out_var = variance;
     return 0;
+}
+
+// estimate (:91-158) in one piece (estimate_debug_)
+__device__ int estimate(double ukx, double uky, double prior_id, double prior_var, const Cam &kc,
+                        const double *__restrict__ key_image, const RefConst &rf, int H, int W,
+                        const EstParams &pr, double &out_id, double &out_var) {
+    SearchState st;
+    const int f = estimate_gate(ukx, uky, prior_id, prior_var, kc, key_image, rf, H, W, pr, st);
+    if (f) return f;
+    return estimate_search(st, ukx, uky, kc, key_image, rf, H, W, pr, out_id, out_var);
 }
 
 // ---- update_depth (:160-234), split into classify + estimate ---------------------
@@ -446,7 +488,13 @@ __global__ __launch_bounds__(kBlock) void k_ud_classify(int N, const TrackKey *_
     }
 }
 
-// One lane per live pixel.
+// One lane per live pixel, in two phases.  A third of the live pixels leaves `estimate` at one
+// of its early exits (texture-less key window, epipolar segment out of range, ...), after about a
+// quarter of the arithmetic; the search that follows is FP64-issue bound, and lanes that left
+// would idle through it.  So the block runs the gate for its 256 pixels, compacts the survivors'
+// state through LDS (15 doubles + 3 ints per lane, structure of arrays) and only as many waves as
+// there are survivors run the search -- same arithmetic per pixel, full waves.
+constexpr int kStateDoubles = 15;
 __global__ __launch_bounds__(kBlock) void k_ud_estimate(int H, int W, const TrackKey *__restrict__ keys,
                                                         const RefConst *__restrict__ refs, int refs_per_track,
                                                         const uint64_t *__restrict__ age,
@@ -458,21 +506,74 @@ __global__ __launch_bounds__(kBlock) void k_ud_estimate(int H, int W, const Trac
                                                         double *__restrict__ out_var,
                                                         int64_t *__restrict__ out_flag) {
     const int track = blockIdx.y;
+    const int n_live = count[track * kCountStride];
+    if ((int)(blockIdx.x * kBlock) >= n_live) return;           // block-uniform
     const int k = blockIdx.x * kBlock + (int)threadIdx.x;
-    if (k >= count[track * kCountStride]) return;
     const int64_t base = (int64_t)track * stride;
-    const int i = list[base + k];
     const TrackKey &key = keys[track];
     const Cam kc{key.cam[0], key.cam[1], key.cam[2], key.cam[3]};
-    const int a = (int)age[base + i];
-    const double d = prior_depth[base + i], v = prior_var[base + i];
-    const double pid = tdk::safe_inv(d);
+    __shared__ double sd[kStateDoubles][kBlock];
+    __shared__ int si[3][kBlock];
+    __shared__ int wave_total[kBlock / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+    // ---- phase 1: the gate ----
+    bool go = false;
+    SearchState st;
+    int i = 0, a = 0;
+    if (k < n_live) {
+        i = list[base + k];
+        a = (int)age[base + i];
+        const double d = prior_depth[base + i], v = prior_var[base + i];
+        const double pid = tdk::safe_inv(d);
+        const int y = i / W, x = i - y * W;
+        // refframes[len - age] (:207): refs[track][age - 1] is the frame `age` steps before the key frame
+        const RefConst &rf = refs[(int64_t)track * refs_per_track + (a - 1)];
+        const int f = estimate_gate((double)x, (double)y, pid, v, kc, key.image, rf, H, W, pr, st);
+        go = f == 0;
+        if (!go) {                                               // Err(flag) => (prior, flag)
+            out_depth[base + i] = tdk::safe_inv(pid);
+            out_var[base + i] = v;
+            out_flag[base + i] = f;
+        }
+    }
+    const uint64_t m = __builtin_amdgcn_ballot_w64(go);
+    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    if (lane == 0) wave_total[wave] = __builtin_popcountll(m);
+    __syncthreads();
+    int slot = before, survivors = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) {
+        if (w < wave) slot += wave_total[w];
+        survivors += wave_total[w];
+    }
+    if (go) {
+        sd[0][slot] = st.xk; sd[1][slot] = st.yk; sd[2][slot] = st.key_step; sd[3][slot] = st.key_gradient;
+        sd[4][slot] = st.xmin_x; sd[5][slot] = st.xmin_y; sd[6][slot] = st.dirx; sd[7][slot] = st.diry;
+        sd[8][slot] = st.rdx; sd[9][slot] = st.rdy;
+#pragma unroll
+        for (int q = 0; q < 5; q++) sd[10 + q][slot] = st.key_I[q];
+        si[0][slot] = i; si[1][slot] = a; si[2][slot] = st.n;
+    }
+    __syncthreads();
+
+    // ---- phase 2: the search, survivors packed into the first waves ----
+    if ((int)threadIdx.x >= survivors) return;
+    const int t = threadIdx.x;
+    st.xk = sd[0][t]; st.yk = sd[1][t]; st.key_step = sd[2][t]; st.key_gradient = sd[3][t];
+    st.xmin_x = sd[4][t]; st.xmin_y = sd[5][t]; st.dirx = sd[6][t]; st.diry = sd[7][t];
+    st.rdx = sd[8][t]; st.rdy = sd[9][t];
+#pragma unroll
+    for (int q = 0; q < 5; q++) st.key_I[q] = sd[10 + q][t];
+    i = si[0][t]; a = si[1][t]; st.n = si[2][t];
     const int y = i / W, x = i - y * W;
-    // refframes[len - age] (:207): refs[track][age - 1] is the frame `age` steps before the key frame
     const RefConst &rf = refs[(int64_t)track * refs_per_track + (a - 1)];
-    double id = pid, var = v;
-    int f = estimate((double)x, (double)y, pid, v, kc, key.image, rf, H, W, pr, id, var);
-    if (f) { id = pid; var = v; }  // Err(flag) => (prior, flag)
+    double id = 0.0, var = 0.0;
+    const int f = estimate_search(st, (double)x, (double)y, kc, key.image, rf, H, W, pr, id, var);
+    if (f) {                                                     // the final range check failed: the prior comes back
+        id = tdk::safe_inv(prior_depth[base + i]);
+        var = prior_var[base + i];
+    }
     out_depth[base + i] = tdk::safe_inv(id);
     out_var[base + i] = var;
     out_flag[base + i] = f;
