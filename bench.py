@@ -9,10 +9,12 @@ batch of independent synthetic 640x480 frame pairs resident in HBM: build the
 pyramids (anti-aliased, as skimage.rescale does by default -- the same constant
 the drop-in tadataka.vo.dvo uses), then per level the fused evaluate/solve
 Gauss-Newton loop, all pairs in lock step on the device.  `value` counts every
-source pixel pushed through one DVO iteration (= one calc_pose_update + one
-photometric_error at one pose, which the fused kernel does in a single pass):
-sum over levels, iterations and still running pairs of the level's pixel count,
-divided by wall time.  `frame_pairs_per_s` is the unambiguous companion.  Pair 0
+source pixel of every pose whose photometric error the loop evaluates (one per
+PhotometricError call of the reference: n updates + n + 1 errors per level; the
+normal equations are formed with the error in one pass, except that a candidate
+pose is probed error-only first and gets its normal equations only if accepted):
+sum over levels, evaluated poses and still running pairs of the level's pixel
+count, divided by wall time.  `frame_pairs_per_s` is the unambiguous companion.  Pair 0
 of the batch is the seed-0 pair of tests/golden/dvo_vga_pyramid.npz: its pose is
 checked against what the REFERENCE's own PoseChangeEstimator returned.
 
@@ -470,9 +472,12 @@ def main():
         blocks += 1
     total_steps = blocks * args.steps
     prof = {"launches": 0, "total_ms": 0.0, "pixels": 0}
+    prof_probe = {"launches": 0, "total_ms": 0.0, "pixels": 0}
     for bt in batches:
-        for key, val in bt.get_profile().items():
+        for key, val in bt.get_profile("full").items():
             prof[key] += val
+        for key, val in bt.get_profile("probe").items():
+            prof_probe[key] += val
         bt.set_profiling(False)
     pixels_all = float(sharding.reduce_scalars([float(pixels)], "sum", comm)[0])
 
@@ -495,6 +500,13 @@ def main():
                       px_per_launch=prof["pixels"] / max(prof["launches"], 1), launches=prof["launches"],
                       limiter="FP64 issue at the package power cap (DESIGN.md 5.1), not HBM")
         rl["traffic"] = traffic
+        rl_probe = None
+        if prof_probe["launches"]:
+            pms = prof_probe["total_ms"] / prof_probe["launches"]
+            rl_probe = roofline(BYTES_PER_PX_EVAL * prof_probe["pixels"] / prof_probe["launches"], pms,
+                                kernel=f"k_dvo_eval<{args.weights}> probing a candidate (error only), full-resolution level",
+                                bytes_per_px=BYTES_PER_PX_EVAL, launches=prof_probe["launches"],
+                                limiter="HBM: D0, I0 streamed, I1 gathered, 50 FP64 operations per pixel")
         out = {
             "metric": "warp+residual+JtJ Mpixels/sec per DVO iter",
             "value": pixels_all / elapsed / 1e6,
@@ -527,6 +539,8 @@ def main():
                          "local": "none (one process)"}[comm.kind],
             "roofline": rl,
         }
+        if rl_probe:
+            out["roofline_probe"] = rl_probe
         if golden is not None and last_batch == 0:
             from scipy.spatial.transform import Rotation
             tag = ("pyr_aa_" if anti_aliasing else "pyr_") + str(weights)

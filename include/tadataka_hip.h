@@ -150,6 +150,12 @@ tdk_status tdk_dvo_get_stream(tdk_dvo *h, void **stream_out);
  * launches, summed milliseconds and summed source pixels since enabling. */
 tdk_status tdk_dvo_set_profiling(tdk_dvo *h, int enabled);
 tdk_status tdk_dvo_get_profile(tdk_dvo *h, int64_t *launches, double *total_ms, int64_t *pixels);
+/* The device loop first PROBES a candidate pose (error only) and forms the normal
+ * equations only for accepted candidates -- as the reference computes n updates and n + 1
+ * errors per level.  kind 0: launches that evaluated only in full (what tdk_dvo_get_profile
+ * returns), 1: only probes, 2: both kinds of pairs in one launch. */
+tdk_status tdk_dvo_get_profile_kind(tdk_dvo *h, int kind, int64_t *launches, double *total_ms,
+                                    int64_t *pixels);
 
 /* ---- least-squares pieces at the reference's own granularity -------------- */
 /* A^T W A (upper triangle, row-major, p(p+1)/2) and A^T W b (p) of an n x p

@@ -347,23 +347,60 @@ struct Samples {     // everything that is loaded for the pixel being accumulate
     double i0, i1, w0;
 };
 
-template <int WMODE>
+// Error-only evaluation (the "probe" of a candidate pose, see reduce_pair): only the four texels
+// of the bilinear sample of I1 are needed -- two 16-byte loads, (c, c + 1) on rows r0 and r0 + 1
+// with c = min(c0, W - 2) and the row clamped, unconditional like every load of the pipeline.
+__device__ __forceinline__ void sp_issue_taps_probe(TapPairs &q, const double *__restrict__ I1, int H, int W, int c0,
+                                                    int r0) {
+    const uint32_t rowb = (uint32_t)W * 8u;
+    const uint32_t row0 = (uint32_t)r0 * rowb;
+    const uint32_t row1 = r0 < H - 1 ? row0 + rowb : row0;
+    const uint32_t cm = (uint32_t)min(c0, W - 2) * 8u;
+    q.a01 = ldo2(I1, row0 + cm);
+    q.b01 = ldo2(I1, row1 + cm);
+}
+
+// I1 at the warped coordinate and the squared photometric error term (metric.py:24-27).  ONE
+// function for the full and the probe evaluation: the same expression, contracted the same way,
+// so both give the same bits for the same pose.
+__device__ __forceinline__ double error_term(double a1, double a2, double b1, double b2, double w00, double w01,
+                                             double w10, double w11, double i0) {
+    const double i1w = a1 * w00 + a2 * w01 + b1 * w10 + b2 * w11;
+    const double e = i0 - i1w;
+    return e * e;
+}
+
+template <int WMODE, bool PROBE>
 __device__ __forceinline__ void sp_issue(Samples &s, const Pixel &p, uint32_t off, const double *__restrict__ I0,
                                          const double *__restrict__ I1, const double *__restrict__ W0, int H,
                                          int W, const double *c) {
     s.i0 = ldo(I0, off);
+    if (PROBE) {
+        sp_issue_taps_probe(s.q, I1, H, W, p.c0, p.r0);
+        return;
+    }
     s.i1 = ldo(I1, off);
     if (WMODE == TDK_W_MAP) s.w0 = ldo(W0, off);
     sp_issue_taps(s.q, I1, H, W, p.c0, p.r0, p.inside);
 }
 
-template <int WMODE>
+template <int WMODE, bool PROBE>
 __device__ __forceinline__ void sp_accumulate(Accum &a, int &n_error, int &n_update, const Samples &s,
                                               const Pixel &p, double ws, int H, int W, const double *c) {
     // mask sizes: one scalar popcount per wave instead of two f64 adds per lane
     n_error += __builtin_popcountll(__builtin_amdgcn_ballot_w64(p.mask != 0));
     n_update += __builtin_popcountll(__builtin_amdgcn_ballot_w64(p.mask == 2));
     if (p.mask == 0) return;
+    if (PROBE) {
+        // texels (r0, c0), (r0, c0 + 1), (r0 + 1, c0), (r0 + 1, c0 + 1), replicated at the right edge
+        const bool last_col = p.c0 == W - 1;
+        const double a1 = last_col ? s.q.a01.y : s.q.a01.x, a2 = s.q.a01.y;
+        const double b1 = last_col ? s.q.b01.y : s.q.b01.x, b2 = s.q.b01.y;
+        const double wx1 = p.wx1, wy1 = p.wy1;
+        const double wx0 = 1.0 - wx1, wy0 = 1.0 - wy1;
+        a.v[27] += error_term(a1, a2, b1, b2, wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1, s.i0);
+        return;
+    }
     Warped w;
     w.c0 = p.c0; w.r0 = p.r0;
     Taps t = sp_unpack(s.q);
@@ -378,9 +415,7 @@ __device__ __forceinline__ void sp_accumulate(Accum &a, int &n_error, int &n_upd
     if (border) gradient2_clamped(t, w, H, W, gx, gy);
     else gradient2_inside(t, w, gx, gy);
     // photometric error term (metric.py:24-27): no z test here
-    double i1w = t.a1 * w.w00 + t.a2 * w.w01 + t.b1 * w.w10 + t.b2 * w.w11;
-    double e = s.i0 - i1w;
-    a.v[27] += e * e;
+    a.v[27] += error_term(t.a1, t.a2, t.b1, t.b2, w.w00, w.w01, w.w10, w.w11, s.i0);
     if (p.mask != 2) return;  // update mask adds P1z > 0 (vo/dvo/__init__.py:49)
     // Jacobian row (vo/dvo/jacobian.py:8-24) with X = x/z, Y = y/z factored out:
     //   [fgx/z, fgy/z, -(fgx X + fgy Y)/z, -fgx XY - fgy (1 + Y^2), fgx (1 + X^2) + fgy XY, fgy X - fgx Y]
@@ -407,20 +442,11 @@ __device__ __forceinline__ void sp_accumulate(Accum &a, int &n_error, int &n_upd
     }
 }
 
-template <int WMODE>
-__global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairParams *__restrict__ params,
-                                                        const double *__restrict__ poses,
-                                                        const int *__restrict__ state,
-                                                        const double *__restrict__ wscale, double scale,
-                                                        int64_t chunk, int n_pairs, int nblk,
-                                                        double *__restrict__ partials) {
-    // 1-D grid.  Workgroups are dealt to the 8 XCDs round-robin, each XCD has its own L2: XCD k
-    // takes pairs k, k + 8, ... one after the other, the blocks of a pair (whose tap halos and
-    // stream lines overlap) consecutively -- so they meet in one L2, close in time.
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int pair = (q / nblk) * 8 + xcd, blk = q - (q / nblk) * nblk;
-    if (pair >= n_pairs) return;
-    if (state != nullptr && state[pair] != ST_RUNNING) return;
+template <int WMODE, bool PROBE>
+__device__ __forceinline__ void eval_body(const LevelPtrs &L, const PairParams *__restrict__ params,
+                                          const double *__restrict__ poses, const double *__restrict__ wscale,
+                                          double scale, int64_t chunk, int pair, int blk, int nblk,
+                                          double *__restrict__ partials) {
     BlockSetup b;
     load_setup(b, params, poses, pair, scale);
     const double ws = (WMODE == TDK_W_STUDENT_T || WMODE == TDK_W_TUKEY) ? wscale[pair] : 1.0;
@@ -476,25 +502,25 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
     d = TDK_DEPTH();
     sp_warp(pb, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
     TDK_ADVANCE();
-    sp_issue<WMODE>(s, pa, TDK_OFF(iw - 2 * kBlock), I0, I1, W0, H, W, b.c);
+    sp_issue<WMODE, PROBE>(s, pa, TDK_OFF(iw - 2 * kBlock), I0, I1, W0, H, W, b.c);
     // steady state: iw - 2 kBlock is the pixel being accumulated, iw the one being warped.
     // The scheduling barriers keep the three stages apart: interleaving them
     // would keep two tap sets and two half-warped pixels alive at once.
 #define TDK_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
     while (iw - 2 * kBlock < end) {
         d = TDK_DEPTH();
-        sp_accumulate<WMODE>(acc, n_error, n_update, s, pa, ws, H, W, b.c);
+        sp_accumulate<WMODE, PROBE>(acc, n_error, n_update, s, pa, ws, H, W, b.c);
         TDK_STAGE_FENCE();
-        sp_issue<WMODE>(s, pb, TDK_OFF(iw - kBlock), I0, I1, W0, H, W, b.c);
+        sp_issue<WMODE, PROBE>(s, pb, TDK_OFF(iw - kBlock), I0, I1, W0, H, W, b.c);
         TDK_STAGE_FENCE();
         sp_warp(pa, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
         TDK_ADVANCE();
         TDK_STAGE_FENCE();
 
         d = TDK_DEPTH();
-        sp_accumulate<WMODE>(acc, n_error, n_update, s, pb, ws, H, W, b.c);
+        sp_accumulate<WMODE, PROBE>(acc, n_error, n_update, s, pb, ws, H, W, b.c);
         TDK_STAGE_FENCE();
-        sp_issue<WMODE>(s, pa, TDK_OFF(iw - kBlock), I0, I1, W0, H, W, b.c);
+        sp_issue<WMODE, PROBE>(s, pa, TDK_OFF(iw - kBlock), I0, I1, W0, H, W, b.c);
         TDK_STAGE_FENCE();
         sp_warp(pb, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
         TDK_ADVANCE();
@@ -511,6 +537,31 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
     store_partials(acc, red, pair, blk, nblk, partials);
 }
 
+enum { MODE_FULL0 = 0, MODE_PROBE = 1, MODE_FULLK = 2, MODE_FUSED = 3 };   // what a pair's next evaluation is (reduce_pair)
+
+template <int WMODE>
+__global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairParams *__restrict__ params,
+                                                        const double *__restrict__ poses,
+                                                        const int *__restrict__ state,
+                                                        const int *__restrict__ mode,
+                                                        const double *__restrict__ wscale, double scale,
+                                                        int64_t chunk, int n_pairs, int nblk,
+                                                        double *__restrict__ partials) {
+    // 1-D grid.  Workgroups are dealt to the 8 XCDs round-robin, each XCD has its own L2: XCD k
+    // takes pairs k, k + 8, ... one after the other, the blocks of a pair (whose tap halos and
+    // stream lines overlap) consecutively -- so they meet in one L2, close in time.
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int pair = (q / nblk) * 8 + xcd, blk = q - (q / nblk) * nblk;
+    if (pair >= n_pairs) return;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    // block-uniform: a candidate pose is first PROBED -- error only, 50 of the 118 FP64 operations
+    // and 4 of the 12 texels per pixel -- and evaluated in full only once it has been accepted
+    if (mode != nullptr && mode[pair] == MODE_PROBE)
+        eval_body<WMODE, true>(L, params, poses, wscale, scale, chunk, pair, blk, nblk, partials);
+    else
+        eval_body<WMODE, false>(L, params, poses, wscale, scale, chunk, pair, blk, nblk, partials);
+}
+
 // ---------------------------------------------------------------------------
 // Gauss-Newton bookkeeping
 // ---------------------------------------------------------------------------
@@ -524,14 +575,19 @@ struct LoopState {   // device arrays, one entry per pair
     int *ticket;       // [1] blocks of the current k_dvo_reduce launch that are through
     unsigned long long *evals;   // [1] evaluations executed at this level, summed over the pairs
     int *warn;         // [n] an evaluation of the current estimate found an EMPTY update mask ("pose change is too large")
-    int *host_flag;    // mapped host memory: [0] `active` as left by the last launch, [2..3] `evals` (64 bit)
+    int *mode;         // [n] what the pair's NEXT evaluation is: MODE_FULL0 / MODE_PROBE / MODE_FULLK
+    int *tested;       // [n] candidates tested at this level (the reference's loop counter k)
+    int *stat_state;   // [n] ST_RUNNING where the next evaluation needs robust statistics (running and not a probe)
+    int *round;        // [2] pairs whose evaluation in the launch just reduced was full / a probe
+    int fuse_first;    // the first candidate of this level is evaluated in full straight away (see reduce_pair)
+    int *host_flag;    // mapped host memory: [0] `active` as left by the last launch, [2..3] `evals` (64 bit),
+                       // [4] / [5] `round`
 };
 
 // Fixed-order reduction of the per-block partials of one pair; in loop mode the
 // bookkeeping of _PoseChangeEstimator.__call__ (:92-111) follows.
 __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials, int nblk,
-                                            double *__restrict__ results, LoopState ls, int loop_mode, int iter,
-                                            int max_iter) {
+                                            double *__restrict__ results, LoopState ls, int loop_mode, int max_iter) {
     const int pair = blockIdx.x;
     __shared__ double red[kBlock / 32][kAccPad];
     const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -550,22 +606,47 @@ __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials,
     __syncthreads();
     if (!loop_mode || threadIdx.x != 0) return;
 
+    // _PoseChangeEstimator.__call__ (:92-111) runs, per level, one PhotometricError at the prior pose
+    // and then up to max_iter rounds of calc_pose_update + PhotometricError(candidate), stopping at the
+    // first candidate whose error is larger: n updates, n + 1 errors -- the normal equations at the
+    // rejected candidate are never formed.  Same here: the first evaluation of a level is FULL (error
+    // + normal equations), a candidate is PROBED (error only, ~40 % of the arithmetic and a third of
+    // the texels), and only an accepted candidate gets its normal equations (a second, full pass at
+    // the same pose).  With the typical 0-1 accepted steps per level that is one full + one probe
+    // instead of two full evaluations.  One exception: the FIRST candidate of the coarsest level
+    // (fuse_first) starts from the caller's prior and is accepted almost always, so it is evaluated
+    // in full straight away -- error and normal equations in one pass, as every evaluation was
+    // before -- instead of probe + full.
     const double *R = red[0];
-    double err = R[27] / R[29];  // mean over the error mask; 0/0 = NaN like np.mean([])
+    const double err = R[27] / R[29];  // mean over the error mask; 0/0 = NaN like np.mean([])
     double *pose = ls.pose + 12 * pair, *cand = ls.cand + 12 * pair;
-    ls.n_evals[pair] += 1;
-    atomicAdd(ls.evals, 1ull);
-    bool finished = false;
-    if (iter > 0) {
+    const int mode = ls.mode[pair];    // what has just been evaluated
+    atomicAdd(&ls.round[mode == MODE_PROBE ? 1 : 0], 1);
+    bool finished = false, solve = false;
+    if (mode == MODE_FULL0) {
+        ls.n_evals[pair] += 1;
+        atomicAdd(ls.evals, 1ull);
+        ls.prev_err[pair] = err;
+        if (max_iter == 0) finished = true;
+        else solve = true;
+    } else if (mode == MODE_PROBE || mode == MODE_FUSED) {
+        ls.n_evals[pair] += 1;
+        atomicAdd(ls.evals, 1ull);
+        const int k = ls.tested[pair] + 1;
+        ls.tested[pair] = k;
         if (err > ls.prev_err[pair]) {
             finished = true;  // candidate rejected: keep the last accepted pose (:105-106)
         } else {
             for (int i = 0; i < 12; i++) pose[i] = cand[i];  // accepted (:107-110)
-            if (iter == max_iter) finished = true;
+            ls.prev_err[pair] = err;
+            if (k == max_iter) finished = true;
+            else if (mode == MODE_FUSED) solve = true;       // its normal equations are in R already
+            else ls.mode[pair] = MODE_FULLK;                 // now its normal equations are needed
         }
+    } else {   // MODE_FULLK: the normal equations at the accepted pose (cand == pose)
+        solve = true;
     }
-    if (!finished) {
-        ls.prev_err[pair] = err;
+    if (solve) {
         if (R[28] == 0.0) {
             finished = true;  // empty update mask: "pose change is too large" (:98-100)
             ls.warn[pair] = 1;
@@ -575,8 +656,10 @@ __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials,
             double next[12];
             tdk::compose_update(xi, pose, next);
             for (int i = 0; i < 12; i++) cand[i] = next[i];
+            ls.mode[pair] = (mode == MODE_FULL0 && ls.fuse_first) ? MODE_FUSED : MODE_PROBE;
         }
     }
+    ls.stat_state[pair] = (!finished && ls.mode[pair] != MODE_PROBE) ? ST_RUNNING : ST_DONE;
     if (finished) {
         ls.state[pair] = ST_DONE;
         atomicSub(ls.active, 1);
@@ -585,9 +668,9 @@ __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials,
 
 __global__ __launch_bounds__(kBlock) void k_dvo_reduce(const double *__restrict__ partials, int nblk,
                                                        double *__restrict__ results, LoopState ls,
-                                                       int loop_mode, int iter, int max_iter) {
+                                                       int loop_mode, int max_iter) {
     const int pair = blockIdx.x;
-    if (!loop_mode || ls.state[pair] == ST_RUNNING) reduce_pair(partials, nblk, results, ls, loop_mode, iter, max_iter);
+    if (!loop_mode || ls.state[pair] == ST_RUNNING) reduce_pair(partials, nblk, results, ls, loop_mode, max_iter);
     if (!loop_mode || threadIdx.x != 0) return;
     // the last block through publishes the number of running pairs to the host:
     // no copy kernel between the iterations, the host just waits for the stream
@@ -595,6 +678,8 @@ __global__ __launch_bounds__(kBlock) void k_dvo_reduce(const double *__restrict_
     if (atomicAdd(ls.ticket, 1) == (int)gridDim.x - 1) {
         *ls.ticket = 0;
         *reinterpret_cast<volatile unsigned long long *>(ls.host_flag + 2) = atomicAdd(ls.evals, 0ull);
+        ls.host_flag[4] = atomicExch(&ls.round[0], 0);
+        ls.host_flag[5] = atomicExch(&ls.round[1], 0);
         *ls.host_flag = atomicAdd(ls.active, 0);
         __threadfence_system();
     }
@@ -610,11 +695,16 @@ __global__ void k_loop_init(LoopState ls, const double *poses_in, int n) {   // 
     }
     ls.prev_err[i] = 0.0;
     ls.state[i] = ST_RUNNING;
+    ls.stat_state[i] = ST_RUNNING;
+    ls.mode[i] = MODE_FULL0;
+    ls.tested[i] = 0;
     ls.n_evals[i] = 0;
     if (i == 0) {
         *ls.active = n;
         *ls.ticket = 0;
         *ls.evals = 0ull;
+        ls.round[0] = 0;
+        ls.round[1] = 0;
     }
 }
 
@@ -1034,8 +1124,9 @@ struct tdk_dvo {
     bool profiling;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used;
-    double prof_ms;
-    int64_t prof_launches, prof_pixels;
+    std::vector<int> ev_round;   // per event: [2 i] pairs evaluated in full, [2 i + 1] pairs probed by launch i
+    double prof_ms[3];           // buckets: full / probe / mixed launches (collect_profile)
+    int64_t prof_launches[3], prof_pixels[3];
     std::vector<double> cams;   // cameras currently on the device: [cam0 (n x 4) | cam1 (n x 4)]
     bool anti_aliasing;         // pyramid levels get skimage's Gaussian prefilter (tdk_dvo_set_anti_aliasing)
     double *d_aa_weights;       // its 1-D kernels, per level and axis (allocated on first use)
@@ -1197,9 +1288,12 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
     return TDK_OK;
 }
 
-tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *d_state, int weight_mode) {
+// d_mode: per-pair evaluation mode of the device loop (NULL: full); d_stat_state: the pairs whose
+// evaluation needs the robust statistics (running and not a probe; NULL: all)
+tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *d_state, const int *d_mode,
+                       const int *d_stat_state, int weight_mode) {
     const tdk_dvo::Level &L = h->lv[level];
-    TDK_TRY(prepare_robust(h, level, d_poses, d_state, weight_mode));
+    TDK_TRY(prepare_robust(h, level, d_poses, d_stat_state, weight_mode));
     int nblk;
     int64_t chunk;
     plan_blocks(h, L, &nblk, &chunk);
@@ -1212,7 +1306,11 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
             hipEvent_t e;
             TDK_HIP(hipEventCreate(&e));
             h->ev_pool.push_back(e);
+            h->ev_round.push_back(0);
         }
+        // until the device loop says otherwise: every pair, in full (tdk_dvo_evaluate)
+        h->ev_round[h->ev_used] = h->n_pairs;
+        h->ev_round[h->ev_used + 1] = 0;
         e0 = h->ev_pool[h->ev_used++];
         e1 = h->ev_pool[h->ev_used++];
         TDK_HIP(hipEventRecord(e0, h->stream));
@@ -1226,7 +1324,7 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
     if (lds > 64 * 1024)   /* beyond the default dynamic-LDS limit of a launch */                      \
         TDK_HIP(hipFuncSetAttribute((const void *)k_dvo_eval<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds));                                                         \
-    k_dvo_eval<WM><<<grid, kBlock, lds, h->stream>>>(P, h->d_params, d_poses, d_state, h->d_wscale, \
+    k_dvo_eval<WM><<<grid, kBlock, lds, h->stream>>>(P, h->d_params, d_poses, d_state, d_mode, h->d_wscale, \
                                                          L.scale, chunk, h->n_pairs, nblk, h->d_partials)
     switch (weight_mode) {
         case TDK_W_NONE: TDK_EVAL(TDK_W_NONE); break;
@@ -1244,12 +1342,12 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
     return TDK_OK;
 }
 
-tdk_status launch_reduce(tdk_dvo *h, int level, int loop_mode, int iter, int max_iter) {
+tdk_status launch_reduce(tdk_dvo *h, int level, int loop_mode, int max_iter) {
     int nblk;
     int64_t chunk;
     plan_blocks(h, h->lv[level], &nblk, &chunk);
     k_dvo_reduce<<<h->n_pairs, kBlock, 0, h->stream>>>(h->d_partials, nblk, h->d_results, h->ls,
-                                                           loop_mode, iter, max_iter);
+                                                           loop_mode, max_iter);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
@@ -1272,12 +1370,18 @@ tdk_status check_weight_mode(const tdk_dvo *h, int weight_mode) {
     return TDK_OK;
 }
 
+// Event pairs of the full-resolution launches since the last collection, sorted into three buckets
+// by what the launch evaluated (ev_round, one entry per pair of events): 0 only full evaluations,
+// 1 only probes, 2 both.
 tdk_status collect_profile(tdk_dvo *h) {
     for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
         float ms = 0.f;
         TDK_HIP(hipEventElapsedTime(&ms, h->ev_pool[i], h->ev_pool[i + 1]));
-        h->prof_ms += ms;
-        h->prof_launches += 1;
+        const int n_full = h->ev_round[i], n_probe = h->ev_round[i + 1];
+        const int b = n_probe == 0 ? 0 : (n_full == 0 ? 1 : 2);
+        h->prof_ms[b] += ms;
+        h->prof_launches[b] += 1;
+        h->prof_pixels[b] += h->lv[0].N * (int64_t)(n_full + n_probe);
     }
     h->ev_used = 0;
     return TDK_OK;
@@ -1294,18 +1398,26 @@ tdk_status collect_profile(tdk_dvo *h) {
 tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64_t *pixel_evals) {
     const bool small = (int64_t)h->n_pairs * h->lv[level].N <= (1ll << 22) && !h->profiling;
     const int burst = small ? 2 : 1;
-    for (int iter = 0; iter <= max_iter;) {
-        const int nb = max_iter + 1 - iter < burst ? max_iter + 1 - iter : burst;
+    // a pair goes through at most 2 max_iter + 1 evaluations: the first, then per tested candidate a
+    // probe and -- if it was accepted and is not the last -- the full evaluation at the accepted pose
+    const int max_rounds = 2 * max_iter + 1;
+    for (int round = 0; round < max_rounds;) {
+        const int nb = max_rounds - round < burst ? max_rounds - round : burst;
         for (int b = 0; b < nb; b++) {
-            TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, weight_mode));
-            TDK_TRY(launch_reduce(h, level, 1, iter + b, max_iter));
+            TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, h->ls.mode, h->ls.stat_state, weight_mode));
+            TDK_TRY(launch_reduce(h, level, 1, max_iter));
         }
-        TDK_HIP(hipStreamSynchronize(h->stream));   // k_dvo_reduce left the count in h_flag
-        iter += nb;
+        TDK_HIP(hipStreamSynchronize(h->stream));   // k_dvo_reduce left the counts in h_flag
+        round += nb;
+        if (h->profiling && level == 0 && h->ev_used >= 2) {   // what the launch just timed evaluated
+            h->ev_round[h->ev_used - 2] = ((volatile int *)h->h_flag)[4];
+            h->ev_round[h->ev_used - 1] = ((volatile int *)h->h_flag)[5];
+        }
         if (*(volatile int *)h->h_flag <= 0) break;
     }
+    // evaluations in the reference's sense: one per PhotometricError call (the full evaluation of an
+    // accepted candidate is the second half of the evaluation its probe began)
     const int64_t evals = (int64_t)*(volatile unsigned long long *)(h->h_flag + 2);
-    if (h->profiling && level == 0) h->prof_pixels += h->lv[0].N * evals;
     if (pixel_evals) *pixel_evals += h->lv[level].N * evals;
     return TDK_OK;
 }
@@ -1360,7 +1472,8 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
     h->max_blocks = 1024;
     h->d_rm = nullptr; h->d_wscale = nullptr; h->d_stat = nullptr; h->d_spartial = nullptr;
     h->d_count = nullptr; h->d_select = nullptr; h->d_hist = nullptr;
-    h->profiling = false; h->ev_used = 0; h->prof_ms = 0; h->prof_launches = 0; h->prof_pixels = 0;
+    h->profiling = false; h->ev_used = 0;
+    for (int b = 0; b < 3; b++) { h->prof_ms[b] = 0; h->prof_launches[b] = 0; h->prof_pixels[b] = 0; }
     for (int l = 0; l < n_levels; l++) {
         tdk_dvo::Level &L = h->lv[l];
         L.scale = 1.0 / pow(ratio, (double)l);  // level_to_scale, vo/dvo/__init__.py:42-43
@@ -1394,8 +1507,12 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
     TDK_HIP(hipMalloc(&h->ls.ticket, sizeof(int)));
     TDK_HIP(hipMalloc(&h->ls.evals, sizeof(unsigned long long)));
     TDK_HIP(hipMalloc(&h->ls.warn, sizeof(int) * n_pairs));
+    TDK_HIP(hipMalloc(&h->ls.mode, sizeof(int) * n_pairs));
+    TDK_HIP(hipMalloc(&h->ls.tested, sizeof(int) * n_pairs));
+    TDK_HIP(hipMalloc(&h->ls.stat_state, sizeof(int) * n_pairs));
+    TDK_HIP(hipMalloc(&h->ls.round, sizeof(int) * 2));
     h->host_warn.assign((size_t)n_pairs, 0);
-    TDK_HIP(hipHostMalloc(&h->h_flag, 4 * sizeof(int), hipHostMallocMapped));
+    TDK_HIP(hipHostMalloc(&h->h_flag, 8 * sizeof(int), hipHostMallocMapped));
     TDK_HIP(hipHostGetDevicePointer((void **)&h->ls.host_flag, h->h_flag, 0));
     return TDK_OK;
 }
@@ -1412,6 +1529,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     (void)hipFree(h->d_results); (void)hipFree(h->ls.pose); (void)hipFree(h->ls.cand);
     (void)hipFree(h->ls.prev_err); (void)hipFree(h->ls.state); (void)hipFree(h->ls.n_evals);
     (void)hipFree(h->ls.active); (void)hipFree(h->ls.ticket); (void)hipFree(h->ls.evals); (void)hipFree(h->ls.warn);
+    (void)hipFree(h->ls.mode); (void)hipFree(h->ls.tested); (void)hipFree(h->ls.stat_state); (void)hipFree(h->ls.round);
     (void)hipFree(h->d_rm); (void)hipFree(h->d_wscale); (void)hipFree(h->d_stat);
     (void)hipFree(h->d_spartial); (void)hipFree(h->d_count); (void)hipFree(h->d_select);
     (void)hipFree(h->d_hist); (void)hipFree(h->d_cand);
@@ -1535,9 +1653,8 @@ tdk_status tdk_dvo_evaluate(tdk_dvo *h, int level, const double *camera0, const 
     TDK_TRY(upload_params(h, camera0, camera1));
     TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * h->n_pairs, hipMemcpyHostToDevice,
                            h->stream));
-    if (h->profiling && level == 0) h->prof_pixels += h->lv[0].N * (int64_t)h->n_pairs;
-    TDK_TRY(launch_eval(h, level, h->d_poses_in, nullptr, weight_mode));
-    TDK_TRY(launch_reduce(h, level, 0, 0, 0));
+    TDK_TRY(launch_eval(h, level, h->d_poses_in, nullptr, nullptr, nullptr, weight_mode));
+    TDK_TRY(launch_reduce(h, level, 0, 0));
     void *stage;
     TDK_TRY(tdk::pinned(1, sizeof(double) * kAccPad * h->n_pairs, &stage));
     TDK_HIP(hipMemcpyAsync(stage, h->d_results, sizeof(double) * kAccPad * h->n_pairs, hipMemcpyDeviceToHost,
@@ -1566,6 +1683,7 @@ tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0, 
                            h->stream));
     int n = h->n_pairs;
     TDK_HIP(hipMemsetAsync(h->ls.warn, 0, sizeof(int) * n, h->stream));
+    h->ls.fuse_first = 1;   // a level on its own starts from the caller's prior
     k_loop_init<<<(n + 255) / 256, 256, 0, h->stream>>>(h->ls, h->d_poses_in, n);
     TDK_LAUNCH_CHECK();
     TDK_TRY(run_level(h, level, weight_mode, max_iter, nullptr));
@@ -1590,6 +1708,7 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
     TDK_HIP(hipMemsetAsync(h->ls.warn, 0, sizeof(int) * n, h->stream));
     for (int level = h->n_levels - 1; level >= 0; level--) {
         // the prior of a level is the result of the coarser one (:131-134), already in ls.pose
+        h->ls.fuse_first = level == h->n_levels - 1;
         k_loop_init<<<(n + 255) / 256, 256, 0, h->stream>>>(h->ls, level == h->n_levels - 1 ? h->d_poses_in : h->ls.pose, n);
         TDK_LAUNCH_CHECK();
         TDK_TRY(run_level(h, level, weight_mode, max_iter, pixel_evals));
@@ -1623,17 +1742,23 @@ tdk_status tdk_dvo_set_profiling(tdk_dvo *h, int enabled) {
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     h->profiling = enabled != 0;
     h->ev_used = 0;
-    h->prof_ms = 0;
-    h->prof_launches = 0;
-    h->prof_pixels = 0;
+    for (int b = 0; b < 3; b++) { h->prof_ms[b] = 0; h->prof_launches[b] = 0; h->prof_pixels[b] = 0; }
     return TDK_OK;
 }
 
 tdk_status tdk_dvo_get_profile(tdk_dvo *h, int64_t *launches, double *total_ms, int64_t *pixels) {
     TDK_REQUIRE(h != nullptr, "handle is NULL");
-    if (launches) *launches = h->prof_launches;
-    if (total_ms) *total_ms = h->prof_ms;
-    if (pixels) *pixels = h->prof_pixels;
+    if (launches) *launches = h->prof_launches[0];
+    if (total_ms) *total_ms = h->prof_ms[0];
+    if (pixels) *pixels = h->prof_pixels[0];
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_get_profile_kind(tdk_dvo *h, int kind, int64_t *launches, double *total_ms, int64_t *pixels) {
+    TDK_REQUIRE(h != nullptr && kind >= 0 && kind <= 2, "bad argument");
+    if (launches) *launches = h->prof_launches[kind];
+    if (total_ms) *total_ms = h->prof_ms[kind];
+    if (pixels) *pixels = h->prof_pixels[kind];
     return TDK_OK;
 }
 

@@ -237,9 +237,12 @@ class DvoBatch(object):
     def set_profiling(self, enabled):
         call("tdk_dvo_set_profiling", self._h, int(bool(enabled)))
 
-    def get_profile(self):
+    def get_profile(self, kind="full"):
+        """Full-resolution evaluation launches since set_profiling(True): kind 'full' (only full
+        evaluations), 'probe' (only error-only probes of candidates), 'mixed'."""
         n = C.c_int64(); ms = C.c_double(); px = C.c_int64()
-        call("tdk_dvo_get_profile", self._h, C.byref(n), C.byref(ms), C.byref(px))
+        call("tdk_dvo_get_profile_kind", self._h, {"full": 0, "probe": 1, "mixed": 2}[kind], C.byref(n),
+             C.byref(ms), C.byref(px))
         return dict(launches=int(n.value), total_ms=float(ms.value), pixels=int(px.value))
 
 
