@@ -532,3 +532,27 @@ def test_semi_dense_vo_loop_on_device(ops, orc):
         T_w_est.append(T_w1)
     assert int(age.max()) == n_frames - 1 and int((flag == 0).sum()) > 500
     dvo.close(); sd.close()
+
+
+@pytest.mark.parametrize("max_iter", [0, 1, 2, 5])
+def test_level_loop_iteration_limits_vs_oracle(ops, orc, max_iter):
+    """The probe / full state machine of the device loop at the edges of the reference's
+    `for k in range(max_iter)`: pose and number of PhotometricError evaluations as the oracle's
+    transcription of _PoseChangeEstimator.__call__ (:92-111) gives them."""
+    from tadataka_amd import synthetic
+    H, W = 72, 96
+    pair = synthetic.make_pair(H, W, seed=21, rot_scale=0.01, trans_scale=0.03)
+    cam = pair["cam"]
+    batch = ops.DvoBatch(1, H, W)
+    batch.upload(0, pair["I0"], pair["D0"], pair["I1"])
+    for wname in (None, "huber", "student-t"):
+        P, n_evals = batch.estimate_level(0, cam, cam, _pose12(np.eye(4))[None], ops.WEIGHT_MODES[wname], max_iter)
+        trace = []
+        rot, t = orc.dvo_estimate_level(pair["I0"], pair["D0"], pair["I1"], cam, cam,
+                                        Rotation.from_rotvec(np.zeros(3)), np.zeros(3), wname, max_iter, trace=trace)
+        assert n_evals[0] == len(trace)               # one entry per PhotometricError call
+        assert np.max(np.abs(P[0, :9].reshape(3, 3) - rot.as_matrix())) < POSE_ATOL
+        assert np.max(np.abs(P[0, 9:] - t)) < POSE_ATOL
+        if max_iter == 0:
+            assert np.array_equal(P[0], _pose12(np.eye(4)))
+    batch.close()
