@@ -1011,7 +1011,8 @@ tdk_status ba_update_dev(tdk_ba *h, double mu, const std::vector<double> &U, con
         TDK_HIP(hipMemsetAsync(h->d_S, 0, (size_t)dim * dim * 8, tdk::stream()));
         TDK_HIP(hipMemsetAsync(h->d_e, 0, (size_t)dim * 8, tdk::stream()));
     }
-    BaTimer *schur_timer = new BaTimer(h, BA_K_SCHUR);
+    {
+    BaTimer schur_timer(h, BA_K_SCHUR);   // closes (second event) at the end of this scope, on every path
     if (mfma) {
         // dense contraction on the FP64 matrix cores (windows of up to 8 poses)
         const int RB = (int)((6 * h->n_poses + 15) / 16);
@@ -1048,8 +1049,8 @@ tdk_status ba_update_dev(tdk_ba *h, double mu, const std::vector<double> &U, con
                                                                 h->d_eb, h->n, h->n_points, dim, h->d_S, h->d_e);
         }
     }
-    delete schur_timer;
     TDK_LAUNCH_CHECK();
+    }
     std::vector<double> S((size_t)dim * dim), e((size_t)dim);
     TDK_HIP(hipMemcpyAsync(S.data(), h->d_S, S.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(e.data(), h->d_e, e.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));

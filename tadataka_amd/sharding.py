@@ -173,7 +173,16 @@ class FileComm(object):
         self._exchange(np.zeros(1))
 
     def close(self):
-        pass
+        """Removes this rank's files (the peers have read them once they passed the same barrier)."""
+        try:
+            self.barrier()
+        except RuntimeError:
+            pass
+        for seq in range(max(1, self._seq - 2), self._seq):          # everything but the closing barrier's file
+            try:
+                os.unlink(os.path.join(self._dir, "%d_%d.npy" % (seq, self.rank)))
+            except OSError:
+                pass
 
 
 def _rendezvous_path():
