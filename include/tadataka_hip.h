@@ -324,7 +324,8 @@ tdk_status tdk_ba_block_sums(tdk_ba *h, const double *poses, const double *point
                              double *ea, double *V, double *eb, double *sum_sq);
 /* Per-kernel timing with HIP events on the library stream.  Index: 0 block reduce
  * (Jacobians + per-pose sums), 1 error-only reduce, 2 per-point sums, 3 Schur
- * complement, 4 back-substitution; launches[5] and total_ms[5] since enabling. */
+ * complement, 4 back-substitution, 5 reduced camera system (device solve);
+ * launches[6] and total_ms[6] since enabling. */
 tdk_status tdk_ba_set_profiling(tdk_ba *h, int enabled);
 tdk_status tdk_ba_get_profile(tdk_ba *h, int64_t *launches, double *total_ms);
 tdk_status tdk_ba_step(tdk_ba *h, const double *poses, const double *points, double mu,

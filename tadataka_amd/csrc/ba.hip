@@ -670,7 +670,8 @@ __global__ __launch_bounds__(kBlock) void k_ba_backsub(const int64_t *__restrict
                                                        const double *__restrict__ Vinv,
                                                        const double *__restrict__ eb,
                                                        const double *__restrict__ da, int64_t n,
-                                                       int64_t n_points, double *__restrict__ db) {
+                                                       int64_t n_points, const double *__restrict__ points,
+                                                       double *__restrict__ db, double *__restrict__ cpoints) {
     const int64_t Q = n_points;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n_points; i += (int64_t)gridDim.x * kBlock) {
         double g[3] = {eb[i], eb[Q + i], eb[2 * Q + i]};
@@ -685,9 +686,14 @@ __global__ __launch_bounds__(kBlock) void k_ba_backsub(const int64_t *__restrict
             }
         }
         const double v[6] = {Vinv[i], Vinv[Q + i], Vinv[2 * Q + i], Vinv[3 * Q + i], Vinv[4 * Q + i], Vinv[5 * Q + i]};
-        db[3 * i] = v[0] * g[0] + v[1] * g[1] + v[2] * g[2];
-        db[3 * i + 1] = v[1] * g[0] + v[3] * g[1] + v[4] * g[2];
-        db[3 * i + 2] = v[2] * g[0] + v[4] * g[1] + v[5] * g[2];
+        const double d0 = v[0] * g[0] + v[1] * g[1] + v[2] * g[2];
+        const double d1 = v[1] * g[0] + v[3] * g[1] + v[4] * g[2];
+        const double d2 = v[2] * g[0] + v[4] * g[1] + v[5] * g[2];
+        db[3 * i] = d0; db[3 * i + 1] = d1; db[3 * i + 2] = d2;
+        // the candidate of the damping trial: points + db
+        cpoints[3 * i] = points[3 * i] + d0;
+        cpoints[3 * i + 1] = points[3 * i + 1] + d1;
+        cpoints[3 * i + 2] = points[3 * i + 2] + d2;
     }
 }
 
@@ -889,7 +895,10 @@ tdk_status tdk_ba_block_reduce(const double *poses, int64_t n_poses, const doubl
 
 }  // extern "C"
 
-enum { BA_K_REDUCE = 0, BA_K_ERROR = 1, BA_K_POINT_SUMS = 2, BA_K_SCHUR = 3, BA_K_BACKSUB = 4, BA_K_COUNT = 5 };
+enum { BA_K_REDUCE = 0, BA_K_ERROR = 1, BA_K_POINT_SUMS = 2, BA_K_SCHUR = 3, BA_K_BACKSUB = 4, BA_K_SOLVE = 5,
+       BA_K_COUNT = 6 };
+
+struct BaSums { double *U, *ea, *V, *eb, *W; };
 
 struct tdk_ba {
     int64_t n_poses, n_points, n;
@@ -906,8 +915,14 @@ struct tdk_ba {
     size_t ev_used;
     double prof_ms[BA_K_COUNT];
     int64_t prof_launches[BA_K_COUNT];
-    double *d_U, *d_ea, *d_V, *d_eb, *d_part, *d_err, *d_W, *d_Vinv, *d_S, *d_e, *d_da, *d_db;
-    double *d_cposes, *d_cpoints;   // candidate parameters of tdk_ba_solve
+    // block sums of one reduce: per pose U (21), ea (6); per point V (6), eb (3) as structure of
+    // arrays; W_ij (18) per observation.  `cur` belongs to the current parameters; `alt` (allocated
+    // by the first tdk_ba_solve) receives the sums at the candidate of a damping trial, so that an
+    // accepted candidate needs no second pass and a rejected one leaves `cur` intact.
+    BaSums cur, alt;
+    double *d_part, *d_err, *d_Vinv, *d_S, *d_e, *d_da, *d_db;
+    double *d_cposes, *d_cpoints;   // candidate parameters: poses + da, points + db
+    bool dev_solve;                 // the reduced camera system is solved on the device (6 P <= kDevSolveMaxDim)
     double *d_Be;       // [8][n]: B_ij (2x3) and the residual of every observation
     // Schur complement by pose pair (k_ba_schur_pairs): dense observation table
     int *d_obs_at;      // [n_poses][n_points] observation index or -1; NULL -> atomics fallback
@@ -955,16 +970,18 @@ void ba_collect_profile(tdk_ba *h) {
 
 // what a reduce computes at parameters that are already on the device
 enum { REDUCE_ERROR = 0, REDUCE_SUMS = 1, REDUCE_STEP = 2 };
-//   REDUCE_ERROR: the residual sum only (damping trials)
+//   REDUCE_ERROR: the residual sum only
 //   REDUCE_SUMS : per-pose and per-point block sums U, ea, V, eb
 //   REDUCE_STEP : ... and W_ij per observation for the Schur complement
-tdk_status ba_reduce_dev(tdk_ba *h, const double *d_poses, const double *d_points, int what, double *err) {
+// Enqueues the kernels; the sums go to `into` (h->cur or h->alt), the per-pose
+// squared errors to h->d_err.  Nothing is waited for.
+tdk_status ba_reduce_launch(tdk_ba *h, const double *d_poses, const double *d_points, int what, const BaSums &into) {
     {
         BaTimer t(h, what == REDUCE_ERROR ? BA_K_ERROR : BA_K_REDUCE);
 #define BA_LAUNCH(MODE)                                                                                          \
     launch_reduce_seg<MODE>(d_poses, d_points, h->d_xt, h->d_obs_sorted, h->d_pt32, h->d_segs, h->d_seg_ptr,      \
-                            h->n_segs, (int)h->n_poses, h->n, nullptr, nullptr, h->d_W, h->d_Be, h->d_part, h->d_ticket, h->d_U, \
-                            h->d_ea, h->d_err, tdk::stream())
+                            h->n_segs, (int)h->n_poses, h->n, nullptr, nullptr, into.W, h->d_Be, h->d_part,       \
+                            h->d_ticket, into.U, into.ea, h->d_err, tdk::stream())
         if (what == REDUCE_ERROR) BA_LAUNCH(MODE_ERROR);
         else if (what == REDUCE_SUMS) BA_LAUNCH(MODE_STORE_B);
         else BA_LAUNCH(MODE_STORE_BW);
@@ -974,36 +991,382 @@ tdk_status ba_reduce_dev(tdk_ba *h, const double *d_poses, const double *d_point
     if (what != REDUCE_ERROR) {
         BaTimer t(h, BA_K_POINT_SUMS);
         k_ba_point_sums<<<grid_for(h->n_points), kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_Be, h->n,
-                                                                             h->n_points, h->d_V, h->d_eb);
+                                                                             h->n_points, into.V, into.eb);
         TDK_LAUNCH_CHECK();
     }
+    return TDK_OK;
+}
+
+// Waits for the stream and returns what the last reduce / solve left in h->d_err:
+// the sum of the per-pose squared errors and the status word of k_ba_rcs_solve.
+tdk_status ba_wait(tdk_ba *h, double *err, bool *singular) {
     void *stage;
-    TDK_TRY(tdk::pinned(3, (size_t)h->n_poses * 8, &stage));
-    TDK_HIP(hipMemcpyAsync(stage, h->d_err, (size_t)h->n_poses * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    const size_t words = (size_t)h->n_poses + 1;
+    TDK_TRY(tdk::pinned(3, words * 8, &stage));
+    TDK_HIP(hipMemcpyAsync(stage, h->d_err, words * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
     if (h->profiling) ba_collect_profile(h);
     double sum = 0.0;
     for (int64_t j = 0; j < h->n_poses; j++) sum += ((const double *)stage)[j];
     *err = sum;
+    if (singular) *singular = ((const double *)stage)[h->n_poses] != 0.0;
+    return TDK_OK;
+}
+
+tdk_status ba_reduce_dev(tdk_ba *h, const double *d_poses, const double *d_points, int what, double *err) {
+    TDK_TRY(ba_reduce_launch(h, d_poses, d_points, what, h->cur));
+    return ba_wait(h, err, nullptr);
+}
+
+tdk_status ba_upload(tdk_ba *h, const double *poses, const double *points) {
+    TDK_HIP(hipMemcpyAsync(h->d_poses, poses, (size_t)h->n_poses * 48, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(h->d_points, points, (size_t)h->n_points * 24, hipMemcpyHostToDevice, tdk::stream()));
     return TDK_OK;
 }
 
 tdk_status ba_reduce(tdk_ba *h, const double *poses, const double *points, int what, double *err) {
-    TDK_HIP(hipMemcpyAsync(h->d_poses, poses, (size_t)h->n_poses * 48, hipMemcpyHostToDevice, tdk::stream()));
-    TDK_HIP(hipMemcpyAsync(h->d_points, points, (size_t)h->n_points * 24, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_TRY(ba_upload(h, poses, points));
     return ba_reduce_dev(h, h->d_poses, h->d_points, what, err);
 }
 
-// Levenberg-Marquardt update for damping mu from the sums of the last
-// ba_reduce_dev(..., REDUCE_STEP): V*^-1, Schur complement, dense solve of the
-// reduced camera system on the host, back-substitution.  U / ea are the host
-// copies of the per-pose sums of THAT reduce (an error evaluation at candidate
-// parameters in between overwrites the device ones).  Leaves dpoints in h->d_db.
-tdk_status ba_update_dev(tdk_ba *h, double mu, const std::vector<double> &U, const std::vector<double> &ea,
-                         std::vector<double> &dposes) {
+// ---------------------------------------------------------------------------
+// Reduced camera system on the device (local BA windows, 6 P <= kDevSolveMaxDim):
+// one workgroup, the augmented matrix [S | e] in LDS, Gaussian elimination with
+// partial pivoting -- S is positive definite in exact arithmetic, but with small
+// damping and near-degenerate points its computed Schur complement can lose
+// definiteness by rounding, which LU tolerates -- and back-substitution by one
+// wave.  Rows are never swapped: a row that has served as pivot is final and
+// drops out (`done` masks), so within one column step every element is read
+// and written by its owner thread only, the pivot row is read-only, and one
+// barrier per column is enough.  Every wave finds the pivot by itself (DPP
+// maximum + ballot; the lowest row among equals, as dense_solve).  S arrives as
+// the Schur kernels leave it (-sum Y W^T; diagonal blocks whole, of the others
+// the block triangle above the diagonal is authoritative); the kernel adds
+// U*_j = U_j + mu I to the diagonal blocks and ea to the right-hand side, writes
+// da, the candidate poses + da, and a status word (1.0: singular).
+// ---------------------------------------------------------------------------
+constexpr int kDevSolveMaxDim = 120;   // padded to [128][129] doubles = 129 KB of the 160 KB of LDS
+
+// value of lane l (uniform) in every lane: v_readlane, no LDS round trip
+__device__ __forceinline__ double lane_value(double x, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), l);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double wave_max(double x) {
+    x = fmax(x, tdk::dpp_move<0xB1>(x));    // quad_perm [1,0,3,2]
+    x = fmax(x, tdk::dpp_move<0x4E>(x));    // quad_perm [2,3,0,1]
+    x = fmax(x, tdk::dpp_move<0x141>(x));   // row_half_mirror
+    x = fmax(x, tdk::dpp_move<0x140>(x));   // row_mirror: every lane holds its row's maximum
+    return fmax(fmax(lane_value(x, 0), lane_value(x, 16)), fmax(lane_value(x, 32), lane_value(x, 48)));
+}
+
+// 1 / a to the last bit or so: v_rcp_f64 and two Newton steps -- a third of the dependent
+// operations of the IEEE division, and it sits on the critical path of every column
+__device__ __forceinline__ double fast_rcp(double a) {
+    double x = __builtin_amdgcn_rcp(a);
+    x = fma(fma(-a, x, 1.0), x, x);
+    return fma(fma(-a, x, 1.0), x, x);
+}
+
+// what the back-substitution needs, kept in registers by every wave: lane l knows the pivot row and
+// the reciprocal pivot of columns l and l + 64, and the column its rows l, l + 64 were pivots of
+struct RcsPivots {
+    int prow0, prow1, ord0, ord1;
+    double rdiag0, rdiag1;
+};
+
+// [S | e] into the padded LDS matrix M[R][P] (padding zero), the diagonal of S into diag0
+template <int NB>
+__device__ __forceinline__ void rcs_load(double *M, double *diag0, const double *__restrict__ S,
+                                         const double *__restrict__ evec, const double *__restrict__ U,
+                                         const double *__restrict__ ea, double mu, int dim) {
+    constexpr int R = 16 * NB, P = R + 1;
+    const int t = threadIdx.x;
+    for (int idx = t; idx < R * P; idx += kBlock) M[idx] = 0.0;
+    __syncthreads();
+    // S first (independent loads, several in flight), then U* on the diagonal blocks
+#pragma unroll 4
+    for (int idx = t; idx < dim * dim; idx += kBlock) {
+        const int r = idx / dim, c = idx - r * dim;
+        M[r * P + c] = c / 6 >= r / 6 ? S[(size_t)r * dim + c] : S[(size_t)c * dim + r];
+    }
+    __syncthreads();
+    for (int idx = t; idx < dim * 6; idx += kBlock) {
+        const int r = idx / 6, b = idx - 6 * r, j = r / 6, a = r - 6 * j;
+        const int lo = a < b ? a : b, hi = a < b ? b : a;
+        const double v = M[r * P + 6 * j + b] + U[21 * j + lo * 6 - lo * (lo - 1) / 2 + (hi - lo)] + (a == b ? mu : 0.0);
+        M[r * P + 6 * j + b] = v;
+        if (a == b) diag0[r] = v;
+    }
+    for (int r = t; r < dim; r += kBlock) M[r * P + dim] = evec[r] + ea[r];
+    __syncthreads();
+}
+
+// Elimination without pivoting, for the positive definite system this is in exact arithmetic
+// (stable without pivoting then; the same numbers as an L D L^T factorisation): pivot row and
+// pivot column are known in advance, so a column step is one LDS round trip, a reciprocal and one
+// barrier.  The columns of one 16-block CB at a time: the row and column blocks that still take
+// part (>= CB) are then compile-time, and the loop body has no branches.  Returns false (in every
+// thread) at the first pivot that is not safely positive relative to the original diagonal; the
+// matrix is then reloaded and eliminated with pivoting.
+template <int NB, int CB>
+__device__ __forceinline__ bool rcs_spd_columns(double *M, const double *diag0, int dim, RcsPivots &pv) {
+    constexpr int R = 16 * NB, P = R + 1, NL = NB - CB;          // NL live blocks each way
+    const int t = threadIdx.x, lane = t & 63, ty = t >> 4, tx = t & 15;
+    double *Mown = M + (16 * CB + ty) * P + 16 * CB + tx;         // the thread's element of block (CB, CB)
+    const int c_end = 16 * CB + 16 < dim ? 16 * CB + 16 : dim;
+    // the thread's elements stay in registers for the 16 columns of the block; per column only the
+    // next pivot row and pivot column go back to LDS, everything else when the block is done
+    double v[NL][NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++)
+#pragma unroll
+        for (int j = 0; j < NL; j++) v[i][j] = Mown[16 * i * P + 16 * j];
+    for (int c = 16 * CB; c < c_end; c++) {
+        const double piv = M[c * P + c], d0 = diag0[c];
+        const double *Mc = M + c * P + 16 * CB + tx;
+        const double *Mf = M + (16 * CB + ty) * P + c;
+        double f[NL], pr[NL];
+#pragma unroll
+        for (int i = 0; i < NL; i++) f[i] = Mf[16 * i * P];
+#pragma unroll
+        for (int j = 0; j < NL; j++) pr[j] = Mc[16 * j];
+        if (!(piv > 1e-12 * fabs(d0))) return false;               // the same value in every thread
+        const double rpiv = fast_rcp(piv);
+        if (CB < 4) { if (lane == c) pv.rdiag0 = rpiv; }
+        else if (lane == c - 64) pv.rdiag1 = rpiv;
+        const bool below = 16 * CB + ty > c, right = 16 * CB + tx > c;   // only block CB straddles the pivot
+#pragma unroll
+        for (int i = 0; i < NL; i++) {
+            const double fi = f[i] * rpiv;
+#pragma unroll
+            for (int j = 0; j < NL; j++) {
+                const double u = v[i][j] - fi * pr[j];
+                v[i][j] = (i > 0 || below) && (j > 0 || right) ? u : v[i][j];
+            }
+        }
+        if (16 * CB + ty == c + 1) {                 // the next pivot row, right of its diagonal and the diagonal itself
+#pragma unroll
+            for (int j = 0; j < NL; j++)
+                if (j > 0 || 16 * CB + tx > c) Mown[16 * j] = v[0][j];
+        }
+        if (16 * CB + tx == c + 1) {                 // the next pivot column, below its diagonal
+#pragma unroll
+            for (int i = 0; i < NL; i++)
+                if (i > 0 || 16 * CB + ty > c + 1) Mown[16 * i * P] = v[i][0];
+        }
+        __syncthreads();
+    }
+    const int c = c_end - 1;
+    const bool below = 16 * CB + ty > c, right = 16 * CB + tx > c;
+#pragma unroll
+    for (int i = 0; i < NL; i++)
+#pragma unroll
+        for (int j = 0; j < NL; j++)
+            if ((i > 0 || below) && (j > 0 || right)) Mown[16 * i * P + 16 * j] = v[i][j];
+    __syncthreads();
+    return true;
+}
+
+template <int NB>
+__device__ __forceinline__ bool rcs_eliminate_spd(double *M, const double *diag0, int dim, RcsPivots &pv) {
+    const int lane = threadIdx.x & 63;
+    bool ok = rcs_spd_columns<NB, 0>(M, diag0, dim, pv);
+    if constexpr (NB > 1) ok = ok && rcs_spd_columns<NB, 1>(M, diag0, dim, pv);
+    if constexpr (NB > 2) ok = ok && rcs_spd_columns<NB, 2>(M, diag0, dim, pv);
+    if constexpr (NB > 3) ok = ok && rcs_spd_columns<NB, 3>(M, diag0, dim, pv);
+    if constexpr (NB > 4) ok = ok && rcs_spd_columns<NB, 4>(M, diag0, dim, pv);
+    if constexpr (NB > 5) ok = ok && rcs_spd_columns<NB, 5>(M, diag0, dim, pv);
+    if constexpr (NB > 6) ok = ok && rcs_spd_columns<NB, 6>(M, diag0, dim, pv);
+    if constexpr (NB > 7) ok = ok && rcs_spd_columns<NB, 7>(M, diag0, dim, pv);
+    pv.prow0 = lane; pv.prow1 = lane + 64;
+    pv.ord0 = lane < dim ? lane : -1;
+    pv.ord1 = lane + 64 < dim ? lane + 64 : -1;
+    return ok;
+}
+
+// Gaussian elimination with partial pivoting (largest magnitude, lowest row among equals).  Rows
+// are never swapped: a row that has served as pivot is final and drops out (`done` masks), so
+// within one column step every element is read and written by its owner thread only, the pivot
+// row is read-only, and one barrier per column is enough.  Every wave finds the pivot by itself
+// (DPP maximum + ballot).  Column blocks left of block CB are finished; every row block may
+// still be live.  Returns false (in every thread) when a column has no non-zero pivot.
+template <int NB, int CB>
+__device__ __forceinline__ bool rcs_pivoted_columns(double *M, int dim, RcsPivots &pv, unsigned long long &done0,
+                                                    unsigned long long &done1) {
+    constexpr int R = 16 * NB, P = R + 1, NL = NB - CB;
+    const int t = threadIdx.x, lane = t & 63, ty = t >> 4, tx = t & 15;
+    double *Mown = M + ty * P + 16 * CB + tx;        // the thread's element of block (0, CB)
+    const int c_end = 16 * CB + 16 < dim ? 16 * CB + 16 : dim;
+    for (int c = 16 * CB; c < c_end; c++) {
+        // loads that do not depend on the pivot go out first: the column, the thread's own elements
+        const bool live0 = lane < dim && !((done0 >> lane) & 1);
+        const double a0 = lane < R ? M[lane * P + c] : 0.0;
+        bool live1 = false;
+        double a1 = 0.0;
+        if (NB > 4) {
+            live1 = lane + 64 < dim && !((done1 >> lane) & 1);
+            a1 = lane + 64 < R ? M[(lane + 64) * P + c] : 0.0;
+        }
+        double f[NB], v[NB][NL];
+#pragma unroll
+        for (int i = 0; i < NB; i++) f[i] = M[(ty + 16 * i) * P + c];
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+#pragma unroll
+            for (int j = 0; j < NL; j++) v[i][j] = Mown[16 * i * P + 16 * j];
+        // every lane inverts its own candidate while the maximum is being found
+        const double v0 = live0 ? fabs(a0) : -1.0, v1 = live1 ? fabs(a1) : -1.0;
+        const double rc0 = 1.0 / a0, rc1 = NB > 4 ? 1.0 / a1 : 0.0;
+        const double best = wave_max(NB > 4 ? fmax(v0, v1) : v0);
+        if (!(best > 0.0)) return false;             // the same in every wave
+        int p;
+        double rpiv;
+        const unsigned long long m0 = __ballot(v0 == best);
+        if (NB <= 4 || m0) {
+            const int q = __ffsll(m0) - 1;
+            done0 |= 1ull << q;
+            if (lane == q) pv.ord0 = c;
+            rpiv = lane_value(rc0, q);
+            p = q;
+        } else {
+            const int q = __ffsll((unsigned long long)__ballot(v1 == best)) - 1;
+            done1 |= 1ull << q;
+            if (lane == q) pv.ord1 = c;
+            rpiv = lane_value(rc1, q);
+            p = q + 64;
+        }
+        if (CB < 4) { if (lane == c) { pv.prow0 = p; pv.rdiag0 = rpiv; } }
+        else if (lane == c - 64) { pv.prow1 = p; pv.rdiag1 = rpiv; }
+        const double *Mp = M + p * P + 16 * CB + tx;
+        const bool right = 16 * CB + tx > c;         // left of and in column c nothing is touched (others read column c)
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int r = ty + 16 * i;
+            const bool live = !(((r < 64 ? done0 : done1) >> (r & 63)) & 1);   // finished rows (the pivot included) stay
+            const double fi = f[i] * rpiv;
+#pragma unroll
+            for (int j = 0; j < NL; j++)
+                if (live && (j > 0 || right)) Mown[16 * i * P + 16 * j] = v[i][j] - fi * Mp[16 * j];
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
+template <int NB>
+__device__ __forceinline__ bool rcs_eliminate_pivoted(double *M, int dim, RcsPivots &pv) {
+    unsigned long long done0 = 0, done1 = 0;         // rows 0..63 / 64..127 that have been pivots (the same in every wave)
+    pv.ord0 = pv.ord1 = -1;
+    bool ok = rcs_pivoted_columns<NB, 0>(M, dim, pv, done0, done1);
+    if constexpr (NB > 1) ok = ok && rcs_pivoted_columns<NB, 1>(M, dim, pv, done0, done1);
+    if constexpr (NB > 2) ok = ok && rcs_pivoted_columns<NB, 2>(M, dim, pv, done0, done1);
+    if constexpr (NB > 3) ok = ok && rcs_pivoted_columns<NB, 3>(M, dim, pv, done0, done1);
+    if constexpr (NB > 4) ok = ok && rcs_pivoted_columns<NB, 4>(M, dim, pv, done0, done1);
+    if constexpr (NB > 5) ok = ok && rcs_pivoted_columns<NB, 5>(M, dim, pv, done0, done1);
+    if constexpr (NB > 6) ok = ok && rcs_pivoted_columns<NB, 6>(M, dim, pv, done0, done1);
+    if constexpr (NB > 7) ok = ok && rcs_pivoted_columns<NB, 7>(M, dim, pv, done0, done1);
+    return ok;
+}
+
+template <int NB>   // 16 NB >= dim + 1: the matrix is padded to [16 NB][16 NB + 1], 16 x 16 threads own NB x NB elements each
+__global__ __launch_bounds__(kBlock) void k_ba_rcs_solve(const double *__restrict__ S, const double *__restrict__ evec,
+                                                         const double *__restrict__ U, const double *__restrict__ ea,
+                                                         double mu, int dim, int pivoted_only,
+                                                         const double *__restrict__ poses, double *__restrict__ da,
+                                                         double *__restrict__ cposes, double *__restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int R = 16 * NB, P = R + 1;            // odd pitch: a column walk touches every bank pair
+    double *M = reinterpret_cast<double *>(smem);    // [R][P]; column `dim` is the right-hand side, the padding is zero
+    double *diag0 = M + R * P;                       // [R] diagonal of S as loaded
+    const int t = threadIdx.x, lane = t & 63;
+    rcs_load<NB>(M, diag0, S, evec, U, ea, mu, dim);
+    RcsPivots pv = {0, 0, -1, -1, 0.0, 0.0};
+    double state = 0.0;                              // 0: positive definite path, 2: pivoted, 1: singular
+    if (pivoted_only || !rcs_eliminate_spd<NB>(M, diag0, dim, pv)) {
+        __syncthreads();
+        rcs_load<NB>(M, diag0, S, evec, U, ea, mu, dim);
+        state = rcs_eliminate_pivoted<NB>(M, dim, pv) ? 2.0 : 1.0;
+    }
+    if (t == 0) status[0] = state == 1.0 ? 1.0 : 0.0;
+    if (t >= 64 || state == 1.0) return;
+    // back-substitution, column oriented, in one wave: lane l keeps the right-hand sides of rows l and
+    // l + 64; the matrix entries of four steps are fetched ahead of the dependent chain
+    double b0 = lane < dim ? M[lane * P + dim] : 0.0;
+    double b1 = NB > 4 && lane + 64 < dim ? M[(lane + 64) * P + dim] : 0.0;
+    double x0 = 0.0, x1 = 0.0;
+    const double *Ml0 = M + (lane < R ? lane : 0) * P, *Ml1 = M + (NB > 4 && lane + 64 < R ? lane + 64 : 0) * P;
+    auto step = [&](int i, double m0, double m1) {
+        int p;
+        double rd, bi;
+        if (NB > 4 && i >= 64) {
+            p = __builtin_amdgcn_readlane(pv.prow1, i - 64);
+            rd = lane_value(pv.rdiag1, i - 64);
+        } else {
+            p = __builtin_amdgcn_readlane(pv.prow0, i);
+            rd = lane_value(pv.rdiag0, i);
+        }
+        if (NB > 4 && p >= 64) bi = lane_value(b1, p - 64);
+        else bi = lane_value(b0, p);
+        const double xi = bi * rd;
+        if (NB > 4 && i >= 64) x1 = lane == i - 64 ? xi : x1;
+        else x0 = lane == i ? xi : x0;
+        b0 = pv.ord0 < i ? b0 - m0 * xi : b0;        // rows that are not pivots (ord -1, padding) carry zeros
+        if (NB > 4) b1 = pv.ord1 < i ? b1 - m1 * xi : b1;
+    };
+    int i = dim - 1;
+    for (; i >= 3; i -= 4) {
+        double m0[4], m1[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            m0[q] = Ml0[i - q];
+            m1[q] = NB > 4 ? Ml1[i - q] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) step(i - q, m0[q], m1[q]);
+    }
+    for (; i >= 0; i--) step(i, Ml0[i], NB > 4 ? Ml1[i] : 0.0);
+    if (lane < dim) { da[lane] = x0; cposes[lane] = poses[lane] + x0; }
+    if (NB > 4 && lane + 64 < dim) { da[lane + 64] = x1; cposes[lane + 64] = poses[lane + 64] + x1; }
+}
+
+typedef void (*rcs_solve_fn)(const double *, const double *, const double *, const double *, double, int, int,
+                             const double *, double *, double *, double *);
+rcs_solve_fn rcs_solve_kernel(int dim) {
+    switch ((dim + 1 + 15) / 16) {
+        case 1: return k_ba_rcs_solve<1>;
+        case 2: return k_ba_rcs_solve<2>;
+        case 3: return k_ba_rcs_solve<3>;
+        case 4: return k_ba_rcs_solve<4>;
+        case 5: return k_ba_rcs_solve<5>;
+        case 6: return k_ba_rcs_solve<6>;
+        case 7: return k_ba_rcs_solve<7>;
+        default: return k_ba_rcs_solve<8>;
+    }
+}
+
+size_t rcs_solve_lds(int dim) { const size_t R = 16 * (size_t)((dim + 16) / 16); return R * (R + 2) * 8; }
+
+// out = a + b (candidate poses when the reduced system was solved on the host)
+__global__ void k_ba_add(const double *__restrict__ a, const double *__restrict__ b, int64_t n,
+                         double *__restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = a[i] + b[i];
+}
+
+// Levenberg-Marquardt update for damping mu from the sums in h->cur (the last
+// ba_reduce_launch(..., REDUCE_STEP, h->cur)) at the parameters h->d_poses /
+// h->d_points: V*^-1, Schur complement, dense solve of the reduced camera system
+// (on the device for local windows, else on the host), back-substitution.
+// Leaves da in h->d_da, db in h->d_db and the candidate parameters in
+// h->d_cposes / h->d_cpoints; with the device solve nothing is waited for and
+// the status word behind h->d_err says whether the system was singular.
+tdk_status ba_update_launch(tdk_ba *h, double mu) {
     const int dim = (int)(6 * h->n_poses);
     const int gp = grid_for(h->n_points);
-    k_ba_invert_V<<<gp, kBlock, 0, tdk::stream()>>>(h->d_V, mu, h->n_points, h->d_Vinv);
+    k_ba_invert_V<<<gp, kBlock, 0, tdk::stream()>>>(h->cur.V, mu, h->n_points, h->d_Vinv);
     TDK_LAUNCH_CHECK();
     static const bool no_mfma = [] { const char *v = getenv("TDK_BA_SCHUR"); return v && !strcmp(v, "pairs"); }();
     const bool mfma = h->d_obs_at != nullptr && h->d_mpart != nullptr && !no_mfma;
@@ -1020,7 +1383,7 @@ tdk_status ba_update_dev(tdk_ba *h, double mu, const std::vector<double> &U, con
         const int nb = n_chunks < h->mfma_blocks ? n_chunks : h->mfma_blocks;
 #define BA_SCHUR_MFMA(RBV)                                                                                         \
     do {                                                                                                           \
-        k_ba_schur_mfma<RBV><<<nb, kBlock, 0, tdk::stream()>>>(h->d_obs_at, h->d_W, h->d_Vinv, h->d_eb, h->n,       \
+        k_ba_schur_mfma<RBV><<<nb, kBlock, 0, tdk::stream()>>>(h->d_obs_at, h->cur.W, h->d_Vinv, h->cur.eb, h->n,   \
                                                                h->n_points, (int)h->n_poses, n_chunks, h->d_mpart); \
         constexpr int per = RBV * (RBV + 1) / 2 * 256 + 64;                                                        \
         k_ba_schur_mfma_finish<RBV><<<(per + 31) / 32, kBlock, 0, tdk::stream()>>>(h->d_mpart, nb, dim,           \
@@ -1033,7 +1396,7 @@ tdk_status ba_update_dev(tdk_ba *h, double mu, const std::vector<double> &U, con
     } else if (h->d_obs_at != nullptr) {
         const int pairs = (int)(h->n_poses * (h->n_poses + 1) / 2);
         dim3 grid((unsigned)h->npchunks, (unsigned)pairs);
-        k_ba_schur_pairs<<<grid, kBlock, 0, tdk::stream()>>>(h->d_obs_at, h->d_W, h->d_Vinv, h->d_eb, h->n,
+        k_ba_schur_pairs<<<grid, kBlock, 0, tdk::stream()>>>(h->d_obs_at, h->cur.W, h->d_Vinv, h->cur.eb, h->n,
                                                              h->n_points, (int)h->n_poses, h->pchunk, h->d_spart);
         TDK_LAUNCH_CHECK();
         k_ba_schur_finish<<<pairs, 64, 0, tdk::stream()>>>(h->d_spart, (int)h->npchunks, (int)h->n_poses, dim, h->d_S,
@@ -1042,64 +1405,72 @@ tdk_status ba_update_dev(tdk_ba *h, double mu, const std::vector<double> &U, con
         int gs = gp > 1024 ? 1024 : gp;
         if (h->n_poses <= kMaxLdsPoses) {
             size_t lds = ((size_t)dim * dim + dim) * 8;
-            k_ba_schur<true><<<gs, kBlock, lds, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv,
-                                                                 h->d_eb, h->n, h->n_points, dim, h->d_S, h->d_e);
+            k_ba_schur<true><<<gs, kBlock, lds, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->cur.W, h->d_Vinv,
+                                                                 h->cur.eb, h->n, h->n_points, dim, h->d_S, h->d_e);
         } else {
-            k_ba_schur<false><<<gs, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv,
-                                                                h->d_eb, h->n, h->n_points, dim, h->d_S, h->d_e);
+            k_ba_schur<false><<<gs, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->cur.W, h->d_Vinv,
+                                                                h->cur.eb, h->n, h->n_points, dim, h->d_S, h->d_e);
         }
     }
     TDK_LAUNCH_CHECK();
     }
-    std::vector<double> S((size_t)dim * dim), e((size_t)dim);
-    TDK_HIP(hipMemcpyAsync(S.data(), h->d_S, S.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipMemcpyAsync(e.data(), h->d_e, e.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
-    // S = blockdiag(U + mu I) - sum Y W^T (upper block triangle from the device), mirrored
-    for (int64_t j = 0; j < h->n_poses; j++) {
-        int m = 0;
-        for (int a = 0; a < 6; a++)
-            for (int b = a; b < 6; b++) {
-                double u = U[(size_t)j * 21 + m++] + (a == b ? mu : 0.0);
-                S[(size_t)(6 * j + a) * dim + 6 * j + b] += u;
-                if (a != b) S[(size_t)(6 * j + b) * dim + 6 * j + a] += u;
-            }
+    if (h->dev_solve) {
+        BaTimer t(h, BA_K_SOLVE);
+        // TDK_BA_SOLVE=pivoted: skip the attempt without pivoting (tests)
+        static const int pivoted_only = [] { const char *v = getenv("TDK_BA_SOLVE"); return v && !strcmp(v, "pivoted"); }();
+        rcs_solve_kernel(dim)<<<1, kBlock, rcs_solve_lds(dim), tdk::stream()>>>(
+            h->d_S, h->d_e, h->cur.U, h->cur.ea, mu, dim, pivoted_only, h->d_poses, h->d_da, h->d_cposes,
+            h->d_err + h->n_poses);
+        TDK_LAUNCH_CHECK();
+    } else {
+        // larger windows: the reduced camera system goes through the host
+        std::vector<double> S((size_t)dim * dim), e((size_t)dim), U((size_t)h->n_poses * 21), ea((size_t)dim);
+        TDK_HIP(hipMemcpyAsync(S.data(), h->d_S, S.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
+        TDK_HIP(hipMemcpyAsync(e.data(), h->d_e, e.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
+        TDK_HIP(hipMemcpyAsync(U.data(), h->cur.U, U.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
+        TDK_HIP(hipMemcpyAsync(ea.data(), h->cur.ea, ea.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
+        TDK_HIP(hipStreamSynchronize(tdk::stream()));
+        // S = blockdiag(U + mu I) - sum Y W^T (upper block triangle from the device), mirrored
+        for (int64_t j = 0; j < h->n_poses; j++) {
+            int m = 0;
+            for (int a = 0; a < 6; a++)
+                for (int b = a; b < 6; b++) {
+                    double u = U[(size_t)j * 21 + m++] + (a == b ? mu : 0.0);
+                    S[(size_t)(6 * j + a) * dim + 6 * j + b] += u;
+                    if (a != b) S[(size_t)(6 * j + b) * dim + 6 * j + a] += u;
+                }
+        }
+        for (int r = 0; r < dim; r++)
+            for (int c = 0; c < dim; c++)
+                if (c / 6 > r / 6) S[(size_t)c * dim + r] = S[(size_t)r * dim + c];
+        for (int i = 0; i < dim; i++) e[(size_t)i] += ea[(size_t)i];
+        if (dense_solve(S, e, dim) != 0) {
+            tdk::set_error("reduced camera system is singular (mu = %g)", mu);
+            return TDK_ERR_SINGULAR;
+        }
+        TDK_HIP(hipMemcpyAsync(h->d_da, e.data(), (size_t)dim * 8, hipMemcpyHostToDevice, tdk::stream()));
+        k_ba_add<<<grid_for(dim), kBlock, 0, tdk::stream()>>>(h->d_poses, h->d_da, dim, h->d_cposes);
+        TDK_LAUNCH_CHECK();
+        TDK_HIP(hipStreamSynchronize(tdk::stream()));   // `e` goes out of scope
     }
-    // the device accumulated full diagonal blocks (ja == jb) and the strictly
-    // upper off-diagonal blocks; mirror the latter
-    for (int r = 0; r < dim; r++)
-        for (int c = 0; c < dim; c++)
-            if (c / 6 > r / 6) S[(size_t)c * dim + r] = S[(size_t)r * dim + c];
-    for (int i = 0; i < dim; i++) e[(size_t)i] += ea[(size_t)i];
-    if (dense_solve(S, e, dim) != 0) {
-        tdk::set_error("reduced camera system is singular (mu = %g)", mu);
-        return TDK_ERR_SINGULAR;
-    }
-    dposes = e;
-    TDK_HIP(hipMemcpyAsync(h->d_da, dposes.data(), (size_t)dim * 8, hipMemcpyHostToDevice, tdk::stream()));
     {
         BaTimer t(h, BA_K_BACKSUB);
-        k_ba_backsub<<<gp, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->d_W, h->d_Vinv, h->d_eb,
-                                                       h->d_da, h->n, h->n_points, h->d_db);
+        k_ba_backsub<<<gp, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->cur.W, h->d_Vinv, h->cur.eb,
+                                                       h->d_da, h->n, h->n_points, h->d_points, h->d_db, h->d_cpoints);
     }
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
 
-// host copies of the per-pose sums of the last reduce
-tdk_status ba_fetch_pose_sums(tdk_ba *h, std::vector<double> &U, std::vector<double> &ea) {
-    U.resize((size_t)h->n_poses * 21);
-    ea.resize((size_t)h->n_poses * 6);
-    TDK_HIP(hipMemcpyAsync(U.data(), h->d_U, U.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipMemcpyAsync(ea.data(), h->d_ea, ea.size() * 8, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+// second set of block sums for the damping trials of tdk_ba_solve
+tdk_status ba_ensure_alt(tdk_ba *h) {
+    if (h->alt.W) return TDK_OK;
+    TDK_HIP(hipMalloc(&h->alt.U, (size_t)h->n_poses * 21 * 8));
+    TDK_HIP(hipMalloc(&h->alt.ea, (size_t)h->n_poses * 6 * 8));
+    TDK_HIP(hipMalloc(&h->alt.V, (size_t)h->n_points * 48));
+    TDK_HIP(hipMalloc(&h->alt.eb, (size_t)h->n_points * 24));
+    TDK_HIP(hipMalloc(&h->alt.W, (size_t)h->n * 18 * 8));
     return TDK_OK;
-}
-
-__global__ void k_ba_add(const double *__restrict__ a, const double *__restrict__ b, int64_t n,
-                         double *__restrict__ out) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = a[i] + b[i];
 }
 
 }  // namespace
@@ -1151,10 +1522,10 @@ static tdk_status ba_allocate(tdk_ba *h, int64_t n_poses, int64_t n_points, cons
     TDK_HIP(hipMalloc(&h->d_pt, (size_t)n * 8));
     TDK_HIP(hipMalloc(&h->d_row_ptr, ((size_t)n_points + 1) * 8));
     TDK_HIP(hipMalloc(&h->d_obs, (size_t)n * 8));
-    TDK_HIP(hipMalloc(&h->d_U, (size_t)n_poses * 21 * 8));
-    TDK_HIP(hipMalloc(&h->d_ea, (size_t)n_poses * 6 * 8));
-    TDK_HIP(hipMalloc(&h->d_V, (size_t)n_points * 48));
-    TDK_HIP(hipMalloc(&h->d_eb, (size_t)n_points * 24));
+    TDK_HIP(hipMalloc(&h->cur.U, (size_t)n_poses * 21 * 8));
+    TDK_HIP(hipMalloc(&h->cur.ea, (size_t)n_poses * 6 * 8));
+    TDK_HIP(hipMalloc(&h->cur.V, (size_t)n_points * 48));
+    TDK_HIP(hipMalloc(&h->cur.eb, (size_t)n_points * 24));
     TDK_HIP(hipMalloc(&h->d_part, (size_t)h->n_segs * kPoseAccPad * 8));
     TDK_HIP(hipMalloc(&h->d_pt32, (size_t)n * sizeof(int)));
     TDK_HIP(hipMalloc(&h->d_segs, plan.segs.size() * sizeof(BaSeg)));
@@ -1169,8 +1540,18 @@ static tdk_status ba_allocate(tdk_ba *h, int64_t n_poses, int64_t n_points, cons
     TDK_HIP(hipMemcpy(h->d_segs, plan.segs.data(), plan.segs.size() * sizeof(BaSeg), hipMemcpyHostToDevice));
     TDK_HIP(hipMemcpy(h->d_seg_ptr, plan.seg_ptr.data(), plan.seg_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
     TDK_HIP(hipMemset(h->d_ticket, 0, (size_t)n_poses * sizeof(int)));
-    TDK_HIP(hipMalloc(&h->d_err, (size_t)n_poses * 8));
-    TDK_HIP(hipMalloc(&h->d_W, (size_t)n * 18 * 8));
+    TDK_HIP(hipMalloc(&h->d_err, ((size_t)n_poses + 1) * 8));   // per-pose squared errors | status word of k_ba_rcs_solve
+    TDK_HIP(hipMemset(h->d_err, 0, ((size_t)n_poses + 1) * 8));
+    h->dev_solve = false;
+    if (dim <= kDevSolveMaxDim) {
+        const size_t lds = rcs_solve_lds(dim);
+        static const bool host_solve = [] { const char *v = getenv("TDK_BA_SOLVE"); return v && !strcmp(v, "host"); }();
+        h->dev_solve = !host_solve &&
+                       (lds <= 64 * 1024 ||
+                        hipFuncSetAttribute(reinterpret_cast<const void *>(rcs_solve_kernel(dim)),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
+    }
+    TDK_HIP(hipMalloc(&h->cur.W, (size_t)n * 18 * 8));
     TDK_HIP(hipMalloc(&h->d_Vinv, (size_t)n_points * 48));
     TDK_HIP(hipMalloc(&h->d_S, (size_t)dim * dim * 8));
     TDK_HIP(hipMalloc(&h->d_e, (size_t)dim * 8));
@@ -1217,10 +1598,10 @@ static tdk_status ba_allocate(tdk_ba *h, int64_t n_poses, int64_t n_points, cons
 tdk_status tdk_ba_destroy(tdk_ba *h) {
     if (!h) return TDK_OK;
     (void)hipStreamSynchronize(tdk::stream());
-    void *ptrs[] = {h->d_poses, h->d_points, h->d_xt, h->d_vp, h->d_pt, h->d_row_ptr, h->d_obs, h->d_U, h->d_ea,
-                    h->d_V, h->d_eb, h->d_part, h->d_err, h->d_W, h->d_Vinv, h->d_S, h->d_e, h->d_da, h->d_db,
+    void *ptrs[] = {h->d_poses, h->d_points, h->d_xt, h->d_vp, h->d_pt, h->d_row_ptr, h->d_obs, h->cur.U, h->cur.ea,
+                    h->cur.V, h->cur.eb, h->d_part, h->d_err, h->cur.W, h->d_Vinv, h->d_S, h->d_e, h->d_da, h->d_db,
                     h->d_Be, h->d_obs_at, h->d_spart, h->d_mpart, h->d_cposes, h->d_cpoints, h->d_obs_sorted, h->d_pt32,
-                    h->d_segs, h->d_seg_ptr, h->d_ticket};
+                    h->d_segs, h->d_seg_ptr, h->d_ticket, h->alt.U, h->alt.ea, h->alt.V, h->alt.eb, h->alt.W};
     for (void *p : ptrs) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
@@ -1238,14 +1619,14 @@ tdk_status tdk_ba_block_sums(tdk_ba *h, const double *poses, const double *point
     double err = 0.0;
     TDK_TRY(ba_reduce(h, poses, points, REDUCE_SUMS, &err));
     if (sum_sq) *sum_sq = err;
-    if (U) TDK_HIP(hipMemcpyAsync(U, h->d_U, (size_t)h->n_poses * 21 * 8, hipMemcpyDeviceToHost, tdk::stream()));
-    if (ea) TDK_HIP(hipMemcpyAsync(ea, h->d_ea, (size_t)h->n_poses * 6 * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    if (U) TDK_HIP(hipMemcpyAsync(U, h->cur.U, (size_t)h->n_poses * 21 * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    if (ea) TDK_HIP(hipMemcpyAsync(ea, h->cur.ea, (size_t)h->n_poses * 6 * 8, hipMemcpyDeviceToHost, tdk::stream()));
     // the per-point sums live as structure of arrays on the device ([6][Q], [3][Q])
     if (V || eb) {
         const size_t Q = (size_t)h->n_points;
         std::vector<double> soa(Q * 9);
-        TDK_HIP(hipMemcpyAsync(soa.data(), h->d_V, Q * 48, hipMemcpyDeviceToHost, tdk::stream()));
-        TDK_HIP(hipMemcpyAsync(soa.data() + 6 * Q, h->d_eb, Q * 24, hipMemcpyDeviceToHost, tdk::stream()));
+        TDK_HIP(hipMemcpyAsync(soa.data(), h->cur.V, Q * 48, hipMemcpyDeviceToHost, tdk::stream()));
+        TDK_HIP(hipMemcpyAsync(soa.data() + 6 * Q, h->cur.eb, Q * 24, hipMemcpyDeviceToHost, tdk::stream()));
         TDK_HIP(hipStreamSynchronize(tdk::stream()));
         for (size_t i = 0; i < Q; i++) {
             if (V) for (int m = 0; m < 6; m++) V[6 * i + m] = soa[(size_t)m * Q + i];
@@ -1274,22 +1655,28 @@ tdk_status tdk_ba_step(tdk_ba *h, const double *poses, const double *points, dou
                        double *dpoints, double *sum_sq) {
     TDK_REQUIRE(h && poses && points && dposes && dpoints && sum_sq, "null pointer");
     TDK_REQUIRE(mu >= 0.0, "mu must be non-negative");
-    TDK_TRY(ba_reduce(h, poses, points, REDUCE_STEP, sum_sq));
-    std::vector<double> U, ea, da;
-    TDK_TRY(ba_fetch_pose_sums(h, U, ea));
-    TDK_TRY(ba_update_dev(h, mu, U, ea, da));
-    memcpy(dposes, da.data(), da.size() * 8);
+    TDK_TRY(ba_upload(h, poses, points));
+    TDK_TRY(ba_reduce_launch(h, h->d_poses, h->d_points, REDUCE_STEP, h->cur));
+    TDK_TRY(ba_update_launch(h, mu));
+    TDK_HIP(hipMemcpyAsync(dposes, h->d_da, (size_t)h->n_poses * 48, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(dpoints, h->d_db, (size_t)h->n_points * 24, hipMemcpyDeviceToHost, tdk::stream()));
-    TDK_HIP(hipStreamSynchronize(tdk::stream()));
-    if (h->profiling) ba_collect_profile(h);
+    bool singular = false;
+    TDK_TRY(ba_wait(h, sum_sq, &singular));
+    if (singular) {
+        tdk::set_error("reduced camera system is singular (mu = %g)", mu);
+        return TDK_ERR_SINGULAR;
+    }
     return TDK_OK;
 }
 
 // LocalBundleAdjustment.compute (tadataka/local_ba.py:91-134) with the
-// parameters resident on the device: per trial damping only the reduced camera
-// system (6P x 6P) and the pose update cross the bus.  The block sums at the
-// current parameters are computed once per accepted step -- every damping trial
-// reuses them (the reference recomputes projection and Jacobians per trial).
+// parameters resident on the device.  Per damping trial one chain of kernels --
+// V*^-1, Schur complement, reduced camera system, back-substitution, and the
+// block sums AT THE CANDIDATE into the alternate buffer set -- and one wait for
+// the candidate's error.  An accepted candidate swaps the buffer sets, so its
+// sums are never computed twice; a rejected one leaves the current sums in place
+// for the next damping (the reference recomputes projection and Jacobians per
+// trial).  For local windows nothing but the per-pose errors crosses the bus.
 tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, double initial_mu, double nu,
                         double absolute_error_threshold, double relative_error_threshold,
                         double *error_history, int *n_iter) {
@@ -1297,10 +1684,9 @@ tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, 
     TDK_REQUIRE(max_iter >= 0 && initial_mu > 0.0 && nu > 1.0, "bad Levenberg-Marquardt parameters");
     const size_t np6 = (size_t)h->n_poses * 6, nq3 = (size_t)h->n_points * 3;
     const double inv_n = 1.0 / (double)h->n;                    // calc_error is the MEAN squared error (:51-56)
-    std::vector<double> cur(poses, poses + np6), cand(np6), da, U, ea;
+    TDK_TRY(ba_ensure_alt(h));
     double sum_sq = 0.0;
     TDK_TRY(ba_reduce(h, poses, points, REDUCE_STEP, &sum_sq)); // uploads the parameters as well
-    TDK_TRY(ba_fetch_pose_sums(h, U, ea));
     double current_error = sum_sq * inv_n, mu = initial_mu;
     if (error_history) error_history[0] = current_error;
     int it = 0;
@@ -1310,13 +1696,14 @@ tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, 
         // trial dampings of lm_update (:96-113): mu / nu, mu, then mu nu, mu nu^2, ... until no worse
         for (int trial = 0;; trial++) {
             new_mu = trial == 0 ? mu / nu : (trial == 1 ? mu : new_mu * nu);
-            TDK_TRY(ba_update_dev(h, new_mu, U, ea, da));
-            for (size_t i = 0; i < np6; i++) cand[i] = cur[i] + da[i];
-            TDK_HIP(hipMemcpyAsync(h->d_cposes, cand.data(), np6 * 8, hipMemcpyHostToDevice, tdk::stream()));
-            k_ba_add<<<grid_for((int64_t)nq3), kBlock, 0, tdk::stream()>>>(h->d_points, h->d_db, (int64_t)nq3,
-                                                                           h->d_cpoints);
-            TDK_LAUNCH_CHECK();
-            TDK_TRY(ba_reduce_dev(h, h->d_cposes, h->d_cpoints, REDUCE_ERROR, &sum_sq));
+            TDK_TRY(ba_update_launch(h, new_mu));
+            TDK_TRY(ba_reduce_launch(h, h->d_cposes, h->d_cpoints, REDUCE_STEP, h->alt));
+            bool singular = false;
+            TDK_TRY(ba_wait(h, &sum_sq, &singular));
+            if (singular) {
+                tdk::set_error("reduced camera system is singular (mu = %g)", new_mu);
+                return TDK_ERR_SINGULAR;
+            }
             new_error = sum_sq * inv_n;
             if (trial < 2 ? new_error < error0 : !(new_error > error0)) break;
             if (trial > 400) {                                   // mu overflowed to inf long ago
@@ -1324,10 +1711,10 @@ tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, 
                 return TDK_ERR_SINGULAR;
             }
         }
-        // accept: the candidate becomes the current parameter set
+        // accept: the candidate becomes the current parameter set, its sums the current sums
         std::swap(h->d_poses, h->d_cposes);
         std::swap(h->d_points, h->d_cpoints);
-        cur = cand;
+        std::swap(h->cur, h->alt);
         mu = new_mu;
         if (error_history) error_history[it + 1] = new_error;
         const double relative_error = fabs((current_error - new_error) / new_error);
@@ -1336,13 +1723,9 @@ tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, 
             break;
         }
         current_error = new_error;
-        if (it + 1 < max_iter) {                                 // sums for the next step at the accepted parameters
-            TDK_TRY(ba_reduce_dev(h, h->d_poses, h->d_points, REDUCE_STEP, &sum_sq));
-            TDK_TRY(ba_fetch_pose_sums(h, U, ea));
-        }
     }
     if (n_iter) *n_iter = it;
-    memcpy(poses, cur.data(), np6 * 8);
+    TDK_HIP(hipMemcpyAsync(poses, h->d_poses, np6 * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(points, h->d_points, nq3 * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
     if (h->profiling) ba_collect_profile(h);

@@ -571,14 +571,14 @@ class BundleAdjustment(object):
              None if V is None else _p(V), None if eb is None else _p(eb), C.byref(err))
         return U, ea, V, eb, float(err.value)
 
-    KERNELS = ("block_reduce", "error_reduce", "point_sums", "schur", "backsub")
+    KERNELS = ("block_reduce", "error_reduce", "point_sums", "schur", "backsub", "rcs_solve")
 
     def set_profiling(self, enabled):
         call("tdk_ba_set_profiling", self._h, int(bool(enabled)))
 
     def get_profile(self):
         """{kernel: (launches, total_ms)} since set_profiling(True)."""
-        n = np.zeros(5, dtype=np.int64); ms = np.zeros(5)
+        n = np.zeros(6, dtype=np.int64); ms = np.zeros(6)
         call("tdk_ba_get_profile", self._h, n.ctypes.data_as(c_int64_p), _p(ms))
         return {k: (int(n[i]), float(ms[i])) for i, k in enumerate(self.KERNELS)}
 

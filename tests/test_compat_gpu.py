@@ -435,7 +435,7 @@ import numpy as np
 from tadataka_amd import ops, synthetic
 out = sys.argv[1]
 res = {}
-for name, (P, Q, seed) in {"lds": (6, 400, 3), "global": (20, 300, 7)}.items():
+for name, (P, Q, seed) in {"lds": (6, 400, 3), "global": (20, 300, 7), "wide": (24, 200, 9)}.items():
     rng = np.random.default_rng(seed)
     c = synthetic.make_ba_case(n_poses=P, n_points=Q, seed=seed)
     keep = rng.uniform(0, 1, len(c["vp_idx"])) < 0.7
@@ -453,23 +453,33 @@ np.savez(out, **res)
 def test_bundle_adjustment_schur_kernels_agree(tmp_path):
     """The pair-wise Schur kernel (dense observation table, no atomics) and the
     general per-point kernel (atomics; LDS-private S for few poses, global S for
-    many) give the same LM step on ragged visibility."""
+    many) give the same LM step on ragged visibility; so do the reduced camera
+    system solved on the device (one workgroup in LDS, up to 20 poses: elimination
+    without pivoting while the pivots stay safely positive, else -- or always with
+    TDK_BA_SOLVE=pivoted -- partial pivoting) and on the host (TDK_BA_SOLVE=host;
+    always for wider windows such as "wide")."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     results = {}
-    for mode in ("pairs", "atomics"):
+    for mode in ("pairs", "atomics", "hostsolve", "pivoted"):
         out = str(tmp_path / f"{mode}.npz")
         env = dict(os.environ, PYTHONPATH=root)
         if mode == "atomics":
             env["TDK_BA_SCHUR"] = "atomics"
+        if mode == "hostsolve":
+            env["TDK_BA_SOLVE"] = "host"
+        if mode == "pivoted":
+            env["TDK_BA_SOLVE"] = "pivoted"
         subprocess.run([sys.executable, "-c", _BA_FALLBACK_SCRIPT, out], env=env, cwd=root, check=True,
                        capture_output=True, text=True, timeout=300)
         results[mode] = np.load(out)
-    a, b = results["pairs"], results["atomics"]
-    for key in a.files:
-        assert np.allclose(a[key], b[key], rtol=1e-8, atol=1e-11), key
+    a = results["pairs"]
+    for other in ("atomics", "hostsolve", "pivoted"):
+        b = results[other]
+        for key in a.files:
+            assert np.allclose(a[key], b[key], rtol=1e-8, atol=1e-11), (other, key)
 
 
 @pytest.mark.parametrize("initial_mu, noise, seed", [(1.0, 1.0, 5), (1e-9, 20.0, 6)])

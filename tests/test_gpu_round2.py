@@ -392,6 +392,48 @@ def test_ba_block_sums_handle_vs_oracle_and_reproducible(ops, orc):
         ba.close()
 
 
+def test_ba_reduced_camera_system_on_device(ops, orc):
+    """The 6P x 6P system is solved by one workgroup on the device.  A pose that sees
+    nothing has U_j = 0: with damping its update is exactly zero; without damping
+    the system is singular -- the elimination without pivoting gives up at the zero
+    pivot, the pivoted one finds no pivot either, and the status comes back as
+    TDK_ERR_SINGULAR.  Sizes around the 16-wide blocks of the kernel (6 P = 12 ... 120)
+    against a dense solve of the damped normal equations."""
+    from tadataka_amd import _lib, synthetic
+    c = synthetic.make_ba_case(n_poses=4, n_points=400, seed=12)
+    x_true = orc.ba_projection(c["poses"], c["points"], c["vp_idx"], c["pt_idx"], jacobians=False)
+    keep = c["vp_idx"] != 2
+    vp, pt, xt = c["vp_idx"][keep], c["pt_idx"][keep], x_true[keep]
+    ba = ops.BundleAdjustment(4, 400, vp, pt, xt)
+    dposes, dpoints, _ = ba.step(c["poses_noisy"], c["points_noisy"], 1e-2)
+    assert np.all(dposes[2] == 0) and np.all(np.isfinite(dposes)) and np.any(dposes[0] != 0)
+    with pytest.raises(_lib.TdkError) as e:
+        ba.step(c["poses_noisy"], c["points_noisy"], 0.0)
+    assert e.value.status == _lib.TDK_ERR_SINGULAR
+    dposes2, _, _ = ba.step(c["poses_noisy"], c["points_noisy"], 1e-2)     # the handle is usable afterwards
+    assert np.array_equal(dposes, dposes2)
+    ba.close()
+    rng = np.random.default_rng(3)
+    for P in (2, 3, 5, 8, 11, 13, 16, 20):
+        Q = 60
+        c = synthetic.make_ba_case(n_poses=P, n_points=Q, seed=20 + P)
+        keep = rng.uniform(size=P * Q) < 0.8
+        vp, pt = c["vp_idx"][keep], c["pt_idx"][keep]
+        xt = orc.ba_projection(c["poses"], c["points"], vp, pt, jacobians=False)
+        ba = ops.BundleAdjustment(P, Q, vp, pt, xt)
+        mu = 0.05
+        dposes, dpoints, _ = ba.step(c["poses_noisy"], c["points_noisy"], mu)
+        ba.close()
+        x_pred, A, B = orc.ba_projection(c["poses_noisy"], c["points_noisy"], vp, pt)
+        J = np.zeros((2 * len(vp), 6 * P + 3 * Q))
+        for k, (j, i) in enumerate(zip(vp, pt)):
+            J[2 * k:2 * k + 2, 6 * j:6 * j + 6] = A[k]
+            J[2 * k:2 * k + 2, 6 * P + 3 * i:6 * P + 3 * i + 3] = B[k]
+        delta = np.linalg.solve(J.T @ J + mu * np.eye(J.shape[1]), J.T @ (xt - x_pred).reshape(-1))
+        assert np.allclose(dposes.reshape(-1), delta[:6 * P], rtol=1e-7, atol=1e-10), P
+        assert np.allclose(dpoints.reshape(-1), delta[6 * P:], rtol=1e-7, atol=1e-10), P
+
+
 # ---------------------------------------------------------------------------
 # RCCL through the C ABI (no torch): 1-rank communicator
 # ---------------------------------------------------------------------------
