@@ -527,6 +527,140 @@ __device__ __forceinline__ void aa_tile(const AaTileArgs &a, int tile, int arr, 
     }
 }
 
+// The tile for a compile-time radius R (both axes): the pyramid levels of the bench (R = 1, 3, 5
+// at ratio 1.5).  Same products and sums in the same order as aa_tile<0> / filtered_tap(), so
+// bit-identical; what differs is the bookkeeping around them -- on this kernel 70 % of the
+// issued VALU work was integer address arithmetic and predication, not the FP64 filter:
+//   * the wave index is made scalar (readfirstlane), so row numbers, boundary reflection of
+//     rows and row base pointers live in SGPRs: a source load is `global_load v, voff, s[row]`
+//     with one per-lane column offset for the whole walk -- no 64-bit multiply per load;
+//   * a wave loads the CH + 2 R source rows of its column walk unconditionally (rows beyond
+//     the wave's share are clamped to the last one and unused): no per-load exec masking;
+//   * a shrinking level has all four taps inside the image, x1 = x0 + 1 and y1 = y0 + 1, so the
+//     two horizontal filters of a V row share 2 R of their 2 R + 1 LDS reads;
+//   * the per-row terms (wy and the V offset of the upper tap) are computed once per tile into
+//     LDS instead of once per wave and output row in FP64 on the vector ALU.
+template <int R>
+__device__ __forceinline__ void aa_tile_fixed(const AaTileArgs &a, int tile, int arr, int pair,
+                                              unsigned char *aa_smem) {
+    static_assert(R > 0, "compile-time radius");
+    constexpr int CH = 8;                                         // V rows per wave held in registers
+    const int SC = a.max_cols;
+    double *V = reinterpret_cast<double *>(aa_smem);              // [max_v_rows][SC] vertically filtered
+    double *row_wy = V + (size_t)a.max_v_rows * SC;               // [tile_rows] weight of the lower row tap
+    int *row_off = reinterpret_cast<int *>(row_wy + a.tile_rows); // [tile_rows] V offset of the upper row tap
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tiles_x = (a.Wo + kAaCols - 1) / kAaCols;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int H = a.H, W = a.W;
+    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    const double sy = (double)H / (double)a.Ho, sx = (double)W / (double)a.Wo;
+    const int oy0 = ty * a.tile_rows, oy1 = min(oy0 + a.tile_rows, a.Ho);
+    const int ox0 = tx * kAaCols, ox1 = min(ox0 + kAaCols, a.Wo);
+    // first / last lower tap of the tile (a shrinking level: all taps lie inside the image)
+    const int yv0 = (int)floor(((double)oy0 + 0.5) * sy - 0.5);
+    const int yv1 = min((int)floor(((double)(oy1 - 1) + 0.5) * sy - 0.5) + 1, H - 1);
+    const int xv0 = (int)floor(((double)ox0 + 0.5) * sx - 0.5);
+    const int xv1 = min((int)floor(((double)(ox1 - 1) + 0.5) * sx - 0.5) + 1, W - 1);
+    const int nv = yv1 - yv0 + 1;                                // V rows
+    const int nc = xv1 - xv0 + 1 + 2 * R;                        // columns incl. the horizontal support
+    const int xs0 = xv0 - R;
+    double wk[R + 1], wck[R + 1];                                // kernel halves (uniform: scalar loads)
+#pragma unroll
+    for (int k = 0; k <= R; k++) { wk[k] = a.aa.wr[k]; wck[k] = a.aa.wc[k]; }
+    if ((int)threadIdx.x < oy1 - oy0) {                          // per-row terms of the blend
+        const double cy = ((double)(oy0 + (int)threadIdx.x) + 0.5) * sy - 0.5;
+        const double fy0 = floor(cy);
+        row_wy[threadIdx.x] = cy - fy0;
+        row_off[threadIdx.x] = ((int)fy0 - yv0) * SC;
+    }
+    // vertical Gaussian straight from global memory: every wave takes a quarter of the V rows and
+    // walks down its columns with the source texels of the whole walk in registers, all loads
+    // issued before the first one is used
+    {
+        const int chunk = (nv + 3) >> 2;
+        const int r0 = wave * chunk, r1 = min(r0 + chunk, nv);
+        const int rows = r1 - r0;                                // wave-uniform
+        const int ytop = yv0 + r0 - R;
+        const bool inside = ytop >= 0 && yv0 + r1 - 1 + R <= H - 1;   // no reflection needed
+        if (rows > 0 && rows <= CH) {
+            const double *rowp[CH + 2 * R];                      // uniform row base pointers
+#pragma unroll
+            for (int k = 0; k < CH + 2 * R; k++) {
+                const int y = ytop + (k < rows + 2 * R ? k : rows + 2 * R - 1);
+                rowp[k] = s + (int64_t)(inside ? y : mirror_idx(y, H)) * W;
+            }
+            for (int c = lane; c < nc; c += 64) {
+                const unsigned xs = (unsigned)mirror_idx(xs0 + c, W);
+                double v[CH + 2 * R];
+#pragma unroll
+                for (int k = 0; k < CH + 2 * R; k++) v[k] = rowp[k][xs];
+#pragma unroll
+                for (int i = 0; i < CH; i++) {
+                    if (i < rows) {                              // uniform
+                        double tmp = v[i + R] * wk[R];
+#pragma unroll
+                        for (int j = -R; j < 0; j++) tmp += (v[i + R + j] + v[i + R - j]) * wk[R + j];
+                        V[(r0 + i) * SC + c] = tmp;
+                    }
+                }
+            }
+        } else if (rows > 0) {                                   // taller tiles (tuning knobs): sliding window
+            for (int c = lane; c < nc; c += 64) {
+                const double *col = s + mirror_idx(xs0 + c, W);
+                double win[2 * R + 1];
+#pragma unroll
+                for (int k = 0; k < 2 * R; k++) {
+                    const int y = ytop + k;
+                    win[k + 1] = col[(int64_t)(inside ? y : mirror_idx(y, H)) * W];
+                }
+                for (int r = r0; r < r1; r++) {
+#pragma unroll
+                    for (int k = 0; k < 2 * R; k++) win[k] = win[k + 1];
+                    const int y = yv0 + r + R;
+                    win[2 * R] = col[(int64_t)(inside ? y : mirror_idx(y, H)) * W];
+                    double tmp = win[R] * wk[R];
+#pragma unroll
+                    for (int j = -R; j < 0; j++) tmp += (win[R + j] + win[R - j]) * wk[R + j];
+                    V[r * SC + c] = tmp;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int ox = ox0 + lane;
+    if (ox >= ox1) return;
+    const double cx = ((double)ox + 0.5) * sx - 0.5;
+    const double fx0 = floor(cx);
+    const double wx = cx - fx0;
+    const double *Vx = V + ((int)fx0 - xs0);                     // the lane's left tap in V row 0
+    double *dst = a.dst[arr] + (int64_t)pair * a.dst_stride;
+    for (int i = wave; i < oy1 - oy0; i += 4) {                  // i is wave-uniform
+        const double wy = row_wy[i];
+        const double *p = Vx + row_off[i];
+        double u[2][2 * R + 2];                                  // V rows y0, y0 + 1, columns x0 - R .. x0 + 1 + R
+#pragma unroll
+        for (int ry = 0; ry < 2; ry++)
+#pragma unroll
+            for (int q = 0; q < 2 * R + 2; q++) u[ry][q] = p[ry * SC + q - R];
+        double f[2][2];
+#pragma unroll
+        for (int ry = 0; ry < 2; ry++) {
+#pragma unroll
+            for (int rx = 0; rx < 2; rx++) {
+                double tmp = u[ry][R + rx] * wck[R];
+#pragma unroll
+                for (int j = -R; j < 0; j++) tmp += (u[ry][R + rx + j] + u[ry][R + rx - j]) * wck[R + j];
+                f[ry][rx] = tmp;
+            }
+        }
+        const double top = f[0][0] * (1.0 - wx) + f[0][1] * wx;
+        const double bot = f[1][0] * (1.0 - wx) + f[1][1] * wx;
+        dst[(int64_t)(oy0 + i) * a.Wo + ox] = top * (1.0 - wy) + bot * wy;
+    }
+}
+
 // Every tiled level of the pyramid in ONE launch.  blockIdx.x enumerates the tiles of
 // level 1, then level 2, ... of one (array, pair); x runs fastest in dispatch order, so
 // the coarser levels of an image are produced right after the finer ones and find the
@@ -546,9 +680,9 @@ __global__ __launch_bounds__(256) void k_rescale_aa_multi(AaMultiArgs m) {
     const AaTileArgs &a = m.lv[l];
     const int R = a.aa.Rr == a.aa.Rc ? a.aa.Rr : 0;
     switch (R) {      // block-uniform
-        case 1: aa_tile<1>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // ratio 1.5, level 1
-        case 3: aa_tile<3>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // level 2
-        case 5: aa_tile<5>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // level 3
+        case 1: aa_tile_fixed<1>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // ratio 1.5, level 1
+        case 3: aa_tile_fixed<3>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // level 2
+        case 5: aa_tile_fixed<5>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // level 3
         default: aa_tile<0>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;
     }
 }
@@ -643,8 +777,9 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
         }
         t.max_v_rows = (int)ceil(t.tile_rows * fy) + 2;
         t.max_cols = (int)ceil(kAaCols * fx) + 2 + 2 * args.aa[l].Rc;
+        // V tile, then either the two kernels (generic radius) or the per-row blend terms (fixed radius)
         const size_t lds = sizeof(double) * ((size_t)t.max_v_rows * t.max_cols + 2 * args.aa[l].Rr +
-                                             2 * args.aa[l].Rc + 2);
+                                             2 * args.aa[l].Rc + 2) + (size_t)t.tile_rows * 12 + 8;
         if (L.Ho > H || L.Wo > W || lds > 64 * 1024 || m.n == kAaMaxFused) {
             general = true;
             continue;
