@@ -727,26 +727,56 @@ __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairP
     const double *__restrict__ D0 = L.D0 + base, *__restrict__ I0 = L.I0 + base, *__restrict__ I1 = L.I1 + base;
     double *__restrict__ out = rm + base;
     int local = 0;
-    // (x, y) advanced incrementally: one division per thread, not per pixel
-    const int step = gridDim.x * kBlock;
-    int i = blockIdx.x * kBlock + threadIdx.x;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    // two consecutive pixels per lane and step: 16-byte loads and stores.  (x, y) of the first one
+    // advanced incrementally: one division per thread, not per pixel
+    const int step = 2 * gridDim.x * kBlock;
+    int i = 2 * (blockIdx.x * kBlock + threadIdx.x);
     int y = i / W, x = i - y * W;
     const int step_y = step / W, step_x = step - step_y * W;
-    for (; i < N; i += step) {
-        Pixel p;
-        sp_warp(p, true, tab[x], tab[W + y], D0[i], H, W, b.P, b.c);
-        bool in = p.mask == 2;
-        out[i] = in ? I0[i] - I1[i] : __longlong_as_double(0x7ff8000000000000ll);
-        local += in ? 1 : 0;
+    for (; i + 1 < N; i += step) {
+        const double2_u d = *reinterpret_cast<const double2_u *>(D0 + i);
+        const double2_u a = *reinterpret_cast<const double2_u *>(I0 + i);
+        const double2_u c = *reinterpret_cast<const double2_u *>(I1 + i);
+        const bool wrap = x + 1 == W;                   // the second pixel starts the next row
+        Pixel p, q;
+        sp_warp(p, true, tab[x], tab[W + y], d.x, H, W, b.P, b.c);
+        sp_warp(q, true, tab[wrap ? 0 : x + 1], tab[W + (wrap ? y + 1 : y)], d.y, H, W, b.P, b.c);
+        const bool in0 = p.mask == 2, in1 = q.mask == 2;
+        double2_u r;
+        r.x = in0 ? a.x - c.x : nan;
+        r.y = in1 ? a.y - c.y : nan;
+        *reinterpret_cast<double2_u *>(out + i) = r;
+        local += (in0 ? 1 : 0) + (in1 ? 1 : 0);
         x += step_x;
         y += step_y;
         if (x >= W) { x -= W; y += 1; }
+    }
+    if (i < N) {                                        // odd N: the last pixel
+        Pixel p;
+        sp_warp(p, true, tab[x], tab[W + y], D0[i], H, W, b.P, b.c);
+        const bool in = p.mask == 2;
+        out[i] = in ? I0[i] - I1[i] : nan;
+        local += in ? 1 : 0;
     }
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&count[pair], local);
 }
 
-// one fixed-point step of compute_weights_student_t (weights.py:13-16)
+// 1 / a to the last bit or so: v_rcp_f64 and two Newton steps instead of the IEEE division sequence
+__device__ __forceinline__ double fast_rcp(double a) {
+    double x = __builtin_amdgcn_rcp(a);
+    x = __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
+    return __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
+}
+
+// one fixed-point step of compute_weights_student_t (weights.py:13-16): the sum of
+// s (nu + 1) / (nu + s / variance) over the masked residuals, s = r^2.  Two residuals per lane
+// and load (16 bytes).  FAST: s / variance as a product with the pair's 1 / variance and the
+// quotient through fast_rcp -- 9 instead of ~35 FP64 operations per residual; the terms differ
+// from the IEEE quotients in the last bit, the variance by ~1e-16 relative (the pose by less
+// than 1e-15).  TDK_STUDENT_EXACT=1 selects the IEEE divisions of the CPU restatement.
+template <bool FAST>
 __global__ __launch_bounds__(kBlock) void k_robust_student_step(const double *__restrict__ rm, int64_t stride,
                                                                 int N, const int *__restrict__ state,
                                                                 const double *__restrict__ variance,
@@ -754,15 +784,24 @@ __global__ __launch_bounds__(kBlock) void k_robust_student_step(const double *__
     const int pair = blockIdx.y;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
     const double var = variance[pair];
+    const double rvar = 1.0 / var;
     const double *r = rm + (int64_t)pair * stride;
     double acc = 0.0;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
-        double v = r[i];
+    auto term = [&](double v) {
         if (v == v) {
             double s = v * v;
-            acc += s * ((kStudentNu + 1.0) / (kStudentNu + s / var));
+            if (FAST) acc += s * ((kStudentNu + 1.0) * fast_rcp(__builtin_fma(s, rvar, kStudentNu)));
+            else acc += s * ((kStudentNu + 1.0) / (kStudentNu + s / var));
         }
+    };
+    const int N2 = N >> 1;
+#pragma unroll 4
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N2; i += gridDim.x * kBlock) {
+        const double2_u v = *reinterpret_cast<const double2_u *>(r + 2 * (int64_t)i);
+        term(v.x);
+        term(v.y);
     }
+    if ((N & 1) && blockIdx.x == 0 && threadIdx.x == 0) term(r[N - 1]);
     __shared__ double red[kWaves];
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -1272,9 +1311,14 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
         k_robust_student_update<<<n, 64, 0, h->stream>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
                                                          h->d_wscale, n, 1);
         TDK_LAUNCH_CHECK();
+        static const bool exact = [] { const char *v = getenv("TDK_STUDENT_EXACT"); return v && atoi(v) != 0; }();
         for (int it = 0; it < 10; it++) {   // n_iter = 10 (weights.py:4)
-            k_robust_student_step<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state,
-                                                                      h->d_wscale, h->d_spartial);
+            if (exact)
+                k_robust_student_step<false><<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state,
+                                                                              h->d_wscale, h->d_spartial);
+            else
+                k_robust_student_step<true><<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state,
+                                                                             h->d_wscale, h->d_spartial);
             TDK_LAUNCH_CHECK();
             k_robust_student_update<<<n, 64, 0, h->stream>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
                                                              h->d_wscale, n, 0);
