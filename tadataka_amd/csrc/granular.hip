@@ -387,12 +387,10 @@ struct AaTileArgs {
     int max_v_rows, max_cols;   // LDS tile bounds (host: ceil(rows * factor) + 2, ceil(cols * factor) + 2 + 2 Rc)
 };
 
-// R > 0: both radii are the compile-time R (loops unrolled, the LDS reads of a tap issue
-// together); R == 0: radii from the arguments.
-template <int R>
-__device__ __forceinline__ void aa_tile(const AaTileArgs &a, int tile, int arr, int pair, unsigned char *aa_smem) {
-    const int Rr = R > 0 ? R : a.aa.Rr, Rc = R > 0 ? R : a.aa.Rc;
-    constexpr int kUnroll = R > 0 ? R : 1;
+// Any radii (from the arguments): the levels aa_tile_fixed<R> has no instantiation for.
+__device__ __forceinline__ void aa_tile_generic(const AaTileArgs &a, int tile, int arr, int pair,
+                                                unsigned char *aa_smem) {
+    const int Rr = a.aa.Rr, Rc = a.aa.Rc;
     const int SC = a.max_cols;
     double *V = reinterpret_cast<double *>(aa_smem);           // [max_v_rows][SC] vertically filtered
     double *wr = V + (size_t)a.max_v_rows * SC;                 // [2 Rr + 1] kernel weights, LDS copies:
@@ -418,80 +416,19 @@ __device__ __forceinline__ void aa_tile(const AaTileArgs &a, int tile, int arr, 
     // vertical Gaussian straight from global memory (a source texel is re-read 2 Rr + 1
     // times by the block: L1 hits); a wave per V row, lanes along it: coalesced, no division
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (R > 0) {
-        // Compile-time radius: every wave takes a quarter of the V rows and walks down its
-        // columns with the source texels of the whole walk in registers: (rows + 2 R) loads
-        // per column walk instead of (2 R + 1) per V element (7x the L1 traffic at R = 3), ALL
-        // issued before the first one is used (one memory latency per walk, not one per row),
-        // and one boundary reflection per loaded texel instead of per tap.  Same products
-        // and sums in the same order as the generic loop below: bit-identical.
-        constexpr int RR = R > 0 ? R : 1;
-        constexpr int CH = 8;                       // V rows per wave held in registers
-        const int chunk = (nv + 3) / 4;
-        const int r0 = wave * chunk, r1 = min(r0 + chunk, nv);
-        const int rows = r1 - r0;                   // wave-uniform
-        const bool inside = yv0 + r0 - RR >= 0 && yv0 + r1 - 1 + RR <= H - 1;   // no reflection needed
-        double wk[RR + 1];
-#pragma unroll
-        for (int k = 0; k <= RR; k++) wk[k] = wr[k];
-        if (rows > 0 && rows <= CH) {
-            for (int c = lane; c < nc; c += 64) {
-                const double *col = s + mirror_idx(xs0 + c, W);
-                double v[CH + 2 * RR];
-#pragma unroll
-                for (int k = 0; k < CH + 2 * RR; k++) {
-                    const int y = yv0 + r0 - RR + k;
-                    v[k] = k < rows + 2 * RR ? col[(int64_t)(inside ? y : mirror_idx(y, H)) * W] : 0.0;
-                }
-#pragma unroll
-                for (int i = 0; i < CH; i++) {
-                    if (i < rows) {
-                        double tmp = v[i + RR] * wk[RR];
-#pragma unroll
-                        for (int j = -RR; j < 0; j++) tmp += (v[i + RR + j] + v[i + RR - j]) * wk[RR + j];
-                        V[(r0 + i) * SC + c] = tmp;
-                    }
-                }
-            }
-        } else {
-            for (int c = lane; c < nc && rows > 0; c += 64) {
-                const double *col = s + mirror_idx(xs0 + c, W);
-                double win[2 * RR + 1];
-#pragma unroll
-                for (int k = 0; k < 2 * RR; k++) {
-                    const int y = yv0 + r0 - RR + k;
-                    win[k + 1] = col[(int64_t)(inside ? y : mirror_idx(y, H)) * W];
-                }
-                for (int r = r0; r < r1; r++) {
-#pragma unroll
-                    for (int k = 0; k < 2 * RR; k++) win[k] = win[k + 1];
-                    const int y = yv0 + r + RR;
-                    win[2 * RR] = col[(int64_t)(inside ? y : mirror_idx(y, H)) * W];
-                    double tmp = win[RR] * wk[RR];
-#pragma unroll
-                    for (int j = -RR; j < 0; j++) tmp += (win[RR + j] + win[RR - j]) * wk[RR + j];
-                    V[r * SC + c] = tmp;
-                }
-            }
-        }
-    } else {
-        for (int r = wave; r < nv; r += 4) {
-            const int y = yv0 + r;
-            for (int c = lane; c < nc; c += 64) {
-                const double *col = s + mirror_idx(xs0 + c, W);
-                double tmp = col[(int64_t)y * W] * wr[Rr];
-                for (int j = -Rr; j < 0; j++)
-                    tmp += (col[(int64_t)mirror_idx(y + j, H) * W] + col[(int64_t)mirror_idx(y - j, H) * W]) * wr[Rr + j];
-                V[r * SC + c] = tmp;
-            }
+    for (int r = wave; r < nv; r += 4) {
+        const int y = yv0 + r;
+        for (int c = lane; c < nc; c += 64) {
+            const double *col = s + mirror_idx(xs0 + c, W);
+            double tmp = col[(int64_t)y * W] * wr[Rr];
+            for (int j = -Rr; j < 0; j++)
+                tmp += (col[(int64_t)mirror_idx(y + j, H) * W] + col[(int64_t)mirror_idx(y - j, H) * W]) * wr[Rr + j];
+            V[r * SC + c] = tmp;
         }
     }
     __syncthreads();
     const int ox = ox0 + (int)(threadIdx.x & 63);
     if (ox >= ox1) return;
-    double wck[kUnroll + 1];                        // horizontal weights in registers (compile-time radius)
-#pragma unroll
-    for (int k = 0; k <= kUnroll; k++) wck[k] = k <= Rc ? wc[k] : 0.0;
     const double cx = ((double)ox + 0.5) * sx - 0.5;
     const double fx0 = floor(cx);
     const double wx = cx - fx0;
@@ -509,15 +446,8 @@ __device__ __forceinline__ void aa_tile(const AaTileArgs &a, int tile, int arr, 
 #pragma unroll
             for (int rx = 0; rx < 2; rx++) {
                 const double *row = V + ((ry ? y1 : y0) - yv0) * SC + ((rx ? x1 : x0) - xs0);
-                double tmp;
-                if (R > 0) {
-                    tmp = row[0] * wck[kUnroll];
-#pragma unroll
-                    for (int j = -kUnroll; j < 0; j++) tmp += (row[j] + row[-j]) * wck[kUnroll + j];
-                } else {
-                    tmp = row[0] * wc[Rc];
-                    for (int j = -Rc; j < 0; j++) tmp += (row[j] + row[-j]) * wc[Rc + j];
-                }
+                double tmp = row[0] * wc[Rc];
+                for (int j = -Rc; j < 0; j++) tmp += (row[j] + row[-j]) * wc[Rc + j];
                 f[ry][rx] = tmp;
             }
         }
@@ -528,7 +458,7 @@ __device__ __forceinline__ void aa_tile(const AaTileArgs &a, int tile, int arr, 
 }
 
 // The tile for a compile-time radius R (both axes): the pyramid levels of the bench (R = 1, 3, 5
-// at ratio 1.5).  Same products and sums in the same order as aa_tile<0> / filtered_tap(), so
+// at ratio 1.5).  Same products and sums in the same order as aa_tile_generic / filtered_tap(), so
 // bit-identical; what differs is the bookkeeping around them -- on this kernel 70 % of the
 // issued VALU work was integer address arithmetic and predication, not the FP64 filter:
 //   * the wave index is made scalar (readfirstlane), so row numbers, boundary reflection of
@@ -683,7 +613,7 @@ __global__ __launch_bounds__(256) void k_rescale_aa_multi(AaMultiArgs m) {
         case 1: aa_tile_fixed<1>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // ratio 1.5, level 1
         case 3: aa_tile_fixed<3>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // level 2
         case 5: aa_tile_fixed<5>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // level 3
-        default: aa_tile<0>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;
+        default: aa_tile_generic(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;
     }
 }
 

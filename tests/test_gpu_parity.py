@@ -229,7 +229,9 @@ def test_anti_aliased_rescale_and_pyramid_bit_exact(ops, orc):
     smaller than the deepest level's kernel)."""
     from tadataka_amd import synthetic
     rng = np.random.default_rng(1)
-    for shape, scale in (((61, 83), 1 / 1.5), ((61, 83), 1 / 1.5 ** 3), ((5, 4), 0.4), ((48, 64), 1.0), ((20, 30), 1.7)):
+    # radii 1, 5, mixed, none, enlarging; 2 (the generic tile), 1 at another stride; several tiles with borders
+    for shape, scale in (((61, 83), 1 / 1.5), ((61, 83), 1 / 1.5 ** 3), ((5, 4), 0.4), ((48, 64), 1.0), ((20, 30), 1.7),
+                         ((97, 131), 0.5), ((97, 131), 0.8), ((150, 200), 1 / 1.5), ((150, 200), 1 / 2.25)):
         img = rng.uniform(0, 1, shape)
         assert np.array_equal(ops.rescale(img, scale, anti_aliasing=True), orc.rescale(img, scale, anti_aliasing=True))
     H, W, B = 61, 83, 3
