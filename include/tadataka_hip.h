@@ -203,6 +203,22 @@ tdk_status tdk_update_depth(const double *key_camera, const double *key_image,
                             const double *prior_variance, int height, int width,
                             const tdk_semi_dense_params *params, double *depth, double *variance,
                             int64_t *flag);
+/* Frame (src/py/semi_dense.rs:53-91) keeps its image for as long as it lives and update_depth
+ * borrows its refframes -- the example appends every frame to the list it passes
+ * (examples/semi_dense_vo.py:199).  tdk_frame is that object on the device: the image is uploaded
+ * once, tdk_update_depth_frames takes the frames by handle (same arithmetic and outputs as
+ * tdk_update_depth; camera and pose still travel as small host arrays), so a call moves the
+ * three maps in and the three results out and nothing per reference frame. */
+typedef struct tdk_frame tdk_frame;
+tdk_status tdk_frame_create(const double *image, int height, int width, tdk_frame **out);
+tdk_status tdk_frame_destroy(tdk_frame *f);
+tdk_status tdk_update_depth_frames(const double *key_camera, const tdk_frame *key_frame,
+                                   const double *key_transform_wf, int n_ref,
+                                   const double *ref_cameras, const tdk_frame *const *ref_frames,
+                                   const double *ref_transforms_wf, const uint64_t *age,
+                                   const double *prior_depth, const double *prior_variance,
+                                   const tdk_semi_dense_params *params, double *depth,
+                                   double *variance, int64_t *flag);
 /* estimate_debug_ (src/py/semi_dense.rs:126-155) */
 tdk_status tdk_estimate_one(const int64_t *u_key, double prior_depth, double prior_variance,
                             const double *key_camera, const double *key_image,

@@ -83,6 +83,10 @@ PROTOTYPES = {
     "tdk_propagate": [_d, _d, _d, _d, _d, _i, _i, C.c_double, C.c_double, C.c_double, _d, _d],
     "tdk_update_depth": [_d, _d, _d, _i, _d, _d, _d, c_uint64_p, _d, _d, _i, _i,
                          C.POINTER(SemiDenseParams), _d, _d, c_int64_p],
+    "tdk_frame_create": [_d, _i, _i, C.POINTER(_vp)],
+    "tdk_frame_destroy": [_vp],
+    "tdk_update_depth_frames": [_d, _vp, _d, _i, _d, C.POINTER(_vp), _d, c_uint64_p, _d, _d,
+                                C.POINTER(SemiDenseParams), _d, _d, c_int64_p],
     "tdk_estimate_one": [c_int64_p, C.c_double, C.c_double, _d, _d, _d, _d, _d, _d, _i, _i,
                          C.POINTER(SemiDenseParams), _d, _d, c_int64_p],
     "tdk_sobel": [_d, _i, _i, _d, _d],

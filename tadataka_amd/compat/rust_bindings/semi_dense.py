@@ -39,6 +39,12 @@ class Frame(object):
     def _as_tuple(self):
         return (self._cam, self._image, self._transform)
 
+    def _resident(self):
+        """(camera, device-resident image, T_wf): the image is uploaded once, at first use."""
+        if getattr(self, "_dev", None) is None:
+            self._dev = ops.DeviceFrame(self._image)
+        return (self._cam, self._dev, self._transform)
+
 
 class Params(object):
     """Params(min_depth, max_depth, geo_coeff, photo_coeff, ref_step_size,
@@ -73,11 +79,12 @@ def update_depth(keyframe, refframes, age_map, prior_depth, prior_variance, para
     shape = age_map.shape
     if prior_depth.shape != shape or prior_variance.shape != shape or keyframe._image.shape != shape:
         raise ValueError("maps and keyframe image must share one shape")   # semi_dense.rs:168-173
-    refs = [r._as_tuple() for r in refframes]
-    if any(r[1].shape != shape for r in refs):
+    if any(r._image.shape != shape for r in refframes):
         raise ValueError("reference frames must have the key frame's shape")
-    return ops.update_depth(keyframe._as_tuple(), refs, age_map, prior_depth, prior_variance,
-                            params._c)
+    # the frames stay on the device from their first use on: the example passes an ever longer
+    # refframes list (examples/semi_dense_vo.py:199), nothing of it is uploaded again
+    return ops.update_depth_frames(keyframe._resident(), [r._resident() for r in refframes], age_map,
+                                   prior_depth, prior_variance, params._c)
 
 
 def estimate_debug_(u_key, prior_depth, prior_variance, keyframe, refframe, params):

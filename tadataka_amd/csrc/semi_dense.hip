@@ -854,21 +854,25 @@ tdk_status tdk_propagate(const double *T10, const double *camera0, const double 
     return TDK_OK;
 }
 
-tdk_status tdk_update_depth(const double *key_camera, const double *key_image, const double *key_T, int n_ref,
-                            const double *ref_cameras, const double *ref_images, const double *ref_Ts,
-                            const uint64_t *age, const double *prior_depth, const double *prior_variance, int H,
-                            int W, const tdk_semi_dense_params *params, double *depth, double *variance,
-                            int64_t *flag) {
-    TDK_REQUIRE(key_camera && key_image && key_T && age && prior_depth && prior_variance && params && depth &&
-                    variance && flag && n_ref >= 0,
-                "bad argument");
-    TDK_REQUIRE(n_ref == 0 || (ref_cameras && ref_images && ref_Ts), "null reference frames");
-    TDK_TRY(check_image_dims(H, W));
+}  // extern "C"
+
+struct tdk_frame {          // a device-resident image (rust_bindings.semi_dense.Frame keeps one per frame)
+    double *image;
+    int H, W;
+};
+
+namespace {
+
+// update_depth with the images already on the device: d_key_image and d_ref_images[r] (host array
+// of n_ref device pointers, in the caller's refframes order).  Maps in and out are host arrays.
+tdk_status update_depth_resident(const double *key_camera, const double *d_key_image, const double *key_T, int n_ref,
+                                 const double *ref_cameras, const double *const *d_ref_images, const double *ref_Ts,
+                                 const uint64_t *age, const double *prior_depth, const double *prior_variance,
+                                 int H, int W, const tdk_semi_dense_params *params, double *depth,
+                                 double *variance, int64_t *flag) {
     const int N = H * W;
     size_t b8 = (size_t)N * 8;
-    void *d_key, *d_refs_img, *d_age, *d_pd, *d_pv, *d_od, *d_ov, *d_of, *d_rc, *d_keys, *d_list, *d_cnt;
-    TDK_TRY(h2d(0, key_image, b8, &d_key));
-    TDK_TRY(h2d(3, ref_images, b8 * (size_t)n_ref, &d_refs_img));
+    void *d_age, *d_pd, *d_pv, *d_od, *d_ov, *d_of, *d_rc, *d_keys, *d_list, *d_cnt;
     TDK_TRY(h2d(4, age, b8, &d_age));
     TDK_TRY(h2d(5, prior_depth, b8, &d_pd));
     TDK_TRY(h2d(6, prior_variance, b8, &d_pv));
@@ -881,13 +885,12 @@ tdk_status tdk_update_depth(const double *key_camera, const double *key_image, c
     std::vector<RefConst> rcs((size_t)(n_ref > 0 ? n_ref : 1));
     for (int a = 1; a <= n_ref; a++) {
         const int r = n_ref - a;
-        TDK_TRY(make_ref_const(key_T, ref_Ts + 16 * r, ref_cameras + 4 * r,
-                               (const double *)d_refs_img + (size_t)r * N, &rcs[a - 1]));
+        TDK_TRY(make_ref_const(key_T, ref_Ts + 16 * r, ref_cameras + 4 * r, d_ref_images[r], &rcs[a - 1]));
     }
     TDK_TRY(h2d(10, rcs.data(), sizeof(RefConst) * rcs.size(), &d_rc));
     TrackKey key;
     memcpy(key.cam, key_camera, sizeof(double) * 4);
-    key.image = (const double *)d_key;
+    key.image = d_key_image;
     key.n_ref = n_ref;
     key.pad = 0;
     TDK_TRY(h2d(11, &key, sizeof(key), &d_keys));
@@ -910,6 +913,82 @@ tdk_status tdk_update_depth(const double *key_camera, const double *key_image, c
     TDK_HIP(hipMemcpyAsync(flag, d_of, b8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
     return TDK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+tdk_status tdk_update_depth(const double *key_camera, const double *key_image, const double *key_T, int n_ref,
+                            const double *ref_cameras, const double *ref_images, const double *ref_Ts,
+                            const uint64_t *age, const double *prior_depth, const double *prior_variance, int H,
+                            int W, const tdk_semi_dense_params *params, double *depth, double *variance,
+                            int64_t *flag) {
+    TDK_REQUIRE(key_camera && key_image && key_T && age && prior_depth && prior_variance && params && depth &&
+                    variance && flag && n_ref >= 0,
+                "bad argument");
+    TDK_REQUIRE(n_ref == 0 || (ref_cameras && ref_images && ref_Ts), "null reference frames");
+    TDK_TRY(check_image_dims(H, W));
+    const size_t b8 = (size_t)H * W * 8;
+    void *d_key, *d_refs_img;
+    TDK_TRY(h2d(0, key_image, b8, &d_key));
+    TDK_TRY(h2d(3, ref_images, b8 * (size_t)n_ref, &d_refs_img));
+    std::vector<const double *> ptrs((size_t)n_ref);
+    for (int r = 0; r < n_ref; r++) ptrs[(size_t)r] = (const double *)d_refs_img + (size_t)r * H * W;
+    return update_depth_resident(key_camera, (const double *)d_key, key_T, n_ref, ref_cameras, ptrs.data(), ref_Ts,
+                                 age, prior_depth, prior_variance, H, W, params, depth, variance, flag);
+}
+
+tdk_status tdk_frame_create(const double *image, int height, int width, tdk_frame **out) {
+    TDK_REQUIRE(image && out, "null pointer");
+    TDK_TRY(check_image_dims(height, width));
+    TDK_TRY(tdk::ensure_device());
+    tdk_frame *f = new tdk_frame();
+    f->H = height; f->W = width;
+    const size_t bytes = (size_t)height * width * 8;
+    if (hipMalloc(&f->image, bytes) != hipSuccess) {
+        delete f;
+        tdk::set_error("hipMalloc of a %d x %d frame failed", height, width);
+        return TDK_ERR_HIP;
+    }
+    hipError_t e = hipMemcpyAsync(f->image, image, bytes, hipMemcpyHostToDevice, tdk::stream());
+    if (e == hipSuccess) e = hipStreamSynchronize(tdk::stream());   // the caller's array may go away
+    if (e != hipSuccess) {
+        (void)hipFree(f->image);
+        delete f;
+        tdk::set_error("frame upload failed: %s", hipGetErrorString(e));
+        return TDK_ERR_HIP;
+    }
+    *out = f;
+    return TDK_OK;
+}
+
+tdk_status tdk_frame_destroy(tdk_frame *f) {
+    if (!f) return TDK_OK;
+    (void)hipStreamSynchronize(tdk::stream());
+    (void)hipFree(f->image);
+    delete f;
+    return TDK_OK;
+}
+
+tdk_status tdk_update_depth_frames(const double *key_camera, const tdk_frame *key_frame, const double *key_T,
+                                   int n_ref, const double *ref_cameras, const tdk_frame *const *ref_frames,
+                                   const double *ref_Ts, const uint64_t *age, const double *prior_depth,
+                                   const double *prior_variance, const tdk_semi_dense_params *params,
+                                   double *depth, double *variance, int64_t *flag) {
+    TDK_REQUIRE(key_camera && key_frame && key_T && age && prior_depth && prior_variance && params && depth &&
+                    variance && flag && n_ref >= 0,
+                "bad argument");
+    TDK_REQUIRE(n_ref == 0 || (ref_cameras && ref_frames && ref_Ts), "null reference frames");
+    const int H = key_frame->H, W = key_frame->W;
+    std::vector<const double *> ptrs((size_t)n_ref);
+    for (int r = 0; r < n_ref; r++) {
+        TDK_REQUIRE(ref_frames[r] && ref_frames[r]->H == H && ref_frames[r]->W == W,
+                    "reference frames must have the key frame's shape");
+        ptrs[(size_t)r] = ref_frames[r]->image;
+    }
+    return update_depth_resident(key_camera, key_frame->image, key_T, n_ref, ref_cameras, ptrs.data(), ref_Ts, age,
+                                 prior_depth, prior_variance, H, W, params, depth, variance, flag);
 }
 
 tdk_status tdk_estimate_one(const int64_t *u_key, double prior_depth, double prior_variance,

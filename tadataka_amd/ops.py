@@ -351,6 +351,45 @@ def update_depth(key, refs, age, prior_depth, prior_variance, params):
     return depth, var, flag
 
 
+class DeviceFrame(object):
+    """An image resident on the device (tdk_frame): what rust_bindings.semi_dense.Frame holds."""
+
+    def __init__(self, image):
+        img = _f64(image)
+        self.shape = img.shape
+        self._h = C.c_void_p()
+        call("tdk_frame_create", _p(img), img.shape[0], img.shape[1], C.byref(self._h))
+
+    def close(self):
+        if self._h:
+            call("tdk_frame_destroy", self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def update_depth_frames(key, refs, age, prior_depth, prior_variance, params):
+    """update_depth with device-resident frames: key = (camera, DeviceFrame, T_wf), refs = list of the
+    same.  Returns (depth, variance, flag)."""
+    kc = camera_vec(key[0]); kT = _f64(key[2], (4, 4))
+    H, W = key[1].shape
+    n_ref = len(refs)
+    rc = _f64([camera_vec(r[0]) for r in refs] if n_ref else np.zeros((0, 4)), (n_ref, 4))
+    rT = _f64([r[2] for r in refs] if n_ref else np.zeros((0, 4, 4)), (n_ref, 4, 4))
+    handles = (C.c_void_p * max(n_ref, 1))(*[r[1]._h for r in refs])
+    age = np.ascontiguousarray(age, dtype=np.uint64).reshape(H, W)
+    pd_ = _f64(prior_depth, (H, W)); pv = _f64(prior_variance, (H, W))
+    depth = np.empty((H, W)); var = np.empty((H, W)); flag = np.empty((H, W), dtype=np.int64)
+    call("tdk_update_depth_frames", _p(kc), key[1]._h, _p(kT), n_ref, _p(rc), handles, _p(rT),
+         age.ctypes.data_as(c_uint64_p), _p(pd_), _p(pv), C.byref(params), _p(depth), _p(var),
+         flag.ctypes.data_as(c_int64_p))
+    return depth, var, flag
+
+
 def estimate_one(u_key, prior_depth, prior_variance, key, ref, params):
     u = np.ascontiguousarray(u_key, dtype=np.int64).reshape(2)
     kc = camera_vec(key[0]); ki = _f64(key[1]); kT = _f64(key[2], (4, 4))

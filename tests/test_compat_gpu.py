@@ -308,6 +308,53 @@ def test_semi_dense_step_through_rust_bindings(golden):
     assert got == exp
 
 
+def test_frames_stay_on_the_device_across_update_depth_calls():
+    """examples/semi_dense_vo.py:182-199: every new frame is appended to `refframes` and the whole
+    list goes into update_depth.  rust_bindings.semi_dense.Frame keeps its image on the device from
+    its first use (tdk_frame), so a call uploads the three maps and nothing per reference frame;
+    results equal the host-pointer entry (tdk_update_depth) and the oracle bit for bit."""
+    from rust_bindings.camera import CameraParameters
+    from rust_bindings.semi_dense import Frame, Params, update_depth
+    from tadataka_amd import ops, synthetic
+    from oracle import oracle as orc
+    H, W = 72, 96
+    c = synthetic.make_semi_dense_case(H, W, seed=9)
+    cam = c["cam"]
+    cp = CameraParameters((cam[0], cam[1]), (cam[2], cam[3]))
+    args = (0.5, 10.0, 0.01, 0.01, 0.002, 0.005)
+    params, po = Params(*args), orc.make_params(*args)
+    rng = np.random.default_rng(5)
+    # a short track: the key frame and three older frames at small offsets of the reference pose
+    olds = []
+    for k in range(3):
+        T = c["T_wr"].copy()
+        T[:3, 3] += 0.02 * (k + 1) * np.array([1.0, 0.3, 0.0])
+        olds.append((c["ref_image"] + 0.01 * k * rng.standard_normal((H, W)), T))
+    key = Frame(cp, c["key_image"], c["T_wk"])
+    refframes = []
+    for k, (img, T) in enumerate(olds):
+        refframes.append(Frame(cp, img, T))
+        n = len(refframes)
+        age = rng.integers(0, n + 1, (H, W)).astype(np.uint64)         # refframes[n - age]
+        got = update_depth(key, refframes, age, c["prior_depth"], c["prior_variance"], params)
+        refs = [(cam, f.image, f.transform_wf) for f in refframes]
+        host = ops.update_depth((cam, c["key_image"], c["T_wk"]), refs, age, c["prior_depth"], c["prior_variance"],
+                                params._c)
+        exp = orc.update_depth((cam, c["key_image"], c["T_wk"]), refs, age, c["prior_depth"], c["prior_variance"], po)
+        for g, h, e in zip(got, host, exp):
+            assert np.array_equal(g, h) and np.array_equal(g, e)
+        assert all(f._dev is not None for f in refframes) and key._dev is not None
+    first = refframes[0]._dev
+    update_depth(key, refframes, np.ones((H, W), dtype=np.uint64), c["prior_depth"], c["prior_variance"], params)
+    assert refframes[0]._dev is first                                  # uploaded once
+    with pytest.raises(ValueError):
+        update_depth(key, [Frame(cp, np.zeros((H + 1, W)), np.eye(4))], np.zeros((H, W), dtype=np.uint64),
+                     c["prior_depth"], c["prior_variance"], params)
+    with pytest.raises(RuntimeError):                                  # age 4 with three reference frames
+        update_depth(key, refframes, np.full((H, W), 4, dtype=np.uint64), c["prior_depth"], c["prior_variance"],
+                     params)
+
+
 # --- bundle adjustment through tadataka.local_ba / tadataka.transform_project -------------------
 def test_local_ba_projection_and_transform_project(golden):
     from tadataka.local_ba import Projection, calc_error
