@@ -711,12 +711,23 @@ __global__ void k_loop_init(LoopState ls, const double *poses_in, int n) {   // 
 // ---------------------------------------------------------------------------
 // Robust scale statistics per pair (Student-t, Tukey)
 // ---------------------------------------------------------------------------
+// 1 / a to the last bit or so: v_rcp_f64 and two Newton steps instead of the IEEE division sequence
+__device__ __forceinline__ double fast_rcp(double a) {
+    double x = __builtin_amdgcn_rcp(a);
+    x = __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
+    return __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
+}
+
 // masked residual map: rm[i] = I0 - I1 where the pixel is in the UPDATE mask of
 // the pose (in range & z > 0), NaN elsewhere; count[pair] = mask size.
+// STUDENT: the first step of the Student-t fixed point (variance 1: s (nu + 1) / (nu + s)) rides along -- its
+// block partials go where k_robust_student_step leaves them -- so the residual map is read nine times, not ten.
+template <bool STUDENT, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairParams *__restrict__ params,
                                                         const double *__restrict__ poses,
                                                         const int *__restrict__ state, double scale,
-                                                        double *__restrict__ rm, int *__restrict__ count) {
+                                                        double *__restrict__ rm, int *__restrict__ count,
+                                                        double *__restrict__ partial) {
     const int pair = blockIdx.y;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
     BlockSetup b;
@@ -727,6 +738,14 @@ __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairP
     const double *__restrict__ D0 = L.D0 + base, *__restrict__ I0 = L.I0 + base, *__restrict__ I1 = L.I1 + base;
     double *__restrict__ out = rm + base;
     int local = 0;
+    double acc = 0.0;
+    auto term = [&](double r, bool in) {
+        if (STUDENT && in) {
+            const double sq = r * r;
+            if (FAST) acc += sq * ((kStudentNu + 1.0) * fast_rcp(kStudentNu + sq));
+            else acc += sq * ((kStudentNu + 1.0) / (kStudentNu + sq / 1.0));
+        }
+    };
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
     // two consecutive pixels per lane and step: 16-byte loads and stores.  (x, y) of the first one
     // advanced incrementally: one division per thread, not per pixel
@@ -747,6 +766,8 @@ __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairP
         r.x = in0 ? a.x - c.x : nan;
         r.y = in1 ? a.y - c.y : nan;
         *reinterpret_cast<double2_u *>(out + i) = r;
+        term(r.x, in0);
+        term(r.y, in1);
         local += (in0 ? 1 : 0) + (in1 ? 1 : 0);
         x += step_x;
         y += step_y;
@@ -756,18 +777,20 @@ __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairP
         Pixel p;
         sp_warp(p, true, tab[x], tab[W + y], D0[i], H, W, b.P, b.c);
         const bool in = p.mask == 2;
-        out[i] = in ? I0[i] - I1[i] : nan;
+        const double r = I0[i] - I1[i];
+        out[i] = in ? r : nan;
+        term(r, in);
         local += in ? 1 : 0;
     }
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&count[pair], local);
-}
-
-// 1 / a to the last bit or so: v_rcp_f64 and two Newton steps instead of the IEEE division sequence
-__device__ __forceinline__ double fast_rcp(double a) {
-    double x = __builtin_amdgcn_rcp(a);
-    x = __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
-    return __builtin_fma(__builtin_fma(-a, x, 1.0), x, x);
+    if (STUDENT) {
+        __shared__ double red[kWaves];
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) partial[(int64_t)pair * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
 }
 
 // one fixed-point step of compute_weights_student_t (weights.py:13-16): the sum of
@@ -1304,15 +1327,21 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
     const int n = h->n_pairs;
     dim3 grid(kStatBlocks, n);
     TDK_HIP(hipMemsetAsync(h->d_count, 0, sizeof(int) * n, h->stream));
-    k_robust_mask<<<grid, kBlock, 0, h->stream>>>(ptrs_of(L), h->d_params, d_poses, d_state, L.scale, h->d_rm,
-                                                      h->d_count);
+    static const bool exact = [] { const char *v = getenv("TDK_STUDENT_EXACT"); return v && atoi(v) != 0; }();
+#define TDK_MASK(ST, FA)                                                                                          \
+    k_robust_mask<ST, FA><<<grid, kBlock, 0, h->stream>>>(ptrs_of(L), h->d_params, d_poses, d_state, L.scale, h->d_rm, \
+                                                          h->d_count, h->d_spartial)
+    if (weight_mode != TDK_W_STUDENT_T) TDK_MASK(false, false);
+    else if (exact) TDK_MASK(true, false);
+    else TDK_MASK(true, true);
+#undef TDK_MASK
     TDK_LAUNCH_CHECK();
     if (weight_mode == TDK_W_STUDENT_T) {
+        // the mask pass has left the partial sums of the first step (variance 1, weights.py:10-13)
         k_robust_student_update<<<n, 64, 0, h->stream>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
-                                                         h->d_wscale, n, 1);
+                                                         h->d_wscale, n, 0);
         TDK_LAUNCH_CHECK();
-        static const bool exact = [] { const char *v = getenv("TDK_STUDENT_EXACT"); return v && atoi(v) != 0; }();
-        for (int it = 0; it < 10; it++) {   // n_iter = 10 (weights.py:4)
+        for (int it = 1; it < 10; it++) {   // n_iter = 10 (weights.py:4)
             if (exact)
                 k_robust_student_step<false><<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state,
                                                                               h->d_wscale, h->d_spartial);
