@@ -591,29 +591,37 @@ __device__ __forceinline__ void aa_tile_fixed(const AaTileArgs &a, int tile, int
     }
 }
 
-// Every tiled level of the pyramid in ONE launch.  blockIdx.x enumerates the tiles of
-// level 1, then level 2, ... of one (array, pair); x runs fastest in dispatch order, so
-// the coarser levels of an image are produced right after the finer ones and find the
-// full-resolution source (2.4 MB per array) in the L2 / Infinity Cache instead of HBM.
+// Every tiled level of the pyramid in ONE launch: the tiles of level 1, then level 2, ... of one
+// (array, pair) are consecutive work items of ONE XCD (see the kernel), so the coarser levels of an
+// image are produced right after the finer ones and find the full-resolution source in that L2.
 constexpr int kAaMaxFused = 4;
 struct AaMultiArgs {
-    int n;
+    int n, n_arrays, batch;
     int tile_end[kAaMaxFused];
     AaTileArgs lv[kAaMaxFused];
 };
 
 __global__ __launch_bounds__(256) void k_rescale_aa_multi(AaMultiArgs m) {
     extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
+    // 1-D grid.  Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2: XCD k
+    // takes images k, k + 8, ... one after the other, all tiles of all levels of an image consecutively
+    // -- so the halo rows that neighbouring tiles share and the second level's pass over the same
+    // source (2.4 MB per VGA array, the L2 holds 4 MB) are L2 hits instead of fabric traffic.
+    const int tiles_total = m.tile_end[m.n - 1];
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int image = (q / tiles_total) * 8 + xcd, t = q - (q / tiles_total) * tiles_total;
+    if (image >= m.n_arrays * m.batch) return;
+    const int pair = image / m.n_arrays, arr = image - pair * m.n_arrays;
     int l = 0;
-    while (l + 1 < m.n && (int)blockIdx.x >= m.tile_end[l]) l++;
-    const int tile = (int)blockIdx.x - (l ? m.tile_end[l - 1] : 0);
+    while (l + 1 < m.n && t >= m.tile_end[l]) l++;
+    const int tile = t - (l ? m.tile_end[l - 1] : 0);
     const AaTileArgs &a = m.lv[l];
     const int R = a.aa.Rr == a.aa.Rc ? a.aa.Rr : 0;
     switch (R) {      // block-uniform
-        case 1: aa_tile_fixed<1>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // ratio 1.5, level 1
-        case 3: aa_tile_fixed<3>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // level 2
-        case 5: aa_tile_fixed<5>(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;   // level 3
-        default: aa_tile_generic(a, tile, blockIdx.y, blockIdx.z, aa_smem); break;
+        case 1: aa_tile_fixed<1>(a, tile, arr, pair, aa_smem); break;   // ratio 1.5, level 1
+        case 3: aa_tile_fixed<3>(a, tile, arr, pair, aa_smem); break;   // level 2
+        case 5: aa_tile_fixed<5>(a, tile, arr, pair, aa_smem); break;   // level 3
+        default: aa_tile_generic(a, tile, arr, pair, aa_smem); break;
     }
 }
 
@@ -696,8 +704,10 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
         AaTileArgs t;
         const int Rk = args.aa[l].Rr == args.aa[l].Rc ? args.aa[l].Rr : 0;
         // output rows per block: 20 for the 3-tap level, 12 from R = 3 on -- the tallest tiles whose
-        // V rows still fit the 8-rows-per-wave register walk of aa_tile (measured on the VGA bench
-        // batch, pyramid time: 4/4 rows 2.56 ms, 16/8 1.61, 20/12 1.45, 20/16 1.88)
+        // V rows still fit the 8-rows-per-wave register walk of aa_tile_fixed (measured on the VGA bench
+        // batch, pyramid time with the current kernel: 10/8 rows 1.33 ms, 14/8 1.20, 20/8 1.13, 20/12 1.09;
+        // 16 rows per wave and taller tiles are slower -- 30/12 1.09 but level 1 alone 0.65 against
+        // 0.57, 20/16 1.35: the LDS footprint leaves fewer blocks per CU)
         t.tile_rows = Rk == 1 ? 20 : 12;
         {   // tuning knobs (experiments): TDK_AA_ROWS_R1 / _R3 / _R5 / _R0
             char name[32];
@@ -726,8 +736,15 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
         if (lds > lds_max) lds_max = lds;
     }
     if (m.n > 0) {
-        dim3 tgrid(tiles_total, n_arrays, batch);
-        k_rescale_aa_multi<<<tgrid, 256, lds_max, stream>>>(m);
+        m.n_arrays = n_arrays;
+        m.batch = batch;
+        const int64_t images = (int64_t)n_arrays * batch;
+        const int64_t blocks = 8 * ((images + 7) / 8) * tiles_total;
+        if (blocks >= (1ll << 31)) {
+            set_error("anti-aliased pyramid: %lld blocks exceed the grid limit", (long long)blocks);
+            return TDK_ERR_INVALID_ARGUMENT;
+        }
+        k_rescale_aa_multi<<<(unsigned)blocks, 256, lds_max, stream>>>(m);
         TDK_LAUNCH_CHECK();
     }
     if (general) {
