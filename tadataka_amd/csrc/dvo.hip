@@ -998,11 +998,11 @@ __global__ __launch_bounds__(kBlock) void k_select_collect(const double *__restr
                                                            const int *__restrict__ state, int mode,
                                                            const double *__restrict__ center,
                                                            SelectState *__restrict__ st,
-                                                           uint64_t *__restrict__ cand) {
+                                                           uint64_t *__restrict__ cand, int pass) {
     const int pair = blockIdx.y;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
-    if (st[pair].group > (unsigned int)kSelectCap) return;    // the digit passes go on instead
-    const int shift = select_shift(1);
+    if (st[pair].done || st[pair].group > (unsigned int)kSelectCap) return;    // the digit passes go on instead
+    const int shift = select_shift(pass);
     const uint64_t group_prefix = st[pair].prefix >> shift;
     const double cen = mode ? center[pair] : 0.0;
     const double *r = rm + (int64_t)pair * stride;
@@ -1037,7 +1037,7 @@ __global__ __launch_bounds__(kBlock) void k_select_finish(SelectState *__restric
     const int pair = blockIdx.x;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
     const unsigned int c = st[pair].group;
-    if (c == 0 || c > (unsigned int)kSelectCap) return;
+    if (st[pair].done || c == 0 || c > (unsigned int)kSelectCap) return;
     __shared__ uint64_t keys[kSelectCap];
     __shared__ uint64_t lo_s, hi_s;
     const uint64_t *mine = cand + (size_t)pair * kSelectCap;
@@ -1301,12 +1301,14 @@ tdk_status device_median(tdk_dvo *h, int level, const int *d_state, int mode, co
         TDK_LAUNCH_CHECK();
         k_select_pick<<<n, kBlock, 0, h->stream>>>(h->d_hist, st, d_state, pass);
         TDK_LAUNCH_CHECK();
-        if (pass == 1) {
-            // usually a handful of keys share 26 bits with the median: finish on those.  Pairs
+        if (pass <= 1) {
+            // usually a handful of keys share 26 bits with the median -- and when the median is close to
+            // zero (the residuals themselves, as opposed to their absolute deviations) already its first
+            // 13 bits (sign, exponent, one mantissa bit) single out a small group: finish on those.  Pairs
             // whose group is larger than kSelectCap (exact ties) are left for the remaining
             // passes, which return at once for every pair that is done.
             k_select_collect<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center, st,
-                                                             h->d_cand);
+                                                             h->d_cand, pass);
             TDK_LAUNCH_CHECK();
             k_select_finish<<<n, kBlock, 0, h->stream>>>(st, h->d_cand, d_state, factor, out);
             TDK_LAUNCH_CHECK();
