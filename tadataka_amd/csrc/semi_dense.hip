@@ -113,20 +113,32 @@ __device__ __forceinline__ void handle_collision(double depth_a, double depth_b,
     else { d = depth_b; v = var_b; }
 }
 
+// 1-D grids of 8 ceil(n_tracks / 8) nb blocks: workgroups are dealt to the 8 XCDs round-robin, so XCD k
+// takes tracks k, k + 8, ... one after the other and all blocks of a track share one L2 (the
+// list walk of the fold and the forward warp of the scatter touch neighbouring lines).
+__device__ __forceinline__ bool xcd_major_track(int nb, int n_tracks, int &track, int &blk) {
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    track = (q / nb) * 8 + xcd;
+    blk = q - (q / nb) * nb;
+    return track < n_tracks;
+}
+
 // Forward warp of every source pixel of every track; in-range sources are pushed
 // onto their target's list: next[i] = previous head, -1 ends a list, -2 marks a
 // source that left the image.  grid = (blocks, n_tracks).
 __global__ __launch_bounds__(kBlock) void k_sd_scatter(int H, int W, const TrackWarp *__restrict__ tw,
                                                        const double *__restrict__ depth0, int64_t stride,
-                                                       int *__restrict__ head, int *__restrict__ next) {
-    const int track = blockIdx.y;
+                                                       int *__restrict__ head, int *__restrict__ next, int nb,
+                                                       int n_tracks) {
+    int track, blk;
+    if (!xcd_major_track(nb, n_tracks, track, blk)) return;
     const TrackWarp &t = tw[track];
     const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
     const int N = H * W;
     const double *__restrict__ d0 = depth0 + (int64_t)track * stride;
     int *__restrict__ hd = head + (int64_t)track * stride;
     int *__restrict__ nx = next + (int64_t)track * stride;
-    for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
+    for (int i = blk * kBlock + threadIdx.x; i < N; i += nb * kBlock) {
         int y0 = i / W, x0 = i - y0 * W;
         double ux, uy, d1;
         tdk::perspective_warp(t.T10, c0, c1, (double)x0, (double)y0, d0[i], ux, uy, d1);
@@ -148,14 +160,15 @@ __global__ __launch_bounds__(kBlock) void k_sd_fold(int H, int W, const TrackWar
                                                     const double *__restrict__ var0, int64_t stride,
                                                     double default_depth, double default_variance, double bias,
                                                     uint64_t *__restrict__ age1, double *__restrict__ depth1,
-                                                    double *__restrict__ var1) {
-    const int track = blockIdx.y;
+                                                    double *__restrict__ var1, int nb, int n_tracks) {
+    int track, blk;
+    if (!xcd_major_track(nb, n_tracks, track, blk)) return;
     const TrackWarp &t = tw[track];
     const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
     const int N = H * W;
     const int64_t base = (int64_t)track * stride;
     const int *__restrict__ nx = next + base;
-    for (int tg = blockIdx.x * kBlock + threadIdx.x; tg < N; tg += gridDim.x * kBlock) {
+    for (int tg = blk * kBlock + threadIdx.x; tg < N; tg += nb * kBlock) {
         const int h = head[base + tg];
         double d = default_depth, v = default_variance;
         int last = -1;
@@ -757,11 +770,13 @@ tdk_status launch_warp_step(int n_tracks, int H, int W, const TrackWarp *d_tw, c
                             double *depth1, double *var1, hipStream_t stream) {
     const int N = H * W;
     TDK_HIP(hipMemsetAsync(head, 0xff, sizeof(int) * (size_t)stride * n_tracks, stream));  // -1: empty list
-    dim3 grid(grid_for(N), n_tracks);
-    k_sd_scatter<<<grid, kBlock, 0, stream>>>(H, W, d_tw, depth0, stride, head, next);
+    const int nb = grid_for(N);
+    const unsigned grid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)nb;
+    k_sd_scatter<<<grid, kBlock, 0, stream>>>(H, W, d_tw, depth0, stride, head, next, nb, n_tracks);
     TDK_LAUNCH_CHECK();
     k_sd_fold<AGE, PROP><<<grid, kBlock, 0, stream>>>(H, W, d_tw, head, next, age0, depth0, var0, stride,
-                                                       default_depth, default_variance, bias, age1, depth1, var1);
+                                                       default_depth, default_variance, bias, age1, depth1, var1,
+                                                       nb, n_tracks);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
