@@ -434,6 +434,51 @@ def test_ba_reduced_camera_system_on_device(ops, orc):
         assert np.allclose(dpoints.reshape(-1), delta[6 * P:], rtol=1e-7, atol=1e-10), P
 
 
+def test_ba_lm_loop_on_a_20_pose_window(ops, orc):
+    """tdk_ba_solve on the widest window the device solve takes (6 P = 120, 129 KB of LDS): the
+    Levenberg-Marquardt loop converges monotonically to the parameters the observations came from
+    (up to the gauge), and a second call from the same start reproduces it bit for bit (no atomics
+    anywhere in the pair-wise / MFMA-free path of a 20-pose window)."""
+    from tadataka_amd import synthetic
+    P, Q = 20, 400
+    rng = np.random.default_rng(17)
+    c = synthetic.make_ba_case(n_poses=P, n_points=Q, seed=31, perturb=5e-3)
+    keep = rng.uniform(size=P * Q) < 0.7
+    vp, pt = c["vp_idx"][keep], c["pt_idx"][keep]
+    xt = orc.ba_projection(c["poses"], c["points"], vp, pt, jacobians=False)
+    ba = ops.BundleAdjustment(P, Q, vp, pt, xt)
+    e0 = ba.sum_squared_error(c["poses_noisy"], c["points_noisy"]) / len(vp)
+    kw = dict(max_iter=15, absolute_error_threshold=1e-22, relative_error_threshold=1e-9)
+    poses, points, errors = ba.solve(c["poses_noisy"], c["points_noisy"], **kw)
+    assert errors[0] == pytest.approx(e0, rel=1e-12) and len(errors) >= 3
+    assert np.all(np.diff(errors) <= 0) and errors[-1] < 1e-6 * errors[0]
+    x_fit = orc.ba_projection(poses, points, vp, pt, jacobians=False)
+    assert np.max(np.abs(x_fit - xt)) < 1e-5                       # reprojection, not parameters: the gauge is free
+    poses2, points2, errors2 = ba.solve(c["poses_noisy"], c["points_noisy"], **kw)
+    assert np.array_equal(poses, poses2) and np.array_equal(points, points2) and np.array_equal(errors, errors2)
+    ba.close()
+
+
+def test_anti_aliased_pyramid_batches_that_do_not_fill_the_xcds(ops, orc):
+    """The pyramid grid deals images to the 8 XCDs: batches with 1, 3 and 9 pairs (3, 9 and 27 images:
+    neither a multiple of 8) and a frame whose width is not a multiple of the 64-column tile."""
+    from tadataka_amd import synthetic
+    H, W = 50, 70
+    for B in (1, 3, 9):
+        batch = ops.DvoBatch(B, H, W, n_levels=3, ratio=1.5)
+        batch.set_anti_aliasing(True)
+        pairs = [synthetic.make_pair(H, W, seed=70 + i) for i in range(B)]
+        for i, pr in enumerate(pairs):
+            batch.upload(i, pr["I0"], pr["D0"], pr["I1"])
+        batch.build_pyramid()
+        for i in (0, B - 1):
+            for level in (1, 2):
+                for name in ("I0", "D0", "I1"):
+                    assert np.array_equal(batch.download(i, level, name),
+                                          orc.rescale(pairs[i][name], 1 / 1.5 ** level, anti_aliasing=True)), (B, i, level, name)
+        batch.close()
+
+
 # ---------------------------------------------------------------------------
 # RCCL through the C ABI (no torch): 1-rank communicator
 # ---------------------------------------------------------------------------
