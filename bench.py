@@ -66,8 +66,12 @@ def parse_args():
     ap.add_argument("--levels", type=int, default=3)
     ap.add_argument("--max-iter", type=int, default=20)
     ap.add_argument("--weights", default="huber", choices=["none", "huber", "student-t", "tukey"])
-    ap.add_argument("--double-buffer", action="store_true",
-                    help="two batches: the next batch's pyramid is built under the current estimation")
+    ap.add_argument("--single-buffer", dest="double_buffer", action="store_false",
+                    help="one batch: its pyramid is rebuilt and then estimated, strictly one after the other.  Default: "
+                         "two batches in flight per GPU -- every step still builds one pyramid and estimates one batch, "
+                         "but the NEXT batch's pyramid is queued on that batch's own stream and runs under the current "
+                         "batch's estimation")
+    ap.set_defaults(double_buffer=True)
     ap.add_argument("--pyramid", choices=["anti-aliased", "bilinear"],
                     default="anti-aliased" if tadataka_amd.PYRAMID_ANTI_ALIASING else "bilinear",
                     help="anti-aliased = what skimage.rescale builds by default (the reference-equivalent one)")
