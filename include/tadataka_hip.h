@@ -114,8 +114,11 @@ tdk_status tdk_dvo_fill_synthetic(tdk_dvo *h, const double *camera, const double
 tdk_status tdk_dvo_build_pyramid(tdk_dvo *h);
 /* Device -> host copy of one array of one pair/level: which = 0 I0, 1 D0, 2 I1, 3 W0. */
 tdk_status tdk_dvo_download(tdk_dvo *h, int pair, int level, int which, double *out);
-/* Pyramid levels with (1) or without (0, the default: SURVEY cfg2's plain
- * bilinear rescale) the anti-aliasing prefilter of tdk_rescale_anti_aliased. */
+/* Pyramid levels with (1, the default) or without (0) the anti-aliasing prefilter of
+ * tdk_rescale_anti_aliased.  The default is what the reference builds:
+ * skimage.transform.rescale(image, scale) (tadataka/vo/dvo/__init__.py:144-148, scikit-image
+ * 0.16.2) low-pass filters with a Gaussian, sigma = (1/scale - 1)/2, before it resamples
+ * bilinearly.  0 = plain bilinear resampling (SURVEY 8(d) cfg2's wording). */
 tdk_status tdk_dvo_set_anti_aliasing(tdk_dvo *h, int enabled);
 tdk_status tdk_dvo_level_shape(tdk_dvo *h, int level, int *height, int *width);
 

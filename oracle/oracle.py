@@ -326,9 +326,12 @@ def dvo_estimate_level(I0, D0, I1, cam0, cam1, rotation, t, weights=None,
 
 
 def dvo_estimate(I0, D0, I1, cam0, cam1, weights=None, n_coarse_to_fine=5,
-                 max_iter=20, layer_size_ratio=1.5, rotation=None, t=None):
+                 max_iter=20, layer_size_ratio=1.5, rotation=None, t=None, anti_aliasing=False):
     """PoseChangeEstimator.__call__ (tadataka/vo/dvo/__init__.py:125-150) with
-    the build's own bilinear pyramid in place of skimage.rescale."""
+    the build's own pyramid (plain bilinear, or with skimage's anti-aliasing prefilter)
+    in place of skimage.rescale."""
+    def rescale(image, scale, _aa=anti_aliasing):
+        return globals()["rescale"](image, scale, anti_aliasing=_aa)
     rotation = Rotation.from_rotvec(np.zeros(3)) if rotation is None else rotation
     t = np.zeros(3) if t is None else t
     cam0 = np.asarray(cam0, dtype=np.float64); cam1 = np.asarray(cam1, dtype=np.float64)

@@ -4,11 +4,14 @@ solve_linear_equation(A, b, weights) minimises ||sqrt(W)(A x - b)||.  The
 reference scales the n x p matrix row by row and hands it to LAPACK's gelsd;
 here the n-row reduction A^T W A, A^T W b runs on the device
 (tdk_weighted_normal_equations) and only the p x p system is solved on the host.
-The solve is minimum-norm, like lstsq, when the system is rank deficient.  Known
-limit (there is deliberately no CPU fallback that would run lstsq on the n rows):
-normal equations square the condition number, so for cond(A) beyond ~1e6 (low
-texture, planar scenes) directions that gelsd would still keep fall under the
-relative eigenvalue cut-off 1e-13 and are truncated.  method="cg" runs scipy's
+The solve is minimum-norm, like lstsq, when the system is rank deficient
+(tests/golden/dvo_ill.npz: the reference's lstsq twists on rank-deficient and badly
+scaled scenes are reproduced to 1e-9).  Known limit (there is deliberately no CPU
+fallback that would run lstsq on the n rows): normal equations square the condition
+number.  Ill-conditioning that is a column scale (one weak gradient direction; cond(A)
+2e7 in the fixture) is removed by the Jacobi scaling of the p x p system; what remains
+out of reach is cond(A) beyond ~1e6 AFTER column scaling, where directions gelsd would
+still keep fall under the relative eigenvalue cut-off 1e-13 and are truncated.  method="cg" runs scipy's
 conjugate gradient on the reduced p x p system, which is the system the reference
 hands to it as well."""
 import numpy as np
@@ -24,17 +27,32 @@ def weighted_mean(x, w):
     return (x * w).sum() / s
 
 
-def solve_normal_equations(M, g):
-    """x with M x = g for symmetric PSD M; pseudo-inverse on a relative
-    eigenvalue cut-off when M is singular."""
-    M = np.asarray(M, dtype=np.float64)
+def solve_normal_equations(M, g, n_rows=0):
+    """x with M x = g for symmetric PSD M.  When M is singular: the minimum-norm
+    least-squares solution, as lstsq returns for a rank-deficient A (the rank is decided
+    on the Jacobi-scaled matrix with a relative eigenvalue cut-off, the norm is taken in
+    the original coordinates).  Same algorithm as tdk::solve6 (csrc/tdk_math.h)."""
+    M = np.array(M, dtype=np.float64)
+    # columns of A whose norm is below gelsd's rcond * sigma_max, rcond = eps * max(n, p)
+    # (numpy's default): dropped there whatever the other columns are; zeroed here before
+    # the scaling would turn their rounding noise into a unit column
+    d = np.diag(M)
+    cut = (np.finfo(np.float64).eps * max(n_rows, M.shape[0])) ** 2
+    tiny = ~(d > cut * d.max())
+    M[tiny, :] = 0.0
+    M[:, tiny] = 0.0
     scale = np.sqrt(np.where(np.diag(M) > 0, np.diag(M), 1.0))
     Ms = M / np.outer(scale, scale)
     lam, V = np.linalg.eigh(Ms)
     keep = lam > 1e-13 * max(lam.max(), 0.0)
     coeff = np.zeros_like(lam)
     coeff[keep] = (V.T @ (g / scale))[keep] / lam[keep]
-    return (V @ coeff) / scale
+    x = (V @ coeff) / scale
+    if not keep.all():
+        # null space of M in the original coordinates; remove x's component in it
+        N, _ = np.linalg.qr(V[:, ~keep] / scale[:, None])
+        x = x - N @ (N.T @ x)
+    return x
 
 
 def solve_linear_equation(A, b, weights=None, method="lstsq", **kwargs):
@@ -54,4 +72,4 @@ def solve_linear_equation(A, b, weights=None, method="lstsq", **kwargs):
         from scipy.sparse import linalg
         x, _ = linalg.cg(M, g, **kwargs)
         return x
-    return solve_normal_equations(M, g)
+    return solve_normal_equations(M, g, A.shape[0])

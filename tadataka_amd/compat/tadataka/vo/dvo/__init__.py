@@ -75,7 +75,7 @@ def calc_pose_update(camera_model1, residuals, GX1, GY1, P1, weights):
                                       np.asarray(weights, dtype=np.float64).reshape(-1))
     if n == 0:
         return None
-    return solve_normal_equations(H, b)
+    return solve_normal_equations(H, b, n)
 
 
 def _update_mask(cam1, P1, shape):

@@ -652,7 +652,7 @@ __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials,
             ls.warn[pair] = 1;
         } else {
             double xi[6];
-            tdk::solve6(R, R + 21, xi);
+            tdk::solve6(R, R + 21, xi, R[28]);   // R[28]: rows of J (update mask count)
             double next[12];
             tdk::compose_update(xi, pose, next);
             for (int i = 0; i < 12; i++) cand[i] = next[i];
@@ -1544,6 +1544,7 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
     TDK_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->n_pairs = n_pairs; h->H = height; h->W = width; h->n_levels = n_levels;
     h->ratio = ratio; h->with_w = with_weight_map != 0;
+    h->anti_aliasing = true;   // the reference-equivalent pyramid (skimage.transform.rescale's default)
     h->max_blocks = 1024;
     h->d_rm = nullptr; h->d_wscale = nullptr; h->d_stat = nullptr; h->d_spartial = nullptr;
     h->d_count = nullptr; h->d_select = nullptr; h->d_hist = nullptr;

@@ -197,12 +197,32 @@ TDK_HD bool solve6_cholesky(const double *H21, const double *b, double *x) {
 // eigen-decomposition with a relative eigenvalue cut-off gives the minimum-norm
 // least-squares solution, as lstsq does when J is rank deficient.  Returns the
 // number of eigen-directions used.
-TDK_HD int solve6(const double *H21, const double *b, double *x) {
-    if (solve6_cholesky(H21, b, x)) return 6;
+TDK_HD int solve6(const double *H21, const double *b, double *x, double n_rows = 0.0) {
+    // gelsd drops singular values below rcond * sigma_max with rcond = eps * max(n, 6)
+    // (numpy's default).  A column of J whose norm is below that bound is such a direction
+    // whatever the other columns are; column scaling would turn its rounding noise into a
+    // unit column, so it is zeroed before anything else (plane scenes with a 1-D texture:
+    // the y-gradient of a resampled pyramid level is 1e-17, not 0).
+    double cut = 2.220446049250313e-16 * fmax(n_rows, 6.0);
+    cut *= cut;
+    double dmax = 0.0;
+    {
+        int k = 0;
+        for (int i = 0; i < 6; i++) { dmax = fmax(dmax, H21[k]); k += 6 - i; }
+    }
+    bool zero_col[6], any_zero = false;
+    {
+        int k = 0;
+        for (int i = 0; i < 6; i++) { zero_col[i] = !(H21[k] > cut * dmax); any_zero |= zero_col[i]; k += 6 - i; }
+    }
+    if (!any_zero && solve6_cholesky(H21, b, x)) return 6;
     double A[6][6], V[6][6];
     int k = 0;
     for (int i = 0; i < 6; i++)
-        for (int j = i; j < 6; j++) { A[i][j] = H21[k]; A[j][i] = H21[k]; k++; }
+        for (int j = i; j < 6; j++) {
+            double v = (zero_col[i] || zero_col[j]) ? 0.0 : H21[k];
+            A[i][j] = v; A[j][i] = v; k++;
+        }
     // Jacobi scaling keeps the rotation/translation columns comparable
     double s[6];
     for (int i = 0; i < 6; i++) s[i] = A[i][i] > 0 ? 1.0 / sqrt(A[i][i]) : 1.0;
@@ -242,9 +262,11 @@ TDK_HD int solve6(const double *H21, const double *b, double *x) {
     for (int i = 0; i < 6; i++) lmax = fmax(lmax, A[i][i]);
     int kept = 0;
     double y[6] = {0, 0, 0, 0, 0, 0};
+    bool dropped[6];
     for (int i = 0; i < 6; i++) {
         double lam = A[i][i];
-        if (!(lam > 1e-13 * lmax)) continue;
+        dropped[i] = !(lam > 1e-13 * lmax);
+        if (dropped[i]) continue;
         kept++;
         double proj = 0.0;
         for (int r = 0; r < 6; r++) proj += V[r][i] * (s[r] * b[r]);
@@ -252,6 +274,35 @@ TDK_HD int solve6(const double *H21, const double *b, double *x) {
         for (int r = 0; r < 6; r++) y[r] += proj * V[r][i];
     }
     for (int r = 0; r < 6; r++) x[r] = s[r] * y[r];
+    if (kept < 6) {
+        // x is the minimum-norm solution in the column-scaled coordinates.  lstsq
+        // (gelsd on the unscaled J, tadataka/math.py:17-19) returns the minimum-norm one
+        // in the original coordinates: remove from x its component in the null space of J,
+        // which is spanned by n_i = S v_i for the dropped eigenvectors v_i (modified
+        // Gram-Schmidt; at most 6 vectors of length 6).
+        double N[6][6];
+        int m = 0;
+        for (int i = 0; i < 6; i++) {
+            if (!dropped[i]) continue;
+            double n[6], nn = 0.0;
+            for (int r = 0; r < 6; r++) n[r] = s[r] * V[r][i];
+            for (int q = 0; q < m; q++) {
+                double d = 0.0;
+                for (int r = 0; r < 6; r++) d += N[q][r] * n[r];
+                for (int r = 0; r < 6; r++) n[r] -= d * N[q][r];
+            }
+            for (int r = 0; r < 6; r++) nn += n[r] * n[r];
+            if (!(nn > 0.0)) continue;
+            nn = 1.0 / sqrt(nn);
+            for (int r = 0; r < 6; r++) N[m][r] = n[r] * nn;
+            m++;
+        }
+        for (int q = 0; q < m; q++) {
+            double d = 0.0;
+            for (int r = 0; r < 6; r++) d += N[q][r] * x[r];
+            for (int r = 0; r < 6; r++) x[r] -= d * N[q][r];
+        }
+    }
     return kept;
 }
 

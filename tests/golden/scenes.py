@@ -1,0 +1,107 @@
+"""Input scenes of the round-3 fixtures, shared by the generator (which runs the
+reference on them in the build container) and by the tests (which rebuild the same
+arrays from seeds / small stored data and compare with the stored reference
+outputs).  NumPy only; nothing here touches the reference or the oracle.
+"""
+import os
+
+import numpy as np
+
+from tadataka_amd import synthetic
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# New-Tsukuba camera (tadataka/dataset/new_tsukuba.py:99); depths are in centimetres there
+TSUKUBA_CAM = np.array([615.0, 615.0, 320.0, 240.0])
+
+
+def gray_from_rgb_u8(rgb):
+    """Luminance of an 8-bit RGB image as float64 in [0, 1] with the Rec.709 weights
+    skimage.color.rgb2gray uses.  One fixed expression (sum in R, G, B order), so that
+    generator and tests build the same doubles."""
+    rgb = np.asarray(rgb)
+    assert rgb.dtype == np.uint8 and rgb.ndim == 3 and rgb.shape[2] == 3
+    f = rgb.astype(np.float64) / 255.0
+    return np.ascontiguousarray(0.2125 * f[..., 0] + 0.7154 * f[..., 1] + 0.0721 * f[..., 2])
+
+
+def tsukuba_depth(height, width, scale=1.0):
+    """Analytic stand-in for the dataset's depth maps (the XMLs are not in the reference
+    checkout): a room-like surface in centimetres, 180 ... 520 cm."""
+    ys, xs = np.mgrid[0:height, 0:width].astype(np.float64)
+    xs = xs / scale
+    ys = ys / scale
+    return np.ascontiguousarray(350.0 + 120.0 * np.sin(xs / 90.0 + 0.3) + 50.0 * np.cos(ys / 70.0))
+
+
+def weight_map(shape, seed):
+    """What examples/semi_dense_vo.py:52 hands to the estimator: safe_invert of a variance
+    map; variances log-uniform in [0.02, 20]."""
+    rng = np.random.default_rng(seed)
+    var = np.exp(rng.uniform(np.log(0.02), np.log(20.0), shape))
+    return np.ascontiguousarray(1.0 / (var + np.finfo(np.float64).eps))     # tadataka/numeric.py
+
+
+def plane_pair(height, width, texture, seed, depth=2.0, rot_scale=0.004, trans_scale=0.008):
+    """Fronto-parallel plane at constant depth, textured by texture(x, y) (vectorised);
+    I0 is rendered by warping the pixel grid with a seeded pose, no noise."""
+    rng = np.random.default_rng(seed)
+    omega, t = synthetic.random_pose(rng, rot_scale, trans_scale)
+    R = synthetic.rodrigues(omega)
+    cam = synthetic.camera_for(width, height)
+    ys, xs = np.mgrid[0:height, 0:width].astype(np.float64)
+    D0 = np.full((height, width), float(depth))
+    I1 = texture(xs, ys)
+    xn = (xs - cam[2]) / cam[0]
+    yn = (ys - cam[3]) / cam[1]
+    P1 = np.stack([xn * D0, yn * D0, D0], axis=-1) @ R.T + t
+    I0 = texture(P1[..., 0] / P1[..., 2] * cam[0] + cam[2], P1[..., 1] / P1[..., 2] * cam[1] + cam[3])
+    return dict(I0=np.ascontiguousarray(I0), D0=D0, I1=np.ascontiguousarray(I1), cam=cam, omega=omega, t=t)
+
+
+def tex_1d(x, y):
+    """Depends on x only: the y-gradient vanishes, column 1 of J is exactly zero and two
+    more are linearly dependent on a plane -> J is rank deficient."""
+    return 0.5 + 0.3 * np.sin(x / 9.0) + 0.0 * y
+
+
+def tex_half_flat(x, y):
+    """Texture on the left 45 % of a 160-wide image, constant elsewhere (>= 50 % of the
+    pixels carry no gradient)."""
+    s = np.clip((72.0 - x) / 6.0, 0.0, 1.0)          # smooth fade to the constant
+    return 0.5 + (synthetic.texture(x, y) - 0.5) * s
+
+
+def tex_weak_y(x, y):
+    """Strong x texture, y texture 1e-5 of it: cond(J) of order 1e5 ... 1e6 without being
+    singular (the range the normal equations still resolve but Cholesky hands to the
+    eigen path)."""
+    return 0.5 + 0.3 * np.sin(x / 9.0) + 3e-6 * np.sin(y / 6.0)
+
+
+def tex_weak_y2(x, y):
+    """As tex_weak_y with the y texture at 1e-7: cond(J) ~ 2e7, cond(J^T J) ~ 3e14.  The
+    ill-conditioning is a column scale, which the Jacobi-scaled 6x6 solve removes."""
+    return 0.5 + 0.3 * np.sin(x / 9.0) + 3e-8 * np.sin(y / 6.0)
+
+
+def tex_diag2(x, y):
+    """A linear ramp in x + 2y: np.gradient gives gy = 2 gx everywhere (borders included),
+    so column 1 of J is twice column 0 -- a null direction (2, -1, 0, 0, 0, 0) that is NOT
+    an axis and whose two columns have different norms: lstsq's minimum-norm answer
+    differs from a minimum-norm answer taken in column-scaled coordinates."""
+    return 0.3 + 0.0005 * (x + 2.0 * y)
+
+
+ILL_SCENES = {
+    "plane1d": (tex_1d, 21),
+    "halfflat": (tex_half_flat, 22),
+    "weaky": (tex_weak_y, 23),
+    "weaky2": (tex_weak_y2, 24),
+    "diag2": (tex_diag2, 25),
+}
+
+
+def ill_pair(name, height=120, width=160):
+    tex, seed = ILL_SCENES[name]
+    return plane_pair(height, width, tex, seed)

@@ -160,6 +160,7 @@ def test_dvo_pyramid_vs_golden(ops, orc, golden):
     pair = synthetic.make_pair(120, 160, seed=4)
     batch = ops.DvoBatch(1, 120, 160, n_levels=3, ratio=1.5)
     batch.upload(0, pair["I0"], pair["D0"], pair["I1"])
+    batch.set_anti_aliasing(False)
     batch.build_pyramid()
     # the device pyramid equals the oracle's (bit-exact), level by level
     for level in (1, 2):
@@ -187,6 +188,7 @@ batch = ops.DvoBatch(B, H, W, n_levels=4, ratio=1.5, with_weight_map=True)
 for i in range(B):
     pr = synthetic.make_pair(H, W, seed=20 + i)
     batch.upload(i, pr["I0"], pr["D0"], pr["I1"], np.full((H, W), 0.5 + 0.1 * i))
+batch.set_anti_aliasing(False)      # the three plain-bilinear builders
 batch.build_pyramid()
 h = hashlib.sha256()
 for i in range(B):

@@ -179,3 +179,64 @@ def test_anti_aliased_rescale_is_prefilter_plus_bilinear():
         assert got.shape == (Ho, Wo)
         assert np.allclose(got, expected, rtol=0, atol=4e-16)     # kernel weights differ by <= 1 ulp
     assert np.array_equal(orc.rescale(img, 1.0, anti_aliasing=True), img)
+
+
+# ---------------------------------------------------------------------------
+# round 3: the oracle's loop against the reference's own loop at the examples' settings,
+# on real image statistics and on ill-conditioned scenes (generate_golden_r3.py)
+# ---------------------------------------------------------------------------
+def _assert_pose(rot, t, g, tag, atol=1e-8):
+    assert np.allclose(rot.as_rotvec(), g[f"{tag}_rotvec"], atol=atol), tag
+    assert np.allclose(t, g[f"{tag}_t"], atol=atol), tag
+
+
+@pytest.mark.parametrize("aa", [False, True])
+def test_example_5_levels_matches_reference(golden, aa):
+    g = golden("dvo_examples.npz")
+    pair = synthetic.make_pair(240, 320, seed=5)
+    rot, t = orc.dvo_estimate(pair["I0"], pair["D0"], pair["I1"], pair["cam"], pair["cam"], "huber",
+                              n_coarse_to_fine=5, anti_aliasing=aa)
+    _assert_pose(rot, t, g, f"ex5_{'aa' if aa else 'bl'}_huber")
+
+
+@pytest.mark.parametrize("name", ["None", "tukey"])
+def test_new_tsukuba_half_resolution_matches_reference(golden, name):
+    """Real frames; `name` tukey is only in the full-resolution fixture, so that one runs the
+    5-level loop at 480x640 once (a few seconds)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import scenes
+    g = golden("dvo_real.npz")
+    I0 = scenes.gray_from_rgb_u8(g["rgb0"]); I1 = scenes.gray_from_rgb_u8(g["rgb1"])
+    D0 = scenes.tsukuba_depth(*I0.shape)
+    cam = scenes.TSUKUBA_CAM
+    if name == "None":
+        I0, D0, I1 = (orc.rescale(a, 0.5, anti_aliasing=True) for a in (I0, D0, I1))
+        rot, t = orc.dvo_estimate(I0, D0, I1, cam * 0.5, cam * 0.5, None, n_coarse_to_fine=5, anti_aliasing=True)
+        _assert_pose(rot, t, g, "half_aa_None", atol=1e-7)
+    else:
+        rot, t = orc.dvo_estimate(I0, D0, I1, cam, cam, name, n_coarse_to_fine=5, anti_aliasing=True)
+        _assert_pose(rot, t, g, f"full_aa_{name}", atol=1e-7)
+
+
+@pytest.mark.parametrize("scene", ["plane1d", "halfflat", "weaky", "weaky2", "diag2"])
+def test_ill_conditioned_scenes_match_reference(golden, scene):
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    import scenes
+    from scipy.spatial.transform import Rotation
+    g = golden("dvo_ill.npz")
+    pair = scenes.ill_pair(scene)
+    trace = []
+    rot, t = orc.dvo_estimate_level(pair["I0"], pair["D0"], pair["I1"], pair["cam"], pair["cam"],
+                                    Rotation.from_rotvec(np.zeros(3)), np.zeros(3), "huber", 20, trace)
+    xis = np.array([tr["xi"] for tr in trace[1:]])
+    ref = g[f"{scene}_huber_xis"]
+    assert xis.shape == ref.shape
+    assert np.max(np.abs(xis - ref)) < 1e-7 * max(1.0, np.max(np.abs(ref)))
+    _assert_pose(rot, t, g, f"{scene}_huber", atol=1e-7)
+    rot, t = orc.dvo_estimate(pair["I0"], pair["D0"], pair["I1"], pair["cam"], pair["cam"], None,
+                              n_coarse_to_fine=3, anti_aliasing=True)
+    _assert_pose(rot, t, g, f"{scene}_aa_None_pyr", atol=1e-7)
