@@ -53,6 +53,9 @@ tdk_status tdk_set_device(int device);
 tdk_status tdk_get_device(int *device);
 tdk_status tdk_sync(void);
 tdk_status tdk_device_name(char *buf, int buflen);
+/* Page-locked host memory for the asynchronous uploads (tdk_dvo_upload_async). */
+tdk_status tdk_pinned_alloc(size_t bytes, void **out);
+tdk_status tdk_pinned_free(void *ptr);
 
 /* ---- parity-granular per-point operators (1:1 with rust_bindings.*) ------- */
 /* tadataka.camera._normalizer.normalize/unnormalize (tadataka/camera/_normalizer.cpp:12-27),
@@ -105,6 +108,20 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h);
 /* Host -> device copy of one pair (level 0).  weight_map may be NULL. */
 tdk_status tdk_dvo_upload(tdk_dvo *h, int pair, const double *I0, const double *D0,
                           const double *I1, const double *weight_map);
+/* As tdk_dvo_upload with every array taken from the host OR from the device: for k = 0..3
+ * (I0, D0, I1, W0) device4[k] (a device pointer: tdk_map_device_ptr / tdk_frame_device_ptr) is
+ * copied on the device if non-NULL, else host4[k] is uploaded if non-NULL, else the array is left
+ * as it is.  What the drop-in PoseChangeEstimator calls when examples/semi_dense_vo.py:44-53 hands
+ * it the depth map and 1 / variance that the previous mapping step left on the device. */
+tdk_status tdk_dvo_upload_mixed(tdk_dvo *h, int pair, const double *const *host4,
+                                const double *const *device4);
+/* Asynchronous upload of one array (which = 0 I0, 1 D0, 2 I1, 3 W0) of pairs
+ * [first_pair, first_pair + n_pairs) from PINNED host memory (tdk_pinned_alloc) laid out
+ * [n_pairs][height * width]: the copy runs on the batch's copy stream, behind the work already
+ * queued on the batch and ahead of whatever is queued next; the call does not wait.  For a
+ * streaming consumer: the next frames of one batch arrive while another batch is estimated. */
+tdk_status tdk_dvo_upload_async(tdk_dvo *h, int which, int first_pair, int n_pairs,
+                                const double *pinned_host);
 /* Fills every pair on the device from the analytic synthetic scene of
  * tadataka_amd/synthetic.py (bench inputs "generated on device"): pair i uses
  * poses12[i] as ground truth and seed seed0+i for the noise. */
@@ -131,6 +148,14 @@ tdk_status tdk_dvo_level_shape(tdk_dvo *h, int level, int *height, int *width);
 tdk_status tdk_dvo_evaluate(tdk_dvo *h, int level, const double *camera0, const double *camera1,
                             const double *poses12, int weight_mode, double *Hout, double *bout,
                             int64_t *n_update, double *sum_sq, int64_t *n_error);
+/* PhotometricError.__call__ / photometric_error (tadataka/metric.py:13-39) for one pose per
+ * pair: sum_sq[pair] = sum of (I0[u0] - I1<warp(u0)>)^2 over the pixels that land inside
+ * image 1, n_error[pair] their count (the error is sum_sq / n_error).  Error-only pass: no
+ * gradients, no Jacobian, no normal equations (the "probe" body of the evaluation kernel:
+ * 24 B/px read, ~45 % of the arithmetic of tdk_dvo_evaluate).  Either output may be NULL. */
+tdk_status tdk_dvo_photometric_error(tdk_dvo *h, int level, const double *camera0,
+                                     const double *camera1, const double *poses12,
+                                     double *sum_sq, int64_t *n_error);
 /* Gauss-Newton loop of one level for all pairs, accept/reject on the device.
  * poses12 is updated in place; n_evals[pair] (optional) = evaluations used. */
 tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0,
@@ -144,6 +169,12 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
  * reference warns "Camera pose change is too large." and returns the pose it had
  * (vo/dvo/__init__.py:97-100), at any iteration and any pyramid level. */
 tdk_status tdk_dvo_get_warnings(tdk_dvo *h, int *too_large);
+/* Work of the last tdk_dvo_estimate / tdk_dvo_estimate_level call in SURVEY 8(d)'s units, summed
+ * over pairs and levels (source pixels of the level): error_pixels counts PhotometricError
+ * evaluations (metric.py:36-39; n + 1 per level and pair), update_pixels counts calc_pose_update
+ * calls whose normal equations were formed and solved (vo/dvo/__init__.py:46-70; n per level and
+ * pair).  One "DVO iter" of the metric = one update + one error.  Either pointer may be NULL. */
+tdk_status tdk_dvo_get_counts(tdk_dvo *h, int64_t *error_pixels, int64_t *update_pixels);
 /* The hipStream_t every launch and copy of this batch is queued on.  Each batch
  * owns its stream: calls on different batches overlap on the device (e.g. the
  * HBM-bound pyramid of one batch under the FP64-bound estimation of another). */
@@ -222,6 +253,40 @@ tdk_status tdk_update_depth_frames(const double *key_camera, const tdk_frame *ke
                                    const double *prior_depth, const double *prior_variance,
                                    const tdk_semi_dense_params *params, double *depth,
                                    double *variance, int64_t *flag);
+/* Device-resident maps.  The loop of examples/semi_dense_vo.py:182-199 hands every map a call
+ * returns straight into the next call (age1 -> update_depth, depth_map1 / variance_map1 ->
+ * update_depth -> next frame's increment_age / propagate / dvo).  A tdk_map is an H x W array of
+ * 8-byte elements (float64, uint64 or int64 -- the caller knows which) that lives on the device;
+ * the three operators below are the host-pointer entries above with maps in and out: same
+ * arithmetic, asynchronous on the library stream, nothing crosses PCIe until tdk_map_download.
+ * rust_bindings.semi_dense returns such maps wrapped as lazily downloaded array objects.
+ *   tdk_map_create        host may be NULL (contents undefined until written)
+ *   tdk_map_destroy       the buffer is recycled for the next map of the same size
+ *   tdk_map_safe_invert   out = 1 / (v + epsilon)  (tadataka/numeric.py:1-2: the DVO weights of
+ *                         examples/semi_dense_vo.py:52), out may be v itself
+ *   tdk_update_depth_maps waits for its kernels before returning: an age beyond n_ref must be
+ *                         reported by the call (TDK_ERR_AGE_EXCEEDS_REFFRAMES) */
+typedef struct tdk_map tdk_map;
+tdk_status tdk_map_create(int height, int width, const void *host, tdk_map **out);
+tdk_status tdk_map_destroy(tdk_map *m);
+tdk_status tdk_map_upload(tdk_map *m, const void *host);
+tdk_status tdk_map_download(const tdk_map *m, void *host);
+tdk_status tdk_map_shape(const tdk_map *m, int *height, int *width);
+tdk_status tdk_map_device_ptr(const tdk_map *m, void **ptr);
+tdk_status tdk_frame_device_ptr(const tdk_frame *f, void **ptr);
+tdk_status tdk_map_safe_invert(const tdk_map *v, double epsilon, tdk_map *out);
+tdk_status tdk_increment_age_maps(const tdk_map *age0, const double *camera0, const double *camera1,
+                                  const double *transform10, const tdk_map *depth0, tdk_map *age1);
+tdk_status tdk_propagate_maps(const double *transform10, const double *camera0, const double *camera1,
+                              const tdk_map *depth0, const tdk_map *variance0, double default_depth,
+                              double default_variance, double uncertaintity_bias, tdk_map *depth1,
+                              tdk_map *variance1);
+tdk_status tdk_update_depth_maps(const double *key_camera, const tdk_frame *key_frame,
+                                 const double *key_transform_wf, int n_ref, const double *ref_cameras,
+                                 const tdk_frame *const *ref_frames, const double *ref_transforms_wf,
+                                 const tdk_map *age, const tdk_map *prior_depth,
+                                 const tdk_map *prior_variance, const tdk_semi_dense_params *params,
+                                 tdk_map *depth, tdk_map *variance, tdk_map *flag);
 /* estimate_debug_ (src/py/semi_dense.rs:126-155) */
 tdk_status tdk_estimate_one(const int64_t *u_key, double prior_depth, double prior_variance,
                             const double *key_camera, const double *key_image,

@@ -48,6 +48,22 @@ PROTOTYPES = {
     "tdk_get_device": [c_int_p],
     "tdk_sync": [],
     "tdk_device_name": [C.c_char_p, _i],
+    "tdk_pinned_alloc": [C.c_size_t, C.POINTER(_vp)],
+    "tdk_pinned_free": [_vp],
+    "tdk_dvo_upload_mixed": [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)],
+    "tdk_dvo_upload_async": [_vp, _i, _i, _i, _vp],
+    "tdk_map_create": [_i, _i, _vp, C.POINTER(_vp)],
+    "tdk_map_destroy": [_vp],
+    "tdk_map_upload": [_vp, _vp],
+    "tdk_map_download": [_vp, _vp],
+    "tdk_map_shape": [_vp, c_int_p, c_int_p],
+    "tdk_map_device_ptr": [_vp, C.POINTER(_vp)],
+    "tdk_frame_device_ptr": [_vp, C.POINTER(_vp)],
+    "tdk_map_safe_invert": [_vp, C.c_double, _vp],
+    "tdk_increment_age_maps": [_vp, _d, _d, _d, _vp, _vp],
+    "tdk_propagate_maps": [_d, _d, _d, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp],
+    "tdk_update_depth_maps": [_vp, _vp, _d, _i, _d, C.POINTER(_vp), _d, _vp, _vp, _vp,
+                              C.POINTER(SemiDenseParams), _vp, _vp, _vp],
     "tdk_normalize": [_d, _i64, _d, _d],
     "tdk_unnormalize": [_d, _i64, _d, _d],
     "tdk_project_vecs": [_d, _i64, _d],
@@ -69,9 +85,11 @@ PROTOTYPES = {
     "tdk_dvo_level_shape": [_vp, _i, c_int_p, c_int_p],
     "tdk_dvo_evaluate": [_vp, _i, _d, _d, _d, _i, _d, _d, c_int64_p, _d, c_int64_p],
     "tdk_dvo_estimate_level": [_vp, _i, _d, _d, _d, _i, _i, c_int_p],
+    "tdk_dvo_photometric_error": [_vp, _i, _d, _d, _d, _d, c_int64_p],
     "tdk_dvo_estimate": [_vp, _d, _d, _d, _i, _i, c_int64_p],
     "tdk_dvo_get_stream": [_vp, C.POINTER(_vp)],
     "tdk_dvo_get_warnings": [_vp, c_int_p],
+    "tdk_dvo_get_counts": [_vp, c_int64_p, c_int64_p],
     "tdk_dvo_set_profiling": [_vp, _i],
     "tdk_dvo_get_profile": [_vp, c_int64_p, _d, c_int64_p],
     "tdk_dvo_get_profile_kind": [_vp, _i, c_int64_p, _d, c_int64_p],

@@ -1,10 +1,40 @@
 """rust_bindings.semi_dense (src/py/semi_dense.rs:35-246): Frame, Params,
-increment_age, propagate, update_depth, estimate_debug_ on the MI355X."""
+increment_age, propagate, update_depth, estimate_debug_ on the MI355X.
+
+The maps stay on the device.  examples/semi_dense_vo.py:182-199 hands every map one
+of these functions returns straight into the next call (and into PoseChangeEstimator
+as depth map and 1 / variance), so the functions return `tadataka_amd.ops.DeviceMap`s:
+array-likes that live in HBM and are downloaded the first time somebody looks at them
+(np.asarray, indexing, arithmetic, plotting ...).  Passed back in, they are used where
+they are; plain ndarrays are accepted as before (and uploaded).  Frame.image is such a
+map too, backed by the image the frame keeps on the device.  Set
+rust_bindings.semi_dense.LAZY_MAPS = False (or TDK_SD_EAGER=1) to get plain ndarrays
+back from every call (one download per returned map)."""
+import os
+
 import numpy as np
 
 from rust_bindings._check import f64, typed
 from rust_bindings.camera import CameraParameters
 from tadataka_amd import ops
+
+
+LAZY_MAPS = os.environ.get("TDK_SD_EAGER", "0") in ("", "0")
+
+
+def _out(*maps):
+    if not LAZY_MAPS:
+        maps = tuple(np.asarray(m) for m in maps)
+    return maps[0] if len(maps) == 1 else maps
+
+
+def _map_arg(a, dtype, name):
+    """An ndarray of the exact dtype (rust-numpy's rule) or a DeviceMap of it."""
+    if isinstance(a, ops.DeviceMap):
+        if a.dtype != np.dtype(dtype):
+            raise TypeError(f"{name} must have dtype {np.dtype(dtype).name}")
+        return a
+    return typed(a, dtype, 2, name)
 
 
 def _camera(camera_params):
@@ -30,7 +60,12 @@ class Frame(object):
 
     @property
     def image(self):
-        return self._image.copy()
+        if not LAZY_MAPS:
+            return self._image.copy()
+        # the frame's image where it lives on the device; the host side is a copy, as in the reference
+        _, dev, _ = self._resident()
+        return ops.DeviceMap(self._image.shape, np.float64, host=self._image.copy(), owner=dev,
+                             device_ptr=dev.device_ptr())
 
     @property
     def transform_wf(self):
@@ -56,35 +91,36 @@ class Params(object):
 
 
 def increment_age(age_map0, camera_params0, camera_params1, transform10, depth_map0):
-    typed(age_map0, np.uint64, 2, "age_map0"); f64(transform10, 2, "transform10")
-    f64(depth_map0, 2, "depth_map0")
+    _map_arg(age_map0, np.uint64, "age_map0"); f64(transform10, 2, "transform10")
+    _map_arg(depth_map0, np.float64, "depth_map0")
     if age_map0.shape != depth_map0.shape:
         raise ValueError("age_map0 and depth_map0 must have the same shape")   # age.rs:13 assert
-    return ops.increment_age(age_map0, _camera(camera_params0), _camera(camera_params1),
-                             transform10, depth_map0)
+    return _out(ops.increment_age_maps(age_map0, _camera(camera_params0), _camera(camera_params1),
+                                       transform10, depth_map0))
 
 
 def propagate(transform10, camera_params0, camera_params1, depth_map0, variance_map0,
               default_depth, default_variance, uncertaintity_bias):
-    f64(transform10, 2, "transform10"); f64(depth_map0, 2, "depth_map0")
-    f64(variance_map0, 2, "variance_map0")
-    return ops.propagate(transform10, _camera(camera_params0), _camera(camera_params1), depth_map0,
-                         variance_map0, default_depth, default_variance, uncertaintity_bias)
+    f64(transform10, 2, "transform10"); _map_arg(depth_map0, np.float64, "depth_map0")
+    _map_arg(variance_map0, np.float64, "variance_map0")
+    return _out(*ops.propagate_maps(transform10, _camera(camera_params0), _camera(camera_params1),
+                                    depth_map0, variance_map0, default_depth, default_variance,
+                                    uncertaintity_bias))
 
 
 def update_depth(keyframe, refframes, age_map, prior_depth, prior_variance, params):
     """Returns (depth, variance, flag) (src/py/semi_dense.rs:182-186)."""
-    typed(age_map, np.uint64, 2, "age_map"); f64(prior_depth, 2, "prior_depth")
-    f64(prior_variance, 2, "prior_variance")
+    _map_arg(age_map, np.uint64, "age_map"); _map_arg(prior_depth, np.float64, "prior_depth")
+    _map_arg(prior_variance, np.float64, "prior_variance")
     shape = age_map.shape
     if prior_depth.shape != shape or prior_variance.shape != shape or keyframe._image.shape != shape:
         raise ValueError("maps and keyframe image must share one shape")   # semi_dense.rs:168-173
     if any(r._image.shape != shape for r in refframes):
         raise ValueError("reference frames must have the key frame's shape")
-    # the frames stay on the device from their first use on: the example passes an ever longer
-    # refframes list (examples/semi_dense_vo.py:199), nothing of it is uploaded again
-    return ops.update_depth_frames(keyframe._resident(), [r._resident() for r in refframes], age_map,
-                                   prior_depth, prior_variance, params._c)
+    # frames and maps stay on the device: the example passes an ever longer refframes list
+    # (examples/semi_dense_vo.py:199) and the maps of the previous call; nothing is uploaded again
+    return _out(*ops.update_depth_maps(keyframe._resident(), [r._resident() for r in refframes], age_map,
+                                       prior_depth, prior_variance, params._c))
 
 
 def estimate_debug_(u_key, prior_depth, prior_variance, keyframe, refframe, params):

@@ -85,9 +85,13 @@ def _update_mask(cam1, P1, shape):
     return is_in_image_range(us1, shape) & (np.asarray(P1)[:, 2] > 0)
 
 
+def _is_map(weights):
+    return isinstance(weights, (np.ndarray, ops.DeviceMap))
+
+
 def _fused_mode(weights):
     """Weight mode of the fused device loop."""
-    if isinstance(weights, np.ndarray):
+    if _is_map(weights):
         return ops.W_MAP
     return ops.WEIGHT_MODES[weights]      # None / "huber" / "student-t" / "tukey"
 
@@ -136,7 +140,7 @@ class _PoseChangeEstimator(object):
 
     def __call__(self, I0, D0, I1, pose10, weights=None):
         _check_weights_name(weights)
-        has_map = isinstance(weights, np.ndarray)
+        has_map = _is_map(weights)
         batch = _batch_for(I0.shape, 1, 1.5, has_map)
         batch.upload(0, I0, D0, I1, weights if has_map else None)
         return _estimate_level(batch, 0, self.camera_model0, self.camera_model1, pose10,
@@ -176,7 +180,7 @@ class PoseChangeEstimator(object):
         assert(np.ndim(I1) == 2)
         _check_weights_name(weights)
         pose10 = Pose.identity() if pose10 is None else pose10
-        has_map = isinstance(weights, np.ndarray)
+        has_map = _is_map(weights)
         batch = _batch_for(I0.shape, self.n_coarse_to_fine, self.layer_size_ratio, has_map)
         batch.upload(0, I0, D0, I1, weights if has_map else None)
         batch.build_pyramid()

@@ -573,15 +573,16 @@ struct LoopState {   // device arrays, one entry per pair
     int *n_evals;      // [n]
     int *active;       // [1] number of pairs still running
     int *ticket;       // [1] blocks of the current k_dvo_reduce launch that are through
-    unsigned long long *evals;   // [1] evaluations executed at this level, summed over the pairs
+    unsigned long long *evals;   // [2] at this level, summed over the pairs: [0] photometric errors evaluated
+                                 //     (PhotometricError calls), [1] pose updates solved (calc_pose_update calls)
     int *warn;         // [n] an evaluation of the current estimate found an EMPTY update mask ("pose change is too large")
     int *mode;         // [n] what the pair's NEXT evaluation is: MODE_FULL0 / MODE_PROBE / MODE_FULLK
     int *tested;       // [n] candidates tested at this level (the reference's loop counter k)
     int *stat_state;   // [n] ST_RUNNING where the next evaluation needs robust statistics (running and not a probe)
     int *round;        // [2] pairs whose evaluation in the launch just reduced was full / a probe
     int fuse_first;    // the first candidate of this level is evaluated in full straight away (see reduce_pair)
-    int *host_flag;    // mapped host memory: [0] `active` as left by the last launch, [2..3] `evals` (64 bit),
-                       // [4] / [5] `round`
+    int *host_flag;    // mapped host memory: [0] `active` as left by the last launch, [2..3] `evals[0]` (64 bit),
+                       // [4] / [5] `round`, [6..7] `evals[1]` (64 bit)
 };
 
 // Fixed-order reduction of the per-block partials of one pair; in loop mode the
@@ -652,6 +653,7 @@ __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials,
             ls.warn[pair] = 1;
         } else {
             double xi[6];
+            atomicAdd(ls.evals + 1, 1ull);
             tdk::solve6(R, R + 21, xi, R[28]);   // R[28]: rows of J (update mask count)
             double next[12];
             tdk::compose_update(xi, pose, next);
@@ -678,6 +680,7 @@ __global__ __launch_bounds__(kBlock) void k_dvo_reduce(const double *__restrict_
     if (atomicAdd(ls.ticket, 1) == (int)gridDim.x - 1) {
         *ls.ticket = 0;
         *reinterpret_cast<volatile unsigned long long *>(ls.host_flag + 2) = atomicAdd(ls.evals, 0ull);
+        *reinterpret_cast<volatile unsigned long long *>(ls.host_flag + 6) = atomicAdd(ls.evals + 1, 0ull);
         ls.host_flag[4] = atomicExch(&ls.round[0], 0);
         ls.host_flag[5] = atomicExch(&ls.round[1], 0);
         *ls.host_flag = atomicAdd(ls.active, 0);
@@ -702,7 +705,8 @@ __global__ void k_loop_init(LoopState ls, const double *poses_in, int n) {   // 
     if (i == 0) {
         *ls.active = n;
         *ls.ticket = 0;
-        *ls.evals = 0ull;
+        ls.evals[0] = 0ull;
+        ls.evals[1] = 0ull;
         ls.round[0] = 0;
         ls.round[1] = 0;
     }
@@ -1190,6 +1194,10 @@ struct tdk_dvo {
     double prof_ms[3];           // buckets: full / probe / mixed launches (collect_profile)
     int64_t prof_launches[3], prof_pixels[3];
     std::vector<double> cams;   // cameras currently on the device: [cam0 (n x 4) | cam1 (n x 4)]
+    hipStream_t copy_stream;    // tdk_dvo_upload_async (created on first use)
+    hipEvent_t ev_copy, ev_xs;  // copy stream <-> batch stream; library stream <-> batch stream
+    int *d_mode_probe;          // [n] MODE_PROBE (tdk_dvo_photometric_error), allocated on first use
+    int64_t count_error_px, count_update_px;   // tdk_dvo_get_counts: source pixels of the last estimate call
     bool anti_aliasing;         // pyramid levels get skimage's Gaussian prefilter (tdk_dvo_set_anti_aliasing)
     double *d_aa_weights;       // its 1-D kernels, per level and axis (allocated on first use)
     int *h_flag;   // "pairs still running", written by k_dvo_reduce (mapped pinned host memory)
@@ -1493,7 +1501,10 @@ tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64
     // evaluations in the reference's sense: one per PhotometricError call (the full evaluation of an
     // accepted candidate is the second half of the evaluation its probe began)
     const int64_t evals = (int64_t)*(volatile unsigned long long *)(h->h_flag + 2);
+    const int64_t updates = (int64_t)*(volatile unsigned long long *)(h->h_flag + 6);
     if (pixel_evals) *pixel_evals += h->lv[level].N * evals;
+    h->count_error_px += h->lv[level].N * evals;
+    h->count_update_px += h->lv[level].N * updates;
     return TDK_OK;
 }
 
@@ -1581,14 +1592,14 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
     TDK_HIP(hipMalloc(&h->ls.n_evals, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.active, sizeof(int)));
     TDK_HIP(hipMalloc(&h->ls.ticket, sizeof(int)));
-    TDK_HIP(hipMalloc(&h->ls.evals, sizeof(unsigned long long)));
+    TDK_HIP(hipMalloc(&h->ls.evals, 2 * sizeof(unsigned long long)));
     TDK_HIP(hipMalloc(&h->ls.warn, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.mode, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.tested, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.stat_state, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.round, sizeof(int) * 2));
     h->host_warn.assign((size_t)n_pairs, 0);
-    TDK_HIP(hipHostMalloc(&h->h_flag, 8 * sizeof(int), hipHostMallocMapped));
+    TDK_HIP(hipHostMalloc(&h->h_flag, 16 * sizeof(int), hipHostMallocMapped));
     TDK_HIP(hipHostGetDevicePointer((void **)&h->ls.host_flag, h->h_flag, 0));
     return TDK_OK;
 }
@@ -1608,10 +1619,13 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     (void)hipFree(h->ls.mode); (void)hipFree(h->ls.tested); (void)hipFree(h->ls.stat_state); (void)hipFree(h->ls.round);
     (void)hipFree(h->d_rm); (void)hipFree(h->d_wscale); (void)hipFree(h->d_stat);
     (void)hipFree(h->d_spartial); (void)hipFree(h->d_count); (void)hipFree(h->d_select);
-    (void)hipFree(h->d_hist); (void)hipFree(h->d_cand);
+    (void)hipFree(h->d_hist); (void)hipFree(h->d_cand); (void)hipFree(h->d_mode_probe);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
     if (h->d_aa_weights) (void)hipFree(h->d_aa_weights);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->ev_copy) (void)hipEventDestroy(h->ev_copy);
+    if (h->ev_xs) (void)hipEventDestroy(h->ev_xs);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return TDK_OK;
@@ -1631,6 +1645,64 @@ tdk_status tdk_dvo_upload(tdk_dvo *h, int pair, const double *I0, const double *
     if (weight_map)
         TDK_HIP(hipMemcpyAsync(L.W0 + off, weight_map, bytes, hipMemcpyHostToDevice, h->stream));
     TDK_HIP(hipStreamSynchronize(h->stream));
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_upload_mixed(tdk_dvo *h, int pair, const double *const *host4, const double *const *device4) {
+    TDK_REQUIRE(h && host4 && device4, "null pointer");
+    TDK_REQUIRE(pair >= 0 && pair < h->n_pairs, "pair out of range");
+    TDK_REQUIRE((host4[3] == nullptr && device4[3] == nullptr) || h->with_w, "batch was created without a weight map");
+    const tdk_dvo::Level &L = h->lv[0];
+    const size_t bytes = (size_t)L.N * sizeof(double);
+    const int64_t off = (int64_t)pair * L.stride;
+    double *dst[4] = {L.I0 + off, L.D0 + off, L.I1 + off, L.W0 ? L.W0 + off : nullptr};
+    bool any_device = false, any_host = false;
+    for (int k = 0; k < 4; k++) any_device |= device4[k] != nullptr;
+    if (any_device) {
+        // device sources are produced on the library stream (tdk_map / tdk_frame): order the copies
+        // behind what is queued there, and what the library stream does next behind the copies
+        if (!h->ev_xs) TDK_HIP(hipEventCreateWithFlags(&h->ev_xs, hipEventDisableTiming));
+        TDK_HIP(hipEventRecord(h->ev_xs, tdk::stream()));
+        TDK_HIP(hipStreamWaitEvent(h->stream, h->ev_xs, 0));
+    }
+    for (int k = 0; k < 4; k++) {
+        if (device4[k])
+            TDK_HIP(hipMemcpyAsync(dst[k], device4[k], bytes, hipMemcpyDeviceToDevice, h->stream));
+        else if (host4[k]) {
+            TDK_HIP(hipMemcpyAsync(dst[k], host4[k], bytes, hipMemcpyHostToDevice, h->stream));
+            any_host = true;
+        }
+    }
+    if (any_device) {
+        TDK_HIP(hipEventRecord(h->ev_xs, h->stream));
+        TDK_HIP(hipStreamWaitEvent(tdk::stream(), h->ev_xs, 0));
+    }
+    if (any_host) TDK_HIP(hipStreamSynchronize(h->stream));   // the caller's arrays may go away
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_upload_async(tdk_dvo *h, int which, int first_pair, int n_pairs, const double *pinned_host) {
+    TDK_REQUIRE(h && pinned_host, "null pointer");
+    TDK_REQUIRE(which >= 0 && which <= 3 && (which != 3 || h->with_w), "no such array");
+    TDK_REQUIRE(first_pair >= 0 && n_pairs >= 1 && first_pair + n_pairs <= h->n_pairs, "pair range out of bounds");
+    const tdk_dvo::Level &L = h->lv[0];
+    double *base = which == 0 ? L.I0 : which == 1 ? L.D0 : which == 2 ? L.I1 : L.W0;
+    if (!h->copy_stream) {
+        TDK_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        TDK_HIP(hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
+    }
+    // after what the batch's own stream still does with the old frames; before what it does next
+    TDK_HIP(hipEventRecord(h->ev_copy, h->stream));
+    TDK_HIP(hipStreamWaitEvent(h->copy_stream, h->ev_copy, 0));
+    const size_t row = (size_t)L.N * sizeof(double);
+    if ((int64_t)L.N == L.stride)
+        TDK_HIP(hipMemcpyAsync(base + (int64_t)first_pair * L.stride, pinned_host, row * (size_t)n_pairs,
+                               hipMemcpyHostToDevice, h->copy_stream));
+    else
+        TDK_HIP(hipMemcpy2DAsync(base + (int64_t)first_pair * L.stride, (size_t)L.stride * sizeof(double), pinned_host,
+                                 row, row, (size_t)n_pairs, hipMemcpyHostToDevice, h->copy_stream));
+    TDK_HIP(hipEventRecord(h->ev_copy, h->copy_stream));
+    TDK_HIP(hipStreamWaitEvent(h->stream, h->ev_copy, 0));
     return TDK_OK;
 }
 
@@ -1749,6 +1821,38 @@ tdk_status tdk_dvo_evaluate(tdk_dvo *h, int level, const double *camera0, const 
     return TDK_OK;
 }
 
+tdk_status tdk_dvo_photometric_error(tdk_dvo *h, int level, const double *camera0, const double *camera1,
+                                     const double *poses12, double *sum_sq, int64_t *n_error) {
+    TDK_TRY(check_level(h, level));
+    TDK_REQUIRE(camera0 && camera1 && poses12, "null pointer");
+    TDK_TRY(upload_params(h, camera0, camera1));
+    const int n = h->n_pairs;
+    if (!h->d_mode_probe) {   // every pair: error only
+        std::vector<int> m((size_t)n, (int)MODE_PROBE);
+        TDK_HIP(hipMalloc(&h->d_mode_probe, sizeof(int) * n));
+        TDK_HIP(hipMemcpy(h->d_mode_probe, m.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    }
+    TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * n, hipMemcpyHostToDevice, h->stream));
+    // the error does not depend on the weights (metric.py:13-39): the unweighted kernel
+    TDK_TRY(launch_eval(h, level, h->d_poses_in, nullptr, h->d_mode_probe, nullptr, TDK_W_NONE));
+    if (h->profiling && level == 0 && h->ev_used >= 2) {   // what the launch just timed evaluated: probes
+        h->ev_round[h->ev_used - 2] = 0;
+        h->ev_round[h->ev_used - 1] = n;
+    }
+    TDK_TRY(launch_reduce(h, level, 0, 0));
+    void *stage;
+    TDK_TRY(tdk::pinned(1, sizeof(double) * kAccPad * n, &stage));
+    TDK_HIP(hipMemcpyAsync(stage, h->d_results, sizeof(double) * kAccPad * n, hipMemcpyDeviceToHost, h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
+    const double *r = (const double *)stage;
+    for (int i = 0; i < n; i++) {
+        if (sum_sq) sum_sq[i] = r[(size_t)kAccPad * i + 27];
+        if (n_error) n_error[i] = (int64_t)r[(size_t)kAccPad * i + 29];
+    }
+    if (h->profiling) TDK_TRY(collect_profile(h));
+    return TDK_OK;
+}
+
 tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0, const double *camera1,
                                   double *poses12, int weight_mode, int max_iter, int *n_evals) {
     TDK_TRY(check_level(h, level));
@@ -1759,6 +1863,7 @@ tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0, 
                            h->stream));
     int n = h->n_pairs;
     TDK_HIP(hipMemsetAsync(h->ls.warn, 0, sizeof(int) * n, h->stream));
+    h->count_error_px = h->count_update_px = 0;
     h->ls.fuse_first = 1;   // a level on its own starts from the caller's prior
     k_loop_init<<<(n + 255) / 256, 256, 0, h->stream>>>(h->ls, h->d_poses_in, n);
     TDK_LAUNCH_CHECK();
@@ -1781,6 +1886,7 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
     TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * n, hipMemcpyHostToDevice,
                            h->stream));
     if (pixel_evals) *pixel_evals = 0;
+    h->count_error_px = h->count_update_px = 0;
     TDK_HIP(hipMemsetAsync(h->ls.warn, 0, sizeof(int) * n, h->stream));
     for (int level = h->n_levels - 1; level >= 0; level--) {
         // the prior of a level is the result of the coarser one (:131-134), already in ls.pose
@@ -1793,6 +1899,13 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
     TDK_HIP(hipMemcpyAsync(h->host_warn.data(), h->ls.warn, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
     TDK_HIP(hipStreamSynchronize(h->stream));
     if (h->profiling) TDK_TRY(collect_profile(h));
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_get_counts(tdk_dvo *h, int64_t *error_pixels, int64_t *update_pixels) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    if (error_pixels) *error_pixels = h->count_error_px;
+    if (update_pixels) *update_pixels = h->count_update_px;
     return TDK_OK;
 }
 

@@ -128,6 +128,18 @@ tdk_status tdk_sync(void) {
     return TDK_OK;
 }
 
+tdk_status tdk_pinned_alloc(size_t bytes, void **out) {
+    TDK_REQUIRE(out != nullptr && bytes > 0, "bad argument");
+    TDK_TRY(tdk::ensure_device());
+    TDK_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return TDK_OK;
+}
+
+tdk_status tdk_pinned_free(void *ptr) {
+    if (ptr) TDK_HIP(hipHostFree(ptr));
+    return TDK_OK;
+}
+
 tdk_status tdk_device_name(char *buf, int buflen) {
     TDK_REQUIRE(buf != nullptr && buflen > 0, "bad buffer");
     TDK_TRY(tdk::ensure_device());

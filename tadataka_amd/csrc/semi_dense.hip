@@ -1006,6 +1006,264 @@ tdk_status tdk_update_depth_frames(const double *key_camera, const tdk_frame *ke
                                  prior_depth, prior_variance, H, W, params, depth, variance, flag);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Device-resident maps (tdk_map): the loop of examples/semi_dense_vo.py:182-199 hands every map a
+// call returns straight back into the next call.  With the host-pointer entries above each of those
+// hand-overs is a download followed by an upload of the same bytes; with maps the three operators
+// take and return handles, run asynchronously on the library stream, and a map crosses PCIe only
+// when the caller looks at it (tdk_map_download).
+// ---------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct tdk_map {            // H x W elements of 8 bytes (float64 / uint64 / int64) on the device
+    void *data;
+    int H, W;
+};
+
+namespace {
+
+// Freed maps are kept for the next create of the same size: the operators are stream-ordered on the
+// library stream, so a buffer can be handed out again while its last reader is still queued, and the
+// loop above (three maps in, six out per frame) never reaches hipMalloc / hipFree after its first frame.
+struct MapPool {
+    std::vector<std::pair<size_t, void *>> free_list;
+};
+MapPool g_map_pool;
+constexpr size_t kMapPoolMax = 48;
+
+tdk_status map_alloc(size_t bytes, void **out) {
+    for (size_t i = g_map_pool.free_list.size(); i-- > 0;)
+        if (g_map_pool.free_list[i].first == bytes) {
+            *out = g_map_pool.free_list[i].second;
+            g_map_pool.free_list.erase(g_map_pool.free_list.begin() + (long)i);
+            return TDK_OK;
+        }
+    TDK_HIP(hipMalloc(out, bytes));
+    return TDK_OK;
+}
+
+void map_release(size_t bytes, void *p) {
+    if (g_map_pool.free_list.size() < kMapPoolMax) {
+        g_map_pool.free_list.emplace_back(bytes, p);
+        return;
+    }
+    (void)hipStreamSynchronize(tdk::stream());
+    (void)hipFree(p);
+}
+
+// Small host structs (per-call constants) go to the device through a ring of pinned blocks, so the
+// caller's stack memory may go away at once and no call has to wait for its own upload.
+constexpr int kRingSlots = 16;
+constexpr size_t kRingBytes = 64 << 10;
+struct StageRing {
+    char *base = nullptr;
+    hipEvent_t ev[kRingSlots];
+    bool pending[kRingSlots] = {};
+    int next = 0;
+};
+StageRing g_ring;
+
+tdk_status h2d_small(int slot, const void *host, size_t bytes, void **dev) {
+    if (bytes > kRingBytes) {   // e.g. thousands of reference frames: plain copy, then wait
+        TDK_TRY(h2d(slot, host, bytes, dev));
+        TDK_HIP(hipStreamSynchronize(tdk::stream()));
+        return TDK_OK;
+    }
+    TDK_TRY(tdk::ensure_device());
+    if (!g_ring.base) {
+        TDK_HIP(hipHostMalloc((void **)&g_ring.base, kRingSlots * kRingBytes, hipHostMallocDefault));
+        for (int i = 0; i < kRingSlots; i++) TDK_HIP(hipEventCreateWithFlags(&g_ring.ev[i], hipEventDisableTiming));
+    }
+    const int i = g_ring.next;
+    g_ring.next = (i + 1) % kRingSlots;
+    if (g_ring.pending[i]) TDK_HIP(hipEventSynchronize(g_ring.ev[i]));
+    char *block = g_ring.base + (size_t)i * kRingBytes;
+    memcpy(block, host, bytes);
+    TDK_TRY(tdk::scratch(slot, bytes, dev));
+    TDK_HIP(hipMemcpyAsync(*dev, block, bytes, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipEventRecord(g_ring.ev[i], tdk::stream()));
+    g_ring.pending[i] = true;
+    return TDK_OK;
+}
+
+__global__ __launch_bounds__(kBlock) void k_safe_invert(const double *__restrict__ v, double eps, double *__restrict__ out,
+                                                        int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        out[i] = 1.0 / (v[i] + eps);   // tadataka/numeric.py:1-2
+}
+
+bool same_shape(const tdk_map *a, const tdk_map *b) { return a->H == b->H && a->W == b->W; }
+
+}  // namespace
+
+extern "C" {
+
+tdk_status tdk_map_create(int height, int width, const void *host, tdk_map **out) {
+    TDK_REQUIRE(out != nullptr, "null pointer");
+    TDK_TRY(check_image_dims(height, width));
+    TDK_TRY(tdk::ensure_device());
+    tdk_map *m = new tdk_map();
+    m->H = height; m->W = width;
+    const size_t bytes = (size_t)height * width * 8;
+    tdk_status st = map_alloc(bytes, &m->data);
+    if (st != TDK_OK) { delete m; return st; }
+    if (host) {
+        hipError_t e = hipMemcpyAsync(m->data, host, bytes, hipMemcpyHostToDevice, tdk::stream());
+        if (e == hipSuccess) e = hipStreamSynchronize(tdk::stream());   // the caller's array may go away
+        if (e != hipSuccess) {
+            map_release(bytes, m->data);
+            delete m;
+            tdk::set_error("map upload failed: %s", hipGetErrorString(e));
+            return TDK_ERR_HIP;
+        }
+    }
+    *out = m;
+    return TDK_OK;
+}
+
+tdk_status tdk_map_destroy(tdk_map *m) {
+    if (!m) return TDK_OK;
+    map_release((size_t)m->H * m->W * 8, m->data);
+    delete m;
+    return TDK_OK;
+}
+
+tdk_status tdk_map_upload(tdk_map *m, const void *host) {
+    TDK_REQUIRE(m && host, "null pointer");
+    TDK_HIP(hipMemcpyAsync(m->data, host, (size_t)m->H * m->W * 8, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    return TDK_OK;
+}
+
+tdk_status tdk_map_download(const tdk_map *m, void *host) {
+    TDK_REQUIRE(m && host, "null pointer");
+    TDK_HIP(hipMemcpyAsync(host, m->data, (size_t)m->H * m->W * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));   // also waits for the kernels that produce the map
+    return TDK_OK;
+}
+
+tdk_status tdk_map_shape(const tdk_map *m, int *height, int *width) {
+    TDK_REQUIRE(m && height && width, "null pointer");
+    *height = m->H; *width = m->W;
+    return TDK_OK;
+}
+
+tdk_status tdk_map_device_ptr(const tdk_map *m, void **ptr) {
+    TDK_REQUIRE(m && ptr, "null pointer");
+    *ptr = m->data;
+    return TDK_OK;
+}
+
+tdk_status tdk_frame_device_ptr(const tdk_frame *f, void **ptr) {
+    TDK_REQUIRE(f && ptr, "null pointer");
+    *ptr = f->image;
+    return TDK_OK;
+}
+
+tdk_status tdk_map_safe_invert(const tdk_map *v, double epsilon, tdk_map *out) {
+    TDK_REQUIRE(v && out && same_shape(v, out), "maps must share one shape");
+    const int64_t n = (int64_t)v->H * v->W;
+    int g = grid_for(n);
+    k_safe_invert<<<g > 4096 ? 4096 : g, kBlock, 0, tdk::stream()>>>((const double *)v->data, epsilon,
+                                                                      (double *)out->data, n);
+    TDK_LAUNCH_CHECK();
+    return TDK_OK;
+}
+
+tdk_status tdk_increment_age_maps(const tdk_map *age0, const double *camera0, const double *camera1,
+                                  const double *T10, const tdk_map *depth0, tdk_map *age1) {
+    TDK_REQUIRE(age0 && camera0 && camera1 && T10 && depth0 && age1, "null pointer");
+    TDK_REQUIRE(same_shape(age0, depth0) && same_shape(age0, age1), "maps must share one shape");
+    TDK_REQUIRE(age1->data != age0->data, "age1 must not alias age0");
+    const int H = age0->H, W = age0->W, N = H * W;
+    void *d_head, *d_next, *d_tw;
+    TDK_TRY(tdk::scratch(2, (size_t)N * 4, &d_head));
+    TDK_TRY(tdk::scratch(3, (size_t)N * 4, &d_next));
+    TrackWarp tw;
+    fill_track_warp(&tw, T10, camera0, camera1);
+    TDK_TRY(h2d_small(10, &tw, sizeof(tw), &d_tw));
+    return launch_warp_step<true, false>(1, H, W, (const TrackWarp *)d_tw, (const uint64_t *)age0->data,
+                                         (const double *)depth0->data, nullptr, N, 0., 0., 0., (int *)d_head,
+                                         (int *)d_next, (uint64_t *)age1->data, nullptr, nullptr, tdk::stream());
+}
+
+tdk_status tdk_propagate_maps(const double *T10, const double *camera0, const double *camera1,
+                              const tdk_map *depth0, const tdk_map *variance0, double default_depth,
+                              double default_variance, double uncertaintity_bias, tdk_map *depth1,
+                              tdk_map *variance1) {
+    TDK_REQUIRE(T10 && camera0 && camera1 && depth0 && variance0 && depth1 && variance1, "null pointer");
+    TDK_REQUIRE(same_shape(depth0, variance0) && same_shape(depth0, depth1) && same_shape(depth0, variance1),
+                "maps must share one shape");
+    TDK_REQUIRE(depth1->data != depth0->data && depth1->data != variance0->data &&
+                    variance1->data != depth0->data && variance1->data != variance0->data &&
+                    depth1->data != variance1->data,
+                "outputs must not alias the inputs");
+    const int H = depth0->H, W = depth0->W, N = H * W;
+    void *d_head, *d_next, *d_tw;
+    TDK_TRY(tdk::scratch(2, (size_t)N * 4, &d_head));
+    TDK_TRY(tdk::scratch(3, (size_t)N * 4, &d_next));
+    TrackWarp tw;
+    fill_track_warp(&tw, T10, camera0, camera1);
+    TDK_TRY(h2d_small(10, &tw, sizeof(tw), &d_tw));
+    return launch_warp_step<false, true>(1, H, W, (const TrackWarp *)d_tw, nullptr, (const double *)depth0->data,
+                                         (const double *)variance0->data, N, default_depth, default_variance,
+                                         uncertaintity_bias, (int *)d_head, (int *)d_next, nullptr,
+                                         (double *)depth1->data, (double *)variance1->data, tdk::stream());
+}
+
+tdk_status tdk_update_depth_maps(const double *key_camera, const tdk_frame *key_frame, const double *key_T, int n_ref,
+                                 const double *ref_cameras, const tdk_frame *const *ref_frames, const double *ref_Ts,
+                                 const tdk_map *age, const tdk_map *prior_depth, const tdk_map *prior_variance,
+                                 const tdk_semi_dense_params *params, tdk_map *depth, tdk_map *variance,
+                                 tdk_map *flag) {
+    TDK_REQUIRE(key_camera && key_frame && key_T && age && prior_depth && prior_variance && params && depth &&
+                    variance && flag && n_ref >= 0,
+                "bad argument");
+    TDK_REQUIRE(n_ref == 0 || (ref_cameras && ref_frames && ref_Ts), "null reference frames");
+    const int H = key_frame->H, W = key_frame->W, N = H * W;
+    for (const tdk_map *m : {age, prior_depth, prior_variance, (const tdk_map *)depth, (const tdk_map *)variance,
+                             (const tdk_map *)flag})
+        TDK_REQUIRE(m->H == H && m->W == W, "maps and keyframe image must share one shape");
+    for (const tdk_map *o : {(const tdk_map *)depth, (const tdk_map *)variance, (const tdk_map *)flag})
+        TDK_REQUIRE(o->data != age->data && o->data != prior_depth->data && o->data != prior_variance->data,
+                    "outputs must not alias the inputs");
+    std::vector<RefConst> rcs((size_t)(n_ref > 0 ? n_ref : 1));
+    for (int a = 1; a <= n_ref; a++) {   // indexed by age - 1: refframes[n_ref - age] (:207)
+        const int r = n_ref - a;
+        TDK_REQUIRE(ref_frames[r] && ref_frames[r]->H == H && ref_frames[r]->W == W,
+                    "reference frames must have the key frame's shape");
+        TDK_TRY(make_ref_const(key_T, ref_Ts + 16 * r, ref_cameras + 4 * r, ref_frames[r]->image, &rcs[a - 1]));
+    }
+    void *d_rc, *d_keys, *d_list, *d_cnt;
+    TDK_TRY(tdk::scratch(1, (size_t)N * 4, &d_list));
+    TDK_TRY(tdk::scratch(4, (kCountStride + 1) * sizeof(int), &d_cnt));
+    TDK_TRY(h2d_small(11, rcs.data(), sizeof(RefConst) * rcs.size(), &d_rc));
+    TrackKey key;
+    memcpy(key.cam, key_camera, sizeof(double) * 4);
+    key.image = key_frame->image;
+    key.n_ref = n_ref;
+    key.pad = 0;
+    TDK_TRY(h2d_small(12, &key, sizeof(key), &d_keys));
+    int *d_err = (int *)d_cnt + kCountStride;
+    TDK_HIP(hipMemsetAsync(d_err, 0, sizeof(int), tdk::stream()));
+    TDK_TRY(launch_update_depth(1, H, W, (const TrackKey *)d_keys, (const RefConst *)d_rc, n_ref > 0 ? n_ref : 1,
+                                (const uint64_t *)age->data, (const double *)prior_depth->data,
+                                (const double *)prior_variance->data, N, est_params(params), (int *)d_list,
+                                (int *)d_cnt, d_err, (double *)depth->data, (double *)variance->data,
+                                (int64_t *)flag->data, tdk::stream()));
+    // the one wait of the step: the reference exits the process if some age exceeds len(refframes)
+    // (semi_dense.rs:202-205); here that is an error code, and it has to be known before the call returns
+    void *h_err;
+    TDK_TRY(tdk::pinned(2, sizeof(int), &h_err));
+    TDK_HIP(hipMemcpyAsync(h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    if (*(const int *)h_err & SD_ERR_AGE) {
+        tdk::set_error("Age exceeds the refframe size");
+        return TDK_ERR_AGE_EXCEEDS_REFFRAMES;
+    }
+    return TDK_OK;
+}
+
 tdk_status tdk_estimate_one(const int64_t *u_key, double prior_depth, double prior_variance,
                             const double *key_camera, const double *key_image, const double *key_T,
                             const double *ref_camera, const double *ref_image, const double *ref_T, int H, int W,

@@ -167,9 +167,32 @@ class DvoBatch(object):
 
     def upload(self, pair, I0, D0, I1, weight_map=None):
         shape = (self.height, self.width)
+        arrays = (I0, D0, I1, weight_map)
+        if any(isinstance(a, DeviceMap) for a in arrays):
+            # maps the previous mapping step left on the device are copied there
+            host = (C.c_void_p * 4)(); dev = (C.c_void_p * 4)()
+            keep = []
+            for k, a in enumerate(arrays):
+                if a is None:
+                    continue
+                if isinstance(a, DeviceMap):
+                    if a.shape != shape or a.dtype != np.float64:
+                        raise ValueError("map shape / dtype does not match the batch")
+                    dev[k] = a.device_ptr()
+                else:
+                    h = _f64(a, shape)
+                    keep.append(h)
+                    host[k] = h.ctypes.data
+            call("tdk_dvo_upload_mixed", self._h, pair, host, dev)
+            return
         I0 = _f64(I0, shape); D0 = _f64(D0, shape); I1 = _f64(I1, shape)
         w = None if weight_map is None else _f64(weight_map, shape)
         call("tdk_dvo_upload", self._h, pair, _p(I0), _p(D0), _p(I1), None if w is None else _p(w))
+
+    def upload_async(self, which, first_pair, n_pairs, pinned):
+        """Queues the upload of one array of a range of pairs from a PinnedBuffer; does not wait."""
+        call("tdk_dvo_upload_async", self._h, {"I0": 0, "D0": 1, "I1": 2, "W0": 3}[which], first_pair, n_pairs,
+             pinned.ptr)
 
     def fill_synthetic(self, camera, poses12, seed0=0, noise=0.02):
         cam = camera_vec(camera)
@@ -209,6 +232,16 @@ class DvoBatch(object):
              nu.ctypes.data_as(c_int64_p), _p(ss), ne.ctypes.data_as(c_int64_p))
         return dict(H=H, b=b, n_update=nu, sum_sq=ss, n_error=ne)
 
+    def photometric_error(self, level, camera0, camera1, poses12):
+        """Error-only pass: (sum_sq [n], n_error [n]) of PhotometricError at poses12."""
+        n = self.n_pairs
+        c0, c1 = self._cams(camera0), self._cams(camera1)
+        P = _f64(poses12, (n, 12))
+        ss = np.empty(n); ne = np.empty(n, dtype=np.int64)
+        call("tdk_dvo_photometric_error", self._h, level, _p(c0), _p(c1), _p(P), _p(ss),
+             ne.ctypes.data_as(c_int64_p))
+        return ss, ne
+
     def estimate_level(self, level, camera0, camera1, poses12, weight_mode=W_NONE, max_iter=20):
         n = self.n_pairs
         c0, c1 = self._cams(camera0), self._cams(camera1)
@@ -234,6 +267,13 @@ class DvoBatch(object):
         call("tdk_dvo_get_warnings", self._h, f.ctypes.data_as(c_int_p))
         return f != 0
 
+    def counts(self):
+        """(error_pixels, update_pixels) of the last estimate() / estimate_level(): source pixels of
+        every PhotometricError evaluation and of every calc_pose_update, summed over pairs and levels."""
+        e = C.c_int64(); u = C.c_int64()
+        call("tdk_dvo_get_counts", self._h, C.byref(e), C.byref(u))
+        return int(e.value), int(u.value)
+
     def set_profiling(self, enabled):
         call("tdk_dvo_set_profiling", self._h, int(bool(enabled)))
 
@@ -244,6 +284,30 @@ class DvoBatch(object):
         call("tdk_dvo_get_profile_kind", self._h, {"full": 0, "probe": 1, "mixed": 2}[kind], C.byref(n),
              C.byref(ms), C.byref(px))
         return dict(launches=int(n.value), total_ms=float(ms.value), pixels=int(px.value))
+
+
+class PinnedBuffer(object):
+    """Page-locked host memory as a float64 ndarray (tdk_pinned_alloc): the source of
+    DvoBatch.upload_async."""
+
+    def __init__(self, shape):
+        self.shape = tuple(int(v) for v in shape)
+        n = int(np.prod(self.shape))
+        self.ptr = C.c_void_p()
+        call("tdk_pinned_alloc", C.c_size_t(n * 8), C.byref(self.ptr))
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, c_double_p), shape=(n,)).reshape(self.shape)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            call("tdk_pinned_free", self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def upper21_to_matrix(H21):
@@ -360,6 +424,11 @@ class DeviceFrame(object):
         self._h = C.c_void_p()
         call("tdk_frame_create", _p(img), img.shape[0], img.shape[1], C.byref(self._h))
 
+    def device_ptr(self):
+        p = C.c_void_p()
+        call("tdk_frame_device_ptr", self._h, C.byref(p))
+        return p.value
+
     def close(self):
         if self._h:
             call("tdk_frame_destroy", self._h)
@@ -387,6 +456,192 @@ def update_depth_frames(key, refs, age, prior_depth, prior_variance, params):
     call("tdk_update_depth_frames", _p(kc), key[1]._h, _p(kT), n_ref, _p(rc), handles, _p(rT),
          age.ctypes.data_as(c_uint64_p), _p(pd_), _p(pv), C.byref(params), _p(depth), _p(var),
          flag.ctypes.data_as(c_int64_p))
+    return depth, var, flag
+
+
+class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
+    """An H x W map that lives on the device (tdk_map) and is downloaded when somebody looks at it.
+
+    It is what rust_bindings.semi_dense.increment_age / propagate / update_depth return and accept:
+    the loop of examples/semi_dense_vo.py:182-199 hands every map it gets straight into the next
+    call, so nothing crosses PCIe there.  Towards NumPy it behaves as an array-like: np.asarray(m),
+    m[...], arithmetic and ufuncs, every ndarray attribute (m.shape, m.copy(), m.max(), ...) work and
+    materialise the host copy once; assigning into it (m[mask] = v) edits the host copy and the
+    device copy is refreshed before its next use.  It is not an ndarray subclass: an ndarray's
+    memory can be read by C code without any hook that could wait for the download."""
+
+    __array_priority__ = 100.0
+
+    def __init__(self, shape, dtype, host=None, owner=None, device_ptr=None):
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.dtype = np.dtype(dtype)
+        assert self.dtype.itemsize == 8
+        self._host = None            # materialised host copy
+        self._stale_device = False   # the host copy was written to
+        self._owner = owner          # keeps a borrowed device buffer alive (a DeviceFrame)
+        self._h = C.c_void_p()
+        self._ptr = device_ptr
+        if owner is None:
+            src = None
+            if host is not None:
+                self._host = np.ascontiguousarray(host, dtype=self.dtype).reshape(self.shape)
+                src = self._host.ctypes.data_as(C.c_void_p)
+            call("tdk_map_create", self.shape[0], self.shape[1], src, C.byref(self._h))
+        elif host is not None:
+            self._host = host
+
+    # -- device side ---------------------------------------------------------------------------
+    @classmethod
+    def empty(cls, shape, dtype):
+        return cls(shape, dtype)
+
+    @classmethod
+    def of(cls, a, dtype):
+        """`a` as a DeviceMap of `dtype`: itself if it is one, uploaded if it is an ndarray."""
+        if isinstance(a, DeviceMap):
+            if a.dtype != np.dtype(dtype):
+                raise TypeError(f"map has dtype {a.dtype}, expected {np.dtype(dtype)}")
+            a._refresh_device()
+            return a
+        return cls(np.shape(a), dtype, host=a)
+
+    def handle(self):
+        if self._owner is not None:
+            raise TypeError("a map that borrows a frame's image has no tdk_map handle")
+        self._refresh_device()
+        return self._h
+
+    def device_ptr(self):
+        self._refresh_device()
+        if self._ptr is None:
+            p = C.c_void_p()
+            call("tdk_map_device_ptr", self._h, C.byref(p))
+            self._ptr = p.value
+        return self._ptr
+
+    def _refresh_device(self):
+        if self._stale_device:
+            if self._owner is not None:
+                raise ValueError("a frame's image cannot be modified in place")
+            call("tdk_map_upload", self._h, self._host.ctypes.data_as(C.c_void_p))
+            self._stale_device = False
+
+    def safe_invert(self, epsilon=1e-16):
+        """1 / (self + epsilon) on the device (tadataka.numeric.safe_invert)."""
+        out = DeviceMap(self.shape, np.float64)
+        if self._owner is not None:
+            raise TypeError("safe_invert of a frame image is not supported")
+        call("tdk_map_safe_invert", self.handle(), float(epsilon), out._h)
+        return out
+
+    def close(self):
+        if self._h:
+            call("tdk_map_destroy", self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- host side -----------------------------------------------------------------------------
+    def _materialise(self):
+        if self._host is None:
+            out = np.empty(self.shape, dtype=self.dtype)
+            call("tdk_map_download", self._h, out.ctypes.data_as(C.c_void_p))
+            self._host = out
+        return self._host
+
+    def __array__(self, dtype=None, copy=None):
+        a = self._materialise()
+        if dtype is not None and np.dtype(dtype) != a.dtype:
+            return a.astype(dtype)
+        return a.copy() if copy else a
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        inputs = tuple(x._materialise() if isinstance(x, DeviceMap) else x for x in inputs)
+        if "out" in kwargs:
+            kwargs["out"] = tuple(x._writable() if isinstance(x, DeviceMap) else x for x in kwargs["out"])
+        return getattr(ufunc, method)(*inputs, **kwargs)
+
+    def _writable(self):
+        a = self._materialise()
+        self._stale_device = True
+        return a
+
+    ndim = 2
+
+    @property
+    def size(self):
+        return self.shape[0] * self.shape[1]
+
+    @property
+    def nbytes(self):
+        return self.size * 8
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __iter__(self):
+        return iter(self._materialise())
+
+    def __getitem__(self, key):
+        return self._materialise()[key]
+
+    def __setitem__(self, key, value):
+        self._writable()[key] = value
+
+    def __getattr__(self, name):           # everything else an ndarray has (copy, max, flatten, T, ...)
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self._materialise(), name)
+
+    def __repr__(self):
+        state = "host copy present" if self._host is not None else "on the device"
+        return f"DeviceMap(shape={self.shape}, dtype={self.dtype}, {state})"
+
+
+def increment_age_maps(age0, camera0, camera1, T10, depth0):
+    """increment_age with device-resident maps in and out (tdk_increment_age_maps)."""
+    a0 = DeviceMap.of(age0, np.uint64); d0 = DeviceMap.of(depth0, np.float64)
+    if a0.shape != d0.shape:
+        raise ValueError("age_map0 and depth_map0 must have the same shape")
+    c0, c1 = camera_vec(camera0), camera_vec(camera1)
+    T10 = _f64(T10, (4, 4))
+    a1 = DeviceMap.empty(a0.shape, np.uint64)
+    call("tdk_increment_age_maps", a0.handle(), _p(c0), _p(c1), _p(T10), d0.handle(), a1._h)
+    return a1
+
+
+def propagate_maps(T10, camera0, camera1, depth0, variance0, default_depth, default_variance,
+                   uncertaintity_bias):
+    d0 = DeviceMap.of(depth0, np.float64); v0 = DeviceMap.of(variance0, np.float64)
+    if d0.shape != v0.shape:
+        raise ValueError("depth_map0 and variance_map0 must have the same shape")
+    c0, c1 = camera_vec(camera0), camera_vec(camera1)
+    T10 = _f64(T10, (4, 4))
+    d1 = DeviceMap.empty(d0.shape, np.float64); v1 = DeviceMap.empty(d0.shape, np.float64)
+    call("tdk_propagate_maps", _p(T10), _p(c0), _p(c1), d0.handle(), v0.handle(), float(default_depth),
+         float(default_variance), float(uncertaintity_bias), d1._h, v1._h)
+    return d1, v1
+
+
+def update_depth_maps(key, refs, age, prior_depth, prior_variance, params):
+    """update_depth with device-resident frames AND maps: key = (camera, DeviceFrame, T_wf), refs =
+    list of the same.  Returns (depth, variance, flag) as DeviceMaps."""
+    kc = camera_vec(key[0]); kT = _f64(key[2], (4, 4))
+    shape = key[1].shape
+    n_ref = len(refs)
+    rc = _f64([camera_vec(r[0]) for r in refs] if n_ref else np.zeros((0, 4)), (n_ref, 4))
+    rT = _f64([r[2] for r in refs] if n_ref else np.zeros((0, 4, 4)), (n_ref, 4, 4))
+    handles = (C.c_void_p * max(n_ref, 1))(*[r[1]._h for r in refs])
+    a = DeviceMap.of(age, np.uint64); pd_ = DeviceMap.of(prior_depth, np.float64)
+    pv = DeviceMap.of(prior_variance, np.float64)
+    depth = DeviceMap.empty(shape, np.float64); var = DeviceMap.empty(shape, np.float64)
+    flag = DeviceMap.empty(shape, np.int64)
+    call("tdk_update_depth_maps", _p(kc), key[1]._h, _p(kT), n_ref, _p(rc), handles, _p(rT), a.handle(),
+         pd_.handle(), pv.handle(), C.byref(params), depth._h, var._h, flag._h)
     return depth, var, flag
 
 

@@ -241,3 +241,254 @@ def test_anti_aliased_pyramid_vga_7_levels_bit_exact(ops):
             assert got.shape == want.shape
             assert np.array_equal(got, want), (level, i, name, float(np.max(np.abs(got - want))))
     batch.close()
+
+
+# ---------------------------------------------------------------------------
+# TDK_STUDENT_EXACT=1: the IEEE-division variant of the Student-t variance fixed point
+# ---------------------------------------------------------------------------
+_STUDENT_EXACT_SCRIPT = """
+import os, sys
+import numpy as np
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+from conftest import b6_err, h21_err
+from tadataka_amd import ops
+from scipy.spatial.transform import Rotation
+d = np.load("tests/golden/dvo_small.npz")
+cam = d["cam"]; H, W = d["I0"].shape
+batch = ops.DvoBatch(1, H, W)
+batch.upload(0, d["I0"], d["D0"], d["I1"])
+iu = np.triu_indices(6)
+worst = 0.0
+for k in range(int(d["s_student-t_n_updates"])):
+    T = d["s_student-t_err_T"][k]
+    ev = batch.evaluate(0, cam, cam, np.concatenate([T[:3, :3].ravel(), T[:3, 3]])[None], ops.W_STUDENT_T)
+    assert ev["n_update"][0] == int(d[f"s_student-t_u{k}_n_valid"])
+    worst = max(worst, h21_err(ev["H"][0], d[f"s_student-t_u{k}_H"][iu]),
+                b6_err(ev["b"][0], d[f"s_student-t_u{k}_b"], d[f"s_student-t_u{k}_H"][iu]))
+P, n = batch.estimate_level(0, cam, cam, np.concatenate([np.eye(3).ravel(), np.zeros(3)])[None], ops.W_STUDENT_T, 20)
+R = Rotation.from_rotvec(d["s_student-t_final_rotvec"]).as_matrix()
+perr = max(np.max(np.abs(P[0, :9].reshape(3, 3) - R)), np.max(np.abs(P[0, 9:] - d["s_student-t_final_t"])))
+assert n[0] == int(d["s_student-t_n_updates"]) + 1
+print("RESULT", worst, perr)
+"""
+
+
+@pytest.mark.parametrize("exact", ["0", "1"])
+def test_student_t_exact_switch(exact):
+    """Both arithmetic variants of the Student-t fixed point against the reference's own
+    per-iteration normal equations (dvo_small.npz): reciprocal arithmetic (default) and
+    TDK_STUDENT_EXACT=1 (IEEE divisions, the CPU restatement's operations).  The switch is
+    read once per process, hence the subprocess."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TDK_STUDENT_EXACT=exact)
+    out = subprocess.run([sys.executable, "-c", _STUDENT_EXACT_SCRIPT], env=env, cwd=root, check=True,
+                         capture_output=True, text=True, timeout=300)
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+    worst, perr = float(line[1]), float(line[2])
+    assert worst < 1e-9 and perr < POSE_ATOL, (worst, perr)
+
+
+# ---------------------------------------------------------------------------
+# error-only entry and the SURVEY 8(d) work counters
+# ---------------------------------------------------------------------------
+def test_photometric_error_entry_and_counts(ops, golden):
+    """tdk_dvo_photometric_error (probe body) returns the double tdk_dvo_evaluate returns for the
+    same pose, and equals the reference's PhotometricError; tdk_dvo_get_counts reports n updates and
+    n + 1 errors per level as the reference loop executes them."""
+    from tadataka_amd import synthetic
+    d = golden("dvo_small.npz")
+    cam = d["cam"]
+    H, W = d["I0"].shape
+    batch = ops.DvoBatch(1, H, W)
+    batch.upload(0, d["I0"], d["D0"], d["I1"])
+    for T, val in zip(d["s_huber_err_T"], d["s_huber_err_val"]):
+        P = _pose12(T)[None]
+        ss, ne = batch.photometric_error(0, cam, cam, P)
+        for mode in (ops.W_NONE, ops.W_HUBER):
+            ev = batch.evaluate(0, cam, cam, P, mode)
+            assert ss[0] == ev["sum_sq"][0] and ne[0] == ev["n_error"][0]
+        assert abs(ss[0] / ne[0] - val) <= 1e-9 * abs(val)
+    P, n_evals = batch.estimate_level(0, cam, cam, _pose12(np.eye(4))[None], ops.W_HUBER, 20)
+    e_px, u_px = batch.counts()
+    assert e_px == int(n_evals[0]) * H * W and u_px == int(d["s_huber_n_updates"]) * H * W
+    batch.close()
+    g = golden("dvo_vga_pyramid.npz")
+    pair = synthetic.make_pair(480, 640, seed=0)
+    batch = ops.DvoBatch(1, 480, 640, n_levels=3, ratio=1.5)
+    batch.upload(0, pair["I0"], pair["D0"], pair["I1"])
+    batch.build_pyramid()
+    P, px = batch.estimate(pair["cam"], pair["cam"], _pose12(np.eye(4))[None], ops.W_HUBER, 20)
+    e_px, u_px = batch.counts()
+    shapes = [batch.level_shape(l) for l in (2, 1, 0)]
+    evals = g["pyr_aa_huber_evals"]
+    assert e_px == px == sum(int(e) * h * w for e, (h, w) in zip(evals, shapes))
+    assert u_px == sum((int(e) - 1) * h * w for e, (h, w) in zip(evals, shapes))
+    batch.close()
+
+
+# ---------------------------------------------------------------------------
+# examples/semi_dense_vo.py:152-207 through the UNCHANGED drop-in calls, maps resident on the device
+# ---------------------------------------------------------------------------
+def _sliding_camera_frames(H, W, n_frames):
+    from tadataka_amd import synthetic
+    cam = synthetic.camera_for(W, H)
+    ys, xs = np.mgrid[0:H, 0:W].astype(np.float64)
+    depth_gt0 = synthetic.depth_map(xs, ys)
+    xn, yn = (xs - cam[2]) / cam[0], (ys - cam[3]) / cam[1]
+    T_w, images = [], []
+    for k in range(n_frames):
+        T = np.eye(4); T[:3, 3] = [0.03 * k, 0.005 * k, 0.01 * k]
+        P = np.stack([xn * depth_gt0, yn * depth_gt0, depth_gt0], axis=-1) + T[:3, 3]
+        images.append(np.ascontiguousarray(synthetic.texture(P[..., 0] / P[..., 2] * cam[0] + cam[2],
+                                                             P[..., 1] / P[..., 2] * cam[1] + cam[3])))
+        T_w.append(T)
+    return cam, depth_gt0, T_w, images
+
+
+def test_semi_dense_vo_example_loop_through_rust_bindings(ops, monkeypatch):
+    """The loop body of examples/semi_dense_vo.py (dvo -> Frame -> increment_age -> propagate ->
+    update_depth -> refframes.append -> hand the maps over), written with the example's own calls
+    and names, on the drop-in packages.  Bit-exact against the oracle chain fed with the same
+    transforms; tracking against the oracle's coarse-to-fine loop; and no map crosses PCIe inside
+    the loop: the only uploads are the new images, the only downloads the ones the test asks for."""
+    import tadataka_amd  # noqa: F401
+    from oracle import oracle as orc
+    from rust_bindings.camera import CameraParameters
+    from rust_bindings.semi_dense import Frame, Params, increment_age, propagate, update_depth
+    from tadataka.camera import CameraModel
+    from tadataka.matrix import inv_motion_matrix
+    from tadataka.numeric import safe_invert
+    from tadataka.vo.dvo import PoseChangeEstimator
+
+    H, W, n_frames, n_levels = 96, 128, 5, 2
+    cam, depth_gt0, T_w, images = _sliding_camera_frames(H, W, n_frames)
+    default_depth, default_variance, uncertaintity_bias = 1.0, 10.0, 0.01
+    pargs = (0.5, 10.0, 0.01, 0.01, 0.004, 0.01)
+    params = Params(*pargs)
+    po = orc.make_params(*pargs)
+
+    def dvo(camera_params0, camera_params1, image0, image1, depth_map0, variance_map0):
+        estimator = PoseChangeEstimator(CameraModel(camera_params0, distortion_model=None),
+                                        CameraModel(camera_params1, distortion_model=None),
+                                        n_coarse_to_fine=n_levels)
+        weights = safe_invert(variance_map0)
+        pose10 = estimator(image0, depth_map0, image1, weights)
+        return pose10.T
+
+    def calc_pose_w1(transform10, transform_w0):
+        return transform_w0.dot(inv_motion_matrix(transform10))
+
+    traffic = {"up": 0, "down": 0, "frames": 0, "dvo_host": 0}
+    real_call = ops.call
+
+    def counting_call(name, *args):
+        if name == "tdk_map_download":
+            traffic["down"] += 1
+        elif name == "tdk_map_upload" or (name == "tdk_map_create" and args[2] is not None):
+            traffic["up"] += 1
+        elif name == "tdk_frame_create":
+            traffic["frames"] += 1
+        elif name == "tdk_dvo_upload":
+            traffic["dvo_host"] += 3
+        elif name == "tdk_dvo_upload_mixed":
+            traffic["dvo_host"] += sum(1 for k in range(4) if args[2][k])
+        return real_call(name, *args)
+    monkeypatch.setattr(ops, "call", counting_call)
+
+    camera_params0 = CameraParameters((cam[0], cam[1]), (cam[2], cam[3]))
+    frame0 = Frame(camera_params0, images[0], T_w[0])
+    refframes = [frame0]
+    rng = np.random.default_rng(0)
+    depth_map0 = depth_gt0 * rng.uniform(0.95, 1.05, (H, W))
+    variance_map0 = np.full((H, W), 0.05)
+    age0 = np.zeros((H, W), dtype=np.uint64)
+    # the oracle's copy of the state
+    o_depth, o_var, o_age = depth_map0.copy(), variance_map0.copy(), age0.copy()
+    o_frames = [(cam, images[0], T_w[0])]
+    checks = []
+
+    for i in range(1, n_frames):
+        camera_params1, image1 = camera_params0, images[i]
+        # ---- the example's loop body (examples/semi_dense_vo.py:175-204, plot() left out) ----
+        transform10 = dvo(frame0.camera_params, camera_params1,
+                          frame0.image, image1, depth_map0, variance_map0)
+
+        transform_w1 = calc_pose_w1(transform10, frame0.transform_wf)
+        frame1 = Frame(camera_params1, image1, transform_w1)
+
+        age1 = increment_age(age0, frame0.camera_params, frame1.camera_params,
+                             transform10, depth_map0)
+
+        depth_map1, variance_map1 = propagate(
+            transform10, frame0.camera_params, frame1.camera_params,
+            depth_map0, variance_map0,
+            default_depth, default_variance, uncertaintity_bias
+        )
+        depth_map1, variance_map1, flag_map = update_depth(
+            frame1, refframes, age1,
+            depth_map1, variance_map1, params
+        )
+        refframes.append(frame1)
+
+        depth_map0, variance_map0, age0 = depth_map1, variance_map1, age1
+        frame0 = frame1
+        # ---- end of the loop body ----
+        checks.append((transform10, transform_w1, depth_map1, variance_map1, age1, flag_map))
+
+    in_loop = dict(traffic)
+    # inside the loop: the caller's initial host maps went up in frame 1 (age0 + depth_map0 into
+    # increment_age, depth_map0 + variance_map0 into propagate), after that no map moves either way
+    assert in_loop["up"] == 4 and in_loop["down"] == 0, in_loop
+    assert in_loop["frames"] == n_frames                       # every image uploaded exactly once as a Frame
+    # DVO took I1 from the host every frame (the new image) and, in frame 1 only, depth / weights too
+    assert in_loop["dvo_host"] == (n_frames - 1) + 2, in_loop
+
+    for i, (T10, T_w1, d1, v1, a1, f1) in enumerate(checks, start=1):
+        rot, t = orc.dvo_estimate(images[i - 1], o_depth, images[i], cam, cam, weights=1.0 / (o_var + 1e-16),
+                                  n_coarse_to_fine=n_levels, max_iter=20, anti_aliasing=True)
+        assert np.max(np.abs(T10[:3, :3] - rot.as_matrix())) < POSE_ATOL
+        assert np.max(np.abs(T10[:3, 3] - t)) < POSE_ATOL
+        key = (cam, images[i], T_w1)
+        o_depth, o_var, o_age, o_flag = orc.semi_dense_step(key, cam, o_frames, T10, o_age, o_depth, o_var, po,
+                                                            default_depth, default_variance, uncertaintity_bias)
+        o_frames.append(key)
+        assert a1.dtype == np.uint64 and f1.dtype == np.int64 and d1.shape == (H, W)
+        assert np.array_equal(a1, o_age) and np.array_equal(f1, o_flag)
+        assert np.array_equal(d1, o_depth) and np.array_equal(v1, o_var)
+    assert int(o_age.max()) == n_frames - 1 and int((o_flag == 0).sum()) > 500
+
+
+def test_device_map_behaves_like_an_array(ops):
+    """What a caller may do with a returned map: look at it, compute with it, write into it and hand
+    it back (the device copy follows), mix it with ndarrays."""
+    from rust_bindings.camera import CameraParameters
+    from rust_bindings.semi_dense import increment_age
+    from oracle import oracle as orc
+    from tadataka_amd import synthetic
+    H, W = 40, 56
+    c = synthetic.make_semi_dense_case(H, W, seed=12)
+    cam = c["cam"]
+    cp = CameraParameters((cam[0], cam[1]), (cam[2], cam[3]))
+    T10 = np.linalg.inv(c["T_wk"]) @ c["T_wr"]
+    a1 = increment_age(c["age"], cp, cp, T10, c["prior_depth"])
+    assert isinstance(a1, ops.DeviceMap) and a1.shape == (H, W) and a1.ndim == 2 and len(a1) == H
+    ref1 = orc.increment_age(c["age"], cam, cam, T10, c["prior_depth"])
+    assert np.array_equal(np.asarray(a1), ref1) and int(a1.max()) == int(ref1.max())
+    assert np.array_equal(a1 + 1, ref1 + 1) and np.array_equal(a1[3:5], ref1[3:5])
+    assert np.array_equal(np.where(a1 > 0, 1, 0), np.where(ref1 > 0, 1, 0))
+    # edit on the host, hand back: the device copy is refreshed
+    a1[0, :] = 7
+    ref1[0, :] = 7
+    a2 = increment_age(a1, cp, cp, T10, c["prior_depth"])
+    assert np.array_equal(a2, orc.increment_age(ref1, cam, cam, T10, c["prior_depth"]))
+    # eager mode: plain ndarrays
+    import rust_bindings.semi_dense as sd
+    sd.LAZY_MAPS = False
+    try:
+        a3 = increment_age(c["age"], cp, cp, T10, c["prior_depth"])
+        assert type(a3) is np.ndarray and np.array_equal(a3, orc.increment_age(c["age"], cam, cam, T10, c["prior_depth"]))
+    finally:
+        sd.LAZY_MAPS = True
+    with pytest.raises(TypeError):
+        increment_age(c["age"].astype(np.int64), cp, cp, T10, c["prior_depth"])
