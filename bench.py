@@ -8,13 +8,15 @@ pyramid, ratio 1.5, max_iter 20, weights="huber" -- BASELINE configs[1]) over on
 batch of independent synthetic 640x480 frame pairs resident in HBM: build the
 pyramids (anti-aliased, as skimage.rescale does by default -- the same constant
 the drop-in tadataka.vo.dvo uses), then per level the fused evaluate/solve
-Gauss-Newton loop, all pairs in lock step on the device.  `value` counts every
-source pixel of every pose whose photometric error the loop evaluates (one per
-PhotometricError call of the reference: n updates + n + 1 errors per level; the
-normal equations are formed with the error in one pass, except that a candidate
-pose is probed error-only first and gets its normal equations only if accepted):
-sum over levels, evaluated poses and still running pairs of the level's pixel
-count, divided by wall time.  `frame_pairs_per_s` is the unambiguous companion.  Pair 0
+Gauss-Newton loop, all pairs in lock step on the device.  `value` is SURVEY 8(d)'s
+unit: one DVO iter = one calc_pose_update (warp, mask, gradients, Jacobian, weights,
+27-entry reduction, solve) + one photometric_error over the source pixels of a level;
+`value` = sum over levels and pairs of (level pixels x pose updates solved) / wall time.
+The reference runs n updates and n + 1 errors per level and pair; both are counted on
+the device (tdk_dvo_get_counts) and reported separately (`update_mpx_per_s`,
+`error_mpx_per_s`, `updates_per_step`, `errors_per_step`); round 1-2's number (every
+PhotometricError evaluation counted as an iteration) stays under
+`error_evaluations_mpx_per_s`.  `frame_pairs_per_s` is the unambiguous companion.  Pair 0
 of the batch is the seed-0 pair of tests/golden/dvo_vga_pyramid.npz: its pose is
 checked against what the REFERENCE's own PoseChangeEstimator returned.
 
@@ -46,6 +48,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X FP64 vector peak (MI355X_MICROARCH.md; SURVEY 8(d)'s secondary ceiling)
 # Algorithmic bytes per unit
 BYTES_PER_PX_EVAL = 24.0      # fused evaluation reads D0, I0, I1 once (f64)
 BYTES_PER_PX_WARP = 56.0      # increment_age 24 + propagate 32
@@ -75,7 +78,7 @@ def parse_args():
     ap.add_argument("--pyramid", choices=["anti-aliased", "bilinear"],
                     default="anti-aliased" if tadataka_amd.PYRAMID_ANTI_ALIASING else "bilinear",
                     help="anti-aliased = what skimage.rescale builds by default (the reference-equivalent one)")
-    ap.add_argument("--min-seconds", type=float, default=1.0,
+    ap.add_argument("--min-seconds", type=float, default=3.0,
                     help="repeat the timed block of --steps steps until this much timed work has run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -132,6 +135,46 @@ def roofline(bytes_per_launch, kernel_ms, **extra):
     return out
 
 
+def load_profile_json(name):
+    path = os.path.join(REPO, "profiles", name)
+    try:
+        return json.load(open(path))
+    except (ValueError, OSError):
+        return None
+
+
+def roofline_fp64(prof_kind):
+    """SURVEY 8(d)'s secondary ceiling: FP64 vector rate of the evaluation kernel.  FLOPs per pixel
+    come from the instruction counters of a rocprofv3 --pmc pass over the same kernel
+    (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64; profiles/r03_fp64_mix.json, made by tools/fp64_mix.sh),
+    the kernel time from this run's HIP events."""
+    mix = load_profile_json("r03_fp64_mix.json")
+    if not mix:
+        return None
+    out = {"bound": "fp64-vector", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "source": "profiles/r03_fp64_mix.json (rocprofv3 --pmc, tools/fp64_mix.sh); kernel time: HIP events of this run",
+           "by_mode": {}}
+    flops, ms = 0.0, 0.0
+    for kind in ("full", "probe"):
+        pk = prof_kind.get(kind)
+        m = mix.get(kind)
+        if not pk or not pk["launches"] or not m:
+            continue
+        f = m["flops_per_px"] * pk["pixels"]
+        flops += f
+        ms += pk["total_ms"]
+        ach = f / (pk["total_ms"] * 1e-3) / 1e12
+        out["by_mode"][kind] = {"flops_per_px": m["flops_per_px"], "fp64_insts_per_px": m.get("fp64_insts_per_px"),
+                                "achieved": ach, "frac": ach / FP64_VECTOR_PEAK_TFLOPS}
+    if ms > 0:
+        out["achieved"] = flops / (ms * 1e-3) / 1e12
+        out["frac"] = out["achieved"] / FP64_VECTOR_PEAK_TFLOPS
+    clock = mix.get("effective_clock_ghz")
+    if clock:
+        out["effective_clock_ghz_in_profile"] = clock
+    return out
+
+
 # ---------------------------------------------------------------------------
 # CPU baselines (the oracle as the thing that is TIMED, on this box's host cores)
 # ---------------------------------------------------------------------------
@@ -148,7 +191,7 @@ def dvo_cpu_baselines(I0, D0, I1, cam, seconds):
         orc.dvo_normal_equations(I0, D0, I1, GX, GY, cam, cam, R, t, "huber")
         orc.photometric_error_sums(I0, D0, I1, cam, cam, T)
 
-    for name, native, share in (("c_port_O3_native", True, 0.4), ("c_port_O2_exact", False, 0.25)):
+    for name, native, share in (("c_port_O3_native", True, 0.3), ("c_port_O2_exact", False, 0.15)):
         try:
             orc.use_library(orc.build_native() if native else None)
             GX, GY = orc.image_gradient(I1)
@@ -162,6 +205,42 @@ def dvo_cpu_baselines(I0, D0, I1, cam, seconds):
             out[name] = {"error": repr(e)}
         finally:
             orc.use_library(None)
+    # the same C restatement on every host core "for context" (SURVEY 8(d)(ii)): pairs are independent, so
+    # one pair per thread (ctypes releases the GIL during the call), every thread with its own arrays
+    try:
+        import threading
+        orc.use_library(orc.build_native())
+        n_thr = max(1, min(os.cpu_count() or 1, 256))
+        GX, GY = orc.image_gradient(I1)
+        work = [tuple(np.array(a) for a in (I0, D0, I1, GX, GY)) for _ in range(n_thr)]
+        counts = [0] * n_thr
+        budget = max(1.0, seconds * 0.2)
+        start = threading.Barrier(n_thr + 1)
+
+        def worker(k):
+            i0, d0, i1, gx, gy = work[k]
+            start.wait()
+            t_end = time.perf_counter() + budget
+            while time.perf_counter() < t_end:
+                orc.dvo_normal_equations(i0, d0, i1, gx, gy, cam, cam, R, t, "huber")
+                orc.photometric_error_sums(i0, d0, i1, cam, cam, T)
+                counts[k] += 1
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(n_thr)]
+        for th in threads:
+            th.start()
+        start.wait()
+        t0 = time.perf_counter()
+        for th in threads:
+            th.join()
+        dt = time.perf_counter() - t0
+        out["c_port_O3_native_all_cores"] = dict(
+            common, cores=n_thr, value=I0.size * sum(counts) / dt / 1e6, kind="port",
+            sample=f"{n_thr} threads, one 640x480 pair each, {sum(counts)} DVO iterations in {dt:.1f} s; "
+                   "oracle/tdk_oracle.c gcc -O3 -march=native, pair-parallel (the reference itself is single-threaded)")
+    except Exception as e:                          # noqa: BLE001
+        out["c_port_O3_native_all_cores"] = {"error": repr(e)}
+    finally:
+        orc.use_library(None)
     level = npp.Level(I0, D0, I1, cam, cam)
     n, dt = _timed_loop(lambda: npp.one_iteration(level, T, "huber"), seconds * 0.35)
     out["numpy_structured"] = dict(common, value=I0.size * n / dt / 1e6, kind="port",
@@ -264,6 +343,7 @@ def workload_semi_dense(args, fixture):
     B, H, W = 64, 480, 640
     N = H * W
     sd = ops.SemiDenseSession(B, H, W, max_refframes=2)
+    sd.set_age_policy(False)       # the two halves run on the fixture's maps as they are (ages not limited)
     pg = ops.make_params(*SD_PARAMS)
     sd.set_params(pg, *SD_DEFAULTS)
     base = synthetic.make_semi_dense_case(H, W, seed=1)
@@ -293,6 +373,15 @@ def workload_semi_dense(args, fixture):
         sd.update_depth(commit=False)
         ud_ms += sd.timing()["update_depth_ms"]
     dt = time.perf_counter() - t0
+    # the chained step of examples/semi_dense_vo.py:182-199 (update_depth on the PROPAGATED maps), not committed
+    T_wk = np.tile(base["T_wk"], (B, 1, 1))
+    sd.set_age_policy(True)        # one reference frame in the ring: ages saturate at 1
+    sd.step(T10s, T_wk, commit=False)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sd.step(T10s, T_wk, commit=False)
+    dt_chain = time.perf_counter() - t0
+    chain_ms = sd.timing()["step_ms"]
     sd.close()
     warp_ms /= reps
     ud_ms /= reps
@@ -301,6 +390,11 @@ def workload_semi_dense(args, fixture):
                      f"{B} tracks per launch, device-resident session (tdk_sd)",
            "value": B * N * reps / dt / 1e6, "unit": "Mpx/s (map pixels through the three operators)",
            "frames_per_s": B * reps / dt, "ms_per_frame_host_api": dt / reps / B * 1e3,
+           "timed_calls": "propagate (increment_age + propagate) and update_depth each on the SAME cfg3 input maps, "
+                          "uncommitted -- the two halves of SURVEY 8(d) cfg3, which the fixture freezes; the chained "
+                          "step (update_depth on the propagated maps) is `chained_step`",
+           "chained_step": {"frames_per_s": B * reps / dt_chain, "ms_per_frame_host_api": dt_chain / reps / B * 1e3,
+                            "kernel_ms_per_step": chain_ms},
            "valid_fraction": p_valid, "flag_histogram_track0": [int(v) for v in hist[0]],
            "roofline": roofline(bytes_ud * N * B, ud_ms, kernel="k_ud_classify + k_ud_estimate (update_depth)",
                                 bytes_per_px=bytes_ud, tracks=B),
@@ -320,6 +414,119 @@ def workload_semi_dense(args, fixture):
         out["cpu_baseline"] = {"value": N * n / cdt / 1e6, "unit": out["unit"], "cores": 1, "kind": "port",
                                "sample": f"{n} frames (the three operators on the track-0 maps) in {cdt:.1f} s, "
                                          "oracle/tdk_oracle.c -O2"}
+    return out
+
+
+def workload_dvo_stream(args):
+    """A streaming consumer: the frame pairs do NOT sit in HBM for ever -- every step the new frame
+    (I1) of each pair of the NEXT batch arrives over PCIe from pinned memory on that batch's copy
+    stream while the CURRENT batch is estimated (tdk_dvo_upload_async[_u8]); I0 / D0 stay.  Two
+    hand-over formats: float64 images as the reference's API carries them (2.46 MB per VGA frame), and
+    8-bit grey frames as a camera delivers them, converted on the device (0.31 MB)."""
+    from tadataka_amd import _lib, ops, synthetic
+    B, H, W = args.pairs, 480, 640
+    cam = synthetic.camera_for(W, H)
+    mode = ops.WEIGHT_MODES[None if args.weights == "none" else args.weights]
+    ident = np.tile(ops.pose12(np.eye(3), np.zeros(3)), (B, 1))
+    out = {"config": f"BASELINE configs[1] as a stream: {B} pairs per batch, per step the I1 "
+                     "frames of the next batch are uploaded from pinned host memory on a copy stream under the "
+                     "current batch's estimation (three batches in flight: upload / pyramid / estimation); 3-level anti-aliased "
+                     "pyramid + estimation as in the headline"}
+    n_b = 3     # frames arrive for batch k + 2, the pyramid of batch k + 1 is built, batch k is estimated
+    batches = []
+    for k in range(n_b):
+        bt = ops.DvoBatch(B, H, W, n_levels=3, ratio=1.5)
+        bt.fill_synthetic(cam, true_poses(B, k * B), seed0=k * B, noise=0.02)
+        batches.append(bt)
+    for fmt, dtype in (("f64", np.float64), ("u8", np.uint8)):
+        pins = []
+        for bt in batches:
+            pin = ops.PinnedBuffer((B, H * W), dtype=dtype)
+            i1 = np.stack([bt.download(i, 0, "I1").ravel() for i in range(0, B, max(B // 8, 1))])
+            reps = (B + i1.shape[0] - 1) // i1.shape[0]
+            src = np.tile(i1, (reps, 1))[:B]
+            pin.array[:] = src if dtype == np.float64 else np.clip(np.rint(src * 255.0), 0, 255).astype(np.uint8)
+            pins.append(pin)
+        batches[0].upload_async("I1", 0, B, pins[0])
+        batches[0].build_pyramid()
+        batches[1].upload_async("I1", 0, B, pins[1])
+
+        def step(k):
+            a, b, c = batches[k % n_b], batches[(k + 1) % n_b], batches[(k + 2) % n_b]
+            c.upload_async("I1", 0, B, pins[(k + 2) % n_b])       # copy stream: PCIe only
+            b.build_pyramid()                                     # its frames arrived during the last step
+            a.estimate(cam, cam, ident, mode, args.max_iter)
+        for k in range(n_b):
+            step(k)
+        _lib.call("tdk_sync")
+        steps = 12 if dtype == np.uint8 else 6
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(k)
+        _lib.call("tdk_sync")
+        dt = time.perf_counter() - t0
+        nbytes = B * H * W * np.dtype(dtype).itemsize
+        out[fmt] = {"ms_per_step": dt / steps * 1e3, "frame_pairs_per_s": B * steps / dt,
+                    "h2d_bytes_per_step": nbytes, "h2d_GBps_sustained": nbytes * steps / dt / 1e9}
+        for pin in pins:
+            pin.close()
+    for bt in batches:
+        bt.close()
+    out["note"] = ("f64: PCIe-bound (the float64 hand-over of the reference's API is 2.46 MB per frame); u8: the "
+                   "upload hides under the estimation, the step is the resident headline step again")
+    return out
+
+
+def workload_semi_dense_dropin(args):
+    """The mapping calls of examples/semi_dense_vo.py:182-199 exactly as the example writes them --
+    Frame(...), increment_age, propagate, update_depth from rust_bindings.semi_dense, one 640x480 frame
+    per iteration, the refframes list growing -- timed per frame on the host.  Lazy maps (the default:
+    maps stay on the device) and eager ndarrays (TDK_SD_EAGER=1 behaviour: six maps downloaded per frame)."""
+    import tadataka_amd  # noqa: F401
+    import rust_bindings.semi_dense as rsd
+    from rust_bindings.camera import CameraParameters
+    from tadataka.matrix import inv_motion_matrix
+    from tadataka_amd import _lib, synthetic
+    H, W, n_frames = 480, 640, 9
+    cam, depth0, T_w, images = synthetic.make_track(H, W, n_frames, step=(0.01, 0.002, 0.003))
+    cp = CameraParameters((cam[0], cam[1]), (cam[2], cam[3]))
+    params = rsd.Params(*SD_PARAMS)
+    rng = np.random.default_rng(3)
+    out = {"config": "examples/semi_dense_vo.py:182-199 through the unchanged rust_bindings.semi_dense calls "
+                     "(Frame, increment_age, propagate, update_depth), 640x480, ages from zero as the example starts, one frame per "
+                     "iteration, refframes growing; host wall time per frame, first frame (uploads of the caller's "
+                     "initial maps) excluded"}
+    for label, lazy in (("lazy_device_maps", True), ("eager_ndarrays", False)):
+        rsd.LAZY_MAPS = lazy
+        try:
+            frame0 = rsd.Frame(cp, images[0], T_w[0])
+            refframes = [frame0]
+            depth_map0 = depth0 * rng.uniform(0.9, 1.1, (H, W))
+            variance_map0 = np.full((H, W), 0.05)
+            age0 = np.zeros((H, W), dtype=np.uint64)              # init_age of the example
+            times = []
+            for i in range(1, n_frames):
+                transform10 = np.dot(inv_motion_matrix(T_w[i]), T_w[i - 1])
+                _lib.call("tdk_sync")
+                t0 = time.perf_counter()
+                frame1 = rsd.Frame(cp, images[i], T_w[i])
+                age1 = rsd.increment_age(age0, frame0.camera_params, frame1.camera_params, transform10, depth_map0)
+                depth_map1, variance_map1 = rsd.propagate(transform10, frame0.camera_params, frame1.camera_params,
+                                                          depth_map0, variance_map0, *SD_DEFAULTS)
+                depth_map1, variance_map1, flag_map = rsd.update_depth(frame1, refframes, age1, depth_map1,
+                                                                       variance_map1, params)
+                refframes.append(frame1)
+                depth_map0, variance_map0, age0 = depth_map1, variance_map1, age1
+                frame0 = frame1
+                _lib.call("tdk_sync")
+                times.append(time.perf_counter() - t0)
+            flags = np.asarray(flag_map)
+            out[label] = {"ms_per_frame": float(np.median(times[1:])) * 1e3,
+                          "ms_per_frame_all": [round(t * 1e3, 3) for t in times],
+                          "success_pixels_last_frame": int((flags == 0).sum()),
+                          "max_age": int(np.asarray(age0).max())}
+        finally:
+            rsd.LAZY_MAPS = True
     return out
 
 
@@ -450,6 +657,7 @@ def main():
         batch.upload(0, host_pair["I0"], host_pair["D0"], host_pair["I1"])
     ident = np.tile(ops.pose12(np.eye(3), np.zeros(3)), (B, 1))
     counter = [0]
+    work_px = [0, 0]          # source pixels of PhotometricError evaluations / of pose updates (device counters)
     pair0_pose = [None]
     gather = sharding.PoseGather(B, comm)
     batches[0].build_pyramid()
@@ -463,6 +671,9 @@ def main():
         else:
             batches[(k + 1) % n_batches].build_pyramid()   # asynchronous, on that batch's stream
         poses, px = cur.estimate(cam, cam, ident, mode, args.max_iter)
+        e_px, u_px = cur.counts()
+        work_px[0] += e_px
+        work_px[1] += u_px
         if k % n_batches == 0:
             pair0_pose[0] = poses[0].copy()             # the golden pair lives in batch 0
         # the only exchange: the recovered poses, all-gathered (RCCL over xGMI) from where the
@@ -483,6 +694,7 @@ def main():
         gather.finish()
     for bt in batches:
         bt.set_profiling(True)
+    work_px[0] = work_px[1] = 0
 
     def timed_block():
         fence()
@@ -515,7 +727,8 @@ def main():
                 prof_kind[kind][key] += val
         bt.set_profiling(False)
     prof = {key: sum(prof_kind[k][key] for k in prof_kind) for key in ("launches", "total_ms", "pixels")}
-    pixels_all = float(sharding.reduce_scalars([float(pixels)], "sum", comm)[0])
+    pixels_all, error_px_all, update_px_all = (float(v) for v in sharding.reduce_scalars(
+        [float(pixels), float(work_px[0]), float(work_px[1])], "sum", comm))
 
     if rank == 0:
         # rank r's batch of the last step holds pairs [r * n_batches * B + offset, ... + B)
@@ -524,13 +737,8 @@ def main():
         assert poses.shape == truth.shape
         t_err = float(np.max(np.linalg.norm(poses[:, 9:] - truth[:, 9:], axis=1)))
         kernel_ms = prof["total_ms"] / max(prof["launches"], 1)
-        traffic = None
-        pmc_file = os.path.join(REPO, "profiles", "pmc_dvo_eval.json")
-        if os.path.exists(pmc_file):
-            try:
-                traffic = json.load(open(pmc_file)).get("hbm_bytes_per_launch")
-            except (ValueError, OSError):
-                traffic = None
+        pmc = load_profile_json("pmc_dvo_eval.json") or {}
+        traffic = pmc.get("hbm_bytes_per_launch")
         rl = roofline(BYTES_PER_PX_EVAL * prof["pixels"] / max(prof["launches"], 1), kernel_ms,
                       kernel=f"k_dvo_eval<{args.weights}>, every full-resolution launch (full evaluations and probes)",
                       bytes_per_px=BYTES_PER_PX_EVAL,
@@ -538,6 +746,11 @@ def main():
                       limiter="full evaluations: FP64 issue at the package power cap (DESIGN.md 5.1); "
                               "probes (error only): HBM")
         rl["traffic"] = traffic
+        rl["traffic_source"] = ("profiles/pmc_dvo_eval.json (%s): separate rocprofv3 --pmc passes over this command, "
+                                "not measured in this run" % pmc.get("source", "?")) if traffic else None
+        rl["timing_note"] = ("kernel_ms: HIP events recorded on the batch's own stream around every full-resolution "
+                             "launch INSIDE the timed region (one event pair + one host wait per launch: the headline "
+                             "is measured with that overhead, i.e. conservatively)")
         by_mode = {}
         for kind, pk in prof_kind.items():
             if pk["launches"]:
@@ -547,8 +760,17 @@ def main():
         rl["by_mode"] = by_mode
         out = {
             "metric": "warp+residual+JtJ Mpixels/sec per DVO iter",
-            "value": pixels_all / elapsed / 1e6,
+            "value": update_px_all / elapsed / 1e6,
             "unit": "Mpx/s",
+            "value_definition": "SURVEY 8(d): one DVO iter = one calc_pose_update + one photometric_error over a "
+                                "level's source pixels; value = level pixels x pose updates solved / wall time "
+                                "(the one extra error evaluation per level and the pyramid are in the time, not in "
+                                "the count)",
+            "update_mpx_per_s": update_px_all / elapsed / 1e6,
+            "error_mpx_per_s": error_px_all / elapsed / 1e6,
+            "error_evaluations_mpx_per_s": pixels_all / elapsed / 1e6,
+            "updates_per_step": update_px_all / total_steps / world / (B * H * W),
+            "errors_per_step": error_px_all / total_steps / world / (B * H * W),
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -577,6 +799,9 @@ def main():
                          "local": "none (one process)"}[comm.kind],
             "roofline": rl,
         }
+        rf = roofline_fp64(prof_kind)
+        if rf:
+            out["roofline_fp64"] = rf
 
         if golden is not None and pair0_pose[0] is not None:
             from scipy.spatial.transform import Rotation
@@ -610,7 +835,9 @@ def main():
             wl = {}
             for name, fn in (("dvo_single_pair_vga", lambda: workload_dvo_single_pair(args, golden)),
                              ("dvo_720p_x64", lambda: workload_dvo_720p(args)),
+                             ("dvo_stream_x256", lambda: workload_dvo_stream(args)),
                              ("semi_dense_vga", lambda: workload_semi_dense(args, fixture)),
+                             ("semi_dense_dropin_vga", lambda: workload_semi_dense_dropin(args)),
                              ("ba_8x50k", lambda: workload_ba(args))):
                 try:
                     wl[name] = fn()

@@ -122,6 +122,11 @@ tdk_status tdk_dvo_upload_mixed(tdk_dvo *h, int pair, const double *const *host4
  * streaming consumer: the next frames of one batch arrive while another batch is estimated. */
 tdk_status tdk_dvo_upload_async(tdk_dvo *h, int which, int first_pair, int n_pairs,
                                 const double *pinned_host);
+/* The same for 8-bit grey frames as a camera delivers them: [n_pairs][height * width] bytes in
+ * pinned memory, converted on the device to the float64 image skimage's img_as_float /
+ * rgb2gray-of-grey gives (x / 255).  An eighth of the PCIe bytes of the float64 hand-over. */
+tdk_status tdk_dvo_upload_async_u8(tdk_dvo *h, int which, int first_pair, int n_pairs,
+                                   const uint8_t *pinned_host);
 /* Fills every pair on the device from the analytic synthetic scene of
  * tadataka_amd/synthetic.py (bench inputs "generated on device"): pair i uses
  * poses12[i] as ground truth and seed seed0+i for the noise. */
@@ -325,9 +330,24 @@ tdk_status tdk_rgb2gray_u8(const uint8_t *rgb, int height, int width, int channe
  * Frames live in a per-track ring of max_refframes + 1 images; the newest pushed
  * frame is the key frame of the step, the one before it is "frame 0" of the warp
  * and the frame `age` steps back is the reference frame of a pixel
- * (refframes[len - age], src/semi_dense/semi_dense.rs:207). */
+ * (refframes[len - age], src/semi_dense/semi_dense.rs:207).
+ *
+ * The ring is the one place where a session departs from the reference's loop, which appends
+ * every frame to an unbounded `refframes` list (examples/semi_dense_vo.py:199, "TODO remove
+ * unused reference frames") while increment_age lets ages grow without bound (age.rs:28).  With
+ * a bounded ring a pixel tracked for more than max_refframes steps would ask for a frame that is
+ * gone.  tdk_sd_set_age_policy chooses what happens then:
+ *   saturate = 1 (default)  increment_age saturates at the number of reference frames the next
+ *                           update_depth will see, min(frames - 1, max_refframes): such a pixel
+ *                           keeps using the OLDEST frame of the ring.  Identical to the reference
+ *                           for every track of at most max_refframes + 1 frames.
+ *   saturate = 0            ages are not limited; a step in which some age exceeds the ring fails
+ *                           with TDK_ERR_AGE_EXCEEDS_REFFRAMES (what update_depth does when
+ *                           age > len(refframes), semi_dense.rs:202-205) and commits nothing --
+ *                           every later step fails too, so size max_refframes for the whole track. */
 typedef struct tdk_sd tdk_sd;
 tdk_status tdk_sd_create(int n_tracks, int height, int width, int max_refframes, tdk_sd **out);
+tdk_status tdk_sd_set_age_policy(tdk_sd *h, int saturate);
 tdk_status tdk_sd_destroy(tdk_sd *h);
 /* Params.new (src/py/semi_dense.rs:93-108) + the three scalars of propagate */
 tdk_status tdk_sd_set_params(tdk_sd *h, const tdk_semi_dense_params *params, double default_depth,

@@ -52,6 +52,7 @@ PROTOTYPES = {
     "tdk_pinned_free": [_vp],
     "tdk_dvo_upload_mixed": [_vp, _i, C.POINTER(_vp), C.POINTER(_vp)],
     "tdk_dvo_upload_async": [_vp, _i, _i, _i, _vp],
+    "tdk_dvo_upload_async_u8": [_vp, _i, _i, _i, _vp],
     "tdk_map_create": [_i, _i, _vp, C.POINTER(_vp)],
     "tdk_map_destroy": [_vp],
     "tdk_map_upload": [_vp, _vp],
@@ -114,6 +115,7 @@ PROTOTYPES = {
     "tdk_rgb2gray_u8": [C.POINTER(C.c_uint8), _i, _i, _i, _d],
     "tdk_sd_create": [_i, _i, _i, _i, C.POINTER(_vp)],
     "tdk_sd_destroy": [_vp],
+    "tdk_sd_set_age_policy": [_vp, _i],
     "tdk_sd_set_params": [_vp, C.POINTER(SemiDenseParams), C.c_double, C.c_double, C.c_double],
     "tdk_sd_set_maps": [_vp, _i, _d, _d, c_uint64_p],
     "tdk_sd_get_maps": [_vp, _i, _d, _d, c_uint64_p, c_int64_p],

@@ -62,10 +62,12 @@ class Frame(object):
     def image(self):
         if not LAZY_MAPS:
             return self._image.copy()
-        # the frame's image where it lives on the device; the host side is a copy, as in the reference
-        _, dev, _ = self._resident()
-        return ops.DeviceMap(self._image.shape, np.float64, host=self._image.copy(), owner=dev,
-                             device_ptr=dev.device_ptr())
+        # the frame's image where it lives on the device (uploaded at its first use there); the host
+        # side is a copy, as in the reference
+        return ops.DeviceMap(self._image.shape, np.float64, host=self._image.copy(), owner=self)
+
+    def _device_image_ptr(self):
+        return self._resident()[1].device_ptr()
 
     @property
     def transform_wf(self):

@@ -562,6 +562,18 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
         eval_body<WMODE, false>(L, params, poses, wscale, scale, chunk, pair, blk, nblk, partials);
 }
 
+// 8-bit frames -> float64 in [0, 1] (skimage.img_as_float: x / 255), one launch for a range of pairs
+__global__ __launch_bounds__(kBlock) void k_u8_to_f64(const uint8_t *__restrict__ src, double *__restrict__ dst,
+                                                      int64_t N, int64_t stride) {
+    const uint8_t *s = src + (int64_t)blockIdx.y * N;
+    double *d = dst + (int64_t)blockIdx.y * stride;
+    for (int64_t i = ((int64_t)blockIdx.x * kBlock + threadIdx.x) * 8; i < N; i += (int64_t)gridDim.x * kBlock * 8) {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (i + k < N) d[i + k] = (double)s[i + k] / 255.0;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Gauss-Newton bookkeeping
 // ---------------------------------------------------------------------------
@@ -1195,6 +1207,8 @@ struct tdk_dvo {
     int64_t prof_launches[3], prof_pixels[3];
     std::vector<double> cams;   // cameras currently on the device: [cam0 (n x 4) | cam1 (n x 4)]
     hipStream_t copy_stream;    // tdk_dvo_upload_async (created on first use)
+    uint8_t *d_u8;              // staging for 8-bit frames (tdk_dvo_upload_async_u8), [n_pairs][N]
+    size_t u8_bytes;
     hipEvent_t ev_copy, ev_xs;  // copy stream <-> batch stream; library stream <-> batch stream
     int *d_mode_probe;          // [n] MODE_PROBE (tdk_dvo_photometric_error), allocated on first use
     int64_t count_error_px, count_update_px;   // tdk_dvo_get_counts: source pixels of the last estimate call
@@ -1624,6 +1638,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     if (h->h_flag) (void)hipHostFree(h->h_flag);
     if (h->d_aa_weights) (void)hipFree(h->d_aa_weights);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->d_u8) (void)hipFree(h->d_u8);
     if (h->ev_copy) (void)hipEventDestroy(h->ev_copy);
     if (h->ev_xs) (void)hipEventDestroy(h->ev_xs);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1703,6 +1718,35 @@ tdk_status tdk_dvo_upload_async(tdk_dvo *h, int which, int first_pair, int n_pai
                                  row, row, (size_t)n_pairs, hipMemcpyHostToDevice, h->copy_stream));
     TDK_HIP(hipEventRecord(h->ev_copy, h->copy_stream));
     TDK_HIP(hipStreamWaitEvent(h->stream, h->ev_copy, 0));
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_upload_async_u8(tdk_dvo *h, int which, int first_pair, int n_pairs, const uint8_t *pinned_host) {
+    TDK_REQUIRE(h && pinned_host, "null pointer");
+    TDK_REQUIRE(which >= 0 && which <= 2, "8-bit frames: I0, D0 (rarely) or I1");
+    TDK_REQUIRE(first_pair >= 0 && n_pairs >= 1 && first_pair + n_pairs <= h->n_pairs, "pair range out of bounds");
+    const tdk_dvo::Level &L = h->lv[0];
+    double *base = which == 0 ? L.I0 : which == 1 ? L.D0 : L.I1;
+    if (!h->copy_stream) {
+        TDK_HIP(hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        TDK_HIP(hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
+    }
+    const size_t need = (size_t)h->n_pairs * (size_t)L.N;
+    if (h->u8_bytes < need) {
+        if (h->d_u8) { TDK_HIP(hipStreamSynchronize(h->stream)); TDK_HIP(hipStreamSynchronize(h->copy_stream)); (void)hipFree(h->d_u8); h->d_u8 = nullptr; }
+        TDK_HIP(hipMalloc(&h->d_u8, need));
+        h->u8_bytes = need;
+    }
+    // the staging bytes of this range may still be read by the previous conversion on the batch stream
+    TDK_HIP(hipEventRecord(h->ev_copy, h->stream));
+    TDK_HIP(hipStreamWaitEvent(h->copy_stream, h->ev_copy, 0));
+    uint8_t *stage = h->d_u8 + (size_t)first_pair * (size_t)L.N;
+    TDK_HIP(hipMemcpyAsync(stage, pinned_host, (size_t)n_pairs * (size_t)L.N, hipMemcpyHostToDevice, h->copy_stream));
+    TDK_HIP(hipEventRecord(h->ev_copy, h->copy_stream));
+    TDK_HIP(hipStreamWaitEvent(h->stream, h->ev_copy, 0));
+    dim3 grid((unsigned)((L.N + kBlock * 8 - 1) / (kBlock * 8)), (unsigned)n_pairs);
+    k_u8_to_f64<<<grid, kBlock, 0, h->stream>>>(stage, base + (int64_t)first_pair * L.stride, L.N, L.stride);
+    TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
 

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(kBlock) void k_sobel(const double *__restrict__ img
 struct TrackWarp {   // per track and step
     double T10[16];
     double cam0[4], cam1[4];
+    uint64_t age_cap;   // increment_age saturates here (session ring, tdk_sd_set_age_policy); ~0 = never
 };
 
 __device__ __forceinline__ double propagate_variance(double depth0, double depth1, double variance0,
@@ -193,7 +194,14 @@ __global__ __launch_bounds__(kBlock) void k_sd_fold(int H, int W, const TrackWar
             }
             last = best;
         }
-        if (AGE) age1[base + tg] = last >= 0 ? age0[base + last] + 1 : 0;
+        if (AGE) {
+            uint64_t a = 0;
+            if (last >= 0) {
+                a = age0[base + last] + 1;
+                a = a > t.age_cap ? t.age_cap : a;
+            }
+            age1[base + tg] = a;
+        }
         if (PROP) { depth1[base + tg] = d; var1[base + tg] = v; }
     }
 }
@@ -756,7 +764,9 @@ tdk_status check_image_dims(int H, int W) {
     return TDK_OK;
 }
 
-void fill_track_warp(TrackWarp *tw, const double *T10, const double *cam0, const double *cam1) {
+void fill_track_warp(TrackWarp *tw, const double *T10, const double *cam0, const double *cam1,
+                     uint64_t age_cap = ~0ull) {
+    tw->age_cap = age_cap;
     memcpy(tw->T10, T10, sizeof(double) * 16);
     memcpy(tw->cam0, cam0, sizeof(double) * 4);
     memcpy(tw->cam1, cam1, sizeof(double) * 4);
@@ -1377,6 +1387,7 @@ struct tdk_sd {
     tdk_semi_dense_params params;
     double default_depth, default_variance, bias;
     bool params_set, have_result, result_has_flag;
+    bool saturate_age;       // tdk_sd_set_age_policy
     hipEvent_t ev[4];
     double ms[3];
 };
@@ -1428,6 +1439,7 @@ tdk_status tdk_sd_create(int n_tracks, int height, int width, int max_refframes,
     h->stride = ((int64_t)h->N + 1) & ~1ll;
     h->cur = 0; h->result_buf = 0;
     h->params_set = false; h->have_result = false; h->result_has_flag = false;
+    h->saturate_age = true;   // see tdk_sd_set_age_policy
     h->n_frames.assign((size_t)n_tracks, 0);
     h->cams.assign((size_t)n_tracks * (h->R + 1) * 4, 0.0);
     h->Twf.assign((size_t)n_tracks * (h->R + 1) * 16, 0.0);
@@ -1484,6 +1496,12 @@ tdk_status tdk_sd_set_params(tdk_sd *h, const tdk_semi_dense_params *params, dou
     h->default_variance = default_variance;
     h->bias = uncertaintity_bias;
     h->params_set = true;
+    return TDK_OK;
+}
+
+tdk_status tdk_sd_set_age_policy(tdk_sd *h, int saturate) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    h->saturate_age = saturate != 0;
     return TDK_OK;
 }
 
@@ -1581,7 +1599,10 @@ tdk_status sd_upload_warp(tdk_sd *h, const double *transforms10) {
     for (int t = 0; t < h->n; t++) {
         const int64_t nf = h->n_frames[t];
         const size_t kb = (size_t)t * (h->R + 1) + sd_slot(h, nf - 1), pb = (size_t)t * (h->R + 1) + sd_slot(h, nf - 2);
-        fill_track_warp(&st.tw[t], transforms10 + 16 * (size_t)t, &h->cams[4 * pb], &h->cams[4 * kb]);
+        // the update_depth that follows sees n_ref = min(frames - 1, R) reference frames; with the
+        // saturating policy a pixel tracked for longer keeps using the oldest frame of the ring
+        const uint64_t cap = h->saturate_age ? (uint64_t)(nf - 1 < h->R ? nf - 1 : h->R) : ~0ull;
+        fill_track_warp(&st.tw[t], transforms10 + 16 * (size_t)t, &h->cams[4 * pb], &h->cams[4 * kb], cap);
     }
     TDK_HIP(hipMemcpyAsync(h->d_tw, st.tw, sizeof(TrackWarp) * h->n, hipMemcpyHostToDevice, h->stream));
     return TDK_OK;

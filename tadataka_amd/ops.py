@@ -191,8 +191,8 @@ class DvoBatch(object):
 
     def upload_async(self, which, first_pair, n_pairs, pinned):
         """Queues the upload of one array of a range of pairs from a PinnedBuffer; does not wait."""
-        call("tdk_dvo_upload_async", self._h, {"I0": 0, "D0": 1, "I1": 2, "W0": 3}[which], first_pair, n_pairs,
-             pinned.ptr)
+        fn = "tdk_dvo_upload_async_u8" if pinned.dtype == np.uint8 else "tdk_dvo_upload_async"
+        call(fn, self._h, {"I0": 0, "D0": 1, "I1": 2, "W0": 3}[which], first_pair, n_pairs, pinned.ptr)
 
     def fill_synthetic(self, camera, poses12, seed0=0, noise=0.02):
         cam = camera_vec(camera)
@@ -287,15 +287,18 @@ class DvoBatch(object):
 
 
 class PinnedBuffer(object):
-    """Page-locked host memory as a float64 ndarray (tdk_pinned_alloc): the source of
+    """Page-locked host memory as a float64 or uint8 ndarray (tdk_pinned_alloc): the source of
     DvoBatch.upload_async."""
 
-    def __init__(self, shape):
+    def __init__(self, shape, dtype=np.float64):
         self.shape = tuple(int(v) for v in shape)
+        self.dtype = np.dtype(dtype)
+        assert self.dtype in (np.dtype(np.float64), np.dtype(np.uint8))
         n = int(np.prod(self.shape))
         self.ptr = C.c_void_p()
-        call("tdk_pinned_alloc", C.c_size_t(n * 8), C.byref(self.ptr))
-        self.array = np.ctypeslib.as_array(C.cast(self.ptr, c_double_p), shape=(n,)).reshape(self.shape)
+        call("tdk_pinned_alloc", C.c_size_t(n * self.dtype.itemsize), C.byref(self.ptr))
+        ctype = c_double_p if self.dtype == np.float64 else C.POINTER(C.c_uint8)
+        self.array = np.ctypeslib.as_array(C.cast(self.ptr, ctype), shape=(n,)).reshape(self.shape)
 
     def close(self):
         if self.ptr:
@@ -472,15 +475,15 @@ class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
 
     __array_priority__ = 100.0
 
-    def __init__(self, shape, dtype, host=None, owner=None, device_ptr=None):
+    def __init__(self, shape, dtype, host=None, owner=None):
         self.shape = (int(shape[0]), int(shape[1]))
         self.dtype = np.dtype(dtype)
         assert self.dtype.itemsize == 8
         self._host = None            # materialised host copy
         self._stale_device = False   # the host copy was written to
-        self._owner = owner          # keeps a borrowed device buffer alive (a DeviceFrame)
+        self._owner = owner          # a Frame whose device image this map borrows (_device_image_ptr())
         self._h = C.c_void_p()
-        self._ptr = device_ptr
+        self._ptr = None
         if owner is None:
             src = None
             if host is not None:
@@ -513,6 +516,8 @@ class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
 
     def device_ptr(self):
         self._refresh_device()
+        if self._owner is not None:
+            return self._owner._device_image_ptr()
         if self._ptr is None:
             p = C.c_void_p()
             call("tdk_map_device_ptr", self._h, C.byref(p))
@@ -717,6 +722,14 @@ class SemiDenseSession(object):
             self.close()
         except Exception:
             pass
+
+    def set_age_policy(self, saturate):
+        """True (default): ages saturate at the ring size (a pixel tracked for longer than
+        max_refframes steps keeps using the oldest retained frame; identical to the reference for
+        tracks of at most max_refframes + 1 frames).  False: ages grow without bound as in
+        src/semi_dense/age.rs:28 and a step whose ages exceed the ring raises
+        TdkError(TDK_ERR_AGE_EXCEEDS_REFFRAMES) -- for good, so size the ring for the track."""
+        call("tdk_sd_set_age_policy", self._h, int(bool(saturate)))
 
     def set_params(self, params, default_depth, default_variance, uncertaintity_bias):
         call("tdk_sd_set_params", self._h, C.byref(params), float(default_depth), float(default_variance),

@@ -100,6 +100,25 @@ def make_semi_dense_case(height=480, width=640, seed=1, valid_fraction=0.3,
                 prior_variance=prior_variance, depth_gt=depth_key)
 
 
+def make_track(height, width, n_frames, step=(0.03, 0.005, 0.01)):
+    """A camera sliding by `step` per frame in front of the textured surface of frame 0
+    (first-order consistent views: the texture is attached to that surface).  Returns
+    (cam, depth of frame 0, [T_wf], [image]) -- the frames of a short semi-dense track."""
+    cam = camera_for(width, height)
+    ys, xs = np.mgrid[0:height, 0:width].astype(np.float64)
+    depth0 = depth_map(xs, ys)
+    xn, yn = (xs - cam[2]) / cam[0], (ys - cam[3]) / cam[1]
+    transforms, images = [], []
+    for k in range(n_frames):
+        T = np.eye(4)
+        T[:3, 3] = [step[0] * k, step[1] * k, step[2] * k]
+        P = np.stack([xn * depth0, yn * depth0, depth0], axis=-1) + T[:3, 3]
+        images.append(np.ascontiguousarray(texture(P[..., 0] / P[..., 2] * cam[0] + cam[2],
+                                                   P[..., 1] / P[..., 2] * cam[1] + cam[3])))
+        transforms.append(T)
+    return cam, depth0, transforms, images
+
+
 def make_ba_case(n_poses=8, n_points=50000, seed=5, perturb=1e-3):
     """all points visible from all poses."""
     rng = np.random.default_rng(seed)

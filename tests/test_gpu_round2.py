@@ -156,6 +156,7 @@ def test_cfg3_vga_bit_exact_and_fixture(ops, orc, golden):
         assert np.array_equal(_sha(arr), fx[name]), name
     # the same three operators through the device-resident session
     sd = ops.SemiDenseSession(2, 480, 640, max_refframes=2)
+    sd.set_age_policy(False)      # the operators on the fixture's maps as they are: ages are not limited
     sd.set_params(pg, *SD_DEFAULTS)
     for t in range(2):
         sd.push_frame(t, c["cam"], c["ref_image"], c["T_wr"])
@@ -237,6 +238,7 @@ def test_sd_session_chain_matches_oracle(ops, orc):
     H, W, n = 96, 128, 3
     pg, po = ops.make_params(0.5, 10.0, 0.01, 0.01, 0.004, 0.01), orc.make_params(0.5, 10.0, 0.01, 0.01, 0.004, 0.01)
     sd = ops.SemiDenseSession(n, H, W, max_refframes=2)
+    sd.set_age_policy(False)      # the reference's rule: ages are not limited, a frame that is gone is an error
     sd.set_params(pg, *SD_DEFAULTS)
     state = []
     for t in range(n):

@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--mode", default="huber")
+    ap.add_argument("--probe", action="store_true", help="error-only evaluations (tdk_dvo_photometric_error)")
+    ap.add_argument("--seconds", type=float, default=0.0, help="loop for this long instead of --reps launches")
     args = ap.parse_args()
     _lib.require_gpu()
     B, H, W = args.pairs, args.height, args.width
@@ -32,17 +34,24 @@ def main():
     batch = ops.DvoBatch(B, H, W, with_weight_map=(args.mode == "map"))
     batch.fill_synthetic(cam, truth, 0, 0.02)
     mode = {"none": ops.W_NONE, "huber": ops.W_HUBER, "map": ops.W_MAP}[args.mode]
+    if args.probe:
+        run = lambda: batch.photometric_error(0, cam, cam, truth)
+    else:
+        run = lambda: batch.evaluate(0, cam, cam, truth, mode)
     for _ in range(3):
-        batch.evaluate(0, cam, cam, truth, mode)
+        run()
     batch.set_profiling(True)
     t0 = time.perf_counter()
-    for _ in range(args.reps):
-        batch.evaluate(0, cam, cam, truth, mode)
+    reps = 0
+    while reps < args.reps or time.perf_counter() - t0 < args.seconds:
+        run()
+        reps += 1
+    args.reps = reps
     wall = time.perf_counter() - t0
-    prof = batch.get_profile()
+    prof = batch.get_profile("probe" if args.probe else "full")
     ms = prof["total_ms"] / prof["launches"]
     px = B * H * W
-    print(f"kernel {ms*1e3:.1f} us  {px/ms/1e6:.1f} Gpx/s  {px*24/ms/1e6:.0f} GB/s (24 B/px)  "
+    print(f"{'probe' if args.probe else 'full'} x{reps}: kernel {ms*1e3:.1f} us  {px/ms/1e6:.1f} Gpx/s  {px*24/ms/1e6:.0f} GB/s (24 B/px)  "
           f"host-loop {wall/args.reps*1e3:.3f} ms/eval")
 
 
