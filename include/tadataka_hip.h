@@ -140,7 +140,12 @@ tdk_status tdk_dvo_download(tdk_dvo *h, int pair, int level, int which, double *
  * tdk_rescale_anti_aliased.  The default is what the reference builds:
  * skimage.transform.rescale(image, scale) (tadataka/vo/dvo/__init__.py:144-148, scikit-image
  * 0.16.2) low-pass filters with a Gaussian, sigma = (1/scale - 1)/2, before it resamples
- * bilinearly.  0 = plain bilinear resampling (SURVEY 8(d) cfg2's wording). */
+ * bilinearly.  0 = plain bilinear resampling (SURVEY 8(d) cfg2's wording).
+ *   1, 2  the filter in scipy.ndimage's operation order (vertical correlate1d, horizontal
+ *         correlate1d, blend): bit-identical with tdk_rescale_anti_aliased and the CPU restatement;
+ *   3     opt-in experiment: I0 / I1 / W0 through one folded tap list per axis evaluated as FMA
+ *         chains (csrc/pyramid_sep.hip; the same linear map, last-bit differences), D0 as in 1.
+ *         Measured slower than 1 on the MI355X (1.39 vs 1.10 ms per 256-pair VGA batch). */
 tdk_status tdk_dvo_set_anti_aliasing(tdk_dvo *h, int enabled);
 tdk_status tdk_dvo_level_shape(tdk_dvo *h, int level, int *height, int *width);
 

@@ -8,7 +8,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtadataka_hip.so")
+# TDK_LIB_TAG=<tag> loads lib/libtadataka_hip_<tag>.so: an experimental build for A/B measurements (tools/ab_build.sh)
+_TAG = os.environ.get("TDK_LIB_TAG", "")
+LIB_PATH = os.path.join(_HERE, "lib", "libtadataka_hip%s.so" % ("_" + _TAG if _TAG else ""))
 
 c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)

@@ -304,11 +304,11 @@ __device__ __forceinline__ void sp_issue_taps(TapPairs &q, const double *__restr
     const uint32_t rowb = (uint32_t)W * 8u;
     uint32_t om, oal, oar, obl, obr, ou;   // byte offsets of the six pairs
     if (__builtin_amdgcn_ballot_w64(!inside) == 0) {   // wave-uniform; address arithmetic only
-        const uint32_t o0 = (uint32_t)(r0 * W + c0) * 8u;
+        const uint32_t o0 = (__umul24((uint32_t)r0, (uint32_t)W) + (uint32_t)c0) * 8u;   // full-rate 24-bit multiply
         om = o0 - rowb; oal = o0 - 8u; oar = o0 + 8u;
         obl = oal + rowb; obr = oar + rowb; ou = o0 + 2u * rowb;
     } else {
-        const uint32_t row0 = (uint32_t)r0 * rowb;
+        const uint32_t row0 = __umul24((uint32_t)r0, rowb);
         const uint32_t rowm = r0 > 0 ? row0 - rowb : row0;
         const uint32_t row1 = r0 < H - 1 ? row0 + rowb : row0;
         const uint32_t row2 = r0 < H - 2 ? row1 + rowb : row1;
@@ -353,7 +353,7 @@ struct Samples {     // everything that is loaded for the pixel being accumulate
 __device__ __forceinline__ void sp_issue_taps_probe(TapPairs &q, const double *__restrict__ I1, int H, int W, int c0,
                                                     int r0) {
     const uint32_t rowb = (uint32_t)W * 8u;
-    const uint32_t row0 = (uint32_t)r0 * rowb;
+    const uint32_t row0 = __umul24((uint32_t)r0, rowb);
     const uint32_t row1 = r0 < H - 1 ? row0 + rowb : row0;
     const uint32_t cm = (uint32_t)min(c0, W - 2) * 8u;
     q.a01 = ldo2(I1, row0 + cm);
@@ -1213,6 +1213,8 @@ struct tdk_dvo {
     int *d_mode_probe;          // [n] MODE_PROBE (tdk_dvo_photometric_error), allocated on first use
     int64_t count_error_px, count_update_px;   // tdk_dvo_get_counts: source pixels of the last estimate call
     bool anti_aliasing;         // pyramid levels get skimage's Gaussian prefilter (tdk_dvo_set_anti_aliasing)
+    bool aa_taplists;           // ... evaluated as folded tap lists (mode 3, pyramid_sep.hip) instead of in ndimage's operation order
+    tdk::PyramidSepPlan *sep_plan;   // tap lists of the separable pyramid kernel (created at the first build)
     double *d_aa_weights;       // its 1-D kernels, per level and axis (allocated on first use)
     int *h_flag;   // "pairs still running", written by k_dvo_reduce (mapped pinned host memory)
     std::vector<int> host_warn;   // ls.warn of the last estimate call
@@ -1570,6 +1572,7 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
     h->n_pairs = n_pairs; h->H = height; h->W = width; h->n_levels = n_levels;
     h->ratio = ratio; h->with_w = with_weight_map != 0;
     h->anti_aliasing = true;   // the reference-equivalent pyramid (skimage.transform.rescale's default)
+    h->aa_taplists = false;
     h->max_blocks = 1024;
     h->d_rm = nullptr; h->d_wscale = nullptr; h->d_stat = nullptr; h->d_spartial = nullptr;
     h->d_count = nullptr; h->d_select = nullptr; h->d_hist = nullptr;
@@ -1637,6 +1640,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
     if (h->d_aa_weights) (void)hipFree(h->d_aa_weights);
+    (void)tdk::pyramid_sep_destroy(h->sep_plan);
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->d_u8) (void)hipFree(h->d_u8);
     if (h->ev_copy) (void)hipEventDestroy(h->ev_copy);
@@ -1783,11 +1787,47 @@ tdk_status tdk_dvo_build_pyramid(tdk_dvo *h) {
             lv[l - 1].dst[0] = L.I0; lv[l - 1].dst[1] = L.D0; lv[l - 1].dst[2] = L.I1; lv[l - 1].dst[3] = L.W0;
             lv[l - 1].stride = L.stride; lv[l - 1].H = L.H; lv[l - 1].W = L.W;
         }
+        const int n_arrays = h->with_w ? 4 : 3, n_out = h->n_levels - 1;
         const bool first = h->d_aa_weights == nullptr;
         if (first)
             TDK_HIP(hipMalloc(&h->d_aa_weights, tdk::pyramid_aa_weight_doubles(h->n_levels - 1) * sizeof(double)));
-        return tdk::launch_pyramid_aa(srcs, h->with_w ? 4 : 3, S.H, S.W, S.stride, h->n_levels - 1, lv, h->n_pairs,
-                                      h->d_aa_weights, first, h->stream);
+        if (!h->aa_taplists)
+            return tdk::launch_pyramid_aa(srcs, n_arrays, S.H, S.W, S.stride, n_out, lv, h->n_pairs, h->d_aa_weights,
+                                          first, h->stream);
+        // Mode 3 (opt-in; measured slower, see pyramid_sep.hip).  The images (and the weight map) go through the separable tap-list kernel
+        // (pyramid_sep.hip) for every level it can take.  The DEPTH map stays on the ndimage-order
+        // kernels: at the identity prior the whole right / bottom border of a level projects exactly
+        // onto the inclusive mask boundary and the last bit of D0 decides on which side a border pixel
+        // falls (a few hundred pixels, 1e-5 in the pose) -- the depth levels are kept bit-identical with
+        // the CPU restatement so that poses are reproducible to 1e-15, the images only enter smoothly.
+        if (!tdk::pyramid_sep_matches(h->sep_plan, S.H, S.W, n_out, lv)) {
+            (void)tdk::pyramid_sep_destroy(h->sep_plan);
+            h->sep_plan = nullptr;
+            int Ho[kMaxLevels], Wo[kMaxLevels];
+            for (int l = 0; l < n_out; l++) { Ho[l] = lv[l].H; Wo[l] = lv[l].W; }
+            TDK_TRY(tdk::pyramid_sep_create(S.H, S.W, n_out, Ho, Wo, h->stream, &h->sep_plan, nullptr));
+        }
+        const unsigned sep_mask = tdk::pyramid_sep_mask(h->sep_plan), all = (1u << n_out) - 1u;
+        const double *img_srcs[4] = {S.I0, S.I1, S.W0, nullptr};
+        const double *depth_srcs[4] = {S.D0, nullptr, nullptr, nullptr};
+        tdk::PyramidLevelDesc img_lv[kMaxLevels], depth_lv[kMaxLevels];
+        for (int l = 0; l < n_out; l++) {
+            img_lv[l] = lv[l];
+            img_lv[l].dst[0] = lv[l].dst[0]; img_lv[l].dst[1] = lv[l].dst[2]; img_lv[l].dst[2] = lv[l].dst[3];
+            img_lv[l].dst[3] = nullptr;
+            depth_lv[l] = lv[l];
+            depth_lv[l].dst[0] = lv[l].dst[1];
+            depth_lv[l].dst[1] = depth_lv[l].dst[2] = depth_lv[l].dst[3] = nullptr;
+        }
+        TDK_TRY(tdk::launch_pyramid_sep(h->sep_plan, img_srcs, n_arrays - 1, S.stride, img_lv, h->n_pairs, h->stream));
+        if (sep_mask == all)
+            return tdk::launch_pyramid_aa(depth_srcs, 1, S.H, S.W, S.stride, n_out, depth_lv, h->n_pairs,
+                                          h->d_aa_weights, first, h->stream);
+        // deep levels whose tiles exceed LDS: every array on the ndimage-order kernels
+        TDK_TRY(tdk::launch_pyramid_aa(depth_srcs, 1, S.H, S.W, S.stride, n_out, depth_lv, h->n_pairs, h->d_aa_weights,
+                                       first, h->stream, all & ~sep_mask));
+        return tdk::launch_pyramid_aa(srcs, n_arrays, S.H, S.W, S.stride, n_out, lv, h->n_pairs, h->d_aa_weights, false,
+                                      h->stream, sep_mask);
     }
     static const int mode = [] {
         const char *v = getenv("TDK_PYRAMID");
@@ -1961,7 +2001,9 @@ tdk_status tdk_dvo_get_warnings(tdk_dvo *h, int *too_large) {
 
 tdk_status tdk_dvo_set_anti_aliasing(tdk_dvo *h, int enabled) {
     TDK_REQUIRE(h != nullptr, "handle is NULL");
+    TDK_REQUIRE(enabled >= 0 && enabled <= 3, "mode must be 0 ... 3");
     h->anti_aliasing = enabled != 0;
+    h->aa_taplists = enabled == 3;
     return TDK_OK;
 }
 

@@ -645,7 +645,7 @@ namespace tdk {
 // kernels of every level are computed here and copied into it.
 tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride, int n_out,
                              const PyramidLevelDesc *levels, int batch, double *weights, bool upload_weights,
-                             hipStream_t stream) {
+                             hipStream_t stream, unsigned skip_mask) {
     if (n_out <= 0) return TDK_OK;
     if (n_out > 15 || n_arrays > 4) {
         set_error("pyramid too deep");
@@ -699,6 +699,7 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
     size_t lds_max = 0;
     int tiles_total = 0;
     for (int l = 0; l < n_out; l++) {
+        if ((skip_mask >> l) & 1u) continue;
         const PyrLevel &L = r.lv[l];
         const double fy = (double)H / (double)L.Ho, fx = (double)W / (double)L.Wo;
         AaTileArgs t;
@@ -752,7 +753,7 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
         int total = 0;
         for (int l = 0; l < n_out; l++) {
             const PyrLevel &L = r.lv[l];
-            if (!is_tiled[l]) total += (int)(((int64_t)L.Ho * L.Wo + 255) / 256);
+            if (!is_tiled[l] && !((skip_mask >> l) & 1u)) total += (int)(((int64_t)L.Ho * L.Wo + 255) / 256);
             r.blk_end[l] = total;
         }
         dim3 grid(total, n_arrays, batch);

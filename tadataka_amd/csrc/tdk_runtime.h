@@ -40,8 +40,21 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
 // the same levels with skimage's anti-aliasing prefilter (Gaussian, sigma = (factor - 1) / 2 per axis)
 tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride, int n_out,
                              const PyramidLevelDesc *levels, int batch, double *weights, bool upload_weights,
-                             hipStream_t stream);
+                             hipStream_t stream, unsigned skip_mask = 0u);   // bit l: level l is built elsewhere
 size_t pyramid_aa_weight_doubles(int n_out);
+
+// pyramid_sep.hip: the same levels as one separable resampling filter per axis (FMA chains over tap
+// lists built on the host; last-bit differences from the ndimage operation order).  A plan holds the
+// tap lists of one pyramid geometry on the device; levels it cannot take (enlarged axes, tiles beyond
+// LDS) are left to launch_pyramid_aa -- pyramid_sep_mask() has a bit per level it builds.
+struct PyramidSepPlan;
+tdk_status pyramid_sep_create(int H, int W, int n_out, const int *Ho, const int *Wo, hipStream_t stream,
+                              PyramidSepPlan **out, unsigned *handled_mask);
+tdk_status pyramid_sep_destroy(PyramidSepPlan *p);
+bool pyramid_sep_matches(const PyramidSepPlan *p, int H, int W, int n_out, const PyramidLevelDesc *levels);
+unsigned pyramid_sep_mask(const PyramidSepPlan *p);
+tdk_status launch_pyramid_sep(PyramidSepPlan *p, const double *const *srcs, int n_arrays, int64_t src_stride,
+                              const PyramidLevelDesc *levels, int batch, hipStream_t stream);
 
 // dvo.hip: level-0 arrays of a DVO batch, for producers that fill it on the device (tdk_sd_export_dvo)
 struct DvoLevel0 {

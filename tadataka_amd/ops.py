@@ -199,8 +199,12 @@ class DvoBatch(object):
         P = _f64(poses12, (self.n_pairs, 12))
         call("tdk_dvo_fill_synthetic", self._h, _p(cam), _p(P), C.c_uint64(seed0), float(noise))
 
-    def set_anti_aliasing(self, enabled):
-        call("tdk_dvo_set_anti_aliasing", self._h, int(bool(enabled)))
+    def set_anti_aliasing(self, enabled, exact=True):
+        """Anti-aliased pyramid levels (the default) or plain bilinear ones.  exact=True (default): the
+        prefilter in scipy.ndimage's operation order, bit-identical with ops.rescale(..., True);
+        exact=False: the opt-in tap-list kernel for I0 / I1 / W0 (csrc/pyramid_sep.hip: same linear
+        map, last-bit differences; measured slower), the depth map as with exact=True."""
+        call("tdk_dvo_set_anti_aliasing", self._h, (1 if exact else 3) if enabled else 0)
 
     def build_pyramid(self):
         call("tdk_dvo_build_pyramid", self._h)

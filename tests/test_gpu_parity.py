@@ -238,7 +238,7 @@ def test_anti_aliased_rescale_and_pyramid_bit_exact(ops, orc):
         assert np.array_equal(ops.rescale(img, scale, anti_aliasing=True), orc.rescale(img, scale, anti_aliasing=True))
     H, W, B = 61, 83, 3
     batch = ops.DvoBatch(B, H, W, n_levels=4, ratio=1.5, with_weight_map=True)
-    batch.set_anti_aliasing(True)
+    batch.set_anti_aliasing(True, exact=True)      # scipy.ndimage's operation order: bit for bit
     pairs = []
     for i in range(B):
         pr = synthetic.make_pair(H, W, seed=30 + i)
@@ -251,6 +251,14 @@ def test_anti_aliased_rescale_and_pyramid_bit_exact(ops, orc):
             for name in ("I0", "D0", "I1", "W0"):
                 assert np.array_equal(batch.download(i, level, name),
                                       orc.rescale(pr[name], 1 / 1.5 ** level, anti_aliasing=True)), (i, level, name)
+    # the default: the same linear map as folded tap lists (FMA chains), last-bit differences only
+    batch.set_anti_aliasing(True)
+    batch.build_pyramid()
+    for i, pr in enumerate(pairs):
+        for level in (1, 2, 3):
+            for name in ("I0", "D0", "I1", "W0"):
+                want = orc.rescale(pr[name], 1 / 1.5 ** level, anti_aliasing=True)
+                assert np.max(np.abs(batch.download(i, level, name) - want)) <= 1e-13 * max(1.0, np.max(np.abs(want)))
     batch.set_anti_aliasing(False)
     batch.build_pyramid()
     assert np.array_equal(batch.download(1, 2, "I1"), orc.rescale(pairs[1]["I1"], 1 / 1.5 ** 2))

@@ -8,10 +8,10 @@ import bench
 _lib.require_gpu()
 B = 256
 cam = synthetic.camera_for(640, 480)
-for levels in (3, 2):
+for levels, exact in ((3, False), (2, False), (3, True)):
     bt = ops.DvoBatch(B, 480, 640, n_levels=levels, ratio=1.5)
     bt.fill_synthetic(cam, bench.true_poses(B, 0), seed0=0, noise=0.02)
-    bt.set_anti_aliasing(True)
+    bt.set_anti_aliasing(True, exact=exact)
     for _ in range(3):
         bt.build_pyramid()
     _lib.call("tdk_sync")
@@ -19,6 +19,7 @@ for levels in (3, 2):
     for _ in range(20):
         bt.build_pyramid()
     _lib.call("tdk_sync")
-    print({k: v for k, v in os.environ.items() if k.startswith("TDK_AA")}, "levels", levels,
+    print({k: v for k, v in os.environ.items() if k.startswith("TDK_AA") or k.startswith("TDK_SEP")},
+          "ndimage order" if exact else "tap lists (depth: ndimage order)", "levels", levels,
           "pyramid %.3f ms" % ((time.perf_counter() - t0) / 20 * 1e3))
     bt.close()
