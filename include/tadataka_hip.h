@@ -256,6 +256,7 @@ tdk_status tdk_update_depth(const double *key_camera, const double *key_image,
 typedef struct tdk_frame tdk_frame;
 tdk_status tdk_frame_create(const double *image, int height, int width, tdk_frame **out);
 tdk_status tdk_frame_destroy(tdk_frame *f);
+tdk_status tdk_frame_download(const tdk_frame *f, double *image);   /* Frame.image getter */
 tdk_status tdk_update_depth_frames(const double *key_camera, const tdk_frame *key_frame,
                                    const double *key_transform_wf, int n_ref,
                                    const double *ref_cameras, const tdk_frame *const *ref_frames,

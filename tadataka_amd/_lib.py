@@ -62,6 +62,7 @@ PROTOTYPES = {
     "tdk_map_shape": [_vp, c_int_p, c_int_p],
     "tdk_map_device_ptr": [_vp, C.POINTER(_vp)],
     "tdk_frame_device_ptr": [_vp, C.POINTER(_vp)],
+    "tdk_frame_download": [_vp, _d],
     "tdk_map_safe_invert": [_vp, C.c_double, _vp],
     "tdk_increment_age_maps": [_vp, _d, _d, _d, _vp, _vp],
     "tdk_propagate_maps": [_d, _d, _d, _vp, _vp, C.c_double, C.c_double, C.c_double, _vp, _vp],

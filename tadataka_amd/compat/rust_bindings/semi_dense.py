@@ -17,6 +17,7 @@ import numpy as np
 from rust_bindings._check import f64, typed
 from rust_bindings.camera import CameraParameters
 from tadataka_amd import ops
+from tadataka_amd._lib import TDK_ERR_NO_DEVICE, TdkError
 
 
 LAZY_MAPS = os.environ.get("TDK_SD_EAGER", "0") in ("", "0")
@@ -46,25 +47,40 @@ def _camera(camera_params):
 
 
 class Frame(object):
-    """Frame(camera_params, image, transform_wf); copies its inputs
-    (src/py/semi_dense.rs:53-91)."""
+    """Frame(camera_params, image, transform_wf); takes a snapshot of its inputs
+    (src/py/semi_dense.rs:53-91 copies them).  The snapshot of the image is taken ON THE
+    DEVICE: the constructor uploads it (tdk_frame) and keeps no host copy -- `image` downloads
+    it when somebody asks.  (Without a GPU the frame keeps a host copy: it is a value type.)"""
 
     def __init__(self, camera_params, image, transform):
         self._cam = _camera(camera_params)
-        self._image = f64(image, 2, "image").copy()
+        img = f64(image, 2, "image")
+        self._shape = img.shape
         self._transform = f64(transform, 2, "transform").copy()
+        self._dev, self._host_image = None, None
+        try:
+            self._dev = ops.DeviceFrame(img)
+        except TdkError as e:
+            if e.status != TDK_ERR_NO_DEVICE:
+                raise
+            self._host_image = img.copy()
 
     @property
     def camera_params(self):
         return CameraParameters(self._cam[0:2], self._cam[2:4])
 
+    def _image_copy(self):
+        """A fresh host array of the image (what the reference's getter returns)."""
+        if self._host_image is not None:
+            return self._host_image.copy()
+        return self._dev.download()
+
     @property
     def image(self):
-        if not LAZY_MAPS:
-            return self._image.copy()
-        # the frame's image where it lives on the device (uploaded at its first use there); the host
-        # side is a copy, as in the reference
-        return ops.DeviceMap(self._image.shape, np.float64, host=self._image.copy(), owner=self)
+        if not LAZY_MAPS or self._dev is None:
+            return self._image_copy()
+        # the frame's image where it lives on the device; the host side is fetched on first look
+        return ops.DeviceMap(self._shape, np.float64, owner=self)
 
     def _device_image_ptr(self):
         return self._resident()[1].device_ptr()
@@ -74,12 +90,12 @@ class Frame(object):
         return self._transform.copy()
 
     def _as_tuple(self):
-        return (self._cam, self._image, self._transform)
+        return (self._cam, self._image_copy(), self._transform)
 
     def _resident(self):
-        """(camera, device-resident image, T_wf): the image is uploaded once, at first use."""
-        if getattr(self, "_dev", None) is None:
-            self._dev = ops.DeviceFrame(self._image)
+        """(camera, device-resident image, T_wf)."""
+        if self._dev is None:
+            self._dev = ops.DeviceFrame(self._host_image)      # raises without a GPU
         return (self._cam, self._dev, self._transform)
 
 
@@ -115,9 +131,9 @@ def update_depth(keyframe, refframes, age_map, prior_depth, prior_variance, para
     _map_arg(age_map, np.uint64, "age_map"); _map_arg(prior_depth, np.float64, "prior_depth")
     _map_arg(prior_variance, np.float64, "prior_variance")
     shape = age_map.shape
-    if prior_depth.shape != shape or prior_variance.shape != shape or keyframe._image.shape != shape:
+    if prior_depth.shape != shape or prior_variance.shape != shape or keyframe._shape != shape:
         raise ValueError("maps and keyframe image must share one shape")   # semi_dense.rs:168-173
-    if any(r._image.shape != shape for r in refframes):
+    if any(r._shape != shape for r in refframes):
         raise ValueError("reference frames must have the key frame's shape")
     # frames and maps stay on the device: the example passes an ever longer refframes list
     # (examples/semi_dense_vo.py:199) and the maps of the previous call; nothing is uploaded again

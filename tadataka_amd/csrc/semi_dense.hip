@@ -124,38 +124,71 @@ __device__ __forceinline__ bool xcd_major_track(int nb, int n_tracks, int &track
     return track < n_tracks;
 }
 
-// Forward warp of every source pixel of every track; in-range sources are pushed
-// onto their target's list: next[i] = previous head, -1 ends a list, -2 marks a
-// source that left the image.  grid = (blocks, n_tracks).
+// Per-target bookkeeping of the forward warp, one set per track (ints, `stride` apart per track):
+//   cnt[t]          number of in-range sources that landed on target t          (zeroed per step)
+//   slots[t][0..3]  the first kSlots of them, in arrival order                    (never initialised)
+//   ovf[t], next[i] sources beyond kSlots: a chain threaded through next[] whose newest entry is
+//                   ovf[t]; it has cnt - kSlots entries, so neither array needs initialising
+// Two sources per target cover > 99 % of a frame and four practically all of it; the chain keeps
+// the operators exact for any warp (a zoom-out that folds a dozen sources onto every target).
+constexpr int kSlots = 4;
+struct WarpLists {
+    int *cnt, *slots, *ovf, *next;
+};
+constexpr size_t kWarpListInts = 1 + kSlots + 1 + 1;   // ints per pixel and track behind a WarpLists (+ 16 of padding)
+inline size_t warp_list_bytes(int64_t stride, int n_tracks) { return sizeof(int) * (kWarpListInts * (size_t)(stride * n_tracks) + 16); }
+
+__host__ __device__ inline WarpLists carve_lists(int *buf, int64_t stride, int n_tracks) {
+    WarpLists L;
+    const int64_t m = (stride * n_tracks + 3) & ~(int64_t)3;   // keeps the slot rows 16-byte aligned
+    L.cnt = buf;
+    L.slots = buf + m;
+    L.ovf = buf + m * (1 + kSlots);
+    L.next = buf + m * (2 + kSlots);
+    return L;
+}
+
+// Forward warp of every source pixel of every track; an in-range source claims the next slot of its
+// target (one returning atomic), writes its index there, or joins the overflow chain.
 __global__ __launch_bounds__(kBlock) void k_sd_scatter(int H, int W, const TrackWarp *__restrict__ tw,
                                                        const double *__restrict__ depth0, int64_t stride,
-                                                       int *__restrict__ head, int *__restrict__ next, int nb,
-                                                       int n_tracks) {
+                                                       WarpLists lists, int nb, int n_tracks) {
     int track, blk;
     if (!xcd_major_track(nb, n_tracks, track, blk)) return;
     const TrackWarp &t = tw[track];
     const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
     const int N = H * W;
     const double *__restrict__ d0 = depth0 + (int64_t)track * stride;
-    int *__restrict__ hd = head + (int64_t)track * stride;
-    int *__restrict__ nx = next + (int64_t)track * stride;
+    int *__restrict__ cn = lists.cnt + (int64_t)track * stride;
+    int *__restrict__ sl = lists.slots + (int64_t)track * stride * kSlots;
+    int *__restrict__ oh = lists.ovf + (int64_t)track * stride;
+    int *__restrict__ nx = lists.next + (int64_t)track * stride;
     for (int i = blk * kBlock + threadIdx.x; i < N; i += nb * kBlock) {
         int y0 = i / W, x0 = i - y0 * W;
         double ux, uy, d1;
         tdk::perspective_warp(t.T10, c0, c1, (double)x0, (double)y0, d0[i], ux, uy, d1);
-        if (!tdk::in_range(ux, uy, H, W)) { nx[i] = -2; continue; }
-        int tg = (int)uy * W + (int)ux;  // `as usize`: truncation
-        nx[i] = atomicExch(&hd[tg], i);
+        if (!tdk::in_range(ux, uy, H, W)) continue;
+        const int tg = (int)uy * W + (int)ux;  // `as usize`: truncation
+        const int k = atomicAdd(&cn[tg], 1);
+        if (k < kSlots) sl[(int64_t)tg * kSlots + k] = i;
+        else nx[i] = atomicExch(&oh[tg], i);
     }
 }
 
-// One thread per target pixel: walk its list in increasing source index.
+__device__ __forceinline__ void sort2(int &a, int &b) {
+    const int lo = min(a, b), hi = max(a, b);
+    a = lo; b = hi;
+}
+
+// One thread per target pixel: its sources in increasing source index (= raster order of the reference's loop).
 //   AGE : age1 = age0[last raster writer] + 1, untouched = 0            (age.rs:18-31)
 //   PROP: sequential fold of (depth1, variance1) with handle_collision,
 //         misses get the defaults                                         (propagation.rs:59-89)
+// The count and the four slots of a target are one 4-byte and one 16-byte coalesced load; up to four
+// sources are ordered by a five-exchange network in registers; the rare longer lists go through the
+// selection loop over slots + chain.
 template <bool AGE, bool PROP>
-__global__ __launch_bounds__(kBlock) void k_sd_fold(int H, int W, const TrackWarp *__restrict__ tw,
-                                                    const int *__restrict__ head, const int *__restrict__ next,
+__global__ __launch_bounds__(kBlock) void k_sd_fold(int H, int W, const TrackWarp *__restrict__ tw, WarpLists lists,
                                                     const uint64_t *__restrict__ age0,
                                                     const double *__restrict__ depth0,
                                                     const double *__restrict__ var0, int64_t stride,
@@ -168,23 +201,21 @@ __global__ __launch_bounds__(kBlock) void k_sd_fold(int H, int W, const TrackWar
     const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
     const int N = H * W;
     const int64_t base = (int64_t)track * stride;
-    const int *__restrict__ nx = next + base;
+    const int *__restrict__ cn = lists.cnt + base;
+    const int4 *__restrict__ sl = reinterpret_cast<const int4 *>(lists.slots + base * kSlots);
+    const int *__restrict__ oh = lists.ovf + base;
+    const int *__restrict__ nx = lists.next + base;
     for (int tg = blk * kBlock + threadIdx.x; tg < N; tg += nb * kBlock) {
-        const int h = head[base + tg];
+        const int k = cn[tg];
         double d = default_depth, v = default_variance;
         int last = -1;
         bool have = false;
-        while (h >= 0) {
-            // next source in raster order: smallest list entry greater than `last`
-            int best = 0x7fffffff;
-            for (int j = h; j >= 0; j = nx[j])
-                if (j > last && j < best) best = j;
-            if (best == 0x7fffffff) break;
+        auto take = [&](int src) {      // the next source in raster order
             if (PROP) {
-                int y0 = best / W, x0 = best - y0 * W;
-                double sd0 = depth0[base + best], ux, uy, sd1;
+                int y0 = src / W, x0 = src - y0 * W;
+                double sd0 = depth0[base + src], ux, uy, sd1;
                 tdk::perspective_warp(t.T10, c0, c1, (double)x0, (double)y0, sd0, ux, uy, sd1);
-                double sv1 = propagate_variance(sd0, sd1, var0[base + best], bias);
+                double sv1 = propagate_variance(sd0, sd1, var0[base + src], bias);
                 if (!have) { d = sd1; v = sv1; have = true; }
                 else {
                     double nd, nv;
@@ -192,7 +223,35 @@ __global__ __launch_bounds__(kBlock) void k_sd_fold(int H, int W, const TrackWar
                     d = nd; v = nv;
                 }
             }
-            last = best;
+            last = src;
+        };
+        if (k > 0) {
+            const int4 q = sl[tg];
+            int s0 = q.x, s1 = k > 1 ? q.y : 0x7fffffff, s2 = k > 2 ? q.z : 0x7fffffff, s3 = k > 3 ? q.w : 0x7fffffff;
+            if (k <= kSlots) {
+                if (k > 1) {      // most targets have one source: skip the network
+                    sort2(s0, s1); sort2(s2, s3); sort2(s0, s2); sort2(s1, s3); sort2(s1, s2);
+                }
+                take(s0);
+                if (k > 1) take(s1);
+                if (k > 2) take(s2);
+                if (k > 3) take(s3);
+            } else {
+                // slots + chain (k - kSlots entries from ovf[tg]): repeatedly the smallest index above `last`
+                for (int n = 0; n < k; n++) {
+                    int best = 0x7fffffff;
+                    if (s0 > last && s0 < best) best = s0;
+                    if (s1 > last && s1 < best) best = s1;
+                    if (s2 > last && s2 < best) best = s2;
+                    if (s3 > last && s3 < best) best = s3;
+                    int j = oh[tg];
+                    for (int m = kSlots; m < k; m++) {
+                        if (j > last && j < best) best = j;
+                        j = nx[j];
+                    }
+                    take(best);
+                }
+            }
         }
         if (AGE) {
             uint64_t a = 0;
@@ -776,15 +835,17 @@ void fill_track_warp(TrackWarp *tw, const double *T10, const double *cam0, const
 template <bool AGE, bool PROP>
 tdk_status launch_warp_step(int n_tracks, int H, int W, const TrackWarp *d_tw, const uint64_t *age0,
                             const double *depth0, const double *var0, int64_t stride, double default_depth,
-                            double default_variance, double bias, int *head, int *next, uint64_t *age1,
+                            double default_variance, double bias, int *list_buf, uint64_t *age1,
                             double *depth1, double *var1, hipStream_t stream) {
+    // list_buf: kWarpListInts * stride * n_tracks ints (carve_lists); stride must be even (16-byte slot rows)
     const int N = H * W;
-    TDK_HIP(hipMemsetAsync(head, 0xff, sizeof(int) * (size_t)stride * n_tracks, stream));  // -1: empty list
+    const WarpLists lists = carve_lists(list_buf, stride, n_tracks);
+    TDK_HIP(hipMemsetAsync(lists.cnt, 0, sizeof(int) * (size_t)stride * n_tracks, stream));
     const int nb = grid_for(N);
     const unsigned grid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)nb;
-    k_sd_scatter<<<grid, kBlock, 0, stream>>>(H, W, d_tw, depth0, stride, head, next, nb, n_tracks);
+    k_sd_scatter<<<grid, kBlock, 0, stream>>>(H, W, d_tw, depth0, stride, lists, nb, n_tracks);
     TDK_LAUNCH_CHECK();
-    k_sd_fold<AGE, PROP><<<grid, kBlock, 0, stream>>>(H, W, d_tw, head, next, age0, depth0, var0, stride,
+    k_sd_fold<AGE, PROP><<<grid, kBlock, 0, stream>>>(H, W, d_tw, lists, age0, depth0, var0, stride,
                                                        default_depth, default_variance, bias, age1, depth1, var1,
                                                        nb, n_tracks);
     TDK_LAUNCH_CHECK();
@@ -835,18 +896,17 @@ tdk_status tdk_increment_age(const uint64_t *age0, int H, int W, const double *c
     TDK_REQUIRE(age0 && camera0 && camera1 && T10 && depth0 && age1, "null pointer");
     TDK_TRY(check_image_dims(H, W));
     const int N = H * W;
-    void *d_age0, *d_depth, *d_head, *d_next, *d_age1, *d_tw;
+    void *d_age0, *d_depth, *d_lists, *d_age1, *d_tw;
     TDK_TRY(h2d(0, age0, (size_t)N * 8, &d_age0));
     TDK_TRY(h2d(1, depth0, (size_t)N * 8, &d_depth));
-    TDK_TRY(tdk::scratch(2, (size_t)N * 4, &d_head));
-    TDK_TRY(tdk::scratch(3, (size_t)N * 4, &d_next));
+    TDK_TRY(tdk::scratch(2, warp_list_bytes(N, 1), &d_lists));
     TDK_TRY(tdk::scratch(4, (size_t)N * 8, &d_age1));
     TrackWarp tw;
     fill_track_warp(&tw, T10, camera0, camera1);
     TDK_TRY(h2d(10, &tw, sizeof(tw), &d_tw));
     TDK_TRY((launch_warp_step<true, false>(1, H, W, (const TrackWarp *)d_tw, (const uint64_t *)d_age0,
-                                           (const double *)d_depth, nullptr, N, 0., 0., 0., (int *)d_head,
-                                           (int *)d_next, (uint64_t *)d_age1, nullptr, nullptr, tdk::stream())));
+                                           (const double *)d_depth, nullptr, N, 0., 0., 0., (int *)d_lists,
+                                           (uint64_t *)d_age1, nullptr, nullptr, tdk::stream())));
     TDK_HIP(hipMemcpyAsync(age1, d_age1, (size_t)N * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));  // tw must outlive the H2D copy
     return TDK_OK;
@@ -858,12 +918,11 @@ tdk_status tdk_propagate(const double *T10, const double *camera0, const double 
     TDK_REQUIRE(T10 && camera0 && camera1 && depth0 && variance0 && depth1 && variance1, "null pointer");
     TDK_TRY(check_image_dims(H, W));
     const int N = H * W;
-    size_t b8 = (size_t)N * 8, b4 = (size_t)N * 4;
-    void *d_d0, *d_v0, *d_head, *d_next, *d_d1, *d_v1, *d_tw;
+    size_t b8 = (size_t)N * 8;
+    void *d_d0, *d_v0, *d_lists, *d_d1, *d_v1, *d_tw;
     TDK_TRY(h2d(0, depth0, b8, &d_d0));
     TDK_TRY(h2d(1, variance0, b8, &d_v0));
-    TDK_TRY(tdk::scratch(2, b4, &d_head));
-    TDK_TRY(tdk::scratch(3, b4, &d_next));
+    TDK_TRY(tdk::scratch(2, warp_list_bytes(N, 1), &d_lists));
     TDK_TRY(tdk::scratch(4, b8, &d_d1));
     TDK_TRY(tdk::scratch(5, b8, &d_v1));
     TrackWarp tw;
@@ -871,7 +930,7 @@ tdk_status tdk_propagate(const double *T10, const double *camera0, const double 
     TDK_TRY(h2d(10, &tw, sizeof(tw), &d_tw));
     TDK_TRY((launch_warp_step<false, true>(1, H, W, (const TrackWarp *)d_tw, nullptr, (const double *)d_d0,
                                            (const double *)d_v0, N, default_depth, default_variance,
-                                           uncertaintity_bias, (int *)d_head, (int *)d_next, nullptr,
+                                           uncertaintity_bias, (int *)d_lists, nullptr,
                                            (double *)d_d1, (double *)d_v1, tdk::stream())));
     TDK_HIP(hipMemcpyAsync(depth1, d_d1, b8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(variance1, d_v1, b8, hipMemcpyDeviceToHost, tdk::stream()));
@@ -1164,6 +1223,13 @@ tdk_status tdk_map_device_ptr(const tdk_map *m, void **ptr) {
     return TDK_OK;
 }
 
+tdk_status tdk_frame_download(const tdk_frame *f, double *image) {
+    TDK_REQUIRE(f && image, "null pointer");
+    TDK_HIP(hipMemcpyAsync(image, f->image, (size_t)f->H * f->W * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    return TDK_OK;
+}
+
 tdk_status tdk_frame_device_ptr(const tdk_frame *f, void **ptr) {
     TDK_REQUIRE(f && ptr, "null pointer");
     *ptr = f->image;
@@ -1186,15 +1252,14 @@ tdk_status tdk_increment_age_maps(const tdk_map *age0, const double *camera0, co
     TDK_REQUIRE(same_shape(age0, depth0) && same_shape(age0, age1), "maps must share one shape");
     TDK_REQUIRE(age1->data != age0->data, "age1 must not alias age0");
     const int H = age0->H, W = age0->W, N = H * W;
-    void *d_head, *d_next, *d_tw;
-    TDK_TRY(tdk::scratch(2, (size_t)N * 4, &d_head));
-    TDK_TRY(tdk::scratch(3, (size_t)N * 4, &d_next));
+    void *d_lists, *d_tw;
+    TDK_TRY(tdk::scratch(2, warp_list_bytes(N, 1), &d_lists));
     TrackWarp tw;
     fill_track_warp(&tw, T10, camera0, camera1);
     TDK_TRY(h2d_small(10, &tw, sizeof(tw), &d_tw));
     return launch_warp_step<true, false>(1, H, W, (const TrackWarp *)d_tw, (const uint64_t *)age0->data,
-                                         (const double *)depth0->data, nullptr, N, 0., 0., 0., (int *)d_head,
-                                         (int *)d_next, (uint64_t *)age1->data, nullptr, nullptr, tdk::stream());
+                                         (const double *)depth0->data, nullptr, N, 0., 0., 0., (int *)d_lists,
+                                         (uint64_t *)age1->data, nullptr, nullptr, tdk::stream());
 }
 
 tdk_status tdk_propagate_maps(const double *T10, const double *camera0, const double *camera1,
@@ -1209,15 +1274,14 @@ tdk_status tdk_propagate_maps(const double *T10, const double *camera0, const do
                     depth1->data != variance1->data,
                 "outputs must not alias the inputs");
     const int H = depth0->H, W = depth0->W, N = H * W;
-    void *d_head, *d_next, *d_tw;
-    TDK_TRY(tdk::scratch(2, (size_t)N * 4, &d_head));
-    TDK_TRY(tdk::scratch(3, (size_t)N * 4, &d_next));
+    void *d_lists, *d_tw;
+    TDK_TRY(tdk::scratch(2, warp_list_bytes(N, 1), &d_lists));
     TrackWarp tw;
     fill_track_warp(&tw, T10, camera0, camera1);
     TDK_TRY(h2d_small(10, &tw, sizeof(tw), &d_tw));
     return launch_warp_step<false, true>(1, H, W, (const TrackWarp *)d_tw, nullptr, (const double *)depth0->data,
                                          (const double *)variance0->data, N, default_depth, default_variance,
-                                         uncertaintity_bias, (int *)d_head, (int *)d_next, nullptr,
+                                         uncertaintity_bias, (int *)d_lists, nullptr,
                                          (double *)depth1->data, (double *)variance1->data, tdk::stream());
 }
 
@@ -1373,7 +1437,8 @@ struct tdk_sd {
     double *prior_depth, *prior_var;
     int64_t *flag;
     int cur, result_buf;
-    int *head, *next, *list, *count, *err;
+    int *warp_lists;         // cnt | slots | ovf | next of every track (carve_lists)
+    int *list, *count, *err;
     unsigned long long *hist;
     TrackWarp *d_tw;
     TrackKey *d_keys;
@@ -1416,7 +1481,7 @@ tdk_status tdk_sd_destroy(tdk_sd *h) {
     (void)hipFree(h->images);
     for (int k = 0; k < 2; k++) { (void)hipFree(h->age[k]); (void)hipFree(h->depth[k]); (void)hipFree(h->var[k]); }
     (void)hipFree(h->prior_depth); (void)hipFree(h->prior_var); (void)hipFree(h->flag);
-    (void)hipFree(h->head); (void)hipFree(h->next); (void)hipFree(h->list); (void)hipFree(h->count);
+    (void)hipFree(h->warp_lists); (void)hipFree(h->list); (void)hipFree(h->count);
     (void)hipFree(h->hist); (void)hipFree(h->d_tw); (void)hipFree(h->d_keys); (void)hipFree(h->d_refs);
     (void)hipFree((void *)h->d_img_ptrs);
     if (h->stage) (void)hipHostFree(h->stage);
@@ -1466,8 +1531,7 @@ tdk_status tdk_sd_create(int n_tracks, int height, int width, int max_refframes,
     SD_ALLOC(hipMalloc(&h->prior_depth, 8 * m));
     SD_ALLOC(hipMalloc(&h->prior_var, 8 * m));
     SD_ALLOC(hipMalloc(&h->flag, 8 * m));
-    SD_ALLOC(hipMalloc(&h->head, 4 * m));
-    SD_ALLOC(hipMalloc(&h->next, 4 * m));
+    SD_ALLOC(hipMalloc(&h->warp_lists, warp_list_bytes(h->stride, n_tracks)));
     SD_ALLOC(hipMalloc(&h->list, 4 * m));
     SD_ALLOC(hipMalloc(&h->count, sizeof(int) * ((size_t)kCountStride * n_tracks + 1)));
     h->err = h->count + (size_t)kCountStride * n_tracks;
@@ -1685,7 +1749,7 @@ tdk_status tdk_sd_step(tdk_sd *h, const double *transforms10, const double *key_
     const int c = h->cur, o = c ^ 1;
     TDK_HIP(hipEventRecord(h->ev[0], s));
     TDK_TRY((launch_warp_step<true, true>(h->n, h->H, h->W, h->d_tw, h->age[c], h->depth[c], h->var[c], h->stride,
-                                          h->default_depth, h->default_variance, h->bias, h->head, h->next,
+                                          h->default_depth, h->default_variance, h->bias, h->warp_lists,
                                           h->age[o], h->prior_depth, h->prior_var, s)));
     TDK_HIP(hipEventRecord(h->ev[1], s));
     TDK_TRY(launch_update_depth(h->n, h->H, h->W, h->d_keys, h->d_refs, h->R, h->age[o], h->prior_depth,
@@ -1704,7 +1768,7 @@ tdk_status tdk_sd_propagate(tdk_sd *h, const double *transforms10, int commit) {
     const int c = h->cur, o = c ^ 1;
     TDK_HIP(hipEventRecord(h->ev[0], s));
     TDK_TRY((launch_warp_step<true, true>(h->n, h->H, h->W, h->d_tw, h->age[c], h->depth[c], h->var[c], h->stride,
-                                          h->default_depth, h->default_variance, h->bias, h->head, h->next,
+                                          h->default_depth, h->default_variance, h->bias, h->warp_lists,
                                           h->age[o], h->depth[o], h->var[o], s)));
     TDK_HIP(hipEventRecord(h->ev[1], s));
     TDK_HIP(hipEventRecord(h->ev[2], s));

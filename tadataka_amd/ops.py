@@ -436,6 +436,11 @@ class DeviceFrame(object):
         call("tdk_frame_device_ptr", self._h, C.byref(p))
         return p.value
 
+    def download(self):
+        out = np.empty(self.shape)
+        call("tdk_frame_download", self._h, _p(out))
+        return out
+
     def close(self):
         if self._h:
             call("tdk_frame_destroy", self._h)
@@ -557,9 +562,12 @@ class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
     # -- host side -----------------------------------------------------------------------------
     def _materialise(self):
         if self._host is None:
-            out = np.empty(self.shape, dtype=self.dtype)
-            call("tdk_map_download", self._h, out.ctypes.data_as(C.c_void_p))
-            self._host = out
+            if self._owner is not None:
+                self._host = self._owner._image_copy()
+            else:
+                out = np.empty(self.shape, dtype=self.dtype)
+                call("tdk_map_download", self._h, out.ctypes.data_as(C.c_void_p))
+                self._host = out
         return self._host
 
     def __array__(self, dtype=None, copy=None):

@@ -583,3 +583,44 @@ def test_session_outlives_its_ring(ops):
 
 
 SD_DEFAULTS = (1.0, 10.0, 0.01)
+
+
+@pytest.mark.parametrize("dz", [0.0, 1.1, 4.5])
+def test_forward_warp_with_many_sources_per_target(ops, dz):
+    """increment_age / propagate when the warp folds many sources onto one target (the camera backs
+    off by dz: 1, ~2.4 and ~10 sources per target): slots (<= 4 sources), slots + overflow chain
+    (more) -- bit-exact against the oracle's raster-order loop, host-pointer entries, device maps and
+    the session alike."""
+    from oracle import oracle as orc
+    from tadataka_amd import synthetic
+    H, W = 60, 81               # odd pixel count
+    rng = np.random.default_rng(17)
+    cam = synthetic.camera_for(W, H)
+    depth0 = 2.0 + 0.2 * rng.uniform(-1, 1, (H, W))
+    var0 = rng.uniform(0.01, 0.2, (H, W))
+    age0 = rng.integers(0, 5, (H, W)).astype(np.uint64)
+    T10 = np.eye(4)
+    T10[:3, 3] = [0.01, -0.02, dz]
+    a1 = ops.increment_age(age0, cam, cam, T10, depth0)
+    d1, v1 = ops.propagate(T10, cam, cam, depth0, var0, *SD_DEFAULTS)
+    oa = orc.increment_age(age0, cam, cam, T10, depth0)
+    od, ov = orc.propagate(T10, cam, cam, depth0, var0, *SD_DEFAULTS)
+    assert np.array_equal(a1, oa) and np.array_equal(d1, od) and np.array_equal(v1, ov)
+    if dz > 4:
+        assert int((oa > 0).sum()) < H * W // 6      # the frame really collapsed onto few targets
+    m_a = ops.increment_age_maps(age0, cam, cam, T10, depth0)
+    m_d, m_v = ops.propagate_maps(T10, cam, cam, depth0, var0, *SD_DEFAULTS)
+    assert np.array_equal(m_a, oa) and np.array_equal(m_d, od) and np.array_equal(m_v, ov)
+    sd = ops.SemiDenseSession(3, H, W, max_refframes=1)
+    sd.set_age_policy(False)
+    sd.set_params(ops.make_params(0.5, 10.0, 0.01, 0.01, 0.004, 0.01), *SD_DEFAULTS)
+    img = rng.uniform(0, 1, (H, W))
+    for t in range(3):
+        sd.push_frame(t, cam, img, np.eye(4))
+        sd.push_frame(t, cam, img, np.linalg.inv(T10))
+        sd.set_maps(t, depth0, var0, age0)
+    sd.propagate(np.tile(T10, (3, 1, 1)), commit=False)
+    for t in range(3):
+        gd, gv, ga = sd.get_results(t, with_flag=False)
+        assert np.array_equal(ga, oa) and np.array_equal(gd, od) and np.array_equal(gv, ov)
+    sd.close()
