@@ -626,9 +626,12 @@ def main():
     _lib.require_gpu()
     # one GPU per rank; on a box with fewer GPUs than ranks (only ever a smoke test) ranks share devices
     _lib.call("tdk_set_device", local_rank % _lib.device_count())
-    # RCCL through the C ABI when WORLD_SIZE > 1.  If RCCL cannot be brought up on this node the few
-    # bytes of poses and scalars go through files instead and the JSON line says so ("exchange").
-    comm, comm_error = sharding.connect_or_fallback()
+    # RCCL through the C ABI when WORLD_SIZE > 1.  Only where ranks have to SHARE a GPU (fewer GPUs than
+    # ranks: the one-GPU smoke test of the multi-process path, RCCL refuses duplicate devices) may the few
+    # bytes of poses and scalars go through files instead -- the JSON line says so ("exchange").  With a GPU
+    # per rank a transport failure is an error: a scaling run must not "pass" without RCCL.
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    comm, comm_error = sharding.connect_or_fallback(allow_file_fallback=_lib.device_count() < local_world)
     if comm_error:
         sys.stderr.write("bench.py: RCCL unavailable (%s); exchanging poses through files\n" % comm_error)
     world, rank = comm.world, comm.rank
@@ -640,7 +643,7 @@ def main():
     anti_aliasing = args.pyramid == "anti-aliased"
     n_batches = 2 if args.double_buffer else 1
     # this rank's shard of the pair ids: n_batches consecutive blocks of B pairs
-    seeds = [int(sharding.pair_seeds(rank, n_batches * B)[0]) + k * B for k in range(n_batches)]
+    seeds = [sharding.batch_seed0(rank, n_batches, B, k) for k in range(n_batches)]
     batches = []
     for seed0 in seeds:
         bt = ops.DvoBatch(B, H, W, n_levels=args.levels, ratio=1.5)
@@ -731,9 +734,8 @@ def main():
         [float(pixels), float(work_px[0]), float(work_px[1])], "sum", comm))
 
     if rank == 0:
-        # rank r's batch of the last step holds pairs [r * n_batches * B + offset, ... + B)
-        offset = seeds[last_batch] - seeds[0]
-        truth = np.concatenate([true_poses(B, r * n_batches * B + offset) for r in range(world)])
+        # the all-gathered poses of the last step: batch `last_batch` of every rank, in rank order
+        truth = np.concatenate([true_poses(B, s0) for s0 in sharding.gathered_seed0s(world, n_batches, B, last_batch)])
         assert poses.shape == truth.shape
         t_err = float(np.max(np.linalg.norm(poses[:, 9:] - truth[:, 9:], axis=1)))
         kernel_ms = prof["total_ms"] / max(prof["launches"], 1)

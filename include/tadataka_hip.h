@@ -459,6 +459,7 @@ tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, 
  * band (tadataka_amd/sharding.py uses a file next to the rendezvous port);
  * tdk_comm_create is collective (ncclCommInitRank) on the current device. */
 typedef struct tdk_comm tdk_comm;
+tdk_status tdk_comm_available(void);   /* TDK_OK if librccl can be opened and has the symbols used here */
 tdk_status tdk_comm_unique_id(uint8_t *id128);
 tdk_status tdk_comm_create(const uint8_t *id128, int rank, int world, tdk_comm **out);
 tdk_status tdk_comm_destroy(tdk_comm *c);

@@ -6,9 +6,11 @@ DVO / semi-dense / bundle-adjustment hot path.
                            the reference's Python API and run on the HIP kernels
 
 Importing this package puts `tadataka_amd/compat` on sys.path, so that
-`import tadataka` / `import rust_bindings` resolve to the MI355X build, and
-appends `tadataka_amd/compat_thirdparty` (a three-function stand-in for
-scikit-image) BEHIND everything else, so a real scikit-image always wins.
+`import tadataka` / `import rust_bindings` resolve to the MI355X build.  The
+three-function stand-in for scikit-image that the reference's examples need
+(`tadataka_amd/compat_thirdparty`) is made importable only if no scikit-image is
+installed (it is appended BEHIND everything else on sys.path, with a warning) or on
+request: `tadataka_amd.install(thirdparty=True)`.
 """
 import os
 import sys
@@ -24,11 +26,23 @@ THIRDPARTY_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "compa
 PYRAMID_ANTI_ALIASING = True
 
 
-def install():
-    """Makes `tadataka` and `rust_bindings` importable (idempotent)."""
+def install(thirdparty=None):
+    """Makes `tadataka` and `rust_bindings` importable (idempotent).  thirdparty: True = also the
+    scikit-image stand-in, False = never, None = only when scikit-image is not installed."""
     if COMPAT_DIR not in sys.path:
         sys.path.insert(0, COMPAT_DIR)
-    if THIRDPARTY_DIR not in sys.path:
+    if thirdparty is None:
+        import importlib.util
+        try:
+            missing = importlib.util.find_spec("skimage") is None
+        except (ImportError, ValueError):
+            missing = True
+        thirdparty = missing
+        if missing and THIRDPARTY_DIR not in sys.path:
+            import warnings
+            warnings.warn("scikit-image is not installed: `import skimage` resolves to tadataka_amd's "
+                          "three-function stand-in (rgb2gray, rescale, resize on the GPU)", ImportWarning)
+    if thirdparty and THIRDPARTY_DIR not in sys.path:
         sys.path.append(THIRDPARTY_DIR)
 
 

@@ -139,6 +139,7 @@ PROTOTYPES = {
     "tdk_ba_block_sums": [_vp, _d, _d, _d, _d, _d, _d, _d],
     "tdk_ba_set_profiling": [_vp, _i],
     "tdk_ba_get_profile": [_vp, c_int64_p, _d],
+    "tdk_comm_available": [],
     "tdk_comm_unique_id": [C.POINTER(C.c_uint8)],
     "tdk_comm_create": [C.POINTER(C.c_uint8), _i, _i, C.POINTER(_vp)],
     "tdk_comm_destroy": [_vp],

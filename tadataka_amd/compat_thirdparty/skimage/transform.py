@@ -2,18 +2,48 @@ import numpy as np
 
 from tadataka_amd import ops
 
+# what scikit-image 0.16.2's rescale / resize default to, and all this stand-in implements
+_DEFAULTS = {"order": 1, "mode": "reflect", "cval": 0, "clip": True, "preserve_range": False,
+             "multichannel": False, "anti_aliasing_sigma": None}
+
+
+def _check_kwargs(kwargs):
+    for key, value in kwargs.items():
+        if key not in _DEFAULTS:
+            raise TypeError(f"unexpected keyword argument '{key}'")
+        if value != _DEFAULTS[key] and not (key == "multichannel" and value is None):
+            raise NotImplementedError(
+                f"{key}={value!r}: this stand-in for scikit-image implements only {key}={_DEFAULTS[key]!r}")
+
+
+def _as_float(image):
+    """img_as_float: unsigned integers are scaled to [0, 1], signed ones to [-1, 1], floats pass."""
+    a = np.asarray(image)
+    if a.dtype.kind == "u":
+        return a.astype(np.float64) / float(np.iinfo(a.dtype).max)
+    if a.dtype.kind == "i":
+        info = np.iinfo(a.dtype)
+        return np.maximum(a.astype(np.float64) / float(info.max), -1.0)
+    if a.dtype.kind == "b":
+        return a.astype(np.float64)
+    return np.asarray(a, dtype=np.float64)
+
 
 def rescale(image, scale, anti_aliasing=True, **kwargs):
     """Bilinear (order=1) rescale of a 2-D image; anti_aliasing as in 0.15+ (Gaussian
-    prefilter with sigma = (1/scale - 1) / 2 when shrinking)."""
-    image = np.asarray(image, dtype=np.float64)
+    prefilter with sigma = (1/scale - 1) / 2 when shrinking).  Any other option raises."""
+    _check_kwargs(kwargs)
+    image = _as_float(image)
     if image.ndim != 2:
         raise NotImplementedError("only 2-D images are rescaled on the hot path")
+    if np.ndim(scale) != 0:
+        raise NotImplementedError("only a scalar scale is implemented")
     return ops.rescale(image, scale, anti_aliasing=bool(anti_aliasing) and scale < 1.0)
 
 
 def resize(image, output_shape, anti_aliasing=True, **kwargs):
-    image = np.asarray(image, dtype=np.float64)
+    _check_kwargs(kwargs)
+    image = _as_float(image)
     if image.ndim != 2:
         raise NotImplementedError("only 2-D images are resized on the hot path")
     return ops.resize(image, tuple(int(v) for v in output_shape[:2]),

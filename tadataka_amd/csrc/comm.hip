@@ -79,11 +79,20 @@ struct tdk_comm {
     // device-resident pose gather (tdk_dvo_gather_poses_start / _finish)
     double *d_poses_all, *h_poses_all;
     size_t poses_cap;        // doubles
-    int64_t pending_count;   // doubles of the gather in flight, 0 = none
-    hipEvent_t done;
+    int64_t pending_count;   // doubles of the gather in flight
+    bool pending;            // a device-resident gather has been started and not collected
+    hipEvent_t done;         // recorded behind it on the batch's stream
 };
 
 namespace {
+
+// NCCL wants the operations of one communicator issued in one order on every rank and not
+// overlapping on the device: the device-resident pose gather runs on a batch's stream, the
+// host-buffer collectives on c->stream -- the latter wait for the former's event first.
+tdk_status order_after_pending_gather(tdk_comm *c) {
+    if (c->pending) TDK_HIP(hipStreamWaitEvent(c->stream, c->done, 0));
+    return TDK_OK;
+}
 
 tdk_status comm_reserve(tdk_comm *c, size_t doubles) {
     if (c->cap >= doubles) return TDK_OK;
@@ -112,8 +121,11 @@ tdk_status tdk_comm_unique_id(uint8_t *id128) {
     return TDK_OK;
 }
 
+tdk_status tdk_comm_available(void) { return load_rccl(); }
+
 tdk_status tdk_comm_destroy(tdk_comm *c) {
     if (!c) return TDK_OK;
+    if (c->pending && c->done) (void)hipEventSynchronize(c->done);   // a gather in flight still writes d_poses_all / h_poses_all
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) (void)g_rccl.CommDestroy(c->comm);
     if (c->d_buf) (void)hipFree(c->d_buf);
@@ -167,6 +179,7 @@ tdk_status tdk_comm_all_gather(tdk_comm *c, const double *send, int64_t count, d
     TDK_TRY(comm_reserve(c, total));
     double *d_send = c->d_buf, *d_recv = c->d_buf + c->cap;
     memcpy(c->h_buf, send, n * sizeof(double));
+    TDK_TRY(order_after_pending_gather(c));
     TDK_HIP(hipMemcpyAsync(d_send, c->h_buf, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     TDK_RCCL(g_rccl.AllGather(d_send, d_recv, n, ncclDouble, c->comm, c->stream));
     TDK_HIP(hipMemcpyAsync(c->h_buf + c->cap, d_recv, total * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -182,6 +195,7 @@ tdk_status tdk_comm_all_reduce(tdk_comm *c, double *values, int64_t count, int o
     TDK_TRY(comm_reserve(c, n));
     double *d_send = c->d_buf, *d_recv = c->d_buf + c->cap;
     memcpy(c->h_buf, values, n * sizeof(double));
+    TDK_TRY(order_after_pending_gather(c));
     TDK_HIP(hipMemcpyAsync(d_send, c->h_buf, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
     TDK_RCCL(g_rccl.AllReduce(d_send, d_recv, n, ncclDouble, op == 0 ? ncclSum : ncclMax, c->comm, c->stream));
     TDK_HIP(hipMemcpyAsync(c->h_buf + c->cap, d_recv, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -197,11 +211,11 @@ tdk_status tdk_comm_barrier(tdk_comm *c) {
 
 tdk_status tdk_dvo_gather_poses_start(tdk_dvo *h, tdk_comm *c) {
     TDK_REQUIRE(h && c, "null pointer");
-    TDK_REQUIRE(c->pending_count == 0, "finish the previous gather first");
+    TDK_REQUIRE(!c->pending, "finish the previous gather first");
     tdk::DvoLevel0 L;
     TDK_TRY(tdk::dvo_level0(h, &L));
     const size_t n = (size_t)L.n_pairs * 12, total = n * (size_t)c->world;
-    if (c->poses_cap < total) {
+    if (c->poses_cap < total || !c->d_poses_all) {
         if (c->d_poses_all) { (void)hipFree(c->d_poses_all); c->d_poses_all = nullptr; }
         if (c->h_poses_all) { (void)hipHostFree(c->h_poses_all); c->h_poses_all = nullptr; }
         c->poses_cap = 0;
@@ -209,20 +223,27 @@ tdk_status tdk_dvo_gather_poses_start(tdk_dvo *h, tdk_comm *c) {
         TDK_HIP(hipHostMalloc(&c->h_poses_all, total * sizeof(double), hipHostMallocDefault));
         c->poses_cap = total;
     }
-    // on the batch's own stream, right behind the estimation that produced the poses
-    TDK_RCCL(g_rccl.AllGather(L.poses, c->d_poses_all, n, ncclDouble, c->comm, L.stream));
-    TDK_HIP(hipMemcpyAsync(c->h_poses_all, c->d_poses_all, total * sizeof(double), hipMemcpyDeviceToHost, L.stream));
+    // on the batch's own stream, right behind the estimation that produced the poses -- and behind
+    // whatever host-buffer collective is still running on the communicator's stream
+    TDK_HIP(hipEventRecord(c->done, c->stream));
+    TDK_HIP(hipStreamWaitEvent(L.stream, c->done, 0));
+    if (n > 0) {
+        TDK_RCCL(g_rccl.AllGather(L.poses, c->d_poses_all, n, ncclDouble, c->comm, L.stream));
+        TDK_HIP(hipMemcpyAsync(c->h_poses_all, c->d_poses_all, total * sizeof(double), hipMemcpyDeviceToHost, L.stream));
+    }
     TDK_HIP(hipEventRecord(c->done, L.stream));
     c->pending_count = (int64_t)total;
+    c->pending = true;
     return TDK_OK;
 }
 
 tdk_status tdk_dvo_gather_poses_finish(tdk_comm *c, double *poses_all) {
     TDK_REQUIRE(c && poses_all, "null pointer");
-    TDK_REQUIRE(c->pending_count > 0, "no gather in flight");
+    TDK_REQUIRE(c->pending, "no gather in flight");
     TDK_HIP(hipEventSynchronize(c->done));
     memcpy(poses_all, c->h_poses_all, (size_t)c->pending_count * sizeof(double));
     c->pending_count = 0;
+    c->pending = false;
     return TDK_OK;
 }
 

@@ -696,10 +696,11 @@ def fusion_arrays(mu1, mu2, var1, var2):
 
 def rgb2gray(image):
     """skimage.color.rgb2gray as the examples call it: [H,W,3|4] float or uint8 -> [H,W] float64;
-    two-dimensional input is returned as float64 unchanged."""
+    two-dimensional input is returned as float64 with its VALUES unchanged (scikit-image 0.16.2 passes
+    grey images through)."""
     a = np.asarray(image)
     if a.ndim == 2:
-        return _f64(a / 255.0 if a.dtype == np.uint8 else a)
+        return _f64(a)
     if a.ndim != 3 or a.shape[2] not in (3, 4):
         raise ValueError("the input array must have a shape == (.., ..,[ ..,] 3)), got " + str(a.shape))
     H, W, ch = a.shape

@@ -82,6 +82,12 @@ class RcclComm(object):
             _lib.call("tdk_comm_create", buf, self.rank, self.world, C.byref(self._h))
 
     @staticmethod
+    def available():
+        """Raises unless librccl can be opened and has the symbols the C ABI uses."""
+        from tadataka_amd import _lib
+        _lib.call("tdk_comm_available")
+
+    @staticmethod
     def unique_id():
         from tadataka_amd import _lib
         buf = (C.c_uint8 * 128)()
@@ -127,25 +133,113 @@ class RcclComm(object):
             pass
 
 
+def launch_key():
+    """What every rank of ONE launch agrees on without talking: TDK_RENDEZVOUS_KEY if set, else the
+    rendezvous port, the launcher's pid (all ranks share the launcher as parent: torch.distributed.run's
+    agent or bench.py's own spawner) and the launcher's start time -- so a stale directory of a crashed
+    run whose pid and port were reused cannot be mistaken for this one."""
+    key = os.environ.get("TDK_RENDEZVOUS_KEY")
+    if key:
+        return "".join(ch if (ch.isalnum() or ch in "-_.") else "_" for ch in key)
+    ppid = os.getppid()
+    start = "0"
+    try:
+        with open("/proc/%d/stat" % ppid) as f:
+            start = f.read().rsplit(")", 1)[1].split()[19]      # field 22: starttime
+    except (OSError, IndexError):
+        pass
+    return "%s_%d_%s" % (os.environ.get("MASTER_PORT", "0"), ppid, start)
+
+
+def rendezvous_dir():
+    """Private directory (0700) of this launch under TMPDIR."""
+    d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "tdk_rdv_%s" % launch_key())
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    return d
+
+
+def _publish(directory, name, data):
+    """Atomically: readers see nothing or all of `data`.  The file is created exclusively, mode 0600."""
+    tmp = os.path.join(directory, ".%s.%d.tmp" % (name, os.getpid()))
+    fd = os.open(tmp, os.O_CREAT | os.O_EXCL | os.O_WRONLY, 0o600)
+    try:
+        os.write(fd, data)
+    finally:
+        os.close(fd)
+    os.replace(tmp, os.path.join(directory, name))
+
+
+def _collect(directory, names, timeout, what):
+    out, t0 = {}, time.time()
+    for name in names:
+        path = os.path.join(directory, name)
+        while True:
+            try:
+                with open(path, "rb") as f:
+                    out[name] = f.read()
+                break
+            except OSError:
+                pass
+            if time.time() - t0 > timeout:
+                raise RuntimeError("%s: %s did not appear in %s within %.0f s" % (what, name, directory, timeout))
+            time.sleep(0.005)
+    return out
+
+
+def _agree(directory, phase, rank, world, error, payload=b"", timeout=300.0):
+    """Every rank publishes ok (+ payload) or its error for `phase` and reads everybody's: all ranks
+    return the same (errors by rank, payloads by rank) -- the decision what to do next is unanimous."""
+    _publish(directory, "%s_%d" % (phase, rank), (b"ok:" + payload) if error is None else b"fail:" + error.encode())
+    got = _collect(directory, ["%s_%d" % (phase, r) for r in range(world)], timeout, "rendezvous phase '%s'" % phase)
+    errors, payloads = {}, {}
+    for r in range(world):
+        data = got["%s_%d" % (phase, r)]
+        if data.startswith(b"ok:"):
+            payloads[r] = data[3:]
+        else:
+            errors[r] = data[5:].decode("utf-8", "replace")
+    return errors, payloads
+
+
+def _retire(directory, phases, rank, world):
+    """After a barrier that follows the last read: remove this rank's files; the last one out removes the directory."""
+    for phase in phases:
+        try:
+            os.unlink(os.path.join(directory, "%s_%d" % (phase, rank)))
+        except OSError:
+            pass
+    try:
+        os.rmdir(directory)
+    except OSError:
+        pass
+
+
+class TransportUnavailable(RuntimeError):
+    """RCCL could not be brought up; every rank of the launch raises this together."""
+
+
 class FileComm(object):
-    """Last-resort exchange through files in TMPDIR for the FEW BYTES this path ever moves
-    between ranks (poses, a handful of scalars): used only when RCCL cannot be brought up, so that
-    a multi-GPU measurement still completes -- and says so (`kind`).  The estimation itself never
-    goes through here; there is no data-path collective to fall back from."""
+    """Last-resort exchange through files for the FEW BYTES this path ever moves between ranks (poses,
+    a handful of scalars): used only when RCCL cannot be brought up AND the ranks share devices (a
+    smoke test of the multi-process path on a one-GPU box), so that the run still completes -- and
+    says so (`kind`).  The estimation itself never goes through here; there is no data-path collective
+    to fall back from."""
     kind = "file"
 
-    def __init__(self, rank, world, key):
+    def __init__(self, rank, world, directory=None):
         self.rank, self.world = int(rank), int(world)
-        self._dir = os.path.join(os.environ.get("TMPDIR", "/tmp"), "tdk_filecomm_%s" % key)
-        os.makedirs(self._dir, exist_ok=True)
+        self._dir = os.path.join(directory or rendezvous_dir(), "filecomm")
+        os.makedirs(self._dir, mode=0o700, exist_ok=True)
         self._seq = 0
 
     def _exchange(self, array):
         a = np.ascontiguousarray(array, dtype=np.float64)
         self._seq += 1
-        mine = os.path.join(self._dir, "%d_%d.npy" % (self._seq, self.rank))
-        np.save(mine + ".tmp.npy", a)
-        os.replace(mine + ".tmp.npy", mine)
+        name = "%d_%d.npy" % (self._seq, self.rank)
+        tmp = os.path.join(self._dir, ".%s.tmp.npy" % name)
+        np.save(tmp, a)
+        os.chmod(tmp, 0o600)
+        os.replace(tmp, os.path.join(self._dir, name))
         parts, t0 = [], time.time()
         for r in range(self.world):
             path = os.path.join(self._dir, "%d_%d.npy" % (self._seq, r))
@@ -173,72 +267,109 @@ class FileComm(object):
         self._exchange(np.zeros(1))
 
     def close(self):
-        """Removes this rank's files (the peers have read them once they passed the same barrier)."""
+        """Two closing barriers: after the first everybody has read everything that mattered, after
+        the second everybody has read the first's files -- then each rank removes what it wrote and the
+        last one out removes the directories."""
         try:
+            self.barrier()
             self.barrier()
         except RuntimeError:
             pass
-        for seq in range(max(1, self._seq - 2), self._seq):          # everything but the closing barrier's file
+        for seq in range(max(1, self._seq - 3), self._seq):
             try:
                 os.unlink(os.path.join(self._dir, "%d_%d.npy" % (seq, self.rank)))
             except OSError:
                 pass
-
-
-def _rendezvous_path():
-    # all ranks of one launch share the launcher as parent and the rendezvous port
-    key = os.environ.get("TDK_RENDEZVOUS_KEY") or "%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
-    return os.path.join(os.environ.get("TMPDIR", "/tmp"), "tdk_rccl_%s.id" % key)
-
-
-def connect_or_fallback(rank=None, world=None):
-    """connect(); if RCCL cannot be initialised, a FileComm and the reason -- (comm, error or None)."""
-    try:
-        return connect(rank, world), None
-    except Exception as e:                          # noqa: BLE001  (library missing, bootstrap failure, ...)
-        rank = int(os.environ.get("RANK", "0")) if rank is None else rank
-        world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
-        key = "%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
-        return FileComm(rank, world, key), repr(e)
+        # the last barrier's own file may still be read by a slower peer: leave it to the last one out
+        time.sleep(0.05)
+        try:
+            os.unlink(os.path.join(self._dir, "%d_%d.npy" % (self._seq, self.rank)))
+        except OSError:
+            pass
+        for d in (self._dir, os.path.dirname(self._dir)):
+            try:
+                os.rmdir(d)
+            except OSError:
+                pass
 
 
 def connect(rank=None, world=None, timeout=300.0):
-    """The communicator of this process from the launcher's environment (RANK,
-    WORLD_SIZE -- what torch.distributed.run and bench.py's own spawner export).
-    Rank 0 publishes the RCCL unique id in a file keyed by the rendezvous port and
-    the launcher's pid; the others wait for it.  One process: LocalComm."""
+    """The communicator of this process from the launcher's environment (RANK, WORLD_SIZE -- what
+    torch.distributed.run and bench.py's own spawner export).  One process: LocalComm.
+
+    More: the ranks first AGREE, through a private directory of the launch, that every one of them
+    can open RCCL (rank 0 adds the unique id to its message); only then do they call
+    ncclCommInitRank together, and they agree once more on how that went.  A rank that cannot do its
+    part says so instead of leaving the others in a collective that never completes; every rank then
+    raises TransportUnavailable with the same list of reasons."""
     rank = int(os.environ.get("RANK", "0")) if rank is None else rank
     world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
     if world <= 1:
         return LocalComm()
-    path = _rendezvous_path()
-    if rank == 0:
-        uid = RcclComm.unique_id()
-        tmp = path + ".%d.tmp" % os.getpid()
-        with open(tmp, "wb") as f:
-            f.write(uid)
-        os.replace(tmp, path)           # atomic: readers see nothing or all 128 bytes
-    else:
-        t0 = time.time()
-        while True:
-            try:
-                with open(path, "rb") as f:
-                    uid = f.read()
-                if len(uid) == 128:
-                    break
-            except OSError:
-                pass
-            if time.time() - t0 > timeout:
-                raise RuntimeError("rank %d: no RCCL unique id at %s after %.0f s" % (rank, path, timeout))
-            time.sleep(0.02)
-    comm = RcclComm(rank, world, uid)   # collective (ncclCommInitRank): returns once every rank has joined
-    comm.barrier()                      # ... and every rank has therefore read the id
-    if rank == 0:
-        try:
-            os.unlink(path)
-        except OSError:
-            pass
+    d = rendezvous_dir()
+    error, uid = None, b""
+    try:
+        RcclComm.available()
+        if rank == 0:
+            uid = RcclComm.unique_id()
+    except Exception as e:                          # noqa: BLE001
+        error = repr(e)
+    errors, payloads = _agree(d, "ready", rank, world, error, uid, timeout)
+    if errors:
+        _retire_after(d, ("ready",), rank, world, timeout)
+        raise TransportUnavailable("RCCL is not available on rank(s) %s" % errors)
+    comm, error = None, None
+    try:
+        comm = RcclComm(rank, world, payloads[0])   # collective (ncclCommInitRank)
+    except Exception as e:                          # noqa: BLE001
+        error = repr(e)
+    errors, _ = _agree(d, "init", rank, world, error, b"", min(timeout, 120.0))
+    if errors:
+        if comm is not None:
+            comm.close()
+        _retire_after(d, ("ready", "init"), rank, world, timeout)
+        raise TransportUnavailable("ncclCommInitRank failed on rank(s) %s" % errors)
+    comm.barrier()                                  # everybody has read everything
+    _retire(d, ("ready", "init"), rank, world)
     return comm
+
+
+def _retire_after(directory, phases, rank, world, timeout):
+    """On the failure paths there is no communicator to put a barrier behind the last read: one more file round does it."""
+    try:
+        _agree(directory, "bye", rank, world, None, b"", min(timeout, 60.0))
+    except RuntimeError:
+        pass
+    time.sleep(0.05)
+    _retire(directory, tuple(phases) + ("bye",), rank, world)
+
+
+def connect_or_fallback(rank=None, world=None, allow_file_fallback=False):
+    """connect(); (comm, None) -- or, when RCCL cannot be brought up, (FileComm, reason) IF the caller
+    allows it.  It should only when the ranks share devices (bench.py: fewer GPUs than ranks, the
+    one-GPU smoke test of the multi-process path): on a node where every rank has its own GPU a
+    multi-GPU run that silently finished on files would "pass" without ever touching xGMI, so there
+    the failure is raised.  The decision is unanimous (see connect)."""
+    try:
+        return connect(rank, world), None
+    except TransportUnavailable as e:
+        if not allow_file_fallback:
+            raise
+        rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        world = int(os.environ.get("WORLD_SIZE", "1")) if world is None else world
+        return FileComm(rank, world), str(e)
+
+
+def batch_seed0(rank, n_batches, pairs_per_batch, k):
+    """First pair id (= synthetic seed) of batch k of `rank`: a rank owns n_batches consecutive blocks
+    of pairs_per_batch pair ids (bench.py keeps two batches in flight)."""
+    return int(pair_seeds(rank, n_batches * pairs_per_batch)[0]) + k * pairs_per_batch
+
+
+def gathered_seed0s(world, n_batches, pairs_per_batch, k):
+    """First pair id of every block of an all-gather of batch k's poses, in the order the gather
+    returns them (rank order)."""
+    return [batch_seed0(r, n_batches, pairs_per_batch, k) for r in range(world)]
 
 
 def all_gather_poses(local_poses, comm=None):

@@ -84,8 +84,16 @@ def rendezvous_main():
             self.rank, self.world, self.uid = rank, world, bytes(unique_id)
 
         @staticmethod
+        def available():
+            if os.environ.get("TDK_TEST_FAIL_RANK") == os.environ["RANK"]:
+                raise RuntimeError("cannot open librccl.so (simulated)")
+
+        @staticmethod
         def unique_id():
             return bytes(((np.arange(128) * 7 + os.getpid()) % 256).astype(np.uint8))
+
+        def close(self):
+            pass
 
         def barrier(self):              # every rank drops a marker, then waits for all of them
             import time
@@ -97,9 +105,47 @@ def rendezvous_main():
                 time.sleep(0.01)
 
     sharding.RcclComm = FakeComm
-    comm = sharding.connect(timeout=60.0)
-    np.save(sys.argv[2], np.frombuffer(comm.uid, dtype=np.uint8))
-    assert comm.world == int(os.environ["WORLD_SIZE"]) and comm.rank == int(os.environ["RANK"])
+    mode = os.environ.get("TDK_TEST_MODE", "connect")
+    if mode == "connect":
+        comm = sharding.connect(timeout=60.0)
+        np.save(sys.argv[2], np.frombuffer(comm.uid, dtype=np.uint8))
+        assert comm.world == int(os.environ["WORLD_SIZE"]) and comm.rank == int(os.environ["RANK"])
+    elif mode == "must_raise":          # one rank cannot open RCCL: EVERY rank raises, none hangs
+        try:
+            sharding.connect_or_fallback(allow_file_fallback=False)
+        except sharding.TransportUnavailable as e:
+            assert "simulated" in str(e)
+            np.save(sys.argv[2], np.zeros(1))
+        else:
+            raise AssertionError("connect succeeded although a rank had no RCCL")
+    elif mode == "fallback":            # ... or, where ranks share a device, every rank gets the file transport
+        comm, why = sharding.connect_or_fallback(allow_file_fallback=True)
+        assert comm.kind == "file" and "simulated" in why
+        got = comm.all_gather(np.full((1, 12), float(comm.rank)))
+        assert np.array_equal(got[:, 0], np.arange(comm.world))
+        comm.close()
+        np.save(sys.argv[2], got)
+    elif mode == "bench_order":         # bench.py's pair bookkeeping over a real multi-process gather
+        world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+        comm = sharding.FileComm(rank, world)
+        B, n_batches = 3, 2
+        pg = sharding.PoseGather(B, comm)
+        for k in range(3):              # steps 0, 1, 2 use batches 0, 1, 0
+            kb = k % n_batches
+            s0 = sharding.batch_seed0(rank, n_batches, B, kb)
+            poses = np.tile(np.arange(s0, s0 + B, dtype=np.float64)[:, None], (1, 12))   # "pose" = pair id
+            previous = pg.finish() if pg.pending else None
+            pg.start(poses)
+            if previous is not None:
+                want = np.concatenate([np.arange(x, x + B) for x in sharding.gathered_seed0s(world, n_batches, B, (k - 1) % n_batches)])
+                assert np.array_equal(previous[:, 0], want), (k, previous[:, 0], want)
+        last = pg.finish()
+        want = np.concatenate([np.arange(x, x + B) for x in sharding.gathered_seed0s(world, n_batches, B, 0)])
+        assert np.array_equal(last[:, 0], want)
+        total = sharding.reduce_scalars([float(B)], "sum", comm)
+        assert total[0] == world * B
+        comm.close()
+        np.save(sys.argv[2], last)
 
 
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "--rendezvous":

@@ -128,3 +128,28 @@ def test_rust_bindings_type_strictness():
     f = semi_dense.Frame(cp, np.ones((4, 5)), np.eye(4))
     assert f.image.shape == (4, 5) and np.array_equal(f.transform_wf, np.eye(4))
     assert np.array_equal(f.camera_params.focal_length, [1., 2.])
+
+
+def test_skimage_stand_in_is_strict_about_what_it_implements():
+    """tadataka_amd/compat_thirdparty/skimage: unsupported options raise instead of being swallowed, the
+    stand-in is only reachable when scikit-image is missing (or on request), 2-D input of rgb2gray passes
+    through unchanged and integer images are scaled as img_as_float does."""
+    import importlib
+    import sys
+    import tadataka_amd
+    tadataka_amd.install(thirdparty=True)
+    transform = importlib.import_module("skimage.transform")
+    color = importlib.import_module("skimage.color")
+    assert "tadataka_amd" in importlib.import_module("skimage").__version__
+    img = np.zeros((4, 5))
+    with pytest.raises(NotImplementedError):
+        transform.rescale(img, 0.5, order=3)
+    with pytest.raises(NotImplementedError):
+        transform.resize(img, (2, 2), mode="constant")
+    with pytest.raises(TypeError):
+        transform.rescale(img, 0.5, no_such_option=1)
+    g = np.arange(6, dtype=np.uint8).reshape(2, 3)
+    assert color.rgb2gray(g) is g or np.array_equal(color.rgb2gray(g), g)      # grey input: unchanged values
+    assert np.array_equal(transform._as_float(np.array([[0, 255]], dtype=np.uint8)), [[0.0, 1.0]])
+    assert np.array_equal(transform._as_float(np.array([[-128, 127]], dtype=np.int8)), [[-1.0, 1.0]])
+    assert sys.path[-1] == tadataka_amd.THIRDPARTY_DIR or tadataka_amd.THIRDPARTY_DIR in sys.path

@@ -46,40 +46,79 @@ def test_two_rank_gloo_shard_and_gather(tmp_path):
     assert np.array_equal(got["stats"], [2., 3.]) and got["total"][0] == 6.
 
 
-def test_unique_id_rendezvous_without_gpu(tmp_path):
-    """sharding.connect(): rank 0 publishes the 128-byte id in a file keyed by MASTER_PORT and the
-    launcher's pid, the other ranks wait for it, rank 0 removes it -- with a recording stand-in for
-    the RCCL communicator (three ranks, started out of order)."""
-    import glob
-    import time
+def _spawn_ranks(tmp_path, world, port, mode, extra_env=None, order=None):
     worker = os.path.join(REPO, "tests", "_dist_worker.py")
     procs, outs = [], []
-    for rank in (2, 1, 0):                                        # rank 0 last: the others must wait
-        out = str(tmp_path / f"uid{rank}.npy")
+    import time
+    for rank in (order or range(world)):
+        out = str(tmp_path / f"out{rank}.npy")
         outs.append(out)
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="3", MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT="29714", TMPDIR=str(tmp_path))
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TMPDIR=str(tmp_path), TDK_TEST_MODE=mode, **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, worker, "--rendezvous", out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-        if rank != 0:
+        if order:
             time.sleep(0.2)
     for p in procs:
-        stdout, _ = p.communicate(timeout=120)
-        assert p.returncode == 0, stdout[-2000:]
+        stdout, _ = p.communicate(timeout=180)
+        assert p.returncode == 0, stdout[-3000:]
+    return outs
+
+
+def test_unique_id_rendezvous_without_gpu(tmp_path):
+    """sharding.connect(): the ranks agree through a private directory of the launch that all of them
+    can open RCCL (rank 0's message carries the 128-byte id), initialise, agree again, and clean up --
+    with a recording stand-in for the RCCL communicator (three ranks, started out of order)."""
+    import glob
+    outs = _spawn_ranks(tmp_path, 3, 29714, "connect", order=(2, 1, 0))     # rank 0 last: the others must wait
     uids = [np.load(o) for o in outs]
     assert uids[0].shape == (128,) and all(np.array_equal(u, uids[0]) for u in uids)
-    assert glob.glob(str(tmp_path / "tdk_rccl_*")) == []          # rank 0 cleaned up
+    assert glob.glob(str(tmp_path / "tdk_rdv_*")) == []           # the last one out removed the directory
+
+
+def test_one_rank_without_rccl_fails_every_rank_together(tmp_path):
+    """A rank that cannot open librccl says so BEFORE anybody enters ncclCommInitRank: every rank raises
+    TransportUnavailable with the reason (no hang, no mixed transports); where the caller allows the file
+    fallback (ranks sharing a GPU) every rank gets it."""
+    import glob
+    _spawn_ranks(tmp_path, 3, 29715, "must_raise", {"TDK_TEST_FAIL_RANK": "1"})
+    outs = _spawn_ranks(tmp_path, 3, 29716, "fallback", {"TDK_TEST_FAIL_RANK": "0"})   # rank 0 itself fails
+    assert all(np.array_equal(np.load(o)[:, 0], [0, 1, 2]) for o in outs)
+    assert glob.glob(str(tmp_path / "tdk_rdv_*")) == []
+
+
+def test_launch_key_and_stale_directories(tmp_path, monkeypatch):
+    """The rendezvous directory is private (0700), keyed by port + launcher pid + launcher start time (a
+    crashed run that left files behind under a reused pid and port is another directory), and
+    TDK_RENDEZVOUS_KEY overrides it for every transport."""
+    import stat
+    from tadataka_amd import sharding
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    monkeypatch.setenv("MASTER_PORT", "29000")
+    monkeypatch.delenv("TDK_RENDEZVOUS_KEY", raising=False)
+    key = sharding.launch_key()
+    assert key.startswith("29000_%d_" % os.getppid()) and key.split("_")[2] not in ("", "0")
+    d = sharding.rendezvous_dir()
+    assert stat.S_IMODE(os.stat(d).st_mode) == 0o700
+    sharding._publish(d, "ready_0", b"ok:x")
+    assert stat.S_IMODE(os.stat(os.path.join(d, "ready_0")).st_mode) == 0o600
+    monkeypatch.setenv("TDK_RENDEZVOUS_KEY", "my/key 1")
+    assert sharding.launch_key() == "my_key_1" and sharding.rendezvous_dir().endswith("tdk_rdv_my_key_1")
+    c = sharding.FileComm(0, 1)
+    assert "tdk_rdv_my_key_1" in c._dir
+    c.close()
+    assert not os.path.exists(c._dir)
 
 
 def test_file_comm_fallback_three_ranks(tmp_path):
-    """FileComm (what bench.py falls back to when RCCL cannot be initialised): gather / reduce /
-    barrier across three processes."""
+    """FileComm (what bench.py may fall back to when RCCL cannot be initialised and ranks share a GPU):
+    gather / reduce / barrier across three processes, directory removed at the end."""
     code = r'''
 import os, sys, numpy as np
 sys.path.insert(0, %r)
 from tadataka_amd import sharding
 rank = int(os.environ["RANK"])
-c = sharding.FileComm(rank, 3, "t")
+c = sharding.FileComm(rank, 3)
 g = c.all_gather(np.full((2, 12), float(rank)))
 assert g.shape == (6, 12) and np.array_equal(g[:, 0], [0, 0, 1, 1, 2, 2])
 assert np.array_equal(c.all_reduce([rank, 1.0], "sum"), [3.0, 3.0])
@@ -89,9 +128,24 @@ for _ in range(5):
 pg = sharding.PoseGather(2, c)
 pg.start(np.full((2, 12), 10.0 + rank))
 assert np.array_equal(pg.finish()[:, 0], [10, 10, 11, 11, 12, 12])
+c.close()
 ''' % REPO
-    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(os.environ, RANK=str(r), TMPDIR=str(tmp_path)),
+    import glob
+    procs = [subprocess.Popen([sys.executable, "-c", code],
+                              env=dict(os.environ, RANK=str(r), TMPDIR=str(tmp_path), TDK_RENDEZVOUS_KEY="fc3"),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(3)]
     for p in procs:
         out, _ = p.communicate(timeout=120)
         assert p.returncode == 0, out[-2000:]
+    assert glob.glob(str(tmp_path / "tdk_rdv_fc3" / "filecomm" / "*.npy")) == []
+
+
+def test_bench_pair_bookkeeping_world_8(tmp_path):
+    """bench.py's sharding arithmetic end to end over eight real processes: every rank owns two
+    consecutive blocks of pair ids (two batches in flight), the gather of step k is collected after step
+    k + 1, and rank 0 compares the gathered poses with the blocks `gathered_seed0s` names, in rank order."""
+    outs = _spawn_ranks(tmp_path, 8, 29717, "bench_order", {"TDK_RENDEZVOUS_KEY": "w8"})
+    last = np.load(outs[0])
+    assert last.shape == (24, 12)
+    assert np.array_equal(last[:, 0], np.concatenate([np.arange(6 * r, 6 * r + 3) for r in range(8)]))
+    assert all(np.array_equal(np.load(o), last) for o in outs)
