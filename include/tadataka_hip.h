@@ -185,6 +185,11 @@ tdk_status tdk_dvo_get_warnings(tdk_dvo *h, int *too_large);
  * calls whose normal equations were formed and solved (vo/dvo/__init__.py:46-70; n per level and
  * pair).  One "DVO iter" of the metric = one update + one error.  Either pointer may be NULL. */
 tdk_status tdk_dvo_get_counts(tdk_dvo *h, int64_t *error_pixels, int64_t *update_pixels);
+/* Diagnostic of the Tukey weights (weights.py:21-35): the two medians of an evaluation come from sampled
+ * brackets + one pass over the residuals; a pair whose order statistics fall outside its brackets (or whose
+ * bracket overflows) is redone by an exact radix select over its residual map.  *pairs = how often that
+ * happened since the batch was created (the results are the same doubles either way). */
+tdk_status tdk_dvo_get_tukey_fallbacks(tdk_dvo *h, int64_t *pairs);
 /* The hipStream_t every launch and copy of this batch is queued on.  Each batch
  * owns its stream: calls on different batches overlap on the device (e.g. the
  * HBM-bound pyramid of one batch under the FP64-bound estimation of another). */

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "tdk_dvo_get_stream": [_vp, C.POINTER(_vp)],
     "tdk_dvo_get_warnings": [_vp, c_int_p],
     "tdk_dvo_get_counts": [_vp, c_int64_p, c_int64_p],
+    "tdk_dvo_get_tukey_fallbacks": [_vp, c_int64_p],
     "tdk_dvo_set_profiling": [_vp, _i],
     "tdk_dvo_get_profile": [_vp, c_int64_p, _d, c_int64_p],
     "tdk_dvo_get_profile_kind": [_vp, _i, c_int64_p, _d, c_int64_p],

@@ -752,12 +752,67 @@ __device__ __forceinline__ double fast_rcp(double a) {
 // the pose (in range & z > 0), NaN elsewhere; count[pair] = mask size.
 // STUDENT: the first step of the Student-t fixed point (variance 1: s (nu + 1) / (nu + s)) rides along -- its
 // block partials go where k_robust_student_step leaves them -- so the residual map is read nine times, not ten.
-template <bool STUDENT, bool FAST>
+constexpr int kTukeySample = 2048;      // sorted sample per pair (one block, LDS)
+constexpr int kTukeyThreads = 1024;
+constexpr double kTukeySigmas = 5.0;
+constexpr int kBandBuf = 1024;          // residuals a block of the collecting passes gathers in LDS before one global append
+
+struct TukeyBracket {
+    double lo, hi;                  // the median lies in [lo, hi]
+    double med;                     // ... the exact median, once it is known
+    double dlo, dhi;                // the MAD lies in [dlo, dhi]
+    unsigned int below, n_med;      // residuals < lo; residuals collected from [lo, hi]
+    unsigned int small, n_dev;      // deviations < dlo; deviations collected from [dlo, dhi]
+    unsigned int overflow, n_sample;   // n_sample: top bit = the sample holds every pixel
+};
+
+// A block gathers the values it collects in LDS (`buf`, `buf_n`: wave-aggregated LDS atomics) and appends them
+// to the pair's band with ONE global atomic (band_flush) -- a global atomic per wave and step put thousands of
+// them on one address per pair and tripled the time of the pass.  Values beyond the buffer go out directly.
+__device__ __forceinline__ void band_append(bool take, double v, double *buf, unsigned int *buf_n, unsigned int *g_count,
+                                            double *band, unsigned int cap, unsigned int *overflow) {
+    const uint64_t m = __builtin_amdgcn_ballot_w64(take);
+    if (m == 0) return;
+    const int lane = threadIdx.x & 63, leader = __builtin_ctzll(m);
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(buf_n, (unsigned int)__builtin_popcountll(m));
+    base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+    if (take) {
+        const unsigned int slot = base + (unsigned int)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        if (slot < (unsigned int)kBandBuf) buf[slot] = v;
+        else {
+            const unsigned int g = atomicAdd(g_count, 1u);
+            if (g < cap) band[g] = v;
+            else *overflow = 1u;
+        }
+    }
+}
+
+__device__ __forceinline__ void band_flush(const double *buf, const unsigned int *buf_n, unsigned int *shared_base,
+                                           unsigned int *g_count, double *band, unsigned int cap, unsigned int *overflow) {
+    __syncthreads();
+    const unsigned int n = *buf_n < (unsigned int)kBandBuf ? *buf_n : (unsigned int)kBandBuf;
+    if (threadIdx.x == 0) *shared_base = n ? atomicAdd(g_count, n) : 0u;
+    __syncthreads();
+    const unsigned int base = *shared_base;
+    for (unsigned int i = threadIdx.x; i < n; i += blockDim.x) {
+        if (base + i < cap) band[base + i] = buf[i];
+        else *overflow = 1u;
+    }
+}
+
+struct TukeyArgs {            // TUKEY: brackets of every pair and the band the pass collects into (see k_tukey_sample)
+    TukeyBracket *brackets;
+    double *med_bands;
+    unsigned int cap;         // doubles per pair in a band
+};
+
+template <bool STUDENT, bool FAST, bool TUKEY>
 __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairParams *__restrict__ params,
                                                         const double *__restrict__ poses,
                                                         const int *__restrict__ state, double scale,
                                                         double *__restrict__ rm, int *__restrict__ count,
-                                                        double *__restrict__ partial) {
+                                                        double *__restrict__ partial, TukeyArgs tka) {
     const int pair = blockIdx.y;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
     BlockSetup b;
@@ -769,7 +824,25 @@ __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairP
     double *__restrict__ out = rm + base;
     int local = 0;
     double acc = 0.0;
+    __shared__ double band_buf[TUKEY ? kBandBuf : 1];
+    __shared__ unsigned int band_n, band_base;
+    TukeyBracket tb;
+    unsigned int tk_below = 0;
+    double *med_band = nullptr;
+    TukeyBracket *tg = nullptr;
+    if (TUKEY) {
+        tb = tka.brackets[pair];
+        tg = tka.brackets + pair;
+        med_band = tka.med_bands + (size_t)pair * tka.cap;
+        if (threadIdx.x == 0) band_n = 0;
+        __syncthreads();
+    }
     auto term = [&](double r, bool in) {
+        if (TUKEY) {        // residuals below the median's bracket are counted, those inside collected
+            const bool lt = in && r < tb.lo;
+            tk_below += lt ? 1u : 0u;
+            band_append(in && !lt && r <= tb.hi, r, band_buf, &band_n, &tg->n_med, med_band, tka.cap, &tg->overflow);
+        }
         if (STUDENT && in) {
             const double sq = r * r;
             if (FAST) acc += sq * ((kStudentNu + 1.0) * fast_rcp(kStudentNu + sq));
@@ -803,17 +876,27 @@ __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairP
         y += step_y;
         if (x >= W) { x -= W; y += 1; }
     }
-    if (i < N) {                                        // odd N: the last pixel
-        Pixel p;
-        sp_warp(p, true, tab[x], tab[W + y], D0[i], H, W, b.P, b.c);
-        const bool in = p.mask == 2;
-        const double r = I0[i] - I1[i];
-        out[i] = in ? r : nan;
-        term(r, in);
-        local += in ? 1 : 0;
+    {                                                   // odd N: the last pixel (one lane of the grid has i == N - 1)
+        const bool tail = i < N;                        // the wave votes together (the Tukey bands are appended by ballot)
+        bool in = false;
+        double r = 0.0;
+        if (tail) {
+            Pixel p;
+            sp_warp(p, true, tab[x], tab[W + y], D0[i], H, W, b.P, b.c);
+            in = p.mask == 2;
+            r = I0[i] - I1[i];
+            out[i] = in ? r : nan;
+            local += in ? 1 : 0;
+        }
+        if (TUKEY || tail) term(r, in);
     }
     for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(&count[pair], local);
+    if (TUKEY) {
+        for (int off = 32; off > 0; off >>= 1) tk_below += __shfl_down(tk_below, off, 64);
+        if ((threadIdx.x & 63) == 0 && tk_below) atomicAdd(&tg->below, tk_below);
+        band_flush(band_buf, &band_n, &band_base, &tg->n_med, med_band, tka.cap, &tg->overflow);
+    }
     if (STUDENT) {
         __shared__ double red[kWaves];
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
@@ -898,6 +981,15 @@ constexpr int kSelectPasses = 5, kSelectBins = 8192;
 __host__ __device__ constexpr int select_shift(int pass) { return pass < 4 ? 51 - 13 * pass : 0; }
 __host__ __device__ constexpr int select_bits(int pass) { return pass < 4 ? 13 : 12; }
 
+// Where a pair's values come from: the residual map (the default), or -- Tukey's brackets -- the few per cent of
+// them a pass has collected around the wanted order statistic, whose rank then counts from `rank_offset`.
+struct SelectSrc {
+    const double *data;
+    int n, mode;                   // mode 1: |value - center|
+    double center;
+    unsigned int rank_offset, pad;
+};
+
 struct SelectState {
     uint64_t prefix, rank;
     uint64_t next_key;             // successor pass: smallest key above the selected one
@@ -907,18 +999,21 @@ struct SelectState {
     uint64_t min_above;            // smallest key whose 26-bit prefix is larger than the selected one
     unsigned int group;            // number of keys that share the 26-bit prefix
     unsigned int n_cand;           // keys collected so far
-    unsigned int done, pad;        // the median of this pair is final
+    unsigned int done, rank0;      // the median of this pair is final; rank of the lower middle order statistic in the source
 };
 constexpr int kSelectCap = 2048;   // candidates kept per pair; a larger group takes all five digit passes
 
 // rank of the LOWER middle order statistic; np.median averages it with its
 // successor when the count is even
-__global__ void k_select_init(SelectState *st, const int *__restrict__ count, int n_pairs) {
+__global__ void k_select_init(SelectState *st, const int *__restrict__ count, const SelectSrc *__restrict__ src,
+                              int n_pairs) {
     int pair = blockIdx.x * blockDim.x + threadIdx.x;
     if (pair >= n_pairs) return;
     int m = count[pair];
     st[pair].prefix = 0;
-    st[pair].rank = (uint64_t)(m > 0 ? (m - 1) / 2 : 0);
+    const unsigned int off = src ? src[pair].rank_offset : 0u;
+    st[pair].rank = (uint64_t)(m > 0 ? (unsigned int)((m - 1) / 2) - off : 0u);
+    st[pair].rank0 = (unsigned int)st[pair].rank;
     st[pair].next_key = ~0ull;
     st[pair].count_le = 0;
     st[pair].even = (m > 0 && (m & 1) == 0) ? 1u : 0u;
@@ -926,6 +1021,17 @@ __global__ void k_select_init(SelectState *st, const int *__restrict__ count, in
     st[pair].group = 0;
     st[pair].n_cand = 0;
     st[pair].done = 0;
+}
+
+__device__ __forceinline__ void select_source(const SelectSrc *__restrict__ src, int pair, const double *__restrict__ rm,
+                                              int64_t stride, const double *__restrict__ center, const double *&r, int &N,
+                                              int &mode, double &cen) {
+    if (src) {
+        r = src[pair].data; N = src[pair].n; mode = src[pair].mode; cen = src[pair].center;
+    } else {
+        r = rm + (int64_t)pair * stride;
+        cen = mode ? center[pair] : 0.0;
+    }
 }
 
 // values: rm (mode 0) or |rm - center[pair]| (mode 1, for the MAD)
@@ -943,6 +1049,7 @@ __device__ __forceinline__ bool select_key(const double *r, int i, int mode, dou
 __global__ __launch_bounds__(kBlock) void k_select_hist(const double *__restrict__ rm, int64_t stride, int N,
                                                         const int *__restrict__ state, int mode,
                                                         const double *__restrict__ center,
+                                                        const SelectSrc *__restrict__ src,
                                                         const SelectState *__restrict__ st, int pass,
                                                         unsigned int *__restrict__ hist) {
     const int pair = blockIdx.y;
@@ -955,8 +1062,9 @@ __global__ __launch_bounds__(kBlock) void k_select_hist(const double *__restrict
     const unsigned int digit_mask = (1u << select_bits(pass)) - 1u;
     const uint64_t prefix = st[pair].prefix;
     const uint64_t mask = pass == 0 ? 0ull : (~0ull << select_shift(pass - 1));
-    const double cen = mode ? center[pair] : 0.0;
-    const double *r = rm + (int64_t)pair * stride;
+    const double *r;
+    double cen;
+    select_source(src, pair, rm, stride, center, r, N, mode, cen);
     const int lane = threadIdx.x & 63;
     for (int i0 = blockIdx.x * kBlock; i0 < N; i0 += gridDim.x * kBlock) {
         const int i = i0 + (int)threadIdx.x;
@@ -1027,6 +1135,7 @@ __global__ __launch_bounds__(kBlock) void k_select_pick(unsigned int *__restrict
 __global__ __launch_bounds__(kBlock) void k_select_collect(const double *__restrict__ rm, int64_t stride, int N,
                                                            const int *__restrict__ state, int mode,
                                                            const double *__restrict__ center,
+                                                           const SelectSrc *__restrict__ src,
                                                            SelectState *__restrict__ st,
                                                            uint64_t *__restrict__ cand, int pass) {
     const int pair = blockIdx.y;
@@ -1034,8 +1143,9 @@ __global__ __launch_bounds__(kBlock) void k_select_collect(const double *__restr
     if (st[pair].done || st[pair].group > (unsigned int)kSelectCap) return;    // the digit passes go on instead
     const int shift = select_shift(pass);
     const uint64_t group_prefix = st[pair].prefix >> shift;
-    const double cen = mode ? center[pair] : 0.0;
-    const double *r = rm + (int64_t)pair * stride;
+    const double *r;
+    double cen;
+    select_source(src, pair, rm, stride, center, r, N, mode, cen);
     uint64_t *mine = cand + (size_t)pair * kSelectCap;
     uint64_t above = ~0ull;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
@@ -1098,13 +1208,15 @@ __global__ __launch_bounds__(kBlock) void k_select_finish(SelectState *__restric
 __global__ __launch_bounds__(kBlock) void k_select_successor(const double *__restrict__ rm, int64_t stride, int N,
                                                              const int *__restrict__ state, int mode,
                                                              const double *__restrict__ center,
+                                                             const SelectSrc *__restrict__ src,
                                                              SelectState *__restrict__ st) {
     const int pair = blockIdx.y;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
     if (st[pair].done || !st[pair].even) return;     // odd count: the median is the selected key itself
     const uint64_t sel = st[pair].prefix;
-    const double cen = mode ? center[pair] : 0.0;
-    const double *r = rm + (int64_t)pair * stride;
+    const double *r;
+    double cen;
+    select_source(src, pair, rm, stride, center, r, N, mode, cen);
     unsigned int le = 0;
     uint64_t next = ~0ull;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < N; i += gridDim.x * kBlock) {
@@ -1136,10 +1248,345 @@ __global__ void k_median_combine(const SelectState *__restrict__ st, const int *
     const double lo = key_to_double(st[pair].prefix);
     double hi = lo;
     if (st[pair].even) {
-        const unsigned int lower_rank = (unsigned int)((count[pair] - 1) / 2);
+        const unsigned int lower_rank = st[pair].rank0;     // in the source the keys were counted in
         if (st[pair].count_le < lower_rank + 2) hi = key_to_double(st[pair].next_key);
     }
     out[pair] = factor * ((lo + hi) / 2.0);
+}
+
+// ---------------------------------------------------------------------------
+// Tukey's two medians (median of the masked residuals, median of their absolute deviations from it,
+// tadataka/robust/weights.py:21-35): the digit-by-digit selection above, run on a few per cent of the data.
+//
+// On the whole residual map the radix select costs 2 x (2-3 histogram passes + a collect pass) per evaluation.
+// A sorted SAMPLE of the pair's masked residuals (k_tukey_sample: 2048 pixels spread over the frame, evaluated
+// and sorted by one block) brackets the median: [lo, hi] holds it with the rank of +-5 standard deviations of a
+// sample quantile to spare, ~11 % of the residuals.  The mask pass, which produces every residual anyway,
+// counts those below lo and collects those in [lo, hi] (k_robust_mask<.., TUKEY>); the selection kernels then
+// run on the collected band with the rank counted from `below` (SelectSrc) -- the same kernels, the same
+// tie / even-count handling, a tenth of the data.  The MAD repeats this with the sample's deviations from the
+// now exact median (k_tukey_dev_bracket) and one 8-byte-per-pixel pass over the residual map
+// (k_tukey_deviations).  A pair whose order statistic turns out to lie outside its bracket (a 1e-6 event by
+// construction) or whose band overflows (huge tie groups) gets the whole residual map as its source instead
+// (k_tukey_plan): slower, same kernels, exact.  Either way the result is the very double the plain radix path
+// returns, so the weights are bit-identical.
+// (Two variants were built first and lost: a single pass that brackets the MAD for ANY median in [lo, hi] --
+// the median's uncertainty widens the MAD band to ~23 % of the residuals, every band overflowed; and finishing
+// by one block per pair that sorts 16384-element bands in LDS -- 200-300 us per kernel, slower than the radix
+// path it was to replace.)
+// ---------------------------------------------------------------------------
+
+// bitonic sort of keys[0 .. n) (n a power of two) in LDS by the whole block, ascending
+__device__ __forceinline__ void block_bitonic_sort(uint64_t *keys, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < (n >> 1); t += blockDim.x) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), p = i | j;
+                const uint64_t a = keys[i], b = keys[p];
+                const bool up = (i & k) == 0;
+                if ((a > b) == up) { keys[i] = b; keys[p] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ int next_pow2(int v) {
+    int n = 1;
+    while (n < v) n <<= 1;
+    return n;
+}
+
+// masked residual of pixel i at the pair's pose (the arithmetic of k_robust_mask)
+__device__ __forceinline__ bool masked_residual(const LevelPtrs &L, const BlockSetup &b, const double *__restrict__ tab,
+                                                int64_t base, int i, double &r) {
+    const int W = L.W, H = L.H;
+    const int y = i / W, x = i - y * W;
+    Pixel p;
+    sp_warp(p, true, tab[x], tab[W + y], L.D0[base + i], H, W, b.P, b.c);
+    r = L.I0[base + i] - L.I1[base + i];
+    return p.mask == 2;
+}
+
+// ranks r_lo < r_hi of a sample of `ms` values that bracket its lower / upper middle order statistic by
+// kTukeySigmas standard deviations of a sample quantile's rank (sqrt(ms) / 2), one more for good measure
+__device__ __forceinline__ void bracket_ranks(int ms, bool exhaustive, int &r_lo, int &r_hi) {
+    const double g = exhaustive ? 0.0 : kTukeySigmas * 0.5 * sqrt((double)ms) + 1.0;
+    r_lo = (int)floor((double)((ms - 1) / 2) - g);
+    r_hi = (int)ceil((double)(ms / 2) + g);
+}
+
+__global__ __launch_bounds__(kTukeyThreads) void k_tukey_sample(LevelPtrs L, const PairParams *__restrict__ params,
+                                                                 const double *__restrict__ poses,
+                                                                 const int *__restrict__ state, double scale,
+                                                                 TukeyBracket *__restrict__ out,
+                                                                 double *__restrict__ samples) {
+    __shared__ uint64_t keys[kTukeySample];
+    __shared__ int s_valid;
+    const int pair = blockIdx.x;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    BlockSetup b;
+    load_setup(b, params, poses, pair, scale);
+    const int64_t base = (int64_t)pair * L.stride;
+    const int N = (int)L.N;
+    const double *__restrict__ tab = L.tab + (size_t)pair * (L.W + L.H);
+    const int m = N < kTukeySample ? N : kTukeySample;        // samples (all pixels of a small level)
+    const int n_sort = next_pow2(m);
+    if (threadIdx.x == 0) s_valid = 0;
+    __syncthreads();
+    int valid = 0;
+    for (int j = threadIdx.x; j < n_sort; j += blockDim.x) {
+        uint64_t key = ~0ull;                                  // outside the mask / padding: sorts last
+        if (j < m) {
+            const int i = (int)(((int64_t)j * N) / m);          // spread over the whole frame
+            double r;
+            if (masked_residual(L, b, tab, base, i, r)) { key = ordered_key(r); valid++; }
+        }
+        keys[j] = key;
+    }
+    for (int off = 32; off > 0; off >>= 1) valid += __shfl_down(valid, off, 64);
+    if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&s_valid, valid);
+    __syncthreads();
+    const int ms = s_valid;
+    block_bitonic_sort(keys, n_sort);
+    double *__restrict__ mine = samples + (size_t)pair * kTukeySample;
+    for (int j = threadIdx.x; j < ms; j += blockDim.x) mine[j] = key_to_double(keys[j]);   // for k_tukey_dev_bracket
+    if (threadIdx.x != 0) return;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    int r_lo, r_hi;
+    bracket_ranks(ms, m == N, r_lo, r_hi);
+    TukeyBracket t;
+    t.lo = (ms > 0 && r_lo >= 0) ? key_to_double(keys[r_lo]) : -inf;
+    t.hi = (ms > 0 && r_hi < ms) ? key_to_double(keys[r_hi]) : inf;
+    t.med = 0.0; t.dlo = 0.0; t.dhi = inf;
+    t.below = 0; t.n_med = 0; t.small = 0; t.n_dev = 0; t.overflow = 0;
+    t.n_sample = (unsigned int)ms | (m == N ? 0x80000000u : 0u);
+    out[pair] = t;
+}
+
+// Source of the selection that follows a collecting pass: the collected band if the wanted order statistics lie
+// inside it, the whole residual map otherwise.  which = 0: median (band of residuals, ranks from `below`);
+// 1: MAD (band of deviations, ranks from `small`; the map itself is read as |r - median|).
+__global__ void k_tukey_plan(const TukeyBracket *__restrict__ tk, const int *__restrict__ count,
+                             const int *__restrict__ state, int which, const double *__restrict__ rm, int64_t stride,
+                             int N, const double *__restrict__ bands, unsigned int cap, const double *__restrict__ median,
+                             int force_fallback, SelectSrc *__restrict__ src, unsigned int *__restrict__ n_fallback,
+                             int n_pairs) {
+    const int pair = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pair >= n_pairs) return;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    const TukeyBracket t = tk[pair];
+    const int n = count[pair];
+    const uint64_t k1 = n > 0 ? (uint64_t)(n - 1) / 2 : 0, k2 = n > 0 ? (uint64_t)n / 2 : 0;
+    const unsigned int off = which ? t.small : t.below, c = which ? t.n_dev : t.n_med;
+    const bool ok = !force_fallback && n > 0 && !t.overflow && c <= cap && k1 >= off && k2 < (uint64_t)off + c;
+    SelectSrc s;
+    if (ok) {
+        s.data = bands + (size_t)pair * cap; s.n = (int)c; s.mode = 0; s.center = 0.0; s.rank_offset = off;
+    } else {
+        s.data = rm + (int64_t)pair * stride; s.n = N; s.mode = which; s.center = which ? median[pair] : 0.0;
+        s.rank_offset = 0;
+        if (n > 0 && n_fallback) atomicAdd(n_fallback, 1u);
+    }
+    s.pad = 0;
+    src[pair] = s;
+}
+
+// k-th smallest (0-based) value of a pair's source: 8-bit MSD radix select by ONE block, histogram in LDS.
+// The source is a collected band (a few ten thousand values: ~10 us) or, for a pair whose bracket failed, the
+// whole residual map (slower, rare).  Values crowd into one or two bins of the leading digits: a wave whose
+// lanes all hit one bin adds its count once instead of serialising 64 LDS atomics on one address.
+__device__ uint64_t block_radix_select(const double *__restrict__ r, int N, int mode, double cen, uint64_t rank,
+                                       unsigned int *hist, uint64_t *sh) {
+    __shared__ unsigned int wave_tot[4];
+    uint64_t prefix = 0;
+    const int lane = threadIdx.x & 63;
+    for (int pass = 0; pass < 8; pass++) {
+        const int shift = 56 - 8 * pass;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        // four independent loads per thread and step: the band comes from L2, one load at a time is all latency
+        for (int i0 = 0; i0 < N; i0 += 4 * blockDim.x) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * (int)blockDim.x + (int)threadIdx.x;
+                v[u] = i < N ? r[i] : __longlong_as_double(0x7ff8000000000000ll);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool valid = v[u] == v[u];
+                const uint64_t k = ordered_key(mode ? fabs(v[u] - cen) : v[u]);
+                const bool hit = valid && (pass == 0 || (k >> (shift + 8)) == (prefix >> (shift + 8)));
+                const unsigned int bin = (unsigned int)(k >> shift) & 255u;
+                const uint64_t hits = __builtin_amdgcn_ballot_w64(hit);
+                if (hits == 0) continue;
+                const int leader = __builtin_ctzll(hits);
+                const unsigned int lb = (unsigned int)__builtin_amdgcn_readlane((int)bin, leader);
+                if (__builtin_amdgcn_ballot_w64(hit && bin == lb) == hits) {
+                    if (lane == leader) atomicAdd(&hist[lb], (unsigned int)__builtin_popcountll(hits));
+                } else if (hit) {
+                    atomicAdd(&hist[bin], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        // the bin that holds the rank: inclusive scan of the 256 counts by the first four waves (shuffles inside a
+        // wave, the three wave totals through LDS) -- a serial walk by one thread cost 16 000 cycles per pass
+        unsigned int inc = 0, mine = 0;
+        if (threadIdx.x < 256) {
+            mine = hist[threadIdx.x];
+            inc = mine;
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned int o = __shfl_up(inc, off, 64);
+                if (lane >= off) inc += o;
+            }
+            if (lane == 63) wave_tot[threadIdx.x >> 6] = inc;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            unsigned int before = 0;
+            for (int w = 0; w < (int)(threadIdx.x >> 6); w++) before += wave_tot[w];
+            inc += before;
+            const uint64_t excl = (uint64_t)(inc - mine);
+            const bool last = threadIdx.x == 255;
+            if ((rank >= excl && rank < (uint64_t)inc) || (last && rank >= (uint64_t)inc)) {   // exactly one thread
+                sh[0] = prefix | ((uint64_t)threadIdx.x << shift);
+                sh[1] = rank - excl;
+            }
+        }
+        __syncthreads();
+        prefix = sh[0];
+        rank = sh[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// np.median of a pair's source: the mean of the two middle order statistics (the same one twice for an odd
+// count), ranks counted from the source's offset; times `factor`
+__global__ __launch_bounds__(kTukeyThreads) void k_band_median(const SelectSrc *__restrict__ src,
+                                                                const int *__restrict__ count,
+                                                                const int *__restrict__ state, double factor,
+                                                                double *__restrict__ out) {
+    __shared__ unsigned int hist[256];
+    __shared__ uint64_t sh[2];
+    const int pair = blockIdx.x;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    const int n = count[pair];
+    if (n <= 0) {                                      // empty update mask: the evaluation flags it, any value will do
+        if (threadIdx.x == 0) out[pair] = factor;
+        return;
+    }
+    const SelectSrc s = src[pair];
+    const uint64_t k1 = (uint64_t)(n - 1) / 2 - s.rank_offset, k2 = (uint64_t)n / 2 - s.rank_offset;
+    const uint64_t sel = block_radix_select(s.data, s.n, s.mode, s.center, k1, hist, sh);
+    const double lo = key_to_double(sel);
+    double hi = lo;
+    if (k2 != k1) {
+        // even count: the next order statistic is the selected key again if more than k1 + 1 values are <= it,
+        // else the smallest key above it -- one more sweep instead of a second selection
+        __shared__ unsigned int s_le;
+        __shared__ unsigned long long s_next;
+        if (threadIdx.x == 0) { s_le = 0; s_next = ~0ull; }
+        __syncthreads();
+        unsigned int le = 0;
+        uint64_t next = ~0ull;
+        for (int i0 = 0; i0 < s.n; i0 += 4 * blockDim.x) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + u * (int)blockDim.x + (int)threadIdx.x;
+                v[u] = i < s.n ? s.data[i] : __longlong_as_double(0x7ff8000000000000ll);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (v[u] != v[u]) continue;
+                const uint64_t k = ordered_key(s.mode ? fabs(v[u] - s.center) : v[u]);
+                if (k <= sel) le++;
+                else if (k < next) next = k;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            le += __shfl_down(le, off, 64);
+            const uint64_t o = __shfl_down(next, off, 64);
+            next = o < next ? o : next;
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (le) atomicAdd(&s_le, le);
+            if (next != ~0ull) atomicMin(&s_next, (unsigned long long)next);
+        }
+        __syncthreads();
+        if ((uint64_t)s_le < k1 + 2) hi = key_to_double((uint64_t)s_next);
+    }
+    if (threadIdx.x == 0) out[pair] = factor * ((lo + hi) / 2.0);
+}
+
+// the MAD's bracket: the sample's deviations from the exact median, sorted
+__global__ __launch_bounds__(kTukeyThreads) void k_tukey_dev_bracket(const int *__restrict__ state,
+                                                                      TukeyBracket *__restrict__ tk,
+                                                                      const double *__restrict__ samples,
+                                                                      const double *__restrict__ median) {
+    __shared__ uint64_t keys[kTukeySample];
+    const int pair = blockIdx.x;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    const unsigned int ns = tk[pair].n_sample;
+    const int ms = (int)(ns & 0x7fffffffu);
+    const bool exhaustive = (ns & 0x80000000u) != 0;
+    const double med = median[pair];
+    const int nsort = next_pow2(ms > 0 ? ms : 1);
+    const double *__restrict__ mine = samples + (size_t)pair * kTukeySample;
+    for (int j = threadIdx.x; j < nsort; j += blockDim.x) keys[j] = j < ms ? ordered_key(fabs(mine[j] - med)) : ~0ull;
+    __syncthreads();
+    block_bitonic_sort(keys, nsort);
+    if (threadIdx.x != 0) return;
+    const double inf = __longlong_as_double(0x7ff0000000000000ll);
+    int r_lo, r_hi;
+    bracket_ranks(ms, exhaustive, r_lo, r_hi);
+    TukeyBracket *g = tk + pair;
+    g->med = med;
+    g->dlo = (ms > 0 && r_lo >= 0) ? key_to_double(keys[r_lo]) : 0.0;
+    g->dhi = (ms > 0 && r_hi < ms) ? key_to_double(keys[r_hi]) : inf;
+    g->overflow = 0;
+}
+
+// one 8-byte-per-pixel pass over the residual map: deviations below the bracket are counted, those inside collected
+__global__ __launch_bounds__(kBlock) void k_tukey_deviations(const double *__restrict__ rm, int64_t stride, int N,
+                                                             const int *__restrict__ state,
+                                                             TukeyBracket *__restrict__ tk,
+                                                             double *__restrict__ dev_bands, unsigned int cap) {
+    __shared__ double band_buf[kBandBuf];
+    __shared__ unsigned int band_n, band_base;
+    const int pair = blockIdx.y;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    const TukeyBracket t = tk[pair];
+    const double *__restrict__ r = rm + (int64_t)pair * stride;
+    double *__restrict__ band = dev_bands + (size_t)pair * cap;
+    TukeyBracket *g = tk + pair;
+    if (threadIdx.x == 0) band_n = 0;
+    __syncthreads();
+    unsigned int small = 0;
+    auto one = [&](double v) {
+        const bool in = v == v;
+        const double d = fabs(v - t.med);
+        const bool sm = in && d < t.dlo;
+        small += sm ? 1u : 0u;
+        band_append(in && !sm && d <= t.dhi, d, band_buf, &band_n, &g->n_dev, band, cap, &g->overflow);
+    };
+    const int N2 = N >> 1;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int i0 = blockIdx.x * kBlock; i0 < N2; i0 += gridDim.x * kBlock) {
+        const int i = i0 + (int)threadIdx.x;
+        double2_u v;
+        v.x = v.y = nan;
+        if (i < N2) v = *reinterpret_cast<const double2_u *>(r + 2 * (int64_t)i);
+        one(v.x);
+        one(v.y);
+    }
+    if ((N & 1) && blockIdx.x == 0) one(threadIdx.x == 0 ? r[N - 1] : nan);
+    for (int off = 32; off > 0; off >>= 1) small += __shfl_down(small, off, 64);
+    if ((threadIdx.x & 63) == 0 && small) atomicAdd(&g->small, small);
+    band_flush(band_buf, &band_n, &band_base, &g->n_dev, band, cap, &g->overflow);
 }
 
 // ---- synthetic scene on the device (tadataka_amd/synthetic.py) ------------
@@ -1212,6 +1659,12 @@ struct tdk_dvo {
     void *d_select;       // SelectState[n]
     unsigned int *d_hist; // [n][kSelectBins]
     uint64_t *d_cand;     // [n][kSelectCap] keys that share 26 bits with the median
+    TukeyBracket *d_tk;   // [n] Tukey: brackets + counters (k_tukey_sample)
+    double *d_tk_med, *d_tk_dev;   // [n][tk_cap] residuals / deviations collected from the median / MAD brackets
+    unsigned int tk_cap;           // doubles per pair in a band: a quarter of the frame
+    void *d_tk_src;                // SelectSrc[n]
+    double *d_tk_sample;           // [n][kTukeySample] sorted sample of the masked residuals
+    unsigned int *d_tk_fallback;   // [1] pairs that took the exact radix path of k_tukey_finish (diagnostic)
     // profiling of the finest-level evaluation kernel (bench.py roofline leg)
     bool profiling;
     std::vector<hipEvent_t> ev_pool;
@@ -1315,6 +1768,14 @@ tdk_status ensure_robust_buffers(tdk_dvo *h) {
     TDK_HIP(hipMalloc(&h->d_count, sizeof(int) * n));
     TDK_HIP(hipMalloc(&h->d_select, sizeof(SelectState) * n));
     TDK_HIP(hipMalloc(&h->d_cand, sizeof(uint64_t) * kSelectCap * n));
+    TDK_HIP(hipMalloc(&h->d_tk, sizeof(TukeyBracket) * n));
+    h->tk_cap = (unsigned int)(h->lv[0].N / 4 > 8192 ? h->lv[0].N / 4 : 8192);
+    TDK_HIP(hipMalloc(&h->d_tk_med, sizeof(double) * (size_t)h->tk_cap * n));
+    TDK_HIP(hipMalloc(&h->d_tk_dev, sizeof(double) * (size_t)h->tk_cap * n));
+    TDK_HIP(hipMalloc(&h->d_tk_src, sizeof(SelectSrc) * n));
+    TDK_HIP(hipMalloc(&h->d_tk_sample, sizeof(double) * kTukeySample * n));
+    TDK_HIP(hipMalloc(&h->d_tk_fallback, sizeof(unsigned int)));
+    TDK_HIP(hipMemsetAsync(h->d_tk_fallback, 0, sizeof(unsigned int), h->stream));
     TDK_HIP(hipMalloc(&h->d_hist, sizeof(unsigned int) * kSelectBins * n));
     TDK_HIP(hipMemsetAsync(h->d_hist, 0, sizeof(unsigned int) * kSelectBins * n, h->stream));
     return TDK_OK;
@@ -1323,18 +1784,18 @@ tdk_status ensure_robust_buffers(tdk_dvo *h) {
 // median over each running pair's masked residuals (mode 0) or absolute
 // deviations from `center` (mode 1), times `factor` -> out[pair]
 tdk_status device_median(tdk_dvo *h, int level, const int *d_state, int mode, const double *center,
-                         double factor, double *out) {
+                         double factor, double *out, const SelectSrc *src = nullptr) {
     const tdk_dvo::Level &L = h->lv[level];
     const int n = h->n_pairs, tpb = 256, gp = (n + tpb - 1) / tpb;
     dim3 grid(kStatBlocks, n);
     SelectState *st = (SelectState *)h->d_select;
-    k_select_init<<<gp, tpb, 0, h->stream>>>(st, h->d_count, n);
+    k_select_init<<<gp, tpb, 0, h->stream>>>(st, h->d_count, src, n);
     TDK_LAUNCH_CHECK();
     // few, long blocks for the histogram passes: zeroing and merging 8192 bins is a
     // fixed cost per block
     dim3 hgrid(kSelectBlocks, n);
     for (int pass = 0; pass < kSelectPasses; pass++) {
-        k_select_hist<<<hgrid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center, st, pass,
+        k_select_hist<<<hgrid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center, src, st, pass,
                                                        h->d_hist);
         TDK_LAUNCH_CHECK();
         k_select_pick<<<n, kBlock, 0, h->stream>>>(h->d_hist, st, d_state, pass);
@@ -1345,14 +1806,14 @@ tdk_status device_median(tdk_dvo *h, int level, const int *d_state, int mode, co
             // 13 bits (sign, exponent, one mantissa bit) single out a small group: finish on those.  Pairs
             // whose group is larger than kSelectCap (exact ties) are left for the remaining
             // passes, which return at once for every pair that is done.
-            k_select_collect<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center, st,
+            k_select_collect<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center, src, st,
                                                              h->d_cand, pass);
             TDK_LAUNCH_CHECK();
             k_select_finish<<<n, kBlock, 0, h->stream>>>(st, h->d_cand, d_state, factor, out);
             TDK_LAUNCH_CHECK();
         }
     }
-    k_select_successor<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center, st);
+    k_select_successor<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, mode, center, src, st);
     TDK_LAUNCH_CHECK();
     k_median_combine<<<gp, tpb, 0, h->stream>>>(st, h->d_count, d_state, n, factor, out);
     TDK_LAUNCH_CHECK();
@@ -1368,14 +1829,56 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
     dim3 grid(kStatBlocks, n);
     TDK_HIP(hipMemsetAsync(h->d_count, 0, sizeof(int) * n, h->stream));
     static const bool exact = [] { const char *v = getenv("TDK_STUDENT_EXACT"); return v && atoi(v) != 0; }();
-#define TDK_MASK(ST, FA)                                                                                          \
-    k_robust_mask<ST, FA><<<grid, kBlock, 0, h->stream>>>(ptrs_of(L), h->d_params, d_poses, d_state, L.scale, h->d_rm, \
-                                                          h->d_count, h->d_spartial)
-    if (weight_mode != TDK_W_STUDENT_T) TDK_MASK(false, false);
-    else if (exact) TDK_MASK(true, false);
-    else TDK_MASK(true, true);
+    // TDK_TUKEY=radix: the two medians by radix select (2 x 3 passes over the residual map) instead of the
+    // sampled brackets + one pass; TDK_TUKEY=fallback: brackets, but every pair takes the exact slow path of
+    // k_tukey_finish (tests).  All three give the same doubles.
+    static const int tukey_mode = [] {
+        const char *v = getenv("TDK_TUKEY");
+        return v && !strcmp(v, "radix") ? 1 : (v && !strcmp(v, "fallback") ? 2 : 0);
+    }();
+    const bool brackets = weight_mode == TDK_W_TUKEY && tukey_mode != 1;
+    TukeyArgs tka{h->d_tk, h->d_tk_med, h->tk_cap};
+    if (brackets) {
+        k_tukey_sample<<<n, kTukeyThreads, 0, h->stream>>>(ptrs_of(L), h->d_params, d_poses, d_state, L.scale, h->d_tk,
+                                                           h->d_tk_sample);
+        TDK_LAUNCH_CHECK();
+    }
+#define TDK_MASK(ST, FA, TK)                                                                                          \
+    k_robust_mask<ST, FA, TK><<<grid, kBlock, 0, h->stream>>>(ptrs_of(L), h->d_params, d_poses, d_state, L.scale, h->d_rm, \
+                                                              h->d_count, h->d_spartial, tka)
+    if (brackets) {
+        // fewer, longer blocks on the coarse levels: a block's set-up (pose, tables, bracket) is a chain of
+        // dependent loads that two pixels per thread cannot amortise (216 us for a 213x284 level with 64 blocks)
+        const int nb = (int)(L.N / 8192 < 8 ? 8 : (L.N / 8192 > kStatBlocks ? kStatBlocks : L.N / 8192));
+        grid = dim3(nb, n);
+        TDK_MASK(false, false, true);
+    }
+    else if (weight_mode != TDK_W_STUDENT_T) TDK_MASK(false, false, false);
+    else if (exact) TDK_MASK(true, false, false);
+    else TDK_MASK(true, true, false);
 #undef TDK_MASK
     TDK_LAUNCH_CHECK();
+    if (brackets) {
+        const int force = tukey_mode == 2 ? 1 : 0, gp = (n + 255) / 256;
+        double *median = h->d_stat + 2 * (size_t)n;
+        SelectSrc *src = (SelectSrc *)h->d_tk_src;
+        k_tukey_plan<<<gp, 256, 0, h->stream>>>(h->d_tk, h->d_count, d_state, 0, h->d_rm, L.stride, (int)L.N, h->d_tk_med,
+                                                h->tk_cap, nullptr, force, src, h->d_tk_fallback, n);
+        TDK_LAUNCH_CHECK();
+        k_band_median<<<n, kTukeyThreads, 0, h->stream>>>(src, h->d_count, d_state, 1.0, median);
+        TDK_LAUNCH_CHECK();
+        k_tukey_dev_bracket<<<n, kTukeyThreads, 0, h->stream>>>(d_state, h->d_tk, h->d_tk_sample, median);
+        TDK_LAUNCH_CHECK();
+        k_tukey_deviations<<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, h->d_tk, h->d_tk_dev,
+                                                           h->tk_cap);
+        TDK_LAUNCH_CHECK();
+        k_tukey_plan<<<gp, 256, 0, h->stream>>>(h->d_tk, h->d_count, d_state, 1, h->d_rm, L.stride, (int)L.N, h->d_tk_dev,
+                                                h->tk_cap, median, force, src, h->d_tk_fallback, n);
+        TDK_LAUNCH_CHECK();
+        k_band_median<<<n, kTukeyThreads, 0, h->stream>>>(src, h->d_count, d_state, kTukeyC, h->d_wscale);   // c * MAD (:34)
+        TDK_LAUNCH_CHECK();
+        return TDK_OK;
+    }
     if (weight_mode == TDK_W_STUDENT_T) {
         // the mask pass has left the partial sums of the first step (variance 1, weights.py:10-13)
         k_robust_student_update<<<n, 64, 0, h->stream>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
@@ -1651,6 +2154,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     (void)hipFree(h->d_rm); (void)hipFree(h->d_wscale); (void)hipFree(h->d_stat);
     (void)hipFree(h->d_spartial); (void)hipFree(h->d_count); (void)hipFree(h->d_select);
     (void)hipFree(h->d_hist); (void)hipFree(h->d_cand); (void)hipFree(h->d_mode_probe);
+    (void)hipFree(h->d_tk); (void)hipFree(h->d_tk_med); (void)hipFree(h->d_tk_dev); (void)hipFree(h->d_tk_sample); (void)hipFree(h->d_tk_fallback); (void)hipFree(h->d_tk_src);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
     if (h->d_aa_weights) (void)hipFree(h->d_aa_weights);
@@ -2001,6 +2505,17 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
     TDK_HIP(hipMemcpyAsync(h->host_warn.data(), h->ls.warn, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
     TDK_HIP(hipStreamSynchronize(h->stream));
     if (h->profiling) TDK_TRY(collect_profile(h));
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_get_tukey_fallbacks(tdk_dvo *h, int64_t *pairs) {
+    TDK_REQUIRE(h && pairs, "null pointer");
+    *pairs = 0;
+    if (!h->d_tk_fallback) return TDK_OK;
+    unsigned int v = 0;
+    TDK_HIP(hipMemcpyAsync(&v, h->d_tk_fallback, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
+    *pairs = (int64_t)v;
     return TDK_OK;
 }
 

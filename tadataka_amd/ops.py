@@ -278,6 +278,12 @@ class DvoBatch(object):
         call("tdk_dvo_get_counts", self._h, C.byref(e), C.byref(u))
         return int(e.value), int(u.value)
 
+    def tukey_fallbacks(self):
+        """Pairs whose Tukey medians were redone by the exact radix select since the batch was created."""
+        v = C.c_int64()
+        call("tdk_dvo_get_tukey_fallbacks", self._h, C.byref(v))
+        return int(v.value)
+
     def set_profiling(self, enabled):
         call("tdk_dvo_set_profiling", self._h, int(bool(enabled)))
 

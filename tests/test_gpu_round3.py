@@ -624,3 +624,54 @@ def test_forward_warp_with_many_sources_per_target(ops, dz):
         gd, gv, ga = sd.get_results(t, with_flag=False)
         assert np.array_equal(ga, oa) and np.array_equal(gd, od) and np.array_equal(gv, ov)
     sd.close()
+
+
+# ---------------------------------------------------------------------------
+# Tukey: sampled brackets + one pass == radix select == the in-kernel exact fallback, bit for bit
+# ---------------------------------------------------------------------------
+_TUKEY_SCRIPT = """
+import hashlib, os, sys
+import numpy as np
+from tadataka_amd import ops, synthetic
+h = hashlib.sha256()
+fall = 0
+ident = np.concatenate([np.eye(3).ravel(), np.zeros(3)])
+for (H, W, B, quant) in ((480, 640, 3, None), (53, 71, 2, None), (120, 160, 4, 64), (96, 128, 2, 4)):
+    batch = ops.DvoBatch(B, H, W)
+    for i in range(B):
+        pr = synthetic.make_pair(H, W, seed=300 + i, rot_scale=0.01, trans_scale=0.03)
+        I0, I1 = pr["I0"], pr["I1"]
+        if quant:            # quantised images: thousands of exactly equal residuals (tie groups)
+            I0, I1 = np.round(I0 * quant) / quant, np.round(I1 * quant) / quant
+        batch.upload(i, I0, pr["D0"], I1)
+    cam = synthetic.camera_for(W, H)
+    P = np.tile(ident, (B, 1))
+    P[:, 9:] = np.linspace(-0.01, 0.01, B)[:, None]
+    ev = batch.evaluate(0, cam, cam, P, ops.W_TUKEY)
+    for k in ("H", "b", "sum_sq", "n_update"):
+        h.update(np.ascontiguousarray(ev[k]).tobytes())
+    Pl, n = batch.estimate_level(0, cam, cam, np.tile(ident, (B, 1)), ops.W_TUKEY, 5)
+    h.update(Pl.tobytes()); h.update(n.tobytes())
+    fall += batch.tukey_fallbacks()
+    batch.close()
+print("RESULT", h.hexdigest(), fall)
+"""
+
+
+def test_tukey_brackets_radix_and_fallback_agree_bit_for_bit():
+    """The three ways to the two medians of compute_weights_tukey give the same doubles: normal equations,
+    poses and evaluation counts hash alike -- on smooth frames (brackets hold), on a level smaller than
+    the sample (exhaustive), on quantised frames (tie groups of thousands: the brackets overflow and the
+    exact path takes over).  The default path must take the exact fallback only for the tie-heavy cases."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("", "radix", "fallback"):
+        env = dict(os.environ, TDK_TUKEY=mode)
+        out = subprocess.run([sys.executable, "-c", _TUKEY_SCRIPT], env=env, cwd=root, check=True,
+                             capture_output=True, text=True, timeout=600)
+        line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1].split()
+        res[mode] = (line[1], int(line[2]))
+    assert res[""][0] == res["radix"][0] == res["fallback"][0], res
+    assert res["radix"][1] == 0 and res["fallback"][1] > res[""][1], res
+    print("fallbacks of the default path:", res[""][1])
