@@ -1826,7 +1826,11 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
     TDK_TRY(ensure_robust_buffers(h));
     const tdk_dvo::Level &L = h->lv[level];
     const int n = h->n_pairs;
-    dim3 grid(kStatBlocks, n);
+    // blocks per pair of the passes over the residuals: 64 at full resolution, fewer and longer ones on the coarse
+    // levels -- a block's set-up (pose, tables, bracket) is a chain of dependent loads that two pixels per thread
+    // cannot amortise (the mask pass of a 213x284 level took 216 us with 64 blocks per pair, 104 us with 8)
+    const int nb = (int)(L.N / 8192 < 8 ? 8 : (L.N / 8192 > kStatBlocks ? kStatBlocks : L.N / 8192));
+    dim3 grid(nb, n);
     TDK_HIP(hipMemsetAsync(h->d_count, 0, sizeof(int) * n, h->stream));
     static const bool exact = [] { const char *v = getenv("TDK_STUDENT_EXACT"); return v && atoi(v) != 0; }();
     // TDK_TUKEY=radix: the two medians by radix select (2 x 3 passes over the residual map) instead of the
@@ -1846,13 +1850,7 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
 #define TDK_MASK(ST, FA, TK)                                                                                          \
     k_robust_mask<ST, FA, TK><<<grid, kBlock, 0, h->stream>>>(ptrs_of(L), h->d_params, d_poses, d_state, L.scale, h->d_rm, \
                                                               h->d_count, h->d_spartial, tka)
-    if (brackets) {
-        // fewer, longer blocks on the coarse levels: a block's set-up (pose, tables, bracket) is a chain of
-        // dependent loads that two pixels per thread cannot amortise (216 us for a 213x284 level with 64 blocks)
-        const int nb = (int)(L.N / 8192 < 8 ? 8 : (L.N / 8192 > kStatBlocks ? kStatBlocks : L.N / 8192));
-        grid = dim3(nb, n);
-        TDK_MASK(false, false, true);
-    }
+    if (brackets) TDK_MASK(false, false, true);
     else if (weight_mode != TDK_W_STUDENT_T) TDK_MASK(false, false, false);
     else if (exact) TDK_MASK(true, false, false);
     else TDK_MASK(true, true, false);
@@ -1881,7 +1879,7 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
     }
     if (weight_mode == TDK_W_STUDENT_T) {
         // the mask pass has left the partial sums of the first step (variance 1, weights.py:10-13)
-        k_robust_student_update<<<n, 64, 0, h->stream>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
+        k_robust_student_update<<<n, 64, 0, h->stream>>>(h->d_spartial, nb, h->d_count, d_state,
                                                          h->d_wscale, n, 0);
         TDK_LAUNCH_CHECK();
         for (int it = 1; it < 10; it++) {   // n_iter = 10 (weights.py:4)
@@ -1892,7 +1890,7 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
                 k_robust_student_step<true><<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state,
                                                                              h->d_wscale, h->d_spartial);
             TDK_LAUNCH_CHECK();
-            k_robust_student_update<<<n, 64, 0, h->stream>>>(h->d_spartial, kStatBlocks, h->d_count, d_state,
+            k_robust_student_update<<<n, 64, 0, h->stream>>>(h->d_spartial, nb, h->d_count, d_state,
                                                              h->d_wscale, n, 0);
             TDK_LAUNCH_CHECK();
         }
