@@ -491,13 +491,13 @@ def workload_semi_dense_dropin(args):
     cam, depth0, T_w, images = synthetic.make_track(H, W, n_frames, step=(0.01, 0.002, 0.003))
     cp = CameraParameters((cam[0], cam[1]), (cam[2], cam[3]))
     params = rsd.Params(*SD_PARAMS)
-    rng = np.random.default_rng(3)
     out = {"config": "examples/semi_dense_vo.py:182-199 through the unchanged rust_bindings.semi_dense calls "
                      "(Frame, increment_age, propagate, update_depth), 640x480, ages from zero as the example starts, one frame per "
                      "iteration, refframes growing; host wall time per frame, first frame (uploads of the caller's "
                      "initial maps) excluded"}
     for label, lazy in (("lazy_device_maps", True), ("eager_ndarrays", False)):
         rsd.LAZY_MAPS = lazy
+        rng = np.random.default_rng(3)             # the same prior for both runs: their results must agree
         try:
             frame0 = rsd.Frame(cp, images[0], T_w[0])
             refframes = [frame0]
@@ -527,6 +527,7 @@ def workload_semi_dense_dropin(args):
                           "max_age": int(np.asarray(age0).max())}
         finally:
             rsd.LAZY_MAPS = True
+    assert out["lazy_device_maps"]["success_pixels_last_frame"] == out["eager_ndarrays"]["success_pixels_last_frame"]
     return out
 
 
