@@ -13,6 +13,7 @@ tests really use.  Runs in the build container only; the .npz outputs travel.
                     float, analytic depth (the depth XMLs are not in the checkout), all
                     five weight options, both pyramid readings, 5 levels at 480x640 and
                     the example's half-resolution call
+  dvo_holes.npz     depth maps with missing readings (zeros as sensors report them, NaNs), four weight options
   dvo_ill.npz       ill-conditioned scenes (tests/golden/scenes.py): per-update twists of
                     the reference's lstsq on J, final poses, singular values of J
 
@@ -193,10 +194,24 @@ def capture_ill():
     return out
 
 
+def capture_holes():
+    """Depth maps with missing readings: zeros and NaNs (tests/golden/scenes.py:holes_pair)."""
+    out = {}
+    for tag, fill in (("zero", 0.0), ("nan", np.nan)):
+        pair = scenes.holes_pair(fill)
+        for name in ("None", "huber", "tukey", "student-t"):
+            for aa in (False, True):
+                rec = run_pyramid(pair["cam"], pair["cam"], pair["I0"], pair["D0"], pair["I1"], mode_arg(name, None), 3, aa)
+                put(out, f"{tag}_{'aa' if aa else 'bl'}_{name}", rec)
+            print("holes", tag, name, rec["evals"], rec["t"], rec["rotvec"])
+    return out
+
+
 def main():
     gg.install_stubs()
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
-    jobs = {"dvo_examples.npz": capture_examples, "dvo_real.npz": capture_real, "dvo_ill.npz": capture_ill}
+    jobs = {"dvo_examples.npz": capture_examples, "dvo_real.npz": capture_real, "dvo_ill.npz": capture_ill,
+            "dvo_holes.npz": capture_holes}
     for fname, fn in jobs.items():
         if only and only not in fname:
             continue

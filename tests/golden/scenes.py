@@ -105,3 +105,18 @@ ILL_SCENES = {
 def ill_pair(name, height=120, width=160):
     tex, seed = ILL_SCENES[name]
     return plane_pair(height, width, tex, seed)
+
+
+def holes_pair(fill, height=120, width=160, seed=8):
+    """A synthetic pair whose depth map has holes (9 % of the pixels in blobs) filled with `fill`: 0.0, as depth
+    sensors report missing readings (the back-projected point is the origin, its image the principal point --
+    the reference keeps such pixels in the error mask and, once the pose has a positive z translation, in the
+    update mask, with a Jacobian that scales with 1 / t_z), or NaN (masked out by every comparison)."""
+    pair = synthetic.make_pair(height, width, seed=seed)
+    ys, xs = np.mgrid[0:height, 0:width]
+    hole = (np.sin(xs / 9.0) * np.cos(ys / 7.0)) > 0.75
+    D0 = pair["D0"].copy()
+    D0[hole] = fill
+    pair["D0"] = np.ascontiguousarray(D0)
+    pair["hole_fraction"] = float(hole.mean())
+    return pair

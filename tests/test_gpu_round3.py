@@ -675,3 +675,21 @@ def test_tukey_brackets_radix_and_fallback_agree_bit_for_bit():
     assert res[""][0] == res["radix"][0] == res["fallback"][0], res
     assert res["radix"][1] == 0 and res["fallback"][1] > res[""][1], res
     print("fallbacks of the default path:", res[""][1])
+
+
+# ---------------------------------------------------------------------------
+# depth maps with missing readings
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("fill", ["zero", "nan"])
+@pytest.mark.parametrize("name", ["None", "huber", "tukey", "student-t"])
+def test_depth_holes_vs_reference_loop(ops, golden, fill, name):
+    """9 % of the depth map is 0 (what a depth sensor reports where it has no reading: the reference keeps those
+    pixels -- back-projected to the origin -- in its masks, with a Jacobian that scales with 1 / t_z) or NaN
+    (every comparison masks them out; the anti-aliasing prefilter spreads them).  Pose after every level and
+    evaluation counts as the reference's own loop, both pyramids."""
+    import scenes
+    g = golden("dvo_holes.npz")
+    pair = scenes.holes_pair(0.0 if fill == "zero" else np.nan)
+    for aa in (False, True):
+        _check_pyramid_run(ops, g, f"{fill}_{'aa' if aa else 'bl'}_{name}", pair["I0"], pair["D0"], pair["I1"], pair["cam"],
+                           name, None, 3, aa)
