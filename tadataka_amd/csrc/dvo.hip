@@ -617,6 +617,7 @@ __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials,
                                             double *__restrict__ results, LoopState ls, int loop_mode, int max_iter) {
     const int pair = blockIdx.x;
     __shared__ double red[kBlock / 32][kAccPad];
+    __shared__ double solve_ws[108];   // workspace of the rank-deficient 6x6 solve (lane 0)
     const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
     double s = 0.0;
     if (k < kAcc)
@@ -680,7 +681,7 @@ __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials,
         } else {
             double xi[6];
             atomicAdd(ls.evals + 1, 1ull);
-            tdk::solve6(R, R + 21, xi, R[28]);   // R[28]: rows of J (update mask count)
+            tdk::solve6<true>(R, R + 21, xi, R[28], solve_ws);   // R[28]: rows of J (update mask count)
             double next[12];
             tdk::compose_update(xi, pose, next);
             for (int i = 0; i < 12; i++) cand[i] = next[i];

@@ -197,7 +197,14 @@ TDK_HD bool solve6_cholesky(const double *H21, const double *b, double *x) {
 // eigen-decomposition with a relative eigenvalue cut-off gives the minimum-norm
 // least-squares solution, as lstsq does when J is rank deficient.  Returns the
 // number of eigen-directions used.
-TDK_HD int solve6(const double *H21, const double *b, double *x, double n_rows = 0.0) {
+// The rank-deficient path works on three 6x6 matrices with run-time indexing.  EXTERNAL: they live in a
+// caller-provided workspace of 108 doubles (LDS for lane 0 of k_dvo_reduce: as private arrays they went to
+// scratch and took the reduce kernel from 16 to 24 us, for a path that almost never runs); otherwise on the stack.
+template <bool EXTERNAL>
+TDK_HD int solve6_eigen(const double *H21, const double *b, double *x, const bool *zero_col, double *ws);
+
+template <bool EXTERNAL = false>
+TDK_HD int solve6(const double *H21, const double *b, double *x, double n_rows = 0.0, double *ws = nullptr) {
     // gelsd drops singular values below rcond * sigma_max with rcond = eps * max(n, 6)
     // (numpy's default).  A column of J whose norm is below that bound is such a direction
     // whatever the other columns are; column scaling would turn its rounding noise into a
@@ -216,7 +223,16 @@ TDK_HD int solve6(const double *H21, const double *b, double *x, double n_rows =
         for (int i = 0; i < 6; i++) { zero_col[i] = !(H21[k] > cut * dmax); any_zero |= zero_col[i]; k += 6 - i; }
     }
     if (!any_zero && solve6_cholesky(H21, b, x)) return 6;
-    double A[6][6], V[6][6];
+    return solve6_eigen<EXTERNAL>(H21, b, x, zero_col, ws);
+}
+
+template <bool EXTERNAL>
+TDK_HD int solve6_eigen(const double *H21, const double *b, double *x, const bool *zero_col, double *ws) {
+    double local[EXTERNAL ? 1 : 108];
+    double *w = EXTERNAL ? ws : local;
+    double(*A)[6] = reinterpret_cast<double(*)[6]>(w);
+    double(*V)[6] = reinterpret_cast<double(*)[6]>(w + 36);
+    double(*N)[6] = reinterpret_cast<double(*)[6]>(w + 72);
     int k = 0;
     for (int i = 0; i < 6; i++)
         for (int j = i; j < 6; j++) {
@@ -280,7 +296,6 @@ TDK_HD int solve6(const double *H21, const double *b, double *x, double n_rows =
         // in the original coordinates: remove from x its component in the null space of J,
         // which is spanned by n_i = S v_i for the dropped eigenvectors v_i (modified
         // Gram-Schmidt; at most 6 vectors of length 6).
-        double N[6][6];
         int m = 0;
         for (int i = 0; i < 6; i++) {
             if (!dropped[i]) continue;
