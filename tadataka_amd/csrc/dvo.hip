@@ -2012,7 +2012,8 @@ tdk_status collect_profile(tdk_dvo *h) {
 // counted on the device (LoopState::evals), so the pixel bookkeeping stays exact.
 tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64_t *pixel_evals) {
     const bool small = (int64_t)h->n_pairs * h->lv[level].N <= (1ll << 22) && !h->profiling;
-    const int burst = small ? 2 : 1;
+    static const int small_burst = [] { const char *v = getenv("TDK_DVO_BURST"); return v && atoi(v) > 0 ? atoi(v) : 2; }();
+    const int burst = small ? small_burst : 1;
     // a pair goes through at most 2 max_iter + 1 evaluations: the first, then per tested candidate a
     // probe and -- if it was accepted and is not the last -- the full evaluation at the accepted pose
     const int max_rounds = 2 * max_iter + 1;
