@@ -190,6 +190,18 @@ tdk_status tdk_dvo_get_counts(tdk_dvo *h, int64_t *error_pixels, int64_t *update
  * bracket overflows) is redone by an exact radix select over its residual map.  *pairs = how often that
  * happened since the batch was created (the results are the same doubles either way). */
 tdk_status tdk_dvo_get_tukey_fallbacks(tdk_dvo *h, int64_t *pairs);
+/* Diagnostic of the Student-t weights (weights.py:4-16): fixed-point steps 2..10 of the variance come from two
+ * passes over the residuals that expand every step around a predicted iterate (sample, then first pass); a pair
+ * whose prediction was too far off for the remainder bound takes a third pass.  *pairs = how often that
+ * happened since the batch was created. */
+tdk_status tdk_dvo_get_student_redos(tdk_dvo *h, int64_t *pairs);
+/* How the Student-t variance is iterated: 0 (default) the Taylor passes above; 1 the nine sequential passes
+ * over the residuals (one per fixed-point step, reciprocal arithmetic); 2 the nine passes with IEEE divisions
+ * (the CPU restatement's operations).  Defaults from TDK_STUDENT=sequential / TDK_STUDENT_EXACT=1 at creation. */
+tdk_status tdk_dvo_set_student_passes(tdk_dvo *h, int mode);
+/* The robust scale the last Student-t / Tukey evaluation of each pair used: the variance after ten steps
+ * (weights.py:16) or c * MAD (weights.py:34).  scale: n_pairs doubles (host). */
+tdk_status tdk_dvo_get_robust_scale(tdk_dvo *h, double *scale);
 /* The hipStream_t every launch and copy of this batch is queued on.  Each batch
  * owns its stream: calls on different batches overlap on the device (e.g. the
  * HBM-bound pyramid of one batch under the FP64-bound estimation of another). */

@@ -1590,6 +1590,279 @@ __global__ __launch_bounds__(kBlock) void k_tukey_deviations(const double *__res
     band_flush(band_buf, &band_n, &band_base, &g->n_dev, band, cap, &g->overflow);
 }
 
+// ---------------------------------------------------------------------------
+// Student-t: the ten fixed-point steps of compute_weights_student_t (weights.py:4-16) in two passes over
+// the residuals instead of nine.
+//
+// v_{k+1} = F(v_k), F(v) = mean_i g(s_i; v), g(s; v) = s (nu + 1) / (nu + s / v), s = r^2, v_0 = 1: every step needs
+// F at a point that only the previous step knows, hence nine sequential 8-byte-per-pixel passes after the
+// mask pass (which gives v_1 = F(1)); they run at 5.2 - 5.8 TB/s, and a working set small enough for the
+// 256 MB memory-side cache is no faster (tools/ktrace_levels.py, 32 / 64 / 256 pairs).  But F is analytic in v,
+// and with u = nu v + s, t = 1 / u, a = s t:
+//     g = (nu+1) v a,   dg/dv = (nu+1) a^2,   d2g/dv2 = -2 nu (nu+1) a^2 t
+// so ONE pass can accumulate, for nine expansion points p_1..p_9 at once, the three sums that give F and its
+// first two derivatives there (k_student_taylor), and the chain
+//     v_{k+1} = F(p_k) + F1(p_k) d + F2(p_k) d^2 / 2,   d = v_k - p_k,   remainder <= (nu + 1) v (d / v)^3
+// is then scalar work (k_student_chain).  Pass A expands around the fixed-point sequence of a 2048-residual
+// SAMPLE of the pair (k_student_predict: a few per cent off) and yields the iterates to ~1e-5 or better; pass B
+// expands around those: remainder far below rounding.  A pair whose pass B still moved a point by more than
+// kStudentRedo takes a pass C -- tdk_dvo_get_student_redos counts them.
+// v_10 agrees with the sequential passes to ~1e-15 relative (tests/test_gpu_round3.py).
+// tdk_dvo_set_student_passes / TDK_STUDENT=sequential keep the nine passes, TDK_STUDENT_EXACT=1 the nine passes
+// with IEEE divisions.
+// ---------------------------------------------------------------------------
+constexpr int kStudentPts = 9, kStudentSums = 3 * kStudentPts;
+constexpr int kStudentRow = kStudentPts + 1;   // expansion points of a pair + its "one more pass" flag
+// pass B moved a step's expansion point by more than this (relative): its remainder, at most (nu + 1) (d / v)^3,
+// may exceed 1e-14 -> the pair takes a third pass around the iterates of pass B.  Pass A lands within that
+// unless the sample estimate was more than ~8 % off.
+constexpr double kStudentRedo = 1e-4;
+
+// the fixed-point sequence v_1 .. v_9 of a sample of the pair's masked residuals: kStudentSample entries of the
+// residual map, spread over the frame (all of a small level)
+constexpr int kStudentSample = 2048;
+__global__ __launch_bounds__(kBlock) void k_student_predict(const double *__restrict__ rm, int64_t stride, int N,
+                                                            const int *__restrict__ state, double *__restrict__ pts) {
+    __shared__ double red[kWaves];
+    __shared__ int red_n[kWaves];
+    const int pair = blockIdx.x;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    const double *__restrict__ r = rm + (int64_t)pair * stride;
+    const int m = N < kStudentSample ? N : kStudentSample;
+    constexpr int kPer = kStudentSample / kBlock;
+    double sq[kPer];
+    int valid = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+        const int k = threadIdx.x + j * kBlock;
+        double x = 0.0;
+        if (k < m) {
+            x = r[(int)(((int64_t)k * N) / m)];
+            if (x == x) valid++; else x = 0.0;
+        }
+        sq[j] = x * x;                                  // outside the mask or the sample: adds nothing to the sum
+    }
+    for (int off = 32; off > 0; off >>= 1) valid += __shfl_down(valid, off, 64);
+    if ((threadIdx.x & 63) == 0) red_n[threadIdx.x >> 6] = valid;
+    __syncthreads();
+    const int ms = (red_n[0] + red_n[1]) + (red_n[2] + red_n[3]);
+    double v = 1.0;
+    for (int k = 0; k < kStudentPts; k++) {
+        double acc = 0.0;
+        const double rv = 1.0 / v;
+#pragma unroll
+        for (int j = 0; j < kPer; j++)
+            acc += sq[j] * ((kStudentNu + 1.0) * fast_rcp(__builtin_fma(sq[j], rv, kStudentNu)));
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        v = ms > 0 ? ((red[0] + red[1]) + (red[2] + red[3])) / (double)ms : 1.0;
+        if (!(v > 0.0)) v = 1.0;                        // an all-zero sample: any positive expansion point will do
+        if (threadIdx.x == 0) pts[(size_t)pair * kStudentRow + k] = v;
+    }
+    if (threadIdx.x == 0) pts[(size_t)pair * kStudentRow + kStudentPts] = 1.0;   // passes A and B always run
+}
+
+// per block and pair: sum a, sum a^2, sum a^2 t' at each of the nine expansion points, in units of c_ref = nu p_9: s' = s / c_ref, u'_k = p_k / p_9 + s', t'_k = 1 / u'_k (a = s' t'_k = s t_k).
+// v_rcp_f64 issues at about a ninth of the FMA rate here; nine of them and their Newton steps were 2/3 of this
+// kernel (430 us per pass at 256 x 640x480).  The nine reciprocals of a residual therefore come from ONE:
+// prefix products of the u'_k, the reciprocal of the last, and a backward sweep (24 multiplications; the scaling
+// keeps the product of nine O(1 + s') factors far from over- and underflow) -- 230 us per pass.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_student_taylor(const double *__restrict__ rm, int64_t stride, int N,
+                                                           const int *__restrict__ state,
+                                                           const double *__restrict__ pts,
+                                                           double *__restrict__ partial) {
+    const int pair = blockIdx.y;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    if (pts[(size_t)pair * kStudentRow + kStudentPts] == 0.0) return;
+    const double p_ref = pts[(size_t)pair * kStudentRow + kStudentPts - 1];
+    const double inv_ref = 1.0 / (kStudentNu * p_ref), inv_p = 1.0 / p_ref;
+    double c[kStudentPts];                              // p_k / p_9 (block-uniform)
+#pragma unroll
+    for (int k = 0; k < kStudentPts; k++) c[k] = pts[(size_t)pair * kStudentRow + k] * inv_p;
+    double acc[kStudentSums];
+#pragma unroll
+    for (int j = 0; j < kStudentSums; j++) acc[j] = 0.0;
+    const double *r = rm + (int64_t)pair * stride;
+#define TDK_STUDENT_TERM(X)                                                                  \
+    {                                                                                        \
+        const double x_ = (X);                                                               \
+        const double s_ = x_ == x_ ? (x_ * x_) * inv_ref : 0.0; /* outside the mask: zeros */\
+        double u[kStudentPts], q[kStudentPts];                                               \
+        _Pragma("unroll") for (int k = 0; k < kStudentPts; k++) u[k] = c[k] + s_;            \
+        q[0] = u[0];                                                                         \
+        _Pragma("unroll") for (int k = 1; k < kStudentPts; k++) q[k] = q[k - 1] * u[k];      \
+        double inv = fast_rcp(q[kStudentPts - 1]);                                           \
+        _Pragma("unroll") for (int k = kStudentPts - 1; k >= 0; k--) {                       \
+            const double t = k > 0 ? inv * q[k > 0 ? k - 1 : 0] : inv;                       \
+            if (k > 0) inv *= u[k];                                                          \
+            const double a = s_ * t, at = a * t;                                             \
+            acc[3 * k + 0] += a;                                                             \
+            acc[3 * k + 1] = __builtin_fma(a, a, acc[3 * k + 1]);                            \
+            acc[3 * k + 2] = __builtin_fma(a, at, acc[3 * k + 2]);                           \
+        }                                                                                    \
+    }
+    const int N2 = N >> 1;
+    // ~170 FP64 instructions per 16-byte load: the next load is issued before the arithmetic of this one
+    const int step = gridDim.x * kBlock;
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    double2_u v = i < N2 ? *reinterpret_cast<const double2_u *>(r + 2 * (int64_t)i) : double2_u{nan, nan};
+#pragma unroll 1
+    for (; i < N2; i += step) {
+        const int nxt = i + step;
+        const double2_u w = nxt < N2 ? *reinterpret_cast<const double2_u *>(r + 2 * (int64_t)nxt) : double2_u{nan, nan};
+        TDK_STUDENT_TERM(v.x)
+        TDK_STUDENT_TERM(v.y)
+        v = w;
+    }
+    if ((N & 1) && blockIdx.x == 0 && threadIdx.x == 0) TDK_STUDENT_TERM(r[N - 1])
+#undef TDK_STUDENT_TERM
+    __shared__ double red[kWaves][kStudentSums];
+#pragma unroll
+    for (int j = 0; j < kStudentSums; j++) {
+        double v = acc[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kStudentSums)
+        partial[((int64_t)pair * gridDim.x + blockIdx.x) * kStudentSums + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// Pass A in packed FP32: its only product is the next set of expansion points, for which 1e-5 is plenty.  The two
+// residuals of a 16-byte load ride in the two halves of v_pk_add/mul/fma_f32 (two FP32 lanes per FP64 issue
+// slot) and v_rcp_f32 needs no Newton steps: 165 us instead of 320 at 256 x 640x480.  s' is capped at 1e4 so that
+// the product of nine factors stays inside FP32 (a = s' / (c' + s') is 0.9999 there; the few pixels beyond it
+// shift the predicted points by less than 1e-4 of their share of the sum).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(kBlock) void k_student_taylor_f32(const double *__restrict__ rm, int64_t stride, int N,
+                                                               const int *__restrict__ state,
+                                                               const double *__restrict__ pts,
+                                                               double *__restrict__ partial) {
+    const int pair = blockIdx.y;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    if (pts[(size_t)pair * kStudentRow + kStudentPts] == 0.0) return;
+    const double p_ref = pts[(size_t)pair * kStudentRow + kStudentPts - 1];
+    const double inv_ref = 1.0 / (kStudentNu * p_ref), inv_p = 1.0 / p_ref;
+    float c[kStudentPts];
+#pragma unroll
+    for (int k = 0; k < kStudentPts; k++) c[k] = (float)(pts[(size_t)pair * kStudentRow + k] * inv_p);
+    f32x2 acc[kStudentSums];
+#pragma unroll
+    for (int j = 0; j < kStudentSums; j++) acc[j] = f32x2{0.0f, 0.0f};
+    const double *r = rm + (int64_t)pair * stride;
+#define TDK_SCALED_SQUARE(X, OUT)  /* s' in FP64 (r^2 may leave the FP32 range), then capped */                    \
+    {                                                                                                                \
+        const double x_ = (X), sd_ = (x_ * x_) * inv_ref;                                                            \
+        OUT = x_ == x_ ? (float)(sd_ < 1e4 ? sd_ : 1e4) : 0.0f;                                                      \
+    }
+#define TDK_STUDENT_TERM(S)                                                                                          \
+    {                                                                                                                \
+        const f32x2 s_ = (S);                                                                                        \
+        f32x2 u[kStudentPts], q[kStudentPts];                                                                        \
+        _Pragma("unroll") for (int k = 0; k < kStudentPts; k++) u[k] = s_ + c[k];                                    \
+        q[0] = u[0];                                                                                                 \
+        _Pragma("unroll") for (int k = 1; k < kStudentPts; k++) q[k] = q[k - 1] * u[k];                              \
+        f32x2 inv = {__builtin_amdgcn_rcpf(q[kStudentPts - 1].x), __builtin_amdgcn_rcpf(q[kStudentPts - 1].y)};      \
+        _Pragma("unroll") for (int k = kStudentPts - 1; k >= 0; k--) {                                               \
+            const f32x2 t = k > 0 ? inv * q[k > 0 ? k - 1 : 0] : inv;                                                \
+            if (k > 0) inv *= u[k];                                                                                  \
+            const f32x2 a = s_ * t, at = a * t;                                                                      \
+            acc[3 * k + 0] += a;                                                                                     \
+            acc[3 * k + 1] = __builtin_elementwise_fma(a, a, acc[3 * k + 1]);                                        \
+            acc[3 * k + 2] = __builtin_elementwise_fma(a, at, acc[3 * k + 2]);                                       \
+        }                                                                                                            \
+    }
+    const int N2 = N >> 1;
+    const int step = gridDim.x * kBlock;
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    double2_u v = i < N2 ? *reinterpret_cast<const double2_u *>(r + 2 * (int64_t)i) : double2_u{nan, nan};
+#pragma unroll 1
+    for (; i < N2; i += step) {
+        const int nxt = i + step;
+        const double2_u w = nxt < N2 ? *reinterpret_cast<const double2_u *>(r + 2 * (int64_t)nxt) : double2_u{nan, nan};
+        f32x2 s2;
+        TDK_SCALED_SQUARE(v.x, s2.x)
+        TDK_SCALED_SQUARE(v.y, s2.y)
+        TDK_STUDENT_TERM(s2)
+        v = w;
+    }
+    if ((N & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        f32x2 s2 = {0.0f, 0.0f};
+        TDK_SCALED_SQUARE(r[N - 1], s2.x)
+        TDK_STUDENT_TERM(s2)
+    }
+#undef TDK_STUDENT_TERM
+#undef TDK_SCALED_SQUARE
+    __shared__ double red[kWaves][kStudentSums];
+#pragma unroll
+    for (int j = 0; j < kStudentSums; j++) {
+        double v = (double)acc[j].x + (double)acc[j].y;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kStudentSums)
+        partial[((int64_t)pair * gridDim.x + blockIdx.x) * kStudentSums + threadIdx.x] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// one wave per pair: block partials -> sums (fixed order), then the chain v_1 -> v_10 through the nine Taylor
+// parabolas.  pass 0 (A): the iterates become the expansion points of pass B.  pass 1 (B): v_10 is the variance,
+// unless a point moved by more than kStudentRedo -- then the pair is flagged for pass 2 (C), which is final.
+__global__ __launch_bounds__(64) void k_student_chain(const double *__restrict__ partial, int nblk,
+                                                      const int *__restrict__ count, const int *__restrict__ state,
+                                                      double *__restrict__ pts, double *__restrict__ variance, int pass,
+                                                      unsigned int *__restrict__ n_redo) {
+    __shared__ double sums[kStudentSums];
+    const int pair = blockIdx.x;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    double *p = pts + (size_t)pair * kStudentRow;
+    if (p[kStudentPts] == 0.0) return;
+    if (threadIdx.x < kStudentSums) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; b++) s += partial[((int64_t)pair * nblk + b) * kStudentSums + threadIdx.x];
+        sums[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int n = count[pair];
+    const double v1 = variance[pair];                   // v_1 = F(1), exact, from the mask pass
+    if (pass == 0 && (n <= 0 || !(v1 > 0.0))) {
+        // empty mask: 0 / 0 as in the reference; all residuals zero: the second step divides 0 by 0 (weights.py:13)
+        variance[pair] = __longlong_as_double(0x7ff8000000000000ll);
+        p[kStudentPts] = 0.0;
+        return;
+    }
+    const double inv_n = 1.0 / (double)n, nu = kStudentNu, q = nu + 1.0;
+    const double inv_ref = 1.0 / (nu * p[kStudentPts - 1]);   // the sums of a^2 t' are in units of c_ref (k_student_taylor)
+    double v = pass == 0 ? v1 : p[0];                   // after pass A, p[0] holds v_1 (variance[] the latest v_10)
+    double moved = 0.0;
+    double it[kStudentPts];
+    for (int k = 0; k < kStudentPts; k++) {
+        const double pk = p[k], d = v - pk;
+        const double F0 = q * pk * sums[3 * k] * inv_n, F1 = q * sums[3 * k + 1] * inv_n;
+        const double F2 = -2.0 * nu * q * (sums[3 * k + 2] * inv_ref) * inv_n;
+        it[k] = v;
+        moved = fmax(moved, fabs(d) / pk);
+        v = F0 + d * (F1 + d * (0.5 * F2));
+        if (!(v > 0.0)) v = pk;                         // a polynomial far outside its range: stay put, pass C repairs
+    }
+    variance[pair] = v;
+    const bool again = pass == 0 || (pass == 1 && moved > kStudentRedo);
+    if (again) {
+        for (int k = 0; k < kStudentPts; k++) p[k] = it[k];
+        if (pass == 1) atomicAdd(n_redo, 1u);
+    }
+    p[kStudentPts] = again ? 1.0 : 0.0;
+}
+
 // ---- synthetic scene on the device (tadataka_amd/synthetic.py) ------------
 __device__ __forceinline__ double tex(double x, double y) {
     return 0.5 + 0.25 * sin(x / 7.0) * cos(y / 5.0) + 0.2 * sin((x + y) / 11.0);
@@ -1655,7 +1928,9 @@ struct tdk_dvo {
     double *d_rm;         // [n][stride0] masked residual map
     double *d_wscale;     // [n] variance (student-t) / sigma_mad (tukey)
     double *d_stat;       // [n][4]: lo, hi, median, spare
-    double *d_spartial;   // [n][kStatBlocks]
+    double *d_spartial;   // [n][kStatBlocks][kStudentSums] block partials of the statistics passes
+    double *d_st_pts;     // [n][kStudentRow] Student-t: expansion points of the Taylor passes, redo flag
+    unsigned int *d_st_redo;   // pairs that took a third Taylor pass (diagnostics)
     int *d_count;         // [n]
     void *d_select;       // SelectState[n]
     unsigned int *d_hist; // [n][kSelectBins]
@@ -1681,6 +1956,8 @@ struct tdk_dvo {
     int *d_mode_probe;          // [n] MODE_PROBE (tdk_dvo_photometric_error), allocated on first use
     int64_t count_error_px, count_update_px;   // tdk_dvo_get_counts: source pixels of the last estimate call
     bool anti_aliasing;         // pyramid levels get skimage's Gaussian prefilter (tdk_dvo_set_anti_aliasing)
+    int n_cu;                   // compute units of the batch's device
+    int student_mode;           // Student-t variance: 0 two Taylor passes, 1 nine sequential passes, 2 ... with IEEE divisions
     bool aa_taplists;           // ... evaluated as folded tap lists (mode 3, pyramid_sep.hip) instead of in ndimage's operation order
     tdk::PyramidSepPlan *sep_plan;   // tap lists of the separable pyramid kernel (created at the first build)
     double *d_aa_weights;       // its 1-D kernels, per level and axis (allocated on first use)
@@ -1765,7 +2042,10 @@ tdk_status ensure_robust_buffers(tdk_dvo *h) {
     TDK_HIP(hipMalloc(&h->d_rm, sizeof(double) * (size_t)h->lv[0].stride * n));
     TDK_HIP(hipMalloc(&h->d_wscale, sizeof(double) * n));
     TDK_HIP(hipMalloc(&h->d_stat, sizeof(double) * 4 * n));
-    TDK_HIP(hipMalloc(&h->d_spartial, sizeof(double) * kStatBlocks * n));
+    TDK_HIP(hipMalloc(&h->d_spartial, sizeof(double) * kStatBlocks * kStudentSums * n));
+    TDK_HIP(hipMalloc(&h->d_st_pts, sizeof(double) * kStudentRow * n));
+    TDK_HIP(hipMalloc(&h->d_st_redo, sizeof(unsigned int)));
+    TDK_HIP(hipMemsetAsync(h->d_st_redo, 0, sizeof(unsigned int), h->stream));
     TDK_HIP(hipMalloc(&h->d_count, sizeof(int) * n));
     TDK_HIP(hipMalloc(&h->d_select, sizeof(SelectState) * n));
     TDK_HIP(hipMalloc(&h->d_cand, sizeof(uint64_t) * kSelectCap * n));
@@ -1833,7 +2113,7 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
     const int nb = (int)(L.N / 8192 < 8 ? 8 : (L.N / 8192 > kStatBlocks ? kStatBlocks : L.N / 8192));
     dim3 grid(nb, n);
     TDK_HIP(hipMemsetAsync(h->d_count, 0, sizeof(int) * n, h->stream));
-    static const bool exact = [] { const char *v = getenv("TDK_STUDENT_EXACT"); return v && atoi(v) != 0; }();
+    const bool exact = h->student_mode == 2;
     // TDK_TUKEY=radix: the two medians by radix select (2 x 3 passes over the residual map) instead of the
     // sampled brackets + one pass; TDK_TUKEY=fallback: brackets, but every pair takes the exact slow path of
     // k_tukey_finish (tests).  All three give the same doubles.
@@ -1841,6 +2121,7 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
         const char *v = getenv("TDK_TUKEY");
         return v && !strcmp(v, "radix") ? 1 : (v && !strcmp(v, "fallback") ? 2 : 0);
     }();
+    const bool taylor = weight_mode == TDK_W_STUDENT_T && h->student_mode == 0;
     const bool brackets = weight_mode == TDK_W_TUKEY && tukey_mode != 1;
     TukeyArgs tka{h->d_tk, h->d_tk_med, h->tk_cap};
     if (brackets) {
@@ -1883,6 +2164,27 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
         k_robust_student_update<<<n, 64, 0, h->stream>>>(h->d_spartial, nb, h->d_count, d_state,
                                                          h->d_wscale, n, 0);
         TDK_LAUNCH_CHECK();
+        if (taylor) {   // steps 2 .. 10 from two passes (see k_student_taylor); a third one for flagged pairs only
+            k_student_predict<<<n, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, h->d_st_pts);
+            TDK_LAUNCH_CHECK();
+            // one round of resident blocks (4 per CU at 128 VGPRs): a block ends with 36 wave reductions -- the price of
+            // ~10 loop iterations -- so it should run many (150 at 256 x 640x480), and a second, partial round would idle CUs
+            const int nbt = std::max(1, std::min(nb, 4 * h->n_cu / n));
+            dim3 tgrid(nbt, n);
+            for (int pass = 0; pass < 3; pass++) {
+                if (pass == 0)
+                    k_student_taylor_f32<<<tgrid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, h->d_st_pts,
+                                                                          h->d_spartial);
+                else
+                    k_student_taylor<<<tgrid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, h->d_st_pts,
+                                                                      h->d_spartial);
+                TDK_LAUNCH_CHECK();
+                k_student_chain<<<n, 64, 0, h->stream>>>(h->d_spartial, nbt, h->d_count, d_state, h->d_st_pts,
+                                                         h->d_wscale, pass, h->d_st_redo);
+                TDK_LAUNCH_CHECK();
+            }
+            return TDK_OK;
+        }
         for (int it = 1; it < 10; it++) {   // n_iter = 10 (weights.py:4)
             if (exact)
                 k_robust_student_step<false><<<grid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state,
@@ -2090,8 +2392,18 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
     h->ratio = ratio; h->with_w = with_weight_map != 0;
     h->anti_aliasing = true;   // the reference-equivalent pyramid (skimage.transform.rescale's default)
     h->aa_taplists = false;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+        h->n_cu = cus > 0 ? cus : 256;
+    }
+    {   // defaults of tdk_dvo_set_student_passes from the environment
+        const char *ex = getenv("TDK_STUDENT_EXACT"), *sq = getenv("TDK_STUDENT");
+        h->student_mode = (ex && atoi(ex) != 0) ? 2 : ((sq && !strcmp(sq, "sequential")) ? 1 : 0);
+    }
     h->max_blocks = 1024;
-    h->d_rm = nullptr; h->d_wscale = nullptr; h->d_stat = nullptr; h->d_spartial = nullptr;
+    h->d_rm = nullptr; h->d_wscale = nullptr; h->d_stat = nullptr; h->d_spartial = nullptr; h->d_st_pts = nullptr; h->d_st_redo = nullptr;
     h->d_count = nullptr; h->d_select = nullptr; h->d_hist = nullptr;
     h->profiling = false; h->ev_used = 0;
     for (int b = 0; b < 3; b++) { h->prof_ms[b] = 0; h->prof_launches[b] = 0; h->prof_pixels[b] = 0; }
@@ -2152,7 +2464,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     (void)hipFree(h->ls.active); (void)hipFree(h->ls.ticket); (void)hipFree(h->ls.evals); (void)hipFree(h->ls.warn);
     (void)hipFree(h->ls.mode); (void)hipFree(h->ls.tested); (void)hipFree(h->ls.stat_state); (void)hipFree(h->ls.round);
     (void)hipFree(h->d_rm); (void)hipFree(h->d_wscale); (void)hipFree(h->d_stat);
-    (void)hipFree(h->d_spartial); (void)hipFree(h->d_count); (void)hipFree(h->d_select);
+    (void)hipFree(h->d_spartial); (void)hipFree(h->d_st_pts); (void)hipFree(h->d_st_redo); (void)hipFree(h->d_count); (void)hipFree(h->d_select);
     (void)hipFree(h->d_hist); (void)hipFree(h->d_cand); (void)hipFree(h->d_mode_probe);
     (void)hipFree(h->d_tk); (void)hipFree(h->d_tk_med); (void)hipFree(h->d_tk_dev); (void)hipFree(h->d_tk_sample); (void)hipFree(h->d_tk_fallback); (void)hipFree(h->d_tk_src);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -2514,6 +2826,32 @@ tdk_status tdk_dvo_get_tukey_fallbacks(tdk_dvo *h, int64_t *pairs) {
     if (!h->d_tk_fallback) return TDK_OK;
     unsigned int v = 0;
     TDK_HIP(hipMemcpyAsync(&v, h->d_tk_fallback, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
+    *pairs = (int64_t)v;
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_set_student_passes(tdk_dvo *h, int mode) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    TDK_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (Taylor passes), 1 (sequential) or 2 (sequential, IEEE divisions)");
+    h->student_mode = mode;
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_get_robust_scale(tdk_dvo *h, double *scale) {
+    TDK_REQUIRE(h && scale, "null pointer");
+    TDK_REQUIRE(h->d_wscale != nullptr, "no robust evaluation has run on this batch");
+    TDK_HIP(hipMemcpyAsync(scale, h->d_wscale, sizeof(double) * h->n_pairs, hipMemcpyDeviceToHost, h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_get_student_redos(tdk_dvo *h, int64_t *pairs) {
+    TDK_REQUIRE(h && pairs, "null pointer");
+    *pairs = 0;
+    if (!h->d_st_redo) return TDK_OK;
+    unsigned int v = 0;
+    TDK_HIP(hipMemcpyAsync(&v, h->d_st_redo, sizeof(v), hipMemcpyDeviceToHost, h->stream));
     TDK_HIP(hipStreamSynchronize(h->stream));
     *pairs = (int64_t)v;
     return TDK_OK;

@@ -284,6 +284,22 @@ class DvoBatch(object):
         call("tdk_dvo_get_tukey_fallbacks", self._h, C.byref(v))
         return int(v.value)
 
+    def set_student_passes(self, mode):
+        """0: Taylor passes (default); 1: nine sequential passes; 2: nine passes with IEEE divisions."""
+        call("tdk_dvo_set_student_passes", self._h, int(mode))
+
+    def robust_scale(self):
+        """Student-t variance / Tukey c * MAD of each pair's last robust evaluation."""
+        out = np.empty(self.n_pairs, dtype=np.float64)
+        call("tdk_dvo_get_robust_scale", self._h, _p(out))
+        return out
+
+    def student_redos(self):
+        """Pairs whose Student-t variance needed a third Taylor pass since the batch was created."""
+        v = C.c_int64()
+        call("tdk_dvo_get_student_redos", self._h, C.byref(v))
+        return int(v.value)
+
     def set_profiling(self, enabled):
         call("tdk_dvo_set_profiling", self._h, int(bool(enabled)))
 

@@ -300,6 +300,102 @@ def test_student_t_exact_switch(exact):
 
 
 # ---------------------------------------------------------------------------
+# Student-t variance: ten fixed-point steps from two Taylor passes (k_student_taylor) vs the nine sequential ones
+# ---------------------------------------------------------------------------
+def _student_scenes():
+    from golden import scenes
+    from tadataka_amd import synthetic
+    out = []
+    pr = synthetic.make_pair(480, 640, seed=0)
+    out.append(("vga", pr["I0"], pr["D0"], pr["I1"], pr["cam"]))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dvo_real.npz"))
+    I0, I1 = scenes.gray_from_rgb_u8(g["rgb0"]), scenes.gray_from_rgb_u8(g["rgb1"])
+    out.append(("tsukuba", I0, scenes.tsukuba_depth(*I0.shape), I1, scenes.TSUKUBA_CAM))
+    hp = scenes.holes_pair(0.0, 480, 640)
+    out.append(("holes", hp["I0"], hp["D0"], hp["I1"], hp["cam"]))
+    # heavy tails: a tenth of the target frame replaced by noise -- the case the t distribution is there for
+    rng = np.random.default_rng(12)
+    I1o = pr["I1"].copy()
+    I1o[rng.random(I1o.shape) < 0.1] = rng.random()
+    out.append(("outliers", pr["I0"], pr["D0"], I1o, pr["cam"]))
+    return out
+
+
+def test_student_t_variance_taylor_passes(ops):
+    """The variance after ten steps (weights.py:4-16) of the default scheme -- two passes that expand every step
+    around a predicted iterate -- against the nine sequential passes (reciprocal and IEEE arithmetic) and against
+    the fixed point iterated in NumPy on the oracle's masked residuals; every pyramid level (the coarse ones
+    fit the sample entirely), several poses, real frames, depth holes, heavy tails."""
+    from oracle import oracle as orc
+    from tadataka_amd import synthetic
+    sys.path.insert(0, os.path.dirname(__file__))
+    scn = _student_scenes()
+    B, H, W, L = len(scn), 480, 640, 5
+    batch = ops.DvoBatch(B, H, W, n_levels=L, ratio=1.5)
+    for i, (_, I0, D0, I1, _) in enumerate(scn):
+        batch.upload(i, I0, D0, I1)
+    batch.build_pyramid()
+    cams = np.stack([np.asarray(c[4], dtype=np.float64) for c in scn])
+    rng = np.random.default_rng(5)
+    poses = [_pose12(np.eye(4))]
+    for scale in (1.0, 6.0):
+        om, t = synthetic.random_pose(rng, 0.004 * scale, 0.008 * scale)
+        T = np.eye(4); T[:3, :3] = synthetic.rodrigues(om); T[:3, 3] = t
+        poses.append(_pose12(T))
+    worst_seq = worst_np = 0.0
+    for level in range(L):
+        for P in poses:
+            PP = np.tile(P, (B, 1))
+            got = {}
+            for mode in (0, 1, 2):
+                batch.set_student_passes(mode)
+                ev = batch.evaluate(level, cams, cams, PP, ops.W_STUDENT_T)
+                got[mode] = (batch.robust_scale(), ev)
+            v0, v1, v2 = got[0][0], got[1][0], got[2][0]
+            assert np.all(np.isfinite(v1)) and np.all(v1 > 0)
+            worst_seq = max(worst_seq, float(np.max(np.abs(v0 - v1) / v1)), float(np.max(np.abs(v0 - v2) / v2)))
+            # the normal equations the three variances lead to
+            for k in ("H", "b"):
+                a, b = got[0][1][k], got[1][1][k]
+                assert np.max(np.abs(a - b)) <= 1e-10 * np.max(np.abs(b)), (level, k)
+            assert np.array_equal(got[0][1]["n_update"], got[1][1]["n_update"])
+            if level >= 2:      # NumPy fixed point on the oracle's masked residuals (small levels: seconds)
+                s_cam = 1 / pow(1.5, level)
+                for i, (_, I0, D0, I1, cam) in enumerate(scn[:2]):
+                    l0, ld, l1 = (batch.download(i, level, n) for n in ("I0", "D0", "I1"))
+                    gx, gy = orc.image_gradient(l1)
+                    cam_l = np.asarray(cam) * s_cam
+                    _, r, _ = orc.dvo_rows(l0, ld, l1, gx, gy, cam_l, cam_l, P[:9].reshape(3, 3), P[9:], None)
+                    s, v = r * r, 1.0
+                    for _ in range(10):
+                        v = np.mean(s * 6.0 / (5.0 + s / v))
+                    worst_np = max(worst_np, abs(v0[i] - v) / v)
+    redos = batch.student_redos()
+    batch.close()
+    print("student-t Taylor vs sequential", worst_seq, "vs numpy", worst_np, "third passes", redos)
+    assert worst_seq < 1e-12, worst_seq
+    assert worst_np < 1e-11, worst_np
+
+
+def test_student_t_degenerate_inputs(ops):
+    """Identical frames (every residual zero): the reference's second step divides 0 by 0 (weights.py:13) -- the
+    variance is NaN in every scheme, no hang, no exception; and an empty update mask likewise."""
+    from tadataka_amd import synthetic
+    pr = synthetic.make_pair(120, 160, seed=3)
+    batch = ops.DvoBatch(2, 120, 160)
+    batch.upload(0, pr["I1"], pr["D0"], pr["I1"])
+    batch.upload(1, pr["I0"], -np.abs(pr["D0"]), pr["I1"])       # every point behind the camera
+    P = np.tile(_pose12(np.eye(4)), (2, 1))
+    for mode in (0, 1, 2):
+        batch.set_student_passes(mode)
+        ev = batch.evaluate(0, pr["cam"], pr["cam"], P, ops.W_STUDENT_T)
+        v = batch.robust_scale()
+        assert np.isnan(v[0]), (mode, v)
+        assert ev["n_update"][1] == 0 and np.isnan(v[1]), (mode, v, ev["n_update"])
+    batch.close()
+
+
+# ---------------------------------------------------------------------------
 # error-only entry and the SURVEY 8(d) work counters
 # ---------------------------------------------------------------------------
 def test_photometric_error_entry_and_counts(ops, golden):
