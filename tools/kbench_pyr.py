@@ -8,7 +8,10 @@ import bench
 _lib.require_gpu()
 B = 256
 cam = synthetic.camera_for(640, 480)
-for levels, exact in ((3, False), (2, False), (3, True)):
+CASES = ((3, False), (2, False), (3, True), (2, True))
+if len(sys.argv) > 1:       # e.g. "3e": three levels, ndimage order only; "2e": level 1 alone
+    CASES = tuple((int(a[0]), a.endswith("e")) for a in sys.argv[1:])
+for levels, exact in CASES:
     bt = ops.DvoBatch(B, 480, 640, n_levels=levels, ratio=1.5)
     bt.fill_synthetic(cam, bench.true_poses(B, 0), seed0=0, noise=0.02)
     bt.set_anti_aliasing(True, exact=exact)
