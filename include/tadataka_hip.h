@@ -292,8 +292,14 @@ tdk_status tdk_update_depth_frames(const double *key_camera, const tdk_frame *ke
  *   tdk_map_destroy       the buffer is recycled for the next map of the same size
  *   tdk_map_safe_invert   out = 1 / (v + epsilon)  (tadataka/numeric.py:1-2: the DVO weights of
  *                         examples/semi_dense_vo.py:52), out may be v itself
- *   tdk_update_depth_maps waits for its kernels before returning: an age beyond n_ref must be
- *                         reported by the call (TDK_ERR_AGE_EXCEEDS_REFFRAMES) */
+ *   tdk_update_depth_maps an age beyond n_ref must be reported by the call (TDK_ERR_AGE_EXCEEDS_REFFRAMES: the
+ *                         reference exits the process there, semi_dense.rs:202-205).  The library keeps, on the
+ *                         host, an upper bound of every map read as uint64 -- the maximum of an uploaded array,
+ *                         + 1 per tdk_increment_age_maps -- and waits for the device's verdict only if that bound
+ *                         exceeds n_ref: the loop of the example, whose refframes grow with the ages, never waits.
+ *                         (A map written through tdk_map_device_ptr by the caller keeps its old bound: upload
+ *                         through tdk_map_upload, or pass n_ref generously, if ages are edited that way.)
+ *   tdk_frame_create      copies on its own stream and waits for that copy only, not for queued kernels */
 typedef struct tdk_map tdk_map;
 tdk_status tdk_map_create(int height, int width, const void *host, tdk_map **out);
 tdk_status tdk_map_destroy(tdk_map *m);

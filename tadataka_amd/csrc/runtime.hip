@@ -10,6 +10,7 @@ namespace tdk {
 
 static thread_local char g_err[512] = "";
 static hipStream_t g_stream = nullptr;
+static hipStream_t g_upload_stream = nullptr;   // uploads of caller-owned arrays: waited for on their own
 static bool g_ready = false;
 static std::mutex g_mu;
 
@@ -26,6 +27,7 @@ void set_error(const char *fmt, ...) {
 }
 
 hipStream_t stream() { return g_stream; }
+hipStream_t upload_stream() { return g_upload_stream; }
 
 tdk_status ensure_device() {
     if (g_ready) return TDK_OK;
@@ -38,6 +40,7 @@ tdk_status ensure_device() {
         return TDK_ERR_NO_DEVICE;
     }
     TDK_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    TDK_HIP(hipStreamCreateWithFlags(&g_upload_stream, hipStreamNonBlocking));
     g_ready = true;
     return TDK_OK;
 }
@@ -110,6 +113,9 @@ tdk_status tdk_set_device(int device) {
         tdk::release_pools();
         TDK_HIP(hipStreamDestroy(tdk::g_stream));
         tdk::g_stream = nullptr;
+        TDK_HIP(hipStreamSynchronize(tdk::g_upload_stream));
+        TDK_HIP(hipStreamDestroy(tdk::g_upload_stream));
+        tdk::g_upload_stream = nullptr;
         tdk::g_ready = false;
     }
     TDK_HIP(hipSetDevice(device));

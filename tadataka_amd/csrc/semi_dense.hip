@@ -1035,8 +1035,9 @@ tdk_status tdk_frame_create(const double *image, int height, int width, tdk_fram
         tdk::set_error("hipMalloc of a %d x %d frame failed", height, width);
         return TDK_ERR_HIP;
     }
-    hipError_t e = hipMemcpyAsync(f->image, image, bytes, hipMemcpyHostToDevice, tdk::stream());
-    if (e == hipSuccess) e = hipStreamSynchronize(tdk::stream());   // the caller's array may go away
+    // on the upload stream: the wait below is for this copy only, the kernels of the previous frame keep running
+    hipError_t e = hipMemcpyAsync(f->image, image, bytes, hipMemcpyHostToDevice, tdk::upload_stream());
+    if (e == hipSuccess) e = hipStreamSynchronize(tdk::upload_stream());   // the caller's array may go away
     if (e != hipSuccess) {
         (void)hipFree(f->image);
         delete f;
@@ -1087,6 +1088,9 @@ tdk_status tdk_update_depth_frames(const double *key_camera, const tdk_frame *ke
 struct tdk_map {            // H x W elements of 8 bytes (float64 / uint64 / int64) on the device
     void *data;
     int H, W;
+    // Read as uint64 (an age map): no element exceeds this; kNoBound = unknown.  Kept on the host so that
+    // tdk_update_depth_maps knows without a device round trip that no age exceeds the reference frames it was given.
+    uint64_t bound;
 };
 
 namespace {
@@ -1163,6 +1167,21 @@ __global__ __launch_bounds__(kBlock) void k_safe_invert(const double *__restrict
 
 bool same_shape(const tdk_map *a, const tdk_map *b) { return a->H == b->H && a->W == b->W; }
 
+constexpr uint64_t kNoBound = ~0ull;
+
+uint64_t max_u64(const void *host, size_t n) {
+    const uint64_t *p = (const uint64_t *)host;
+    uint64_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4) {
+        m0 = p[i] > m0 ? p[i] : m0; m1 = p[i + 1] > m1 ? p[i + 1] : m1;
+        m2 = p[i + 2] > m2 ? p[i + 2] : m2; m3 = p[i + 3] > m3 ? p[i + 3] : m3;
+    }
+    for (; i < n; i++) m0 = p[i] > m0 ? p[i] : m0;
+    m0 = m0 > m1 ? m0 : m1; m2 = m2 > m3 ? m2 : m3;
+    return m0 > m2 ? m0 : m2;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1176,8 +1195,11 @@ tdk_status tdk_map_create(int height, int width, const void *host, tdk_map **out
     const size_t bytes = (size_t)height * width * 8;
     tdk_status st = map_alloc(bytes, &m->data);
     if (st != TDK_OK) { delete m; return st; }
+    m->bound = kNoBound;
     if (host) {
+        // stream-ordered after the last queued reader of a pooled buffer
         hipError_t e = hipMemcpyAsync(m->data, host, bytes, hipMemcpyHostToDevice, tdk::stream());
+        m->bound = max_u64(host, (size_t)height * width);              // while the copy runs
         if (e == hipSuccess) e = hipStreamSynchronize(tdk::stream());   // the caller's array may go away
         if (e != hipSuccess) {
             map_release(bytes, m->data);
@@ -1200,6 +1222,7 @@ tdk_status tdk_map_destroy(tdk_map *m) {
 tdk_status tdk_map_upload(tdk_map *m, const void *host) {
     TDK_REQUIRE(m && host, "null pointer");
     TDK_HIP(hipMemcpyAsync(m->data, host, (size_t)m->H * m->W * 8, hipMemcpyHostToDevice, tdk::stream()));
+    m->bound = max_u64(host, (size_t)m->H * m->W);
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
     return TDK_OK;
 }
@@ -1243,6 +1266,7 @@ tdk_status tdk_map_safe_invert(const tdk_map *v, double epsilon, tdk_map *out) {
     k_safe_invert<<<g > 4096 ? 4096 : g, kBlock, 0, tdk::stream()>>>((const double *)v->data, epsilon,
                                                                       (double *)out->data, n);
     TDK_LAUNCH_CHECK();
+    out->bound = kNoBound;
     return TDK_OK;
 }
 
@@ -1257,6 +1281,8 @@ tdk_status tdk_increment_age_maps(const tdk_map *age0, const double *camera0, co
     TrackWarp tw;
     fill_track_warp(&tw, T10, camera0, camera1);
     TDK_TRY(h2d_small(10, &tw, sizeof(tw), &d_tw));
+    // age1 = age0 + 1 where a source pixel lands, 0 elsewhere (age.rs:6-32)
+    age1->bound = age0->bound >= kNoBound - 1 ? kNoBound : age0->bound + 1;
     return launch_warp_step<true, false>(1, H, W, (const TrackWarp *)d_tw, (const uint64_t *)age0->data,
                                          (const double *)depth0->data, nullptr, N, 0., 0., 0., (int *)d_lists,
                                          (uint64_t *)age1->data, nullptr, nullptr, tdk::stream());
@@ -1279,6 +1305,7 @@ tdk_status tdk_propagate_maps(const double *T10, const double *camera0, const do
     TrackWarp tw;
     fill_track_warp(&tw, T10, camera0, camera1);
     TDK_TRY(h2d_small(10, &tw, sizeof(tw), &d_tw));
+    depth1->bound = variance1->bound = kNoBound;
     return launch_warp_step<false, true>(1, H, W, (const TrackWarp *)d_tw, nullptr, (const double *)depth0->data,
                                          (const double *)variance0->data, N, default_depth, default_variance,
                                          uncertaintity_bias, (int *)d_lists, nullptr,
@@ -1325,8 +1352,12 @@ tdk_status tdk_update_depth_maps(const double *key_camera, const tdk_frame *key_
                                 (const double *)prior_variance->data, N, est_params(params), (int *)d_list,
                                 (int *)d_cnt, d_err, (double *)depth->data, (double *)variance->data,
                                 (int64_t *)flag->data, tdk::stream()));
-    // the one wait of the step: the reference exits the process if some age exceeds len(refframes)
-    // (semi_dense.rs:202-205); here that is an error code, and it has to be known before the call returns
+    depth->bound = variance->bound = flag->bound = kNoBound;
+    // The reference exits the process if some age exceeds len(refframes) (semi_dense.rs:202-205); here that is an
+    // error code, and it has to be known before the call returns -- a wait for everything queued so far, unless
+    // the host already knows that no age can (an uploaded map's maximum, + 1 per tdk_increment_age_maps): the
+    // loop of examples/semi_dense_vo.py, whose refframes grow with the ages, never waits.
+    if (age->bound != kNoBound && age->bound <= (uint64_t)n_ref) return TDK_OK;
     void *h_err;
     TDK_TRY(tdk::pinned(2, sizeof(int), &h_err));
     TDK_HIP(hipMemcpyAsync(h_err, d_err, sizeof(int), hipMemcpyDeviceToHost, tdk::stream()));

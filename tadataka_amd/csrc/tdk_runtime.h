@@ -13,6 +13,10 @@ namespace tdk {
 
 void set_error(const char *fmt, ...);
 hipStream_t stream();
+// A second stream for uploads of arrays the caller owns: such a call has to wait for ITS copy before it returns
+// (the array may go away), and on this stream that wait does not include the kernels queued on stream().  The
+// destination must not be in use on stream() (a fresh allocation, or the caller has ordered it).
+hipStream_t upload_stream();
 tdk_status ensure_device();
 
 // Grow-only device buffers, indexed by slot; contents are undefined between calls.

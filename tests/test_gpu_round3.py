@@ -554,6 +554,71 @@ def test_semi_dense_vo_example_loop_through_rust_bindings(ops, monkeypatch):
     assert int(o_age.max()) == n_frames - 1 and int((o_flag == 0).sum()) > 500
 
 
+def test_update_depth_maps_age_check_without_a_wait(ops):
+    """tdk_update_depth_maps has to report an age beyond the reference frames (the reference exits there,
+    semi_dense.rs:202-205).  It knows a host-side bound of every age map (maximum of an uploaded array, + 1 per
+    increment_age) and reads the device flag only when that bound does not already rule the error out: the
+    error is still raised whenever an age exceeds the list -- from an uploaded map, from a chain of increments --
+    results are the same on both paths, and the loop of the example (ages grow with the list) never takes the
+    waiting path."""
+    import tadataka_amd  # noqa: F401
+    from rust_bindings.camera import CameraParameters
+    from rust_bindings.semi_dense import Frame, Params, increment_age, propagate, update_depth
+    from tadataka.matrix import inv_motion_matrix
+    from tadataka_amd import _lib
+    H, W, n_frames = 96, 128, 5
+    cam, depth_gt0, T_w, images = _sliding_camera_frames(H, W, n_frames)
+    cp = CameraParameters((cam[0], cam[1]), (cam[2], cam[3]))
+    params = Params(0.5, 10.0, 0.01, 0.01, 0.004, 0.01)
+    frames = [Frame(cp, images[i], T_w[i]) for i in range(n_frames)]
+    T10 = [None] + [np.dot(inv_motion_matrix(T_w[i]), T_w[i - 1]) for i in range(1, n_frames)]
+    d0, v0 = depth_gt0.copy(), np.full((H, W), 0.05)
+
+    # (1) an uploaded age map that exceeds the list: raised (bound 2 > 1 reference frame -> device check)
+    with pytest.raises(_lib.TdkError) as e:
+        update_depth(frames[1], [frames[0]], np.full((H, W), 2, dtype=np.uint64), d0, v0, params)
+    assert e.value.status == _lib.TDK_ERR_AGE_EXCEEDS_REFFRAMES
+    # ... an uploaded map whose bound exceeds the list only at pixels the check never sees is impossible: every
+    # pixel with age != 0 is checked, so bound > n_ref with all ages checked in range means the bound was loose:
+    ages = np.zeros((H, W), dtype=np.uint64); ages[3, 4] = 1
+    d_a, v_a, f_a = (np.asarray(m) for m in update_depth(frames[1], [frames[0]], ages, d0, v0, params))
+    assert f_a[3, 4] != -9 and (f_a == -9).sum() == H * W - 1
+
+    # (2) a chain of increments with a list that stops growing: frame 2 has ages of 2 against one reference frame
+    a = np.zeros((H, W), dtype=np.uint64)
+    a = increment_age(a, cp, cp, T10[1], d0)
+    a = increment_age(a, cp, cp, T10[2], d0)
+    assert int(np.asarray(a).max()) == 2
+    with pytest.raises(_lib.TdkError) as e:
+        update_depth(frames[2], [frames[1]], a, d0, v0, params)
+    assert e.value.status == _lib.TDK_ERR_AGE_EXCEEDS_REFFRAMES
+    # a loose bound (two increments, but the second warp lands nowhere: every age is 0) is not an error
+    far = T10[2].copy(); far[:3, 3] = (1e6, 0.0, 0.0)
+    b = increment_age(increment_age(np.zeros((H, W), dtype=np.uint64), cp, cp, T10[1], d0), cp, cp, far, d0)
+    assert int(np.asarray(b).max()) == 0
+    _, _, f_b = update_depth(frames[2], [frames[1]], b, d0, v0, params)
+    assert np.all(np.asarray(f_b) == -9)
+
+    # (3) the example's loop: no device round trip for the check, same maps as with the bound unknown
+    def run(force_unknown):
+        a0, dm, vm, refs, out = np.zeros((H, W), dtype=np.uint64), d0, v0, [frames[0]], []
+        for i in range(1, n_frames):
+            a1 = increment_age(a0, cp, cp, T10[i], dm)
+            d1, v1 = propagate(T10[i], cp, cp, dm, vm, 1.0, 10.0, 0.01)
+            if force_unknown:       # an age map that went through the host loses nothing but its provenance
+                a1 = np.asarray(a1) + np.uint64(0)
+                a1[0, 0] = np.uint64(min(int(a1[0, 0]), len(refs)))
+            d1, v1, f1 = update_depth(frames[i], refs, a1, d1, v1, params)
+            refs.append(frames[i]); a0, dm, vm = a1, d1, v1
+            out.append([np.asarray(m).copy() for m in (a1, d1, v1, f1)])
+        return out
+    fast, slow = run(False), run(True)
+    for fa, sl in zip(fast, slow):
+        for x, y in zip(fa, sl):
+            assert np.array_equal(x, y, equal_nan=True)
+    assert int(fast[-1][0].max()) == n_frames - 1
+
+
 def test_device_map_behaves_like_an_array(ops):
     """What a caller may do with a returned map: look at it, compute with it, write into it and hand
     it back (the device copy follows), mix it with ndarrays."""
