@@ -377,6 +377,32 @@ def test_student_t_variance_taylor_passes(ops):
     assert worst_np < 1e-11, worst_np
 
 
+def test_student_t_taylor_passes_many_small_pairs(ops):
+    """More pairs than one resident round of blocks (one block per pair and pass) and levels smaller than the
+    sample (24x32, 16x21): the Taylor passes against the sequential ones."""
+    from tadataka_amd import synthetic
+    B, H, W = 1100, 24, 32
+    batch = ops.DvoBatch(B, H, W, n_levels=2, ratio=1.5)
+    cam = synthetic.camera_for(W, H)
+    true = np.empty((B, 12))
+    for i in range(B):
+        om, t = synthetic.random_pose(np.random.default_rng(100 + i))
+        true[i, :9] = synthetic.rodrigues(om).ravel(); true[i, 9:] = t
+    batch.fill_synthetic(cam, true, seed0=5, noise=0.05)
+    batch.build_pyramid()
+    P = np.tile(_pose12(np.eye(4)), (B, 1))
+    for level in (0, 1):
+        got = []
+        for mode in (0, 1):
+            batch.set_student_passes(mode)
+            batch.evaluate(level, cam, cam, P, ops.W_STUDENT_T)
+            got.append(batch.robust_scale())
+        assert np.all(got[1] > 0)
+        assert np.max(np.abs(got[0] - got[1]) / got[1]) < 1e-12, level
+        assert len(np.unique(got[1])) > B // 2        # the pairs are different scenes
+    batch.close()
+
+
 def test_student_t_degenerate_inputs(ops):
     """Identical frames (every residual zero): the reference's second step divides 0 by 0 (weights.py:13) -- the
     variance is NaN in every scheme, no hang, no exception; and an empty update mask likewise."""
