@@ -134,6 +134,9 @@ tdk_status tdk_dvo_fill_synthetic(tdk_dvo *h, const double *camera, const double
                                   uint64_t seed0, double noise);
 /* Builds pyramid levels 1..n_levels-1 on the device from level 0. */
 tdk_status tdk_dvo_build_pyramid(tdk_dvo *h);
+/* The same for a subset of the arrays: bit 0 I0, bit 1 D0, bit 2 I1, bit 3 W0.  A consumer of a stream of frames
+ * that replaces only I1 of every pair per step (tdk_dvo_upload_async*) rebuilds a third of the pyramid. */
+tdk_status tdk_dvo_build_pyramid_arrays(tdk_dvo *h, unsigned int arrays);
 /* Device -> host copy of one array of one pair/level: which = 0 I0, 1 D0, 2 I1, 3 W0. */
 tdk_status tdk_dvo_download(tdk_dvo *h, int pair, int level, int which, double *out);
 /* Pyramid levels with (1, the default) or without (0) the anti-aliasing prefilter of

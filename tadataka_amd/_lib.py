@@ -85,6 +85,7 @@ PROTOTYPES = {
     "tdk_dvo_upload": [_vp, _i, _d, _d, _d, _d],
     "tdk_dvo_fill_synthetic": [_vp, _d, _d, _u64, C.c_double],
     "tdk_dvo_build_pyramid": [_vp],
+    "tdk_dvo_build_pyramid_arrays": [_vp, C.c_uint],
     "tdk_dvo_download": [_vp, _i, _i, _i, _d],
     "tdk_dvo_level_shape": [_vp, _i, c_int_p, c_int_p],
     "tdk_dvo_evaluate": [_vp, _i, _d, _d, _d, _i, _d, _d, c_int64_p, _d, c_int64_p],

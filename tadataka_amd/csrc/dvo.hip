@@ -2604,29 +2604,41 @@ tdk_status tdk_dvo_fill_synthetic(tdk_dvo *h, const double *camera, const double
     return TDK_OK;
 }
 
-tdk_status tdk_dvo_build_pyramid(tdk_dvo *h) {
-    TDK_REQUIRE(h != nullptr, "handle is NULL");
+// arrays: bit 0 I0, bit 1 D0, bit 2 I1, bit 3 W0 -- the arrays whose levels 1 .. n_levels - 1 are (re)built
+static tdk_status build_pyramid_of(tdk_dvo *h, unsigned arrays) {
     const tdk_dvo::Level &S = h->lv[0];
+    if (!h->with_w) arrays &= 7u;
+    if (arrays == 0u || h->n_levels <= 1) return TDK_OK;
+    const int n_out = h->n_levels - 1;
+    // the selected arrays, in the fixed order I0, D0, I1, W0
+    int sel[4], n_sel = 0;
+    for (int k = 0; k < 4; k++)
+        if ((arrays >> k) & 1u) sel[n_sel++] = k;
+    auto src_of = [&](const tdk_dvo::Level &L, int k) -> double * { return k == 0 ? L.I0 : k == 1 ? L.D0 : k == 2 ? L.I1 : L.W0; };
+    // sources and per-level destinations of a subset `idx` of the arrays
+    auto describe = [&](const int *idx, int n, const double **srcs, tdk::PyramidLevelDesc *lv) {
+        for (int k = 0; k < 4; k++) srcs[k] = k < n ? src_of(S, idx[k]) : nullptr;
+        for (int l = 1; l < h->n_levels; l++) {
+            const tdk_dvo::Level &L = h->lv[l];
+            for (int k = 0; k < 4; k++) lv[l - 1].dst[k] = k < n ? src_of(L, idx[k]) : nullptr;
+            lv[l - 1].stride = L.stride; lv[l - 1].H = L.H; lv[l - 1].W = L.W;
+        }
+    };
     // every level is resampled from the full-resolution frame, exactly as
     // _estimate_at rescales the original I0/D0/I1/W0 (vo/dvo/__init__.py:144-148).
     // Default: one launch, levels of one image dispatched together so the
     // re-reads of level 0 stay on die.  TDK_PYRAMID=lds stages level-0 tiles in
     // LDS (one read, slower as measured), TDK_PYRAMID=levels runs one k_rescale
     // per (array, level).  All three are bit-identical.
-    if (h->anti_aliasing && h->n_levels > 1) {
-        const double *srcs[4] = {S.I0, S.D0, S.I1, S.W0};
+    if (h->anti_aliasing) {
+        const double *srcs[4];
         tdk::PyramidLevelDesc lv[kMaxLevels];
-        for (int l = 1; l < h->n_levels; l++) {
-            const tdk_dvo::Level &L = h->lv[l];
-            lv[l - 1].dst[0] = L.I0; lv[l - 1].dst[1] = L.D0; lv[l - 1].dst[2] = L.I1; lv[l - 1].dst[3] = L.W0;
-            lv[l - 1].stride = L.stride; lv[l - 1].H = L.H; lv[l - 1].W = L.W;
-        }
-        const int n_arrays = h->with_w ? 4 : 3, n_out = h->n_levels - 1;
+        describe(sel, n_sel, srcs, lv);
         const bool first = h->d_aa_weights == nullptr;
         if (first)
             TDK_HIP(hipMalloc(&h->d_aa_weights, tdk::pyramid_aa_weight_doubles(h->n_levels - 1) * sizeof(double)));
         if (!h->aa_taplists)
-            return tdk::launch_pyramid_aa(srcs, n_arrays, S.H, S.W, S.stride, n_out, lv, h->n_pairs, h->d_aa_weights,
+            return tdk::launch_pyramid_aa(srcs, n_sel, S.H, S.W, S.stride, n_out, lv, h->n_pairs, h->d_aa_weights,
                                           first, h->stream);
         // Mode 3 (opt-in; measured slower, see pyramid_sep.hip).  The images (and the weight map) go through the separable tap-list kernel
         // (pyramid_sep.hip) for every level it can take.  The DEPTH map stays on the ndimage-order
@@ -2642,25 +2654,25 @@ tdk_status tdk_dvo_build_pyramid(tdk_dvo *h) {
             TDK_TRY(tdk::pyramid_sep_create(S.H, S.W, n_out, Ho, Wo, h->stream, &h->sep_plan, nullptr));
         }
         const unsigned sep_mask = tdk::pyramid_sep_mask(h->sep_plan), all = (1u << n_out) - 1u;
-        const double *img_srcs[4] = {S.I0, S.I1, S.W0, nullptr};
-        const double *depth_srcs[4] = {S.D0, nullptr, nullptr, nullptr};
+        int img[4], n_img = 0;
+        for (int k = 0; k < n_sel; k++)
+            if (sel[k] != 1) img[n_img++] = sel[k];
+        const int depth_idx[1] = {1};
+        const bool depth = (arrays >> 1) & 1u;
+        const double *img_srcs[4], *depth_srcs[4];
         tdk::PyramidLevelDesc img_lv[kMaxLevels], depth_lv[kMaxLevels];
-        for (int l = 0; l < n_out; l++) {
-            img_lv[l] = lv[l];
-            img_lv[l].dst[0] = lv[l].dst[0]; img_lv[l].dst[1] = lv[l].dst[2]; img_lv[l].dst[2] = lv[l].dst[3];
-            img_lv[l].dst[3] = nullptr;
-            depth_lv[l] = lv[l];
-            depth_lv[l].dst[0] = lv[l].dst[1];
-            depth_lv[l].dst[1] = depth_lv[l].dst[2] = depth_lv[l].dst[3] = nullptr;
+        describe(img, n_img, img_srcs, img_lv);
+        describe(depth_idx, 1, depth_srcs, depth_lv);
+        bool weights_up = first;
+        if (n_img > 0) TDK_TRY(tdk::launch_pyramid_sep(h->sep_plan, img_srcs, n_img, S.stride, img_lv, h->n_pairs, h->stream));
+        if (depth) {
+            // (deep levels whose tiles exceed LDS are skipped here and built with every array below)
+            TDK_TRY(tdk::launch_pyramid_aa(depth_srcs, 1, S.H, S.W, S.stride, n_out, depth_lv, h->n_pairs, h->d_aa_weights,
+                                           weights_up, h->stream, all & ~sep_mask));
+            weights_up = false;
         }
-        TDK_TRY(tdk::launch_pyramid_sep(h->sep_plan, img_srcs, n_arrays - 1, S.stride, img_lv, h->n_pairs, h->stream));
-        if (sep_mask == all)
-            return tdk::launch_pyramid_aa(depth_srcs, 1, S.H, S.W, S.stride, n_out, depth_lv, h->n_pairs,
-                                          h->d_aa_weights, first, h->stream);
-        // deep levels whose tiles exceed LDS: every array on the ndimage-order kernels
-        TDK_TRY(tdk::launch_pyramid_aa(depth_srcs, 1, S.H, S.W, S.stride, n_out, depth_lv, h->n_pairs, h->d_aa_weights,
-                                       first, h->stream, all & ~sep_mask));
-        return tdk::launch_pyramid_aa(srcs, n_arrays, S.H, S.W, S.stride, n_out, lv, h->n_pairs, h->d_aa_weights, false,
+        if (sep_mask == all) return TDK_OK;
+        return tdk::launch_pyramid_aa(srcs, n_sel, S.H, S.W, S.stride, n_out, lv, h->n_pairs, h->d_aa_weights, weights_up,
                                       h->stream, sep_mask);
     }
     static const int mode = [] {
@@ -2670,25 +2682,30 @@ tdk_status tdk_dvo_build_pyramid(tdk_dvo *h) {
         return 0;
     }();
     if (mode != 2) {
-        const double *srcs[4] = {S.I0, S.D0, S.I1, S.W0};
+        const double *srcs[4];
         tdk::PyramidLevelDesc lv[kMaxLevels];
-        for (int l = 1; l < h->n_levels; l++) {
-            const tdk_dvo::Level &L = h->lv[l];
-            lv[l - 1].dst[0] = L.I0; lv[l - 1].dst[1] = L.D0; lv[l - 1].dst[2] = L.I1; lv[l - 1].dst[3] = L.W0;
-            lv[l - 1].stride = L.stride; lv[l - 1].H = L.H; lv[l - 1].W = L.W;
-        }
-        return tdk::launch_pyramid(srcs, h->with_w ? 4 : 3, S.H, S.W, S.stride, h->n_levels - 1, lv, h->n_pairs,
-                                   mode, h->stream);
+        describe(sel, n_sel, srcs, lv);
+        return tdk::launch_pyramid(srcs, n_sel, S.H, S.W, S.stride, n_out, lv, h->n_pairs, mode, h->stream);
     }
     for (int l = 1; l < h->n_levels; l++) {
         const tdk_dvo::Level &L = h->lv[l];
-        TDK_TRY(tdk::launch_rescale(S.I0, S.H, S.W, L.I0, L.H, L.W, h->n_pairs, S.stride, L.stride, h->stream));
-        TDK_TRY(tdk::launch_rescale(S.D0, S.H, S.W, L.D0, L.H, L.W, h->n_pairs, S.stride, L.stride, h->stream));
-        TDK_TRY(tdk::launch_rescale(S.I1, S.H, S.W, L.I1, L.H, L.W, h->n_pairs, S.stride, L.stride, h->stream));
-        if (h->with_w)
-            TDK_TRY(tdk::launch_rescale(S.W0, S.H, S.W, L.W0, L.H, L.W, h->n_pairs, S.stride, L.stride, h->stream));
+        for (int k = 0; k < n_sel; k++)
+            TDK_TRY(tdk::launch_rescale(src_of(S, sel[k]), S.H, S.W, src_of(L, sel[k]), L.H, L.W, h->n_pairs, S.stride,
+                                        L.stride, h->stream));
     }
     return TDK_OK;
+}
+
+tdk_status tdk_dvo_build_pyramid(tdk_dvo *h) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    return build_pyramid_of(h, 15u);
+}
+
+tdk_status tdk_dvo_build_pyramid_arrays(tdk_dvo *h, unsigned int arrays) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    TDK_REQUIRE(arrays != 0u && arrays <= 15u, "arrays: bit 0 I0, bit 1 D0, bit 2 I1, bit 3 W0");
+    TDK_REQUIRE(h->with_w || !(arrays & 8u), "no weight map in this batch");
+    return build_pyramid_of(h, arrays);
 }
 
 tdk_status tdk_dvo_level_shape(tdk_dvo *h, int level, int *height, int *width) {

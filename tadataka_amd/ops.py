@@ -206,8 +206,16 @@ class DvoBatch(object):
         map, last-bit differences; measured slower), the depth map as with exact=True."""
         call("tdk_dvo_set_anti_aliasing", self._h, (1 if exact else 3) if enabled else 0)
 
-    def build_pyramid(self):
-        call("tdk_dvo_build_pyramid", self._h)
+    def build_pyramid(self, arrays=None):
+        """Levels 1 .. n_levels - 1 of every array, or of the named ones only: arrays = iterable of
+        "I0", "D0", "I1", "W0" (a stream that replaces I1 per step rebuilds only that)."""
+        if arrays is None:
+            call("tdk_dvo_build_pyramid", self._h)
+            return
+        mask = 0
+        for name in arrays:
+            mask |= 1 << {"I0": 0, "D0": 1, "I1": 2, "W0": 3}[name]
+        call("tdk_dvo_build_pyramid_arrays", self._h, mask)
 
     def level_shape(self, level):
         h, w = C.c_int(), C.c_int()

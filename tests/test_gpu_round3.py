@@ -680,6 +680,60 @@ def test_device_map_behaves_like_an_array(ops):
         increment_age(c["age"].astype(np.int64), cp, cp, T10, c["prior_depth"])
 
 
+@pytest.mark.parametrize("mode", ["aa", "aa_taplists", "bilinear"])
+def test_partial_pyramid_rebuild(ops, mode):
+    """tdk_dvo_build_pyramid_arrays: the levels of the named arrays are rebuilt, bit for bit as the full build
+    produces them, the others are left alone (a stream that replaces I1 per step rebuilds only I1)."""
+    from tadataka_amd import synthetic
+    B, H, W, L = 3, 120, 160, 4
+    batch = ops.DvoBatch(B, H, W, n_levels=L, ratio=1.5, with_weight_map=True)
+    if mode == "bilinear":
+        batch.set_anti_aliasing(False)
+    else:
+        batch.set_anti_aliasing(True, exact=(mode == "aa"))
+    rng = np.random.default_rng(2)
+    pairs = [synthetic.make_pair(H, W, seed=30 + i) for i in range(B)]
+    W0s = [rng.uniform(0.1, 5.0, (H, W)) for _ in range(B)]
+    for i, p in enumerate(pairs):
+        batch.upload(i, p["I0"], p["D0"], p["I1"], W0s[i])
+    batch.build_pyramid()
+    names = ("I0", "D0", "I1", "W0")
+    before = {(i, l, n): batch.download(i, l, n) for i in range(B) for l in range(1, L) for n in names}
+    # new frames for I1 (and, second round, new depth + weights); nothing is rebuilt yet
+    new_I1 = [synthetic.make_pair(H, W, seed=60 + i)["I1"] for i in range(B)]
+    for i, p in enumerate(pairs):
+        batch.upload(i, p["I0"], p["D0"], new_I1[i], W0s[i])
+    batch.build_pyramid(["I1"])
+    for i in range(B):
+        for l in range(1, L):
+            for n in ("I0", "D0", "W0"):
+                assert np.array_equal(batch.download(i, l, n), before[(i, l, n)]), (i, l, n)
+            assert not np.array_equal(batch.download(i, l, "I1"), before[(i, l, "I1")])
+    part = {(i, l): batch.download(i, l, "I1") for i in range(B) for l in range(1, L)}
+    batch.build_pyramid()                                  # the full build of the same contents
+    for i in range(B):
+        for l in range(1, L):
+            assert np.array_equal(batch.download(i, l, "I1"), part[(i, l)]), (i, l)
+    # two arrays at once, W0 among them
+    new_D0 = [p["D0"] * 1.25 for p in pairs]
+    new_W0 = [rng.uniform(0.1, 5.0, (H, W)) for _ in range(B)]
+    for i, p in enumerate(pairs):
+        batch.upload(i, p["I0"], new_D0[i], new_I1[i], new_W0[i])
+    batch.build_pyramid(["D0", "W0"])
+    part = {(i, l, n): batch.download(i, l, n) for i in range(B) for l in range(1, L) for n in names}
+    batch.build_pyramid()
+    for key, v in part.items():
+        assert np.array_equal(batch.download(*key), v), key
+    with pytest.raises(Exception):
+        batch.build_pyramid([])                            # an empty selection is a caller's mistake
+    batch.close()
+    plain = ops.DvoBatch(1, H, W, n_levels=2, ratio=1.5)
+    plain.upload(0, pairs[0]["I0"], pairs[0]["D0"], pairs[0]["I1"])
+    with pytest.raises(Exception):
+        plain.build_pyramid(["W0"])                        # no weight map in this batch
+    plain.close()
+
+
 def test_async_uploads_from_pinned_memory(ops):
     """tdk_dvo_upload_async / _u8: ranges of pairs from pinned memory on the copy stream, ordered
     with the batch's own stream; float64 bit for bit, 8-bit frames as x / 255."""
