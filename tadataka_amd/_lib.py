@@ -169,6 +169,11 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (or `make -C tadataka_amd/csrc`).  There is no CPU fallback.")
+    # HIP maps all streams of a process onto a few hardware queues (4 by default) and a stream that waits for an
+    # event of another stream holds up every stream behind it in its queue.  Each DvoBatch owns a stream, uploads
+    # and the stateless operators have theirs: give them queues of their own unless the caller decided otherwise.
+    # (Read by the HIP runtime when it starts: no effect if something else initialised HIP in this process first.)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = C.CDLL(LIB_PATH)
     lib.tdk_version.restype = C.c_char_p
     lib.tdk_last_error.restype = C.c_char_p

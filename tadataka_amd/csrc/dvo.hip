@@ -739,6 +739,14 @@ __global__ void k_loop_init(LoopState ls, const double *poses_in, int n) {   // 
     }
 }
 
+// final poses and warnings of a call, written where the host reads them (tdk_dvo::h_io)
+__global__ void k_publish(LoopState ls, double *__restrict__ poses_out, int *__restrict__ warn_out, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int k = 0; k < 12; k++) poses_out[12 * i + k] = ls.pose[12 * i + k];
+    warn_out[i] = ls.warn[i];
+}
+
 // ---------------------------------------------------------------------------
 // Robust scale statistics per pair (Student-t, Tukey)
 // ---------------------------------------------------------------------------
@@ -1953,6 +1961,13 @@ struct tdk_dvo {
     uint8_t *d_u8;              // staging for 8-bit frames (tdk_dvo_upload_async_u8), [n_pairs][N]
     size_t u8_bytes;
     hipEvent_t ev_copy, ev_xs;  // copy stream <-> batch stream; library stream <-> batch stream
+    // tdk_dvo_upload_async*: recorded on the copy stream after the last queued upload (and its conversion).  The
+    // batch's stream waits for it when it next touches the arrays (after_uploads), not when the upload is queued:
+    // a wait queued at once sits in the stream's hardware queue for the whole transfer, and HIP maps all streams
+    // onto a few hardware queues (4 unless GPU_MAX_HW_QUEUES says otherwise) -- other batches' kernels stood
+    // behind that barrier (the 8-bit stream of bench.py ran 3.4 ms per step instead of 2.5).
+    hipEvent_t ev_uploaded;
+    bool uploads_pending;
     int *d_mode_probe;          // [n] MODE_PROBE (tdk_dvo_photometric_error), allocated on first use
     int64_t count_error_px, count_update_px;   // tdk_dvo_get_counts: source pixels of the last estimate call
     bool anti_aliasing;         // pyramid levels get skimage's Gaussian prefilter (tdk_dvo_set_anti_aliasing)
@@ -1962,6 +1977,10 @@ struct tdk_dvo {
     tdk::PyramidSepPlan *sep_plan;   // tap lists of the separable pyramid kernel (created at the first build)
     double *d_aa_weights;       // its 1-D kernels, per level and axis (allocated on first use)
     int *h_flag;   // "pairs still running", written by k_dvo_reduce (mapped pinned host memory)
+    // Prior poses in, final poses and warnings out of tdk_dvo_estimate*: mapped pinned host memory that the first /
+    // last kernel of a call reads / writes directly.  As hipMemcpyAsync these few kilobytes queued behind whatever
+    // bulk upload was in flight on the copy engine -- 1.4 ms per 78 MB of frames -- and with them the estimation.
+    double *h_io, *d_io;   // [n x 12 in][n x 12 out][n ints]
     std::vector<int> host_warn;   // ls.warn of the last estimate call
 };
 
@@ -2006,7 +2025,17 @@ LevelPtrs ptrs_of(const tdk_dvo::Level &L) {
     return p;
 }
 
+// the batch's stream waits for the asynchronous uploads queued so far (no-op when there are none)
+tdk_status after_uploads(tdk_dvo *h) {
+    if (!h->uploads_pending) return TDK_OK;
+    TDK_HIP(hipStreamWaitEvent(h->stream, h->ev_uploaded, 0));
+    h->uploads_pending = false;
+    return TDK_OK;
+}
+
 tdk_status upload_params(tdk_dvo *h, const double *cam0, const double *cam1) {
+    // every evaluation / estimation entry comes through here: frames uploaded asynchronously are waited for first
+    TDK_TRY(after_uploads(h));
     // same cameras as last time (the usual case for a sequence): nothing to do
     const size_t n4 = (size_t)4 * h->n_pairs;
     if (h->cams.size() == 2 * n4 && !memcmp(h->cams.data(), cam0, sizeof(double) * n4) &&
@@ -2312,34 +2341,59 @@ tdk_status collect_profile(tdk_dvo *h) {
 // returns at once for pairs that finished in the first (state != RUNNING) -- which
 // halves the host waits of the typical 2-3 evaluation level.  Evaluations are
 // counted on the device (LoopState::evals), so the pixel bookkeeping stays exact.
-tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64_t *pixel_evals) {
+// The loop in two halves: queue_round puts the next evaluation(s) of a level on the batch's stream, after_round --
+// once that stream has drained -- reads what k_dvo_reduce left in h_flag and says whether the level goes on.
+// (Several batches driven in lockstep through these halves, so that one batch's kernels fill the other's round
+// trips, was built and measured on the 8-bit stream of bench.py: 2.79 ms per batch against 2.58 ms one after the
+// other -- the pyramid and the conversion of the next batches already fill the gaps.  Not kept.)
+struct LevelRun {
+    int level, round, max_rounds, burst;
+};
+
+static LevelRun begin_level(tdk_dvo *h, int level, int max_iter) {
     const bool small = (int64_t)h->n_pairs * h->lv[level].N <= (1ll << 22) && !h->profiling;
     static const int small_burst = [] { const char *v = getenv("TDK_DVO_BURST"); return v && atoi(v) > 0 ? atoi(v) : 2; }();
-    const int burst = small ? small_burst : 1;
     // a pair goes through at most 2 max_iter + 1 evaluations: the first, then per tested candidate a
     // probe and -- if it was accepted and is not the last -- the full evaluation at the accepted pose
-    const int max_rounds = 2 * max_iter + 1;
-    for (int round = 0; round < max_rounds;) {
-        const int nb = max_rounds - round < burst ? max_rounds - round : burst;
-        for (int b = 0; b < nb; b++) {
-            TDK_TRY(launch_eval(h, level, h->ls.cand, h->ls.state, h->ls.mode, h->ls.stat_state, weight_mode));
-            TDK_TRY(launch_reduce(h, level, 1, max_iter));
-        }
-        TDK_HIP(hipStreamSynchronize(h->stream));   // k_dvo_reduce left the counts in h_flag
-        round += nb;
-        if (h->profiling && level == 0 && h->ev_used >= 2) {   // what the launch just timed evaluated
-            h->ev_round[h->ev_used - 2] = ((volatile int *)h->h_flag)[4];
-            h->ev_round[h->ev_used - 1] = ((volatile int *)h->h_flag)[5];
-        }
-        if (*(volatile int *)h->h_flag <= 0) break;
+    return LevelRun{level, 0, 2 * max_iter + 1, small ? small_burst : 1};
+}
+
+static tdk_status queue_round(tdk_dvo *h, LevelRun &r, int weight_mode, int max_iter) {
+    const int nb = r.max_rounds - r.round < r.burst ? r.max_rounds - r.round : r.burst;
+    for (int b = 0; b < nb; b++) {
+        TDK_TRY(launch_eval(h, r.level, h->ls.cand, h->ls.state, h->ls.mode, h->ls.stat_state, weight_mode));
+        TDK_TRY(launch_reduce(h, r.level, 1, max_iter));
     }
+    r.round += nb;
+    return TDK_OK;
+}
+
+// the batch's stream has been waited for; true: another round is needed
+static bool after_round(tdk_dvo *h, const LevelRun &r) {
+    if (h->profiling && r.level == 0 && h->ev_used >= 2) {   // what the launch just timed evaluated
+        h->ev_round[h->ev_used - 2] = ((volatile int *)h->h_flag)[4];
+        h->ev_round[h->ev_used - 1] = ((volatile int *)h->h_flag)[5];
+    }
+    return *(volatile int *)h->h_flag > 0 && r.round < r.max_rounds;
+}
+
+static void end_level(tdk_dvo *h, const LevelRun &r, int64_t *pixel_evals) {
     // evaluations in the reference's sense: one per PhotometricError call (the full evaluation of an
     // accepted candidate is the second half of the evaluation its probe began)
     const int64_t evals = (int64_t)*(volatile unsigned long long *)(h->h_flag + 2);
     const int64_t updates = (int64_t)*(volatile unsigned long long *)(h->h_flag + 6);
-    if (pixel_evals) *pixel_evals += h->lv[level].N * evals;
-    h->count_error_px += h->lv[level].N * evals;
-    h->count_update_px += h->lv[level].N * updates;
+    if (pixel_evals) *pixel_evals += h->lv[r.level].N * evals;
+    h->count_error_px += h->lv[r.level].N * evals;
+    h->count_update_px += h->lv[r.level].N * updates;
+}
+
+tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64_t *pixel_evals) {
+    LevelRun r = begin_level(h, level, max_iter);
+    do {
+        TDK_TRY(queue_round(h, r, weight_mode, max_iter));
+        TDK_HIP(hipStreamSynchronize(h->stream));   // k_dvo_reduce left the counts in h_flag
+    } while (after_round(h, r));
+    end_level(h, r, pixel_evals);
     return TDK_OK;
 }
 
@@ -2445,6 +2499,8 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
     TDK_HIP(hipMalloc(&h->ls.stat_state, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.round, sizeof(int) * 2));
     h->host_warn.assign((size_t)n_pairs, 0);
+    TDK_HIP(hipHostMalloc((void **)&h->h_io, sizeof(double) * 24 * (size_t)n_pairs + sizeof(int) * (size_t)n_pairs, hipHostMallocMapped));
+    TDK_HIP(hipHostGetDevicePointer((void **)&h->d_io, h->h_io, 0));
     TDK_HIP(hipHostMalloc(&h->h_flag, 16 * sizeof(int), hipHostMallocMapped));
     TDK_HIP(hipHostGetDevicePointer((void **)&h->ls.host_flag, h->h_flag, 0));
     return TDK_OK;
@@ -2469,10 +2525,13 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     (void)hipFree(h->d_tk); (void)hipFree(h->d_tk_med); (void)hipFree(h->d_tk_dev); (void)hipFree(h->d_tk_sample); (void)hipFree(h->d_tk_fallback); (void)hipFree(h->d_tk_src);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
+    if (h->h_io) (void)hipHostFree(h->h_io);
     if (h->d_aa_weights) (void)hipFree(h->d_aa_weights);
     (void)tdk::pyramid_sep_destroy(h->sep_plan);
     if (h->d_u8) (void)hipFree(h->d_u8);
+    if (h->uploads_pending && h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (h->ev_copy) (void)hipEventDestroy(h->ev_copy);
+    if (h->ev_uploaded) (void)hipEventDestroy(h->ev_uploaded);
     if (h->ev_xs) (void)hipEventDestroy(h->ev_xs);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -2487,6 +2546,7 @@ tdk_status tdk_dvo_upload(tdk_dvo *h, int pair, const double *I0, const double *
     const tdk_dvo::Level &L = h->lv[0];
     size_t bytes = (size_t)L.N * sizeof(double);
     int64_t off = (int64_t)pair * L.stride;
+    TDK_TRY(after_uploads(h));
     TDK_HIP(hipMemcpyAsync(L.I0 + off, I0, bytes, hipMemcpyHostToDevice, h->stream));
     TDK_HIP(hipMemcpyAsync(L.D0 + off, D0, bytes, hipMemcpyHostToDevice, h->stream));
     TDK_HIP(hipMemcpyAsync(L.I1 + off, I1, bytes, hipMemcpyHostToDevice, h->stream));
@@ -2504,6 +2564,7 @@ tdk_status tdk_dvo_upload_mixed(tdk_dvo *h, int pair, const double *const *host4
     const size_t bytes = (size_t)L.N * sizeof(double);
     const int64_t off = (int64_t)pair * L.stride;
     double *dst[4] = {L.I0 + off, L.D0 + off, L.I1 + off, L.W0 ? L.W0 + off : nullptr};
+    TDK_TRY(after_uploads(h));
     bool any_device = false, any_host = false;
     for (int k = 0; k < 4; k++) any_device |= device4[k] != nullptr;
     if (any_device) {
@@ -2537,6 +2598,7 @@ static tdk_status ensure_copy_stream(tdk_dvo *h) {
     if (!g_copy_stream) TDK_HIP(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
     h->copy_stream = g_copy_stream;
     if (!h->ev_copy) TDK_HIP(hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
+    if (!h->ev_uploaded) TDK_HIP(hipEventCreateWithFlags(&h->ev_uploaded, hipEventDisableTiming));
     return TDK_OK;
 }
 
@@ -2547,7 +2609,7 @@ tdk_status tdk_dvo_upload_async(tdk_dvo *h, int which, int first_pair, int n_pai
     const tdk_dvo::Level &L = h->lv[0];
     double *base = which == 0 ? L.I0 : which == 1 ? L.D0 : which == 2 ? L.I1 : L.W0;
     TDK_TRY(ensure_copy_stream(h));
-    // after what the batch's own stream still does with the old frames; before what it does next
+    // after what the batch's own stream still does with the old frames ...
     TDK_HIP(hipEventRecord(h->ev_copy, h->stream));
     TDK_HIP(hipStreamWaitEvent(h->copy_stream, h->ev_copy, 0));
     const size_t row = (size_t)L.N * sizeof(double);
@@ -2557,8 +2619,9 @@ tdk_status tdk_dvo_upload_async(tdk_dvo *h, int which, int first_pair, int n_pai
     else
         TDK_HIP(hipMemcpy2DAsync(base + (int64_t)first_pair * L.stride, (size_t)L.stride * sizeof(double), pinned_host,
                                  row, row, (size_t)n_pairs, hipMemcpyHostToDevice, h->copy_stream));
-    TDK_HIP(hipEventRecord(h->ev_copy, h->copy_stream));
-    TDK_HIP(hipStreamWaitEvent(h->stream, h->ev_copy, 0));
+    // ... and before what it does next (see tdk_dvo::ev_uploaded)
+    TDK_HIP(hipEventRecord(h->ev_uploaded, h->copy_stream));
+    h->uploads_pending = true;
     return TDK_OK;
 }
 
@@ -2575,22 +2638,24 @@ tdk_status tdk_dvo_upload_async_u8(tdk_dvo *h, int which, int first_pair, int n_
         TDK_HIP(hipMalloc(&h->d_u8, need));
         h->u8_bytes = need;
     }
-    // the staging bytes of this range may still be read by the previous conversion on the batch stream
+    // the conversion overwrites frames the batch's own stream may still be reading
     TDK_HIP(hipEventRecord(h->ev_copy, h->stream));
     TDK_HIP(hipStreamWaitEvent(h->copy_stream, h->ev_copy, 0));
     uint8_t *stage = h->d_u8 + (size_t)first_pair * (size_t)L.N;
     TDK_HIP(hipMemcpyAsync(stage, pinned_host, (size_t)n_pairs * (size_t)L.N, hipMemcpyHostToDevice, h->copy_stream));
-    TDK_HIP(hipEventRecord(h->ev_copy, h->copy_stream));
-    TDK_HIP(hipStreamWaitEvent(h->stream, h->ev_copy, 0));
+    // converted on the copy stream, in order behind the transfer (and before the next one reuses the staging bytes)
     dim3 grid((unsigned)((L.N + kBlock * 4 - 1) / (kBlock * 4)), (unsigned)n_pairs);   // two sweeps of two pixels
-    k_u8_to_f64<<<grid, kBlock, 0, h->stream>>>(stage, base + (int64_t)first_pair * L.stride, L.N, L.stride);
+    k_u8_to_f64<<<grid, kBlock, 0, h->copy_stream>>>(stage, base + (int64_t)first_pair * L.stride, L.N, L.stride);
     TDK_LAUNCH_CHECK();
+    TDK_HIP(hipEventRecord(h->ev_uploaded, h->copy_stream));
+    h->uploads_pending = true;
     return TDK_OK;
 }
 
 tdk_status tdk_dvo_fill_synthetic(tdk_dvo *h, const double *camera, const double *poses12, uint64_t seed0,
                                   double noise) {
     TDK_REQUIRE(h && camera && poses12, "null pointer");
+    TDK_TRY(after_uploads(h));
     TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * h->n_pairs, hipMemcpyHostToDevice,
                            h->stream));
     const tdk_dvo::Level &L = h->lv[0];
@@ -2608,6 +2673,7 @@ tdk_status tdk_dvo_fill_synthetic(tdk_dvo *h, const double *camera, const double
 static tdk_status build_pyramid_of(tdk_dvo *h, unsigned arrays) {
     const tdk_dvo::Level &S = h->lv[0];
     if (!h->with_w) arrays &= 7u;
+    TDK_TRY(after_uploads(h));
     if (arrays == 0u || h->n_levels <= 1) return TDK_OK;
     const int n_out = h->n_levels - 1;
     // the selected arrays, in the fixed order I0, D0, I1, W0
@@ -2721,6 +2787,7 @@ tdk_status tdk_dvo_download(tdk_dvo *h, int pair, int level, int which, double *
     const tdk_dvo::Level &L = h->lv[level];
     const double *src = which == 0 ? L.I0 : which == 1 ? L.D0 : which == 2 ? L.I1 : L.W0;
     TDK_REQUIRE(src != nullptr, "no weight map in this batch");
+    TDK_TRY(after_uploads(h));
     TDK_HIP(hipMemcpyAsync(out, src + (int64_t)pair * L.stride, (size_t)L.N * sizeof(double),
                            hipMemcpyDeviceToHost, h->stream));
     TDK_HIP(hipStreamSynchronize(h->stream));
@@ -2788,6 +2855,17 @@ tdk_status tdk_dvo_photometric_error(tdk_dvo *h, int level, const double *camera
     return TDK_OK;
 }
 
+// the final poses and warnings of a call -> h_io, wait, -> the caller's array
+static tdk_status publish_and_wait(tdk_dvo *h, double *poses12) {
+    const int n = h->n_pairs;
+    k_publish<<<(n + 255) / 256, 256, 0, h->stream>>>(h->ls, h->d_io + 12 * (size_t)n, (int *)(h->d_io + 24 * (size_t)n), n);
+    TDK_LAUNCH_CHECK();
+    TDK_HIP(hipStreamSynchronize(h->stream));
+    memcpy(poses12, h->h_io + 12 * (size_t)n, sizeof(double) * 12 * n);
+    memcpy(h->host_warn.data(), h->h_io + 24 * (size_t)n, sizeof(int) * n);
+    return TDK_OK;
+}
+
 tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0, const double *camera1,
                                   double *poses12, int weight_mode, int max_iter, int *n_evals) {
     TDK_TRY(check_level(h, level));
@@ -2818,21 +2896,18 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
     TDK_TRY(check_weight_mode(h, weight_mode));
     TDK_TRY(upload_params(h, camera0, camera1));
     int n = h->n_pairs;
-    TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * n, hipMemcpyHostToDevice,
-                           h->stream));
+    memcpy(h->h_io, poses12, sizeof(double) * 12 * n);     // read by k_loop_init over the bus (see tdk_dvo::h_io)
     if (pixel_evals) *pixel_evals = 0;
     h->count_error_px = h->count_update_px = 0;
     TDK_HIP(hipMemsetAsync(h->ls.warn, 0, sizeof(int) * n, h->stream));
     for (int level = h->n_levels - 1; level >= 0; level--) {
         // the prior of a level is the result of the coarser one (:131-134), already in ls.pose
         h->ls.fuse_first = level == h->n_levels - 1;
-        k_loop_init<<<(n + 255) / 256, 256, 0, h->stream>>>(h->ls, level == h->n_levels - 1 ? h->d_poses_in : h->ls.pose, n);
+        k_loop_init<<<(n + 255) / 256, 256, 0, h->stream>>>(h->ls, level == h->n_levels - 1 ? h->d_io : h->ls.pose, n);
         TDK_LAUNCH_CHECK();
         TDK_TRY(run_level(h, level, weight_mode, max_iter, pixel_evals));
     }
-    TDK_HIP(hipMemcpyAsync(poses12, h->ls.pose, sizeof(double) * 12 * n, hipMemcpyDeviceToHost, h->stream));
-    TDK_HIP(hipMemcpyAsync(h->host_warn.data(), h->ls.warn, sizeof(int) * n, hipMemcpyDeviceToHost, h->stream));
-    TDK_HIP(hipStreamSynchronize(h->stream));
+    TDK_TRY(publish_and_wait(h, poses12));
     if (h->profiling) TDK_TRY(collect_profile(h));
     return TDK_OK;
 }

@@ -952,3 +952,4 @@ class BundleAdjustment(object):
         err = C.c_double()
         call("tdk_ba_step", self._h, _p(poses), _p(points), float(mu), _p(dposes), _p(dpoints), C.byref(err))
         return dposes, dpoints, float(err.value)
+

@@ -32,3 +32,4 @@ _lib.call("tdk_sync"); t0 = time.perf_counter()
 for k in range(12): step(k, True)
 _lib.call("tdk_sync")
 print("step %.3f ms" % ((time.perf_counter() - t0) / 12 * 1e3), {k: round(float(np.median(v)) * 1e3, 3) for k, v in acc.items()})
+
