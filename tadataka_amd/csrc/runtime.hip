@@ -94,7 +94,7 @@ tdk_status pinned(int slot, size_t bytes, void **ptr) {
 
 extern "C" {
 
-const char *tdk_version(void) { return "tadataka_hip 0.2 (gfx950)"; }
+const char *tdk_version(void) { return "tadataka_hip 0.3 (gfx950)"; }
 
 const char *tdk_last_error(void) { return tdk::g_err; }
 
