@@ -772,6 +772,49 @@ def test_async_uploads_from_pinned_memory(ops):
     single.close(); batch.close(); pin.close(); pin8.close()
 
 
+def test_async_upload_is_waited_for_by_whatever_touches_the_arrays_next(ops):
+    """The batch's stream waits for an asynchronous upload when it next touches the arrays, not when the upload is
+    queued: a transfer long enough to still be in flight (48 VGA frames, 8-bit and float64) followed AT ONCE by a
+    download, a partial pyramid build and an estimation -- each must see the new frames."""
+    from tadataka_amd import _lib, synthetic
+    B, H, W = 48, 480, 640
+    cam = synthetic.camera_for(W, H)
+    rng = np.random.default_rng(21)
+    batch = ops.DvoBatch(B, H, W, n_levels=2, ratio=1.5)
+    ref = ops.DvoBatch(1, H, W, n_levels=2, ratio=1.5)
+    pr = synthetic.make_pair(H, W, seed=3)
+    for i in range(B):
+        batch.upload(i, pr["I0"], pr["D0"], pr["I1"])
+    batch.build_pyramid()
+    ident = np.tile(_pose12(np.eye(4)), (B, 1))
+    gray = rng.integers(0, 256, (B, H * W), dtype=np.uint8)
+    pin8 = ops.PinnedBuffer((B, H * W), dtype=np.uint8)
+    pin8.array[:] = gray
+    f64 = rng.uniform(0.0, 1.0, (B, H * W))
+    pin = ops.PinnedBuffer((B, H * W))
+    pin.array[:] = f64
+    for which, buf, want in (("I1", pin8, gray / 255.0), ("I1", pin, f64)):
+        # download straight after the upload call
+        batch.upload_async(which, 0, B, buf)
+        assert np.array_equal(batch.download(B - 1, 0, which).ravel(), want[B - 1])
+        # partial pyramid straight after the upload call
+        batch.upload_async(which, 0, B, buf)
+        batch.build_pyramid([which])
+        ref.upload(0, pr["I0"], pr["D0"], want[B - 1].reshape(H, W))
+        ref.build_pyramid()
+        assert np.array_equal(batch.download(B - 1, 1, which), ref.download(0, 1, which))
+        # estimation straight after the upload call (the pyramid of the new frames is in place)
+        batch.upload_async(which, 0, B, buf)
+        P, px = batch.estimate(cam, cam, ident, ops.W_HUBER, 3)
+        _lib.call("tdk_sync")
+        P_again, px_again = batch.estimate(cam, cam, ident, ops.W_HUBER, 3)     # the frames are certainly there now
+        assert np.array_equal(P, P_again) and px == px_again
+        P1, px1 = ref.estimate(cam, cam, ident[:1], ops.W_HUBER, 3)            # (another block partition: last bits)
+        assert np.max(np.abs(P[B - 1] - P1[0])) < 1e-12
+    for x in (batch, ref, pin, pin8):
+        x.close()
+
+
 def test_session_outlives_its_ring(ops):
     """More committed steps than max_refframes.  Saturating ages (default): the session keeps going and
     equals the oracle chain with the same rule (ages clamped to the frames the ring still holds, the
