@@ -762,7 +762,7 @@ __device__ __forceinline__ double fast_rcp(double a) {
 // STUDENT: the first step of the Student-t fixed point (variance 1: s (nu + 1) / (nu + s)) rides along -- its
 // block partials go where k_robust_student_step leaves them -- so the residual map is read nine times, not ten.
 constexpr int kTukeySample = 2048;      // sorted sample per pair (one block, LDS)
-constexpr int kTukeyThreads = 1024;
+constexpr int kTukeyThreads = 512;     // 8 waves: a 16-wave block waited up to 0.6 ms for a CU with that much room beside the pyramid kernel
 constexpr double kTukeySigmas = 5.0;
 constexpr int kBandBuf = 1024;          // residuals a block of the collecting passes gathers in LDS before one global append
 
@@ -997,6 +997,8 @@ struct SelectSrc {
     int n, mode;                   // mode 1: |value - center|
     double center;
     unsigned int rank_offset, pad;
+    double lo, hi;                 // a collected band: the bracket its values lie in (k_band_median bins by value);
+                                   // lo > hi: unknown (the whole residual map)
 };
 
 struct SelectState {
@@ -1392,7 +1394,9 @@ __global__ void k_tukey_plan(const TukeyBracket *__restrict__ tk, const int *__r
     SelectSrc s;
     if (ok) {
         s.data = bands + (size_t)pair * cap; s.n = (int)c; s.mode = 0; s.center = 0.0; s.rank_offset = off;
+        s.lo = which ? t.dlo : t.lo; s.hi = which ? t.dhi : t.hi;
     } else {
+        s.lo = 1.0; s.hi = 0.0;
         s.data = rm + (int64_t)pair * stride; s.n = N; s.mode = which; s.center = which ? median[pair] : 0.0;
         s.rank_offset = 0;
         if (n > 0 && n_fallback) atomicAdd(n_fallback, 1u);
@@ -1474,11 +1478,106 @@ __device__ uint64_t block_radix_select(const double *__restrict__ r, int N, int 
 
 // np.median of a pair's source: the mean of the two middle order statistics (the same one twice for an odd
 // count), ranks counted from the source's offset; times `factor`
+// The order statistics k1 <= k2 <= k1 + 1 of a band whose values lie in [lo, hi], in two sweeps: values binned
+// LINEARLY between the bounds (monotone, so order is kept across bins; a band is a narrow slice of the residuals,
+// whose 64-bit images share their leading digits -- the radix passes below spend five of their eight sweeps telling
+// nothing apart), the bins of the two ranks found by a scan, their few members collected and ranked by counting.
+// Returns false (nothing written) when the band does not qualify: bounds not finite, or more members in the
+// selected bins than kBinCand (exact ties) -- the caller then takes the radix path.  Same doubles either way.
+constexpr int kSelBins = 2048, kBinCand = 512;   // 12 KB of LDS: a block still fits beside four pyramid tiles (140 of 160 KB) -- with 24 KB it waited for them, 0.6 ms
+__device__ bool block_bin_select(const double *__restrict__ r, int N, double lo, double hi, uint64_t k1, uint64_t k2,
+                                 unsigned int *hist /* kSelBins */, double *cand /* kBinCand */, double &v1, double &v2) {
+    __shared__ unsigned int wave_tot[kTukeyThreads / 64];
+    __shared__ unsigned int sel_bin[2], sel_before[2], n_cand;
+    __shared__ double res[2];
+    const double width = hi - lo;
+    if (!(width > 0.0) || !(width < 1e300) || !(fabs(lo) < 1e300)) return false;     // block-uniform
+    const double scale = (double)kSelBins / width;
+    auto bin_of = [&](double x) {
+        const double b = (x - lo) * scale;
+        return b >= (double)(kSelBins - 1) ? kSelBins - 1 : (b > 0.0 ? (int)b : 0);
+    };
+    for (int i = threadIdx.x; i < kSelBins; i += blockDim.x) hist[i] = 0;
+    if (threadIdx.x == 0) n_cand = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < N; i0 += 4 * blockDim.x) {        // four independent loads per thread and step (L2 latency)
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * (int)blockDim.x + (int)threadIdx.x;
+            v[u] = i < N ? r[i] : __longlong_as_double(0x7ff8000000000000ll);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (v[u] == v[u]) atomicAdd(&hist[bin_of(v[u])], 1u);
+    }
+    __syncthreads();
+    // inclusive scan of the bin counts, kSelBins / blockDim.x bins per thread
+    constexpr int kPer = kSelBins / kTukeyThreads;
+    unsigned int c[kPer], mine = 0;
+#pragma unroll
+    for (int j = 0; j < kPer; j++) { c[j] = hist[threadIdx.x * kPer + j]; mine += c[j]; }
+    unsigned int inc = mine;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    unsigned int before = inc - mine;
+    for (int w = 0; w < wave; w++) before += wave_tot[w];
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+        const uint64_t a = before, b = (uint64_t)before + c[j];
+        if (k1 >= a && k1 < b) { sel_bin[0] = threadIdx.x * kPer + j; sel_before[0] = before; }
+        if (k2 >= a && k2 < b) { sel_bin[1] = threadIdx.x * kPer + j; sel_before[1] = before; }
+        before += c[j];
+    }
+    __syncthreads();
+    const unsigned int b1 = sel_bin[0], b2 = sel_bin[1];
+    const unsigned int members = hist[b1] + (b2 != b1 ? hist[b2] : 0u);
+    if (members > (unsigned int)kBinCand) return false;                              // block-uniform
+    for (int i0 = 0; i0 < N; i0 += 4 * blockDim.x) {
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = i0 + u * (int)blockDim.x + (int)threadIdx.x;
+            v[u] = i < N ? r[i] : __longlong_as_double(0x7ff8000000000000ll);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (v[u] != v[u]) continue;
+            const unsigned int b = (unsigned int)bin_of(v[u]);
+            if (b == b1 || b == b2) cand[atomicAdd(&n_cand, 1u)] = v[u];
+        }
+    }
+    __syncthreads();
+    // rank of every member among the members (ties broken by position: a permutation of 0 .. members - 1); the
+    // members of bin b1 come first in value, so rank k - sel_before[0] addresses both statistics
+    const unsigned int t1 = (unsigned int)(k1 - sel_before[0]), t2 = (unsigned int)(k2 - sel_before[0]);
+    for (unsigned int j = threadIdx.x; j < members; j += blockDim.x) {
+        const double x = cand[j];
+        unsigned int rank = 0;
+        for (unsigned int i = 0; i < members; i++) {
+            const double y = cand[i];
+            rank += (y < x || (y == x && i < j)) ? 1u : 0u;
+        }
+        if (rank == t1) res[0] = x;
+        if (rank == t2) res[1] = x;
+    }
+    __syncthreads();
+    v1 = res[0];
+    v2 = res[1];
+    return true;
+}
+
 __global__ __launch_bounds__(kTukeyThreads) void k_band_median(const SelectSrc *__restrict__ src,
                                                                 const int *__restrict__ count,
                                                                 const int *__restrict__ state, double factor,
-                                                                double *__restrict__ out) {
-    __shared__ unsigned int hist[256];
+                                                                double *__restrict__ out, int use_bins) {
+    __shared__ unsigned int hist[kSelBins];
+    __shared__ double cand[kBinCand];
     __shared__ uint64_t sh[2];
     const int pair = blockIdx.x;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
@@ -1489,6 +1588,14 @@ __global__ __launch_bounds__(kTukeyThreads) void k_band_median(const SelectSrc *
     }
     const SelectSrc s = src[pair];
     const uint64_t k1 = (uint64_t)(n - 1) / 2 - s.rank_offset, k2 = (uint64_t)n / 2 - s.rank_offset;
+    if (use_bins && s.mode == 0 && s.lo <= s.hi) {
+        double v1, v2;
+        if (block_bin_select(s.data, s.n, s.lo, s.hi, k1, k2, hist, cand, v1, v2)) {
+            if (threadIdx.x == 0) out[pair] = factor * ((v1 + v2) / 2.0);
+            return;
+        }
+        __syncthreads();
+    }
     const uint64_t sel = block_radix_select(s.data, s.n, s.mode, s.center, k1, hist, sh);
     const double lo = key_to_double(sel);
     double hi = lo;
@@ -2174,7 +2281,9 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
         k_tukey_plan<<<gp, 256, 0, h->stream>>>(h->d_tk, h->d_count, d_state, 0, h->d_rm, L.stride, (int)L.N, h->d_tk_med,
                                                 h->tk_cap, nullptr, force, src, h->d_tk_fallback, n);
         TDK_LAUNCH_CHECK();
-        k_band_median<<<n, kTukeyThreads, 0, h->stream>>>(src, h->d_count, d_state, 1.0, median);
+        // TDK_TUKEY_BAND=radix: the band's order statistics by the eight radix sweeps of round 3's first version
+        static const int use_bins = [] { const char *v = getenv("TDK_TUKEY_BAND"); return v && !strcmp(v, "radix") ? 0 : 1; }();
+        k_band_median<<<n, kTukeyThreads, 0, h->stream>>>(src, h->d_count, d_state, 1.0, median, use_bins);
         TDK_LAUNCH_CHECK();
         k_tukey_dev_bracket<<<n, kTukeyThreads, 0, h->stream>>>(d_state, h->d_tk, h->d_tk_sample, median);
         TDK_LAUNCH_CHECK();
@@ -2184,7 +2293,7 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
         k_tukey_plan<<<gp, 256, 0, h->stream>>>(h->d_tk, h->d_count, d_state, 1, h->d_rm, L.stride, (int)L.N, h->d_tk_dev,
                                                 h->tk_cap, median, force, src, h->d_tk_fallback, n);
         TDK_LAUNCH_CHECK();
-        k_band_median<<<n, kTukeyThreads, 0, h->stream>>>(src, h->d_count, d_state, kTukeyC, h->d_wscale);   // c * MAD (:34)
+        k_band_median<<<n, kTukeyThreads, 0, h->stream>>>(src, h->d_count, d_state, kTukeyC, h->d_wscale, use_bins);   // c * MAD (:34)
         TDK_LAUNCH_CHECK();
         return TDK_OK;
     }
