@@ -6,7 +6,7 @@ import bench
 B,H,W=256,480,640
 cam=synthetic.camera_for(W,H)
 bt=ops.DvoBatch(B,H,W,n_levels=3,ratio=1.5)
-bt.fill_synthetic(cam, bench.true_poses(B,0), seed0=0, noise=0.02)
+SEED=int(os.environ.get("SEED","0")); bt.fill_synthetic(cam, bench.true_poses(B,SEED), seed0=SEED, noise=0.02)
 bt.build_pyramid()
 ident=np.tile(ops.pose12(np.eye(3),np.zeros(3)),(B,1))
 for lvl in (2,1,0):
