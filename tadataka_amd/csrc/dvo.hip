@@ -2091,7 +2091,7 @@ struct tdk_dvo {
     int *d_mode_probe;          // [n] MODE_PROBE (tdk_dvo_photometric_error), allocated on first use
     int64_t count_error_px, count_update_px;   // tdk_dvo_get_counts: source pixels of the last estimate call
     bool anti_aliasing;         // pyramid levels get skimage's Gaussian prefilter (tdk_dvo_set_anti_aliasing)
-    int n_cu;                   // compute units of the batch's device
+    int n_cu, device;           // compute units and index of the batch's device
     int student_mode;           // Student-t variance: 0 two Taylor passes, 1 nine sequential passes, 2 ... with IEEE divisions
     bool aa_taplists;           // ... evaluated as folded tap lists (mode 3, pyramid_sep.hip) instead of in ndimage's operation order
     tdk::PyramidSepPlan *sep_plan;   // tap lists of the separable pyramid kernel (created at the first build)
@@ -2573,6 +2573,7 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
         if (hipGetDevice(&dev) != hipSuccess ||
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
         h->n_cu = cus > 0 ? cus : 256;
+        h->device = dev;
     }
     {   // defaults of tdk_dvo_set_student_passes from the environment
         const char *ex = getenv("TDK_STUDENT_EXACT"), *sq = getenv("TDK_STUDENT");
@@ -2716,9 +2717,14 @@ tdk_status tdk_dvo_upload_mixed(tdk_dvo *h, int pair, const double *const *host4
 // with a stream per batch the 8-bit upload of three rotating batches ran at 22 GB/s instead of 50), one event
 // per batch to order it with the batch's own stream.
 static tdk_status ensure_copy_stream(tdk_dvo *h) {
-    static hipStream_t g_copy_stream = nullptr;
-    if (!g_copy_stream) TDK_HIP(hipStreamCreateWithFlags(&g_copy_stream, hipStreamNonBlocking));
-    h->copy_stream = g_copy_stream;
+    // one copy stream per device for all batches (a stream belongs to the device it was created on)
+    static hipStream_t g_copy_stream[16] = {};
+    if (!h->copy_stream) {
+        const int dev = h->device;
+        TDK_REQUIRE(dev >= 0 && dev < 16, "device index beyond the copy-stream table");
+        if (!g_copy_stream[dev]) TDK_HIP(hipStreamCreateWithFlags(&g_copy_stream[dev], hipStreamNonBlocking));
+        h->copy_stream = g_copy_stream[dev];
+    }
     if (!h->ev_copy) TDK_HIP(hipEventCreateWithFlags(&h->ev_copy, hipEventDisableTiming));
     if (!h->ev_uploaded) TDK_HIP(hipEventCreateWithFlags(&h->ev_uploaded, hipEventDisableTiming));
     return TDK_OK;
