@@ -562,6 +562,21 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
         eval_body<WMODE, false>(L, params, poses, wscale, scale, chunk, pair, blk, nblk, partials);
 }
 
+// The probe body on its own, for launches in which every running pair tests a candidate (the round after a level's
+// first evaluation, typically; tdk_dvo_photometric_error): inside k_dvo_eval it shares the full body's 156 VGPRs and
+// runs at 3 waves per SIMD; alone it needs 62 and runs at 8 -- 403 -> 352 us per full-resolution launch, 5.4 TB/s
+// (0.67 of the HBM peak) on the 24 B/px it reads.  The error does not depend on the weights (metric.py:13-39).
+__global__ __launch_bounds__(kBlock) void k_dvo_probe(LevelPtrs L, const PairParams *__restrict__ params,
+                                                      const double *__restrict__ poses,
+                                                      const int *__restrict__ state, double scale, int64_t chunk,
+                                                      int n_pairs, int nblk, double *__restrict__ partials) {
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int pair = (q / nblk) * 8 + xcd, blk = q - (q / nblk) * nblk;
+    if (pair >= n_pairs) return;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    eval_body<TDK_W_NONE, true>(L, params, poses, nullptr, scale, chunk, pair, blk, nblk, partials);
+}
+
 // 8-bit frames -> float64 in [0, 1] (skimage.img_as_float: x / 255), one launch for a range of pairs.
 // Two pixels per thread: a 2-byte load and one 16-byte store per lane, both fully coalesced.
 __global__ __launch_bounds__(kBlock) void k_u8_to_f64(const uint8_t *__restrict__ src, double *__restrict__ dst,
@@ -606,9 +621,10 @@ struct LoopState {   // device arrays, one entry per pair
     int *tested;       // [n] candidates tested at this level (the reference's loop counter k)
     int *stat_state;   // [n] ST_RUNNING where the next evaluation needs robust statistics (running and not a probe)
     int *round;        // [2] pairs whose evaluation in the launch just reduced was full / a probe
+    int *next;         // [2] pairs still running whose NEXT evaluation is full / a probe
     int fuse_first;    // the first candidate of this level is evaluated in full straight away (see reduce_pair)
     int *host_flag;    // mapped host memory: [0] `active` as left by the last launch, [2..3] `evals[0]` (64 bit),
-                       // [4] / [5] `round`, [6..7] `evals[1]` (64 bit)
+                       // [4] / [5] `round`, [6..7] `evals[1]` (64 bit), [8] / [9] `next`
 };
 
 // Fixed-order reduction of the per-block partials of one pair; in loop mode the
@@ -689,6 +705,7 @@ __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials,
         }
     }
     ls.stat_state[pair] = (!finished && ls.mode[pair] != MODE_PROBE) ? ST_RUNNING : ST_DONE;
+    if (!finished) atomicAdd(&ls.next[ls.mode[pair] == MODE_PROBE ? 1 : 0], 1);
     if (finished) {
         ls.state[pair] = ST_DONE;
         atomicSub(ls.active, 1);
@@ -710,6 +727,8 @@ __global__ __launch_bounds__(kBlock) void k_dvo_reduce(const double *__restrict_
         *reinterpret_cast<volatile unsigned long long *>(ls.host_flag + 6) = atomicAdd(ls.evals + 1, 0ull);
         ls.host_flag[4] = atomicExch(&ls.round[0], 0);
         ls.host_flag[5] = atomicExch(&ls.round[1], 0);
+        ls.host_flag[8] = atomicExch(&ls.next[0], 0);
+        ls.host_flag[9] = atomicExch(&ls.next[1], 0);
         *ls.host_flag = atomicAdd(ls.active, 0);
         __threadfence_system();
     }
@@ -736,6 +755,8 @@ __global__ void k_loop_init(LoopState ls, const double *poses_in, int n) {   // 
         ls.evals[1] = 0ull;
         ls.round[0] = 0;
         ls.round[1] = 0;
+        ls.next[0] = 0;
+        ls.next[1] = 0;
     }
 }
 
@@ -2358,10 +2379,12 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
 
 // d_mode: per-pair evaluation mode of the device loop (NULL: full); d_stat_state: the pairs whose
 // evaluation needs the robust statistics (running and not a probe; NULL: all)
+// probe_only: the caller knows that every running pair is in probe mode -- the statistics (for normal equations
+// only) are skipped altogether and the probe body runs as its own kernel (k_dvo_probe)
 tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *d_state, const int *d_mode,
-                       const int *d_stat_state, int weight_mode) {
+                       const int *d_stat_state, int weight_mode, bool probe_only = false) {
     const tdk_dvo::Level &L = h->lv[level];
-    TDK_TRY(prepare_robust(h, level, d_poses, d_stat_state, weight_mode));
+    if (!probe_only) TDK_TRY(prepare_robust(h, level, d_poses, d_stat_state, weight_mode));
     int nblk;
     int64_t chunk;
     plan_blocks(h, L, &nblk, &chunk);
@@ -2394,6 +2417,12 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
                                     (int)lds));                                                         \
     k_dvo_eval<WM><<<grid, kBlock, lds, h->stream>>>(P, h->d_params, d_poses, d_state, d_mode, h->d_wscale, \
                                                          L.scale, chunk, h->n_pairs, nblk, h->d_partials)
+    if (probe_only) {
+        if (lds > 64 * 1024)
+            TDK_HIP(hipFuncSetAttribute((const void *)k_dvo_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        k_dvo_probe<<<grid, kBlock, lds, h->stream>>>(P, h->d_params, d_poses, d_state, L.scale, chunk, h->n_pairs, nblk,
+                                                      h->d_partials);
+    } else
     switch (weight_mode) {
         case TDK_W_NONE: TDK_EVAL(TDK_W_NONE); break;
         case TDK_W_HUBER: TDK_EVAL(TDK_W_HUBER); break;
@@ -2470,6 +2499,7 @@ tdk_status collect_profile(tdk_dvo *h) {
 // other -- the pyramid and the conversion of the next batches already fill the gaps.  Not kept.)
 struct LevelRun {
     int level, round, max_rounds, burst;
+    bool probe_only;    // every pair still running tests a candidate next (h_flag[8..9] of the last round)
 };
 
 static LevelRun begin_level(tdk_dvo *h, int level, int max_iter) {
@@ -2477,13 +2507,15 @@ static LevelRun begin_level(tdk_dvo *h, int level, int max_iter) {
     static const int small_burst = [] { const char *v = getenv("TDK_DVO_BURST"); return v && atoi(v) > 0 ? atoi(v) : 2; }();
     // a pair goes through at most 2 max_iter + 1 evaluations: the first, then per tested candidate a
     // probe and -- if it was accepted and is not the last -- the full evaluation at the accepted pose
-    return LevelRun{level, 0, 2 * max_iter + 1, small ? small_burst : 1};
+    return LevelRun{level, 0, 2 * max_iter + 1, small ? small_burst : 1, false};   // a level starts with full evaluations
 }
 
 static tdk_status queue_round(tdk_dvo *h, LevelRun &r, int weight_mode, int max_iter) {
     const int nb = r.max_rounds - r.round < r.burst ? r.max_rounds - r.round : r.burst;
     for (int b = 0; b < nb; b++) {
-        TDK_TRY(launch_eval(h, r.level, h->ls.cand, h->ls.state, h->ls.mode, h->ls.stat_state, weight_mode));
+        // (the modes of a burst's second round are not known here: the combined kernel)
+        TDK_TRY(launch_eval(h, r.level, h->ls.cand, h->ls.state, h->ls.mode, h->ls.stat_state, weight_mode,
+                            b == 0 && r.probe_only));
         TDK_TRY(launch_reduce(h, r.level, 1, max_iter));
     }
     r.round += nb;
@@ -2491,7 +2523,8 @@ static tdk_status queue_round(tdk_dvo *h, LevelRun &r, int weight_mode, int max_
 }
 
 // the batch's stream has been waited for; true: another round is needed
-static bool after_round(tdk_dvo *h, const LevelRun &r) {
+static bool after_round(tdk_dvo *h, LevelRun &r) {
+    r.probe_only = ((volatile int *)h->h_flag)[8] == 0 && ((volatile int *)h->h_flag)[9] > 0;
     if (h->profiling && r.level == 0 && h->ev_used >= 2) {   // what the launch just timed evaluated
         h->ev_round[h->ev_used - 2] = ((volatile int *)h->h_flag)[4];
         h->ev_round[h->ev_used - 1] = ((volatile int *)h->h_flag)[5];
@@ -2620,6 +2653,7 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
     TDK_HIP(hipMalloc(&h->ls.mode, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.tested, sizeof(int) * n_pairs));
     TDK_HIP(hipMalloc(&h->ls.stat_state, sizeof(int) * n_pairs));
+    TDK_HIP(hipMalloc(&h->ls.next, 2 * sizeof(int)));
     TDK_HIP(hipMalloc(&h->ls.round, sizeof(int) * 2));
     h->host_warn.assign((size_t)n_pairs, 0);
     TDK_HIP(hipHostMalloc((void **)&h->h_io, sizeof(double) * 24 * (size_t)n_pairs + sizeof(int) * (size_t)n_pairs, hipHostMallocMapped));
@@ -2641,7 +2675,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     (void)hipFree(h->d_results); (void)hipFree(h->ls.pose); (void)hipFree(h->ls.cand);
     (void)hipFree(h->ls.prev_err); (void)hipFree(h->ls.state); (void)hipFree(h->ls.n_evals);
     (void)hipFree(h->ls.active); (void)hipFree(h->ls.ticket); (void)hipFree(h->ls.evals); (void)hipFree(h->ls.warn);
-    (void)hipFree(h->ls.mode); (void)hipFree(h->ls.tested); (void)hipFree(h->ls.stat_state); (void)hipFree(h->ls.round);
+    (void)hipFree(h->ls.mode); (void)hipFree(h->ls.tested); (void)hipFree(h->ls.stat_state); (void)hipFree(h->ls.round); (void)hipFree(h->ls.next);
     (void)hipFree(h->d_rm); (void)hipFree(h->d_wscale); (void)hipFree(h->d_stat);
     (void)hipFree(h->d_spartial); (void)hipFree(h->d_st_pts); (void)hipFree(h->d_st_redo); (void)hipFree(h->d_count); (void)hipFree(h->d_select);
     (void)hipFree(h->d_hist); (void)hipFree(h->d_cand); (void)hipFree(h->d_mode_probe);
@@ -2964,7 +2998,7 @@ tdk_status tdk_dvo_photometric_error(tdk_dvo *h, int level, const double *camera
     }
     TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * n, hipMemcpyHostToDevice, h->stream));
     // the error does not depend on the weights (metric.py:13-39): the unweighted kernel
-    TDK_TRY(launch_eval(h, level, h->d_poses_in, nullptr, h->d_mode_probe, nullptr, TDK_W_NONE));
+    TDK_TRY(launch_eval(h, level, h->d_poses_in, nullptr, h->d_mode_probe, nullptr, TDK_W_NONE, true));
     if (h->profiling && level == 0 && h->ev_used >= 2) {   // what the launch just timed evaluated: probes
         h->ev_round[h->ev_used - 2] = 0;
         h->ev_round[h->ev_used - 1] = n;
