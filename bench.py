@@ -771,7 +771,7 @@ def main():
         pmc = load_profile_json("pmc_dvo_eval.json") or {}
         traffic = pmc.get("hbm_bytes_per_launch")
         rl = roofline(BYTES_PER_PX_EVAL * prof["pixels"] / max(prof["launches"], 1), kernel_ms,
-                      kernel=f"k_dvo_eval<{args.weights}>, every full-resolution launch (full evaluations and probes)",
+                      kernel=f"k_dvo_eval<{args.weights}> + k_dvo_probe, every full-resolution launch (by_mode: the two kernels on their own)",
                       bytes_per_px=BYTES_PER_PX_EVAL,
                       px_per_launch=prof["pixels"] / max(prof["launches"], 1), launches=prof["launches"],
                       limiter="full evaluations: FP64 issue at the package power cap (DESIGN.md 5.1); "
