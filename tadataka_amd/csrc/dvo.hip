@@ -1756,7 +1756,7 @@ __global__ __launch_bounds__(kBlock) void k_tukey_deviations(const double *__res
 // SAMPLE of the pair (k_student_predict: a few per cent off) and yields the iterates to ~1e-5 or better; pass B
 // expands around those: remainder far below rounding.  A pair whose pass B still moved a point by more than
 // kStudentRedo takes a pass C -- tdk_dvo_get_student_redos counts them.
-// v_10 agrees with the sequential passes to ~1e-15 relative (tests/test_gpu_round3.py).
+// v_10 agrees with the sequential passes to < 1e-13 relative (tests/test_gpu_round3.py holds 1e-12).
 // tdk_dvo_set_student_passes / TDK_STUDENT=sequential keep the nine passes, TDK_STUDENT_EXACT=1 the nine passes
 // with IEEE divisions.
 // ---------------------------------------------------------------------------
