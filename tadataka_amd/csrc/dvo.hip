@@ -104,6 +104,13 @@ __device__ __forceinline__ void div2_shared(double nx, double ny, double z, doub
 
 // Load base[byte_off / 8] with a 32-bit unsigned byte offset from a
 // block-uniform base (global_load_dwordx2 v, voffset, s[base]).
+// ... for data that is read once (the D0 / I0 / W0 streams): non-temporal, so that it does not push the I1 rows the
+// neighbouring pixels are about to gather out of the caches (the probe's HBM traffic was 28.3 B/px for 24 algorithmic:
+// half of the second touches of an I1 row missed; 350 -> 327 us per full-resolution probe, full evaluation 569 -> 564)
+__device__ __forceinline__ double ldo_stream(const double *__restrict__ base, uint32_t byte_off) {
+    return __builtin_nontemporal_load(reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off));
+}
+
 __device__ __forceinline__ double ldo(const double *__restrict__ base, uint32_t byte_off) {
     return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
 }
@@ -374,13 +381,13 @@ template <int WMODE, bool PROBE>
 __device__ __forceinline__ void sp_issue(Samples &s, const Pixel &p, uint32_t off, const double *__restrict__ I0,
                                          const double *__restrict__ I1, const double *__restrict__ W0, int H,
                                          int W, const double *c) {
-    s.i0 = ldo(I0, off);
+    s.i0 = ldo_stream(I0, off);
     if (PROBE) {
         sp_issue_taps_probe(s.q, I1, H, W, p.c0, p.r0);
         return;
     }
     s.i1 = ldo(I1, off);
-    if (WMODE == TDK_W_MAP) s.w0 = ldo(W0, off);
+    if (WMODE == TDK_W_MAP) s.w0 = ldo_stream(W0, off);
     sp_issue_taps(s.q, I1, H, W, p.c0, p.r0, p.inside);
 }
 
@@ -489,7 +496,7 @@ __device__ __forceinline__ void eval_body(const LevelPtrs &L, const PairParams *
     // stream loads run up to 3 kBlock pixels past `end` (masked out by `live`): into the
     // next chunk or, for the last pair, into the padding every level array is allocated with
 #define TDK_OFF(i) ((uint32_t)(i) * 8u)
-#define TDK_DEPTH() ldo(D0, TDK_OFF(iw))
+#define TDK_DEPTH() ldo_stream(D0, TDK_OFF(iw))
 
     Pixel pa, pb;
     Samples s;
