@@ -406,9 +406,11 @@ def estimate_debug(u_key, prior_depth, prior_variance, key, ref, params):
     return float(od.value), float(ov.value), int(f)
 
 
-def update_depth(key, refs, age, prior_depth, prior_variance, params):
+def update_depth(key, refs, age, prior_depth, prior_variance, params, T_rks=None):
     """key = (cam, image, T); refs = list of (cam, image, T).
-    Returns (depth, variance, flag) like src/py/semi_dense.rs:182-186."""
+    Returns (depth, variance, flag) like src/py/semi_dense.rs:182-186.
+    T_rks (n_ref x 4 x 4): use these instead of orc_transform_rk's inv(T_wr) T_wk --
+    the sensitivity tests pass the LAPACK inverse the reference calls (semi_dense.rs:83-89)."""
     kc, pkc = _cam(key[0]); ki, pki = _d(key[1]); kT, pkT = _d(key[2])
     H, W = ki.shape
     n_ref = len(refs)
@@ -418,8 +420,11 @@ def update_depth(key, refs, age, prior_depth, prior_variance, params):
     age = np.ascontiguousarray(age, dtype=np.uint64)
     pd_, ppd = _d(prior_depth); pv_, ppv = _d(prior_variance)
     depth = np.empty((H, W)); var = np.empty((H, W)); flag = np.empty((H, W), dtype=np.int64)
-    rc = lib().orc_update_depth(pkc, pki, pkT, C.c_int(n_ref), rcams.ctypes.data_as(_dp),
-                                rimgs.ctypes.data_as(_dp), rTs.ctypes.data_as(_dp),
+    if T_rks is not None:
+        T_rks = np.ascontiguousarray(T_rks, dtype=np.float64).reshape(n_ref, 4, 4)
+    ptrk = T_rks.ctypes.data_as(_dp) if T_rks is not None else None
+    rc = lib().orc_update_depth_trk(pkc, pki, pkT, C.c_int(n_ref), rcams.ctypes.data_as(_dp),
+                                rimgs.ctypes.data_as(_dp), rTs.ctypes.data_as(_dp), ptrk,
                                 age.ctypes.data_as(_u64p), ppd, ppv, C.c_int(H), C.c_int(W),
                                 C.byref(params), depth.ctypes.data_as(_dp),
                                 var.ctypes.data_as(_dp), flag.ctypes.data_as(_i64p))

@@ -991,6 +991,23 @@ int orc_update_depth(const double *key_cam, const double *key_image,
                      const double *prior_variance, int H, int W,
                      const orc_params *params, double *out_depth,
                      double *out_variance, int64_t *out_flag) {
+    return orc_update_depth_trk(key_cam, key_image, key_T, n_ref, ref_cams, ref_images,
+                                ref_Ts, NULL, age, prior_depth, prior_variance, H, W,
+                                params, out_depth, out_variance, out_flag);
+}
+
+/* The same loop with T_rk = inv(T_wr) T_wk supplied by the caller (n_ref x 16, or NULL
+ * for orc_transform_rk): the sensitivity tests feed the inverse LAPACK's dgetrf + dgetri
+ * give -- what ndarray_linalg::Inverse calls at src/semi_dense/semi_dense.rs:83-89 --
+ * to count how many flags / depths the last bits of the 4x4 inverse decide. */
+int orc_update_depth_trk(const double *key_cam, const double *key_image,
+                         const double *key_T, int n_ref, const double *ref_cams,
+                         const double *ref_images, const double *ref_Ts,
+                         const double *T_rks_in,
+                         const uint64_t *age, const double *prior_depth,
+                         const double *prior_variance, int H, int W,
+                         const orc_params *params, double *out_depth,
+                         double *out_variance, int64_t *out_flag) {
     int64_t N = (int64_t)H * W;
     for (int64_t i = 0; i < N; i++)
         if (age[i] > (uint64_t)n_ref) return -1;
@@ -998,7 +1015,10 @@ int orc_update_depth(const double *key_cam, const double *key_image,
     double *gy = (double *)malloc((size_t)N * sizeof(double));
     orc_sobel(key_image, H, W, gx, gy);
     double *T_rks = (double *)malloc((size_t)(n_ref > 0 ? n_ref : 1) * 16 * sizeof(double));
-    for (int r = 0; r < n_ref; r++) orc_transform_rk(key_T, &ref_Ts[16 * r], &T_rks[16 * r]);
+    for (int r = 0; r < n_ref; r++) {
+        if (T_rks_in) memcpy(&T_rks[16 * r], &T_rks_in[16 * r], 16 * sizeof(double));
+        else orc_transform_rk(key_T, &ref_Ts[16 * r], &T_rks[16 * r]);
+    }
 
     for (int y = 0; y < H; y++) {
         for (int x = 0; x < W; x++) {

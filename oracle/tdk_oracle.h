@@ -114,6 +114,14 @@ int orc_update_depth(const double *key_cam, const double *key_image,
                      const double *prior_variance, int H, int W,
                      const orc_params *params, double *out_depth,
                      double *out_variance, int64_t *out_flag);
+int orc_update_depth_trk(const double *key_cam, const double *key_image,
+                         const double *key_T, int n_ref, const double *ref_cams,
+                         const double *ref_images, const double *ref_Ts,
+                         const double *T_rks_in,
+                         const uint64_t *age, const double *prior_depth,
+                         const double *prior_variance, int H, int W,
+                         const orc_params *params, double *out_depth,
+                         double *out_variance, int64_t *out_flag);
 
 /* ---- semi-dense post-steps and colour conversion ---------------- */
 int orc_regularize_patch(const double *inv_depth, const double *inv_variance,
