@@ -4,6 +4,7 @@ Everything here runs on the MI355X through libtadataka_hip.so; there is no CPU
 implementation behind these functions.
 """
 import ctypes as C
+import sys
 
 import numpy as np
 
@@ -501,16 +502,58 @@ def update_depth_frames(key, refs, age, prior_depth, prior_variance, params):
     return depth, var, flag
 
 
+# ndarray attributes that cannot hand out a writable alias of the buffer (they return scalars, tuples or
+# fresh arrays): reading them leaves the device copy valid.  Everything else -- views (T, flat, real,
+# reshape, ravel, squeeze, view, ...), mutating methods (fill, sort, put, itemset, partition, ...), ctypes /
+# __array_interface__ -- counts as a writable reference that escaped.
+_MAP_PURE_ATTRS = frozenset((
+    "all", "any", "argmax", "argmin", "argsort", "astype", "choose", "clip", "compress", "conj", "conjugate",
+    "copy", "cumprod", "cumsum", "dot", "dump", "dumps", "flatten", "item", "itemsize", "max", "mean", "min",
+    "nonzero", "prod", "ptp", "repeat", "round", "searchsorted", "std", "strides", "sum", "take", "tobytes",
+    "tofile", "tolist", "tostring", "trace", "var"))
+
+
+# NumPy functions that neither write into their array arguments nor return views of them (unless given
+# out=): running them on the host copy leaves the device copy valid.  Anything not listed is treated as if
+# it could (np.copyto, np.putmask, np.reshape, np.transpose, np.ravel, np.split, ...).
+_MAP_PURE_FUNCS = frozenset((
+    "all", "allclose", "amax", "amin", "any", "argmax", "argmin", "argsort", "argwhere", "array_equal",
+    "array_equiv", "average", "bincount", "clip", "concatenate", "copy", "count_nonzero", "cumsum", "diff",
+    "dot", "flatnonzero", "histogram", "isclose", "max", "mean", "median", "min", "nanmax", "nanmean",
+    "nanmedian", "nanmin", "nansum", "nonzero", "percentile", "prod", "ptp", "quantile", "round", "sort",
+    "stack", "std", "sum", "unique", "var", "where", "zeros_like", "ones_like", "empty_like", "full_like"))
+
+
+def _host_args(x, pure):
+    """DeviceMaps -> their host arrays inside the positional / keyword arguments of a NumPy function."""
+    if isinstance(x, DeviceMap):
+        return x._materialise() if pure else x._expose()
+    if isinstance(x, (list, tuple)):
+        return type(x)(_host_args(y, pure) for y in x)
+    if isinstance(x, dict):
+        return {k: _host_args(v, pure and k != "out") for k, v in x.items()}
+    return x
+
+
 class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
     """An H x W map that lives on the device (tdk_map) and is downloaded when somebody looks at it.
 
     It is what rust_bindings.semi_dense.increment_age / propagate / update_depth return and accept:
     the loop of examples/semi_dense_vo.py:182-199 hands every map it gets straight into the next
     call, so nothing crosses PCIe there.  Towards NumPy it behaves as an array-like: np.asarray(m),
-    m[...], arithmetic and ufuncs, every ndarray attribute (m.shape, m.copy(), m.max(), ...) work and
-    materialise the host copy once; assigning into it (m[mask] = v) edits the host copy and the
-    device copy is refreshed before its next use.  It is not an ndarray subclass: an ndarray's
-    memory can be read by C code without any hook that could wait for the download."""
+    m[...], arithmetic and ufuncs, NumPy functions (np.copyto, np.where, np.stack, ...), every ndarray
+    attribute (m.shape, m.copy(), m.max(), m.fill(0), ...) work and materialise the host copy once.
+    It is not an ndarray subclass: an ndarray's memory can be read by C code without any hook that
+    could wait for the download.
+
+    Host and device copy cannot diverge: writes through the map (m[mask] = v, ufunc out=, m.fill)
+    and every *writable reference to the host copy that leaves the object* -- np.asarray(m), a slice
+    m[a:b], m.T, iteration, a bound method -- mark the map `escaped`; an escaped map's host copy is
+    sent to the device again before each device use, for as long as such a reference is alive
+    (sys.getrefcount of the host array: views keep their base alive), so
+    `np.asarray(depth_map)[mask] = 0` followed by update_depth behaves as it does with the ndarrays
+    the reference returns.  A map that borrows a frame's image (Frame.image) becomes a map of its own
+    at that point; the frame keeps its image, as the reference's getter returns a copy."""
 
     __array_priority__ = 100.0
 
@@ -519,15 +562,17 @@ class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
         self.dtype = np.dtype(dtype)
         assert self.dtype.itemsize == 8
         self._host = None            # materialised host copy
-        self._stale_device = False   # the host copy was written to
+        self._escaped = False        # the host copy was written to, or a writable reference to it is out
         self._owner = owner          # a Frame whose device image this map borrows (_device_image_ptr())
         self._h = C.c_void_p()
         self._ptr = None
         if owner is None:
             src = None
             if host is not None:
-                self._host = np.ascontiguousarray(host, dtype=self.dtype).reshape(self.shape)
-                src = self._host.ctypes.data_as(C.c_void_p)
+                # uploaded synchronously and not kept: the caller's array stays the caller's (a later
+                # write to it must not reach this map), and a look at the map downloads it
+                host = np.ascontiguousarray(host, dtype=self.dtype).reshape(self.shape)
+                src = host.ctypes.data_as(C.c_void_p)
             call("tdk_map_create", self.shape[0], self.shape[1], src, C.byref(self._h))
         elif host is not None:
             self._host = host
@@ -543,14 +588,13 @@ class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
         if isinstance(a, DeviceMap):
             if a.dtype != np.dtype(dtype):
                 raise TypeError(f"map has dtype {a.dtype}, expected {np.dtype(dtype)}")
-            a._refresh_device()
-            return a
+            return a            # handle() / device_ptr() bring the device copy up to date
         return cls(np.shape(a), dtype, host=a)
 
     def handle(self):
+        self._refresh_device()
         if self._owner is not None:
             raise TypeError("a map that borrows a frame's image has no tdk_map handle")
-        self._refresh_device()
         return self._h
 
     def device_ptr(self):
@@ -564,17 +608,23 @@ class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
         return self._ptr
 
     def _refresh_device(self):
-        if self._stale_device:
-            if self._owner is not None:
-                raise ValueError("a frame's image cannot be modified in place")
+        """Before every device use: if the host copy may have been written to, it goes up again."""
+        if not self._escaped:
+            return
+        if self._owner is not None:
+            # the frame's image is not ours to change: from here on this is a map of its own
+            h = C.c_void_p()
+            call("tdk_map_create", self.shape[0], self.shape[1], self._host.ctypes.data_as(C.c_void_p), C.byref(h))
+            self._h, self._owner, self._ptr = h, None, None
+        else:
             call("tdk_map_upload", self._h, self._host.ctypes.data_as(C.c_void_p))
-            self._stale_device = False
+        # 2 = our attribute + getrefcount's argument: nobody else holds the array or a view of it
+        if sys.getrefcount(self._host) <= 2:
+            self._escaped = False
 
     def safe_invert(self, epsilon=1e-16):
         """1 / (self + epsilon) on the device (tadataka.numeric.safe_invert)."""
         out = DeviceMap(self.shape, np.float64)
-        if self._owner is not None:
-            raise TypeError("safe_invert of a frame image is not supported")
         call("tdk_map_safe_invert", self.handle(), float(epsilon), out._h)
         return out
 
@@ -589,8 +639,19 @@ class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
         except Exception:
             pass
 
+    def __copy__(self):
+        """A map of its own (a shallow copy of the attributes would destroy one handle twice)."""
+        return DeviceMap(self.shape, self.dtype, host=self._materialise())
+
+    def __deepcopy__(self, memo):
+        return self.__copy__()
+
+    def __reduce__(self):
+        return (np.array, (self._materialise(),))       # pickles as the ndarray it stands for
+
     # -- host side -----------------------------------------------------------------------------
     def _materialise(self):
+        """The host copy, for reading inside this module (the reference does not leave it)."""
         if self._host is None:
             if self._owner is not None:
                 self._host = self._owner._image_copy()
@@ -600,22 +661,35 @@ class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
                 self._host = out
         return self._host
 
-    def __array__(self, dtype=None, copy=None):
+    def _expose(self):
+        """The host copy as a writable array that leaves the object (or is written to here)."""
         a = self._materialise()
-        if dtype is not None and np.dtype(dtype) != a.dtype:
-            return a.astype(dtype)
-        return a.copy() if copy else a
+        self._escaped = True
+        return a
+
+    _writable = _expose
+
+    def __array__(self, dtype=None, copy=None):
+        if dtype is not None and np.dtype(dtype) != self.dtype:
+            return self._materialise().astype(dtype)
+        if copy:
+            return self._materialise().copy()
+        return self._expose()
 
     def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
         inputs = tuple(x._materialise() if isinstance(x, DeviceMap) else x for x in inputs)
         if "out" in kwargs:
-            kwargs["out"] = tuple(x._writable() if isinstance(x, DeviceMap) else x for x in kwargs["out"])
+            kwargs["out"] = tuple(x._expose() if isinstance(x, DeviceMap) else x for x in kwargs["out"])
         return getattr(ufunc, method)(*inputs, **kwargs)
 
-    def _writable(self):
-        a = self._materialise()
-        self._stale_device = True
-        return a
+    def __array_function__(self, func, types, args, kwargs):
+        """np.copyto(m, ...), np.putmask(m, ...), np.where(m > 0, ...), np.stack([m1, m2]), ...: the
+        function runs on the host copies; it may write into them or return views of them."""
+        name = getattr(func, "__name__", "")
+        if name in ("ndim", "shape", "size") and len(args) == 1 and not kwargs and isinstance(args[0], DeviceMap):
+            return getattr(args[0], name)               # no reason to fetch the data for these
+        pure = name in _MAP_PURE_FUNCS
+        return func(*_host_args(args, pure), **_host_args(kwargs, pure))
 
     ndim = 2
 
@@ -631,18 +705,22 @@ class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
         return self.shape[0]
 
     def __iter__(self):
-        return iter(self._materialise())
+        return iter(self._expose())
 
     def __getitem__(self, key):
-        return self._materialise()[key]
+        r = self._materialise()[key]
+        if isinstance(r, np.ndarray) and r.base is not None:        # a view: writes to it land in the host copy
+            self._escaped = True
+        return r
 
     def __setitem__(self, key, value):
-        self._writable()[key] = value
+        self._expose()[key] = value._materialise() if isinstance(value, DeviceMap) else value
 
-    def __getattr__(self, name):           # everything else an ndarray has (copy, max, flatten, T, ...)
+    def __getattr__(self, name):           # everything else an ndarray has (copy, max, flatten, T, fill, ...)
         if name.startswith("_"):
             raise AttributeError(name)
-        return getattr(self._materialise(), name)
+        host = self._materialise() if name in _MAP_PURE_ATTRS else self._expose()
+        return getattr(host, name)
 
     def __repr__(self):
         state = "host copy present" if self._host is not None else "on the device"
