@@ -625,6 +625,226 @@ __global__ __launch_bounds__(256) void k_rescale_aa_multi(AaMultiArgs m) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Row-streaming form of the anti-aliased pyramid (round 4): one pass over the source for
+// up to TWO levels.
+//
+// The tiles above re-load a tile's source rows once per level and once per 8 V rows
+// (14 loads per 8 rows at R = 3), a block lives for two short phases that do not overlap,
+// and level 2 costs as much as level 1 although it moves no HBM bytes.  Here a block owns
+// a full-height strip of source columns, one column per thread, and walks DOWN it:
+//   * every source texel is loaded exactly once (rows of the strip are contiguous:
+//     coalesced 8-byte loads), the loads of chunk c + 1 are issued before chunk c is
+//     computed (software prefetch in registers);
+//   * the thread keeps the last 2 RM rows of its column in registers, so the vertical
+//     Gaussians of BOTH levels (radius RA and RB) come from the same registers: K new V rows
+//     per level per chunk, written to per-level LDS rings;
+//   * after a barrier the waves take (output row, 64-column group) units of both levels
+//     whose two V rows are now complete: horizontal Gaussian at the four taps from LDS,
+//     blend, store -- aa_tile_fixed's arithmetic, operation by operation (centre tap, pairs
+//     from the outermost inwards; top / bottom / rows), so the output is bit-identical.
+// V rows live in rings of 2 K + 1 rows: the rows a chunk's outputs read are not the ones the
+// next chunk overwrites, so ONE barrier per chunk orders everything.
+// ---------------------------------------------------------------------------
+constexpr int kStreamK = 8;                       // source rows per chunk
+constexpr int kStreamRing = 2 * kStreamK + 1;     // V rows per level ring
+constexpr int kStreamSW = 256;                    // ring row pitch = threads = columns incl. halo
+constexpr int kStreamMaxGroups = 4;               // 64-column groups of outputs per strip and level
+
+struct StreamLevel {
+    double *dst[4];
+    int64_t dst_stride;
+    int Ho, Wo;
+    const double *wr, *wc;                        // device: kernel halves incl. centre (R + 1 used)
+};
+
+struct StreamArgs {
+    const double *src[4];
+    int64_t src_stride;
+    int H, W, n_arrays, batch;
+    int n_strips, strip_w;                        // owned source columns per strip
+    StreamLevel lv[2];
+};
+
+template <int R>
+__device__ __forceinline__ double stream_vtap(const double *w, int c, const double (&wk)[R + 1]) {
+    double tmp = w[c] * wk[R];
+#pragma unroll
+    for (int j = -R; j < 0; j++) tmp += (w[c + j] + w[c - j]) * wk[R + j];
+    return tmp;
+}
+
+// the horizontal pass + blend of one level for the output rows [oy_lo, oy_hi) of this chunk
+template <int R>
+__device__ __forceinline__ void stream_emit(const StreamLevel &L, const double *__restrict__ ring, double *dst,
+                                            const double *row_wy, const int *row_y0, int oy_first, int oy_lo,
+                                            int oy_hi, int ya, int n_groups, int ncols, int ox_first,
+                                            const int (&xoff)[kStreamMaxGroups],
+                                            const double (&wxs)[kStreamMaxGroups], const double (&wck)[R + 1],
+                                            int wave, int lane, int &unit) {
+    for (int oy = oy_lo; oy < oy_hi; oy++) {                      // wave-uniform
+        const int y0 = __builtin_amdgcn_readfirstlane(row_y0[oy - oy_first]);
+        const double wy = row_wy[oy - oy_first];
+        const int slot0 = (y0 - ya) % kStreamRing, slot1 = (y0 + 1 - ya) % kStreamRing;
+#pragma unroll
+        for (int g = 0; g < kStreamMaxGroups; g++) {
+            if (g >= n_groups) break;
+            const bool mine = ((unit++) & 3) == wave;             // units dealt round-robin to the waves
+            if (!mine) continue;
+            if (g * 64 + lane >= ncols) continue;
+            const double *p0 = ring + slot0 * kStreamSW + xoff[g];
+            const double *p1 = ring + slot1 * kStreamSW + xoff[g];
+            double u[2][2 * R + 2];                               // V rows y0, y0 + 1, columns x0 - R .. x0 + 1 + R
+#pragma unroll
+            for (int q = 0; q < 2 * R + 2; q++) { u[0][q] = p0[q - R]; u[1][q] = p1[q - R]; }
+            double f[2][2];
+#pragma unroll
+            for (int ry = 0; ry < 2; ry++) {
+#pragma unroll
+                for (int rx = 0; rx < 2; rx++) {
+                    double tmp = u[ry][R + rx] * wck[R];
+#pragma unroll
+                    for (int j = -R; j < 0; j++) tmp += (u[ry][R + rx + j] + u[ry][R + rx - j]) * wck[R + j];
+                    f[ry][rx] = tmp;
+                }
+            }
+            const double wx = wxs[g];
+            const double top = f[0][0] * (1.0 - wx) + f[0][1] * wx;
+            const double bot = f[1][0] * (1.0 - wx) + f[1][1] * wx;
+            dst[(int64_t)oy * L.Wo + ox_first + g * 64 + lane] = top * (1.0 - wy) + bot * wy;
+        }
+    }
+}
+
+template <int RA, int RB>
+__global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
+    constexpr int RM = RA > RB ? RA : RB;
+    constexpr int NL = RB > 0 ? 2 : 1;
+    constexpr int K = kStreamK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
+    double *ringA = reinterpret_cast<double *>(aa_smem);                    // [Ring][SW]
+    double *ringB = ringA + (NL > 1 ? kStreamRing * kStreamSW : 0);
+    double *row_wyA = ringB + kStreamRing * kStreamSW;                      // [HoA] weight of the lower row tap
+    double *row_wyB = row_wyA + a.lv[0].Ho;
+    int *row_y0A = reinterpret_cast<int *>(row_wyB + (NL > 1 ? a.lv[1].Ho : 0));   // [HoA] upper row tap
+    int *row_y0B = row_y0A + a.lv[0].Ho;
+
+    // 1-D grid, XCD-major like k_rescale_aa_multi: XCD k takes images k, k + 8, ...; the strips of an
+    // image are neighbours in dispatch order (their halo columns meet in one L2)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int image = (q / a.n_strips) * 8 + xcd, strip = q - (q / a.n_strips) * a.n_strips;
+    if (image >= a.n_arrays * a.batch) return;
+    const int pair = image / a.n_arrays, arr = image - pair * a.n_arrays;
+    const int H = a.H, W = a.W;
+    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xa = strip * a.strip_w, xb = min(xa + a.strip_w, W);
+    // this thread's source column; threads beyond the strip's support (owned columns + RM on the left,
+    // RM + 1 on the right) repeat its last column
+    const unsigned xcol = (unsigned)mirror_idx(xa - RM + min((int)threadIdx.x, xb - xa + 2 * RM), W);
+
+    // per level: the strip's output columns (those whose left tap lies in [xa, xb)), per 64-column
+    // group the lane's left tap as a ring column and its blend weight; per-row terms into LDS
+    double wkA[RA + 1], wckA[RA + 1];
+    double wkB[RB + 1], wckB[RB + 1];
+    int oxA0, ncolsA, ngA, xoffA[kStreamMaxGroups];
+    double wxA[kStreamMaxGroups];
+    int oxB0 = 0, ncolsB = 0, ngB = 0, xoffB[kStreamMaxGroups];
+    double wxB[kStreamMaxGroups];
+    double syA, syB = 1.0;
+    {
+        const StreamLevel &L = a.lv[0];
+#pragma unroll
+        for (int k = 0; k <= RA; k++) { wkA[k] = L.wr[k]; wckA[k] = L.wc[k]; }
+        const double sx = (double)W / (double)L.Wo;
+        syA = (double)H / (double)L.Ho;
+        oxA0 = first_owned(xa, sx, L.Wo);
+        ncolsA = (xb >= W ? L.Wo : first_owned(xb, sx, L.Wo)) - oxA0;
+        ngA = (ncolsA + 63) >> 6;
+#pragma unroll
+        for (int g = 0; g < kStreamMaxGroups; g++) {
+            const double cx = ((double)(oxA0 + g * 64 + lane) + 0.5) * sx - 0.5;
+            const double fx0 = floor(cx);
+            wxA[g] = cx - fx0;
+            xoffA[g] = min(max((int)fx0 - (xa - RM), RA), kStreamSW - RA - 2);   // clamp: lanes beyond ncols
+        }
+        for (int i = threadIdx.x; i < L.Ho; i += 256) {
+            const double cy = ((double)i + 0.5) * syA - 0.5;
+            const double fy0 = floor(cy);
+            row_wyA[i] = cy - fy0;
+            row_y0A[i] = (int)fy0;
+        }
+    }
+    if constexpr (NL > 1) {
+        const StreamLevel &L = a.lv[1];
+#pragma unroll
+        for (int k = 0; k <= RB; k++) { wkB[k] = L.wr[k]; wckB[k] = L.wc[k]; }
+        const double sx = (double)W / (double)L.Wo;
+        syB = (double)H / (double)L.Ho;
+        oxB0 = first_owned(xa, sx, L.Wo);
+        ncolsB = (xb >= W ? L.Wo : first_owned(xb, sx, L.Wo)) - oxB0;
+        ngB = (ncolsB + 63) >> 6;
+#pragma unroll
+        for (int g = 0; g < kStreamMaxGroups; g++) {
+            const double cx = ((double)(oxB0 + g * 64 + lane) + 0.5) * sx - 0.5;
+            const double fx0 = floor(cx);
+            wxB[g] = cx - fx0;
+            xoffB[g] = min(max((int)fx0 - (xa - RM), RB), kStreamSW - RB - 2);
+        }
+        for (int i = threadIdx.x; i < L.Ho; i += 256) {
+            const double cy = ((double)i + 0.5) * syB - 0.5;
+            const double fy0 = floor(cy);
+            row_wyB[i] = cy - fy0;
+            row_y0B[i] = (int)fy0;
+        }
+    }
+    double *dstA = a.lv[0].dst[arr] + (int64_t)pair * a.lv[0].dst_stride;
+    double *dstB = NL > 1 ? a.lv[1].dst[arr] + (int64_t)pair * a.lv[1].dst_stride : nullptr;
+
+    // the column's window: w[i] = source row (y - RM + i) for the chunk that starts at V row y
+    double w[K + 2 * RM], nxt[K];
+#pragma unroll
+    for (int i = 0; i < 2 * RM; i++) w[i] = s[(int64_t)mirror_idx(i - RM, H) * W + xcol];
+#pragma unroll
+    for (int i = 0; i < K; i++) w[2 * RM + i] = s[(int64_t)mirror_idx(RM + i, H) * W + xcol];
+    int nextA = 0, nextB = 0, unit = 0;
+    const int n_chunks = (H + K - 1) / K;
+    for (int c = 0; c < n_chunks; c++) {
+        const int y = c * K;                                      // first V row of this chunk
+        if (c + 1 < n_chunks) {                                   // prefetch the next chunk's K rows
+#pragma unroll
+            for (int i = 0; i < K; i++) nxt[i] = s[(int64_t)mirror_idx(y + K + RM + i, H) * W + xcol];
+        }
+        // vertical Gaussians of both levels at V rows y .. y + K - 1 (rows >= H: computed, never read)
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const int slot = (y + j) % kStreamRing;
+            ringA[slot * kStreamSW + threadIdx.x] = stream_vtap<RA>(w, j + RM, wkA);
+            if constexpr (NL > 1) ringB[slot * kStreamSW + threadIdx.x] = stream_vtap<RB>(w, j + RM, wkB);
+        }
+        __syncthreads();
+        // outputs whose lower row tap y0 + 1 is now in the ring: y0 + 1 <= y + K - 1
+        const int ynew = min(y + K - 1, H - 1);
+        {
+            const int hi = ynew >= H - 1 ? a.lv[0].Ho : __builtin_amdgcn_readfirstlane(first_owned(ynew, syA, a.lv[0].Ho));
+            stream_emit<RA>(a.lv[0], ringA, dstA, row_wyA, row_y0A, 0, nextA, hi, 0, ngA, ncolsA, oxA0, xoffA, wxA,
+                            wckA, wave, lane, unit);
+            nextA = hi;
+        }
+        if constexpr (NL > 1) {
+            const int hi = ynew >= H - 1 ? a.lv[1].Ho : __builtin_amdgcn_readfirstlane(first_owned(ynew, syB, a.lv[1].Ho));
+            stream_emit<RB>(a.lv[1], ringB, dstB, row_wyB, row_y0B, 0, nextB, hi, 0, ngB, ncolsB, oxB0,
+                                           xoffB, wxB, wckB, wave, lane, unit);
+            nextB = hi;
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * RM; i++) w[i] = w[K + i];
+#pragma unroll
+        for (int i = 0; i < K; i++) w[2 * RM + i] = nxt[i];
+    }
+}
+
 // scipy.ndimage._filters._gaussian_kernel1d (order 0), radius int(4 sigma + 0.5)
 void gaussian_weights(double sigma, int radius, double *w) {
     const double sigma2 = sigma * sigma;
@@ -688,6 +908,50 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
     if (upload_weights) {   // they depend on the shapes only: a batch uploads them once
         TDK_HIP(hipMemcpyAsync(weights, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, stream));
         TDK_HIP(hipStreamSynchronize(stream));   // `host` goes out of scope
+    }
+    // The first level (R = 1) or the first two (R = 1, 3: ratio 1.5) of a batch large enough to fill the
+    // chip with full-height strips: one streaming pass over the source (k_pyramid_stream).
+    // TDK_PYRAMID_STREAM=0 keeps them on the tiles below (bit-identical either way: tested).
+    {
+        const char *env = getenv("TDK_PYRAMID_STREAM");       // 0 (default): never, 1: large batches, 2: always
+        const int use_stream = env ? atoi(env) : 0;
+        auto fits = [&](int l, int R) {
+            return l < n_out && !((skip_mask >> l) & 1u) && args.aa[l].Rr == R && args.aa[l].Rc == R &&
+                   r.lv[l].Ho < H && r.lv[l].Wo < W;
+        };
+        const int n_strips = (W + 247) / 248, strip_w = (W + n_strips - 1) / n_strips;
+        const int64_t images = (int64_t)n_arrays * batch;
+        if (use_stream && fits(0, 1) && (images * n_strips >= 256 || use_stream == 2)) {
+            const int nl = fits(1, 3) ? 2 : 1;
+            StreamArgs sa;
+            for (int i = 0; i < 4; i++) sa.src[i] = r.src[i];
+            sa.src_stride = src_stride; sa.H = H; sa.W = W; sa.n_arrays = n_arrays; sa.batch = batch;
+            sa.n_strips = n_strips; sa.strip_w = strip_w;
+            size_t lds = 0;
+            for (int l = 0; l < 2; l++) {
+                const int k = l < nl ? l : 0;
+                for (int i = 0; i < 4; i++) sa.lv[l].dst[i] = r.lv[k].dst[i];
+                sa.lv[l].dst_stride = r.lv[k].stride; sa.lv[l].Ho = r.lv[k].Ho; sa.lv[l].Wo = r.lv[k].Wo;
+                sa.lv[l].wr = args.aa[k].wr; sa.lv[l].wc = args.aa[k].wc;
+                if (l < nl) lds += sizeof(double) * kStreamRing * kStreamSW + (size_t)r.lv[k].Ho * 12;
+            }
+            lds += 16;
+            const int64_t blocks = 8 * ((images + 7) / 8) * n_strips;
+            if (blocks < (1ll << 31) && lds <= 160 * 1024) {
+                static bool attr_set = false;
+                if (!attr_set) {   // > 64 KiB of dynamic LDS has to be asked for
+                    TDK_HIP(hipFuncSetAttribute((const void *)k_pyramid_stream<1, 3>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    TDK_HIP(hipFuncSetAttribute((const void *)k_pyramid_stream<1, 0>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attr_set = true;
+                }
+                if (nl == 2) k_pyramid_stream<1, 3><<<(unsigned)blocks, 256, lds, stream>>>(sa);
+                else k_pyramid_stream<1, 0><<<(unsigned)blocks, 256, lds, stream>>>(sa);
+                TDK_LAUNCH_CHECK();
+                skip_mask |= nl == 2 ? 3u : 1u;
+            }
+        }
     }
     // levels that shrink both axes and whose tiles fit in LDS take the tiled kernel -- all of
     // them in one launch (k_rescale_aa_multi); whatever is left (an enlarged axis, very deep

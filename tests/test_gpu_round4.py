@@ -257,3 +257,42 @@ def test_device_map_escape_tracking(ops, orc, monkeypatch):
     img = frame.image
     np.asarray(img)[:] = 0.0
     assert float(np.asarray(img).max()) == 0.0 and np.array_equal(frame.image, c["key_image"])
+
+
+# ---------------------------------------------------------------------------
+# the row-streaming pyramid kernel (k_pyramid_stream): bit-identical with the tiles and the oracle
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,levels", [((480, 640), 3), ((480, 640), 2), ((120, 160), 3), ((97, 131), 3),
+                                          ((720, 1280), 3), ((250, 249), 3), ((251, 497), 5)])
+def test_streaming_pyramid_is_bit_identical(ops, orc, monkeypatch, shape, levels):
+    """TDK_PYRAMID_STREAM=2 forces the streaming kernel for the first one / two levels of any batch
+    (by default it takes batches of >= 256 strips); =0 keeps the tiled kernel.  Every level of every
+    array must come out bit for bit the same, and equal to the oracle's anti-aliased rescale: one
+    strip (W < 249), three strips (VGA), strips that do not divide the width, odd heights, a frame
+    whose last chunk is partial, deeper pyramids whose later levels stay on the tiles."""
+    from tadataka_amd import synthetic
+    H, W = shape
+    B = 2
+    rng = np.random.default_rng(11)
+    pairs = []
+    for i in range(B):
+        pr = synthetic.make_pair(H, W, seed=60 + i)
+        pr["W0"] = rng.uniform(0.05, 50.0, (H, W))
+        pairs.append(pr)
+    got = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("TDK_PYRAMID_STREAM", mode)
+        batch = ops.DvoBatch(B, H, W, n_levels=levels, ratio=1.5, with_weight_map=True)
+        batch.set_anti_aliasing(True)
+        for i, pr in enumerate(pairs):
+            batch.upload(i, pr["I0"], pr["D0"], pr["I1"], pr["W0"])
+        batch.build_pyramid()
+        got[mode] = {(l, i, n): batch.download(i, l, n) for l in range(1, levels) for i in range(B)
+                     for n in ("I0", "D0", "I1", "W0")}
+        batch.close()
+    for key, tiles in got["0"].items():
+        assert np.array_equal(got["2"][key], tiles), (key, float(np.max(np.abs(got["2"][key] - tiles))))
+    for (l, i, n) in ((1, 0, "D0"), (1, 1, "W0"), (2, 0, "I1"), (2, 1, "D0")):
+        if l < levels:
+            want = orc.rescale(pairs[i][n], 1 / 1.5 ** l, anti_aliasing=True)
+            assert np.array_equal(got["2"][(l, i, n)], want), (l, i, n)
