@@ -646,8 +646,15 @@ __global__ __launch_bounds__(256) void k_rescale_aa_multi(AaMultiArgs m) {
 // V rows live in rings of 2 K + 1 rows: the rows a chunk's outputs read are not the ones the
 // next chunk overwrites, so ONE barrier per chunk orders everything.
 // ---------------------------------------------------------------------------
-constexpr int kStreamK = 8;                       // source rows per chunk
-constexpr int kStreamRing = 2 * kStreamK + 1;     // V rows per level ring
+#ifndef TDK_STREAM_K
+#define TDK_STREAM_K 8
+#endif
+#ifndef TDK_STREAM_RING
+#define TDK_STREAM_RING (TDK_STREAM_K + 2)
+#endif
+constexpr int kStreamK = TDK_STREAM_K;            // source rows per chunk
+constexpr int kStreamRing = TDK_STREAM_RING;      // V rows per level ring (>= K + 2; < 2 K + 1: a second barrier per chunk)
+static_assert(kStreamRing >= kStreamK + 2 && kStreamK <= 32, "ring too small");
 constexpr int kStreamSW = 256;                    // ring row pitch = threads = columns incl. halo
 constexpr int kStreamMaxGroups = 4;               // 64-column groups of outputs per strip and level
 
@@ -663,6 +670,7 @@ struct StreamArgs {
     int64_t src_stride;
     int H, W, n_arrays, batch;
     int n_strips, strip_w;                        // owned source columns per strip
+    int n_segs, seg_rows;                         // row segments: a block emits the outputs whose upper tap lies in its segment
     StreamLevel lv[2];
 };
 
@@ -676,16 +684,25 @@ __device__ __forceinline__ double stream_vtap(const double *w, int c, const doub
 
 // the horizontal pass + blend of one level for the output rows [oy_lo, oy_hi) of this chunk
 template <int R>
-__device__ __forceinline__ void stream_emit(const StreamLevel &L, const double *__restrict__ ring, double *dst,
-                                            const double *row_wy, const int *row_y0, int oy_first, int oy_lo,
-                                            int oy_hi, int ya, int n_groups, int ncols, int ox_first,
-                                            const int (&xoff)[kStreamMaxGroups],
-                                            const double (&wxs)[kStreamMaxGroups], const double (&wck)[R + 1],
-                                            int wave, int lane, int &unit) {
-    for (int oy = oy_lo; oy < oy_hi; oy++) {                      // wave-uniform
-        const int y0 = __builtin_amdgcn_readfirstlane(row_y0[oy - oy_first]);
-        const double wy = row_wy[oy - oy_first];
+__device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *__restrict__ ring, double *dst,
+                                           double sy, int oy_lo, int oy_end, int ynew, int ya, int n_groups,
+                                           int ncols, int ox_first,
+                                           const int (&xoff)[kStreamMaxGroups],
+                                           const double (&wxs)[kStreamMaxGroups], const double (&wck)[R + 1],
+                                           int wave, int lane, int &unit) {
+    // the row terms of the next rows: lane i computes those of row oy_lo + i, the rows read them by lane;
+    // the rows to emit now are those whose lower tap y0 + 1 is in the ring (a prefix: y0 is monotone)
+    const double my_cy = ((double)(oy_lo + lane) + 0.5) * sy - 0.5;
+    const double my_fy = floor(my_cy);
+    const double my_wy = my_cy - my_fy;
+    const int my_y0 = (int)my_fy;
+    const int n_rows = __builtin_popcountll(__ballot(oy_lo + lane < oy_end && my_y0 + 1 <= ynew));
+    for (int i = 0; i < n_rows; i++) {                            // wave-uniform
+        const int y0 = __builtin_amdgcn_readlane(my_y0, i);
+        const double wy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_wy), i),
+                                           __builtin_amdgcn_readlane(__double2loint(my_wy), i));
         const int slot0 = (y0 - ya) % kStreamRing, slot1 = (y0 + 1 - ya) % kStreamRing;
+        double *dst_row = dst + (int64_t)(oy_lo + i) * L.Wo + ox_first;   // uniform base, the lane is the offset
 #pragma unroll
         for (int g = 0; g < kStreamMaxGroups; g++) {
             if (g >= n_groups) break;
@@ -711,9 +728,10 @@ __device__ __forceinline__ void stream_emit(const StreamLevel &L, const double *
             const double wx = wxs[g];
             const double top = f[0][0] * (1.0 - wx) + f[0][1] * wx;
             const double bot = f[1][0] * (1.0 - wx) + f[1][1] * wx;
-            dst[(int64_t)oy * L.Wo + ox_first + g * 64 + lane] = top * (1.0 - wy) + bot * wy;
+            (dst_row + g * 64)[lane] = top * (1.0 - wy) + bot * wy;
         }
     }
+    return oy_lo + n_rows;
 }
 
 template <int RA, int RB>
@@ -724,15 +742,13 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
     double *ringA = reinterpret_cast<double *>(aa_smem);                    // [Ring][SW]
     double *ringB = ringA + (NL > 1 ? kStreamRing * kStreamSW : 0);
-    double *row_wyA = ringB + kStreamRing * kStreamSW;                      // [HoA] weight of the lower row tap
-    double *row_wyB = row_wyA + a.lv[0].Ho;
-    int *row_y0A = reinterpret_cast<int *>(row_wyB + (NL > 1 ? a.lv[1].Ho : 0));   // [HoA] upper row tap
-    int *row_y0B = row_y0A + a.lv[0].Ho;
 
     // 1-D grid, XCD-major like k_rescale_aa_multi: XCD k takes images k, k + 8, ...; the strips of an
     // image are neighbours in dispatch order (their halo columns meet in one L2)
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int image = (q / a.n_strips) * 8 + xcd, strip = q - (q / a.n_strips) * a.n_strips;
+    const int per_image = a.n_strips * a.n_segs;
+    const int image = (q / per_image) * 8 + xcd, part = q - (q / per_image) * per_image;
+    const int seg = part / a.n_strips, strip = part - seg * a.n_strips;
     if (image >= a.n_arrays * a.batch) return;
     const int pair = image / a.n_arrays, arr = image - pair * a.n_arrays;
     const int H = a.H, W = a.W;
@@ -740,6 +756,7 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int xa = strip * a.strip_w, xb = min(xa + a.strip_w, W);
+    const int ya = seg * a.seg_rows, yb = min(ya + a.seg_rows, H);   // V rows ya .. min(yb, H - 1) are needed
     // this thread's source column; threads beyond the strip's support (owned columns + RM on the left,
     // RM + 1 on the right) repeat its last column
     const unsigned xcol = (unsigned)mirror_idx(xa - RM + min((int)threadIdx.x, xb - xa + 2 * RM), W);
@@ -769,12 +786,6 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
             wxA[g] = cx - fx0;
             xoffA[g] = min(max((int)fx0 - (xa - RM), RA), kStreamSW - RA - 2);   // clamp: lanes beyond ncols
         }
-        for (int i = threadIdx.x; i < L.Ho; i += 256) {
-            const double cy = ((double)i + 0.5) * syA - 0.5;
-            const double fy0 = floor(cy);
-            row_wyA[i] = cy - fy0;
-            row_y0A[i] = (int)fy0;
-        }
     }
     if constexpr (NL > 1) {
         const StreamLevel &L = a.lv[1];
@@ -792,12 +803,6 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
             wxB[g] = cx - fx0;
             xoffB[g] = min(max((int)fx0 - (xa - RM), RB), kStreamSW - RB - 2);
         }
-        for (int i = threadIdx.x; i < L.Ho; i += 256) {
-            const double cy = ((double)i + 0.5) * syB - 0.5;
-            const double fy0 = floor(cy);
-            row_wyB[i] = cy - fy0;
-            row_y0B[i] = (int)fy0;
-        }
     }
     double *dstA = a.lv[0].dst[arr] + (int64_t)pair * a.lv[0].dst_stride;
     double *dstB = NL > 1 ? a.lv[1].dst[arr] + (int64_t)pair * a.lv[1].dst_stride : nullptr;
@@ -805,39 +810,43 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
     // the column's window: w[i] = source row (y - RM + i) for the chunk that starts at V row y
     double w[K + 2 * RM], nxt[K];
 #pragma unroll
-    for (int i = 0; i < 2 * RM; i++) w[i] = s[(int64_t)mirror_idx(i - RM, H) * W + xcol];
+    for (int i = 0; i < 2 * RM; i++) w[i] = s[(int64_t)mirror_idx(ya + i - RM, H) * W + xcol];
 #pragma unroll
-    for (int i = 0; i < K; i++) w[2 * RM + i] = s[(int64_t)mirror_idx(RM + i, H) * W + xcol];
-    int nextA = 0, nextB = 0, unit = 0;
-    const int n_chunks = (H + K - 1) / K;
+    for (int i = 0; i < K; i++) w[2 * RM + i] = s[(int64_t)mirror_idx(ya + RM + i, H) * W + xcol];
+    const bool last_seg = yb >= H;
+    int nextA = first_owned(ya, syA, a.lv[0].Ho), nextB = NL > 1 ? first_owned(ya, syB, a.lv[1].Ho) : 0, unit = 0;
+    const int endA = last_seg ? a.lv[0].Ho : first_owned(yb, syA, a.lv[0].Ho);
+    const int endB = NL > 1 ? (last_seg ? a.lv[1].Ho : first_owned(yb, syB, a.lv[1].Ho)) : 0;
+    const int y_last = min(yb, H - 1);                            // last V row this block needs
+    const int n_chunks = (y_last - ya + K) / K;
     for (int c = 0; c < n_chunks; c++) {
-        const int y = c * K;                                      // first V row of this chunk
+        const int y = ya + c * K;                                 // first V row of this chunk
         if (c + 1 < n_chunks) {                                   // prefetch the next chunk's K rows
+            const int r0 = y + K + RM;
+            if (r0 + K - 1 <= H - 1) {                            // inside the image: uniform row bases, the column is the offset
 #pragma unroll
-            for (int i = 0; i < K; i++) nxt[i] = s[(int64_t)mirror_idx(y + K + RM + i, H) * W + xcol];
+                for (int i = 0; i < K; i++) nxt[i] = (s + (int64_t)(r0 + i) * W)[xcol];
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; i++) nxt[i] = s[(int64_t)mirror_idx(r0 + i, H) * W + xcol];
+            }
         }
         // vertical Gaussians of both levels at V rows y .. y + K - 1 (rows >= H: computed, never read)
 #pragma unroll
         for (int j = 0; j < K; j++) {
-            const int slot = (y + j) % kStreamRing;
+            const int slot = (c * K + j) % kStreamRing;
             ringA[slot * kStreamSW + threadIdx.x] = stream_vtap<RA>(w, j + RM, wkA);
             if constexpr (NL > 1) ringB[slot * kStreamSW + threadIdx.x] = stream_vtap<RB>(w, j + RM, wkB);
         }
         __syncthreads();
         // outputs whose lower row tap y0 + 1 is now in the ring: y0 + 1 <= y + K - 1
-        const int ynew = min(y + K - 1, H - 1);
-        {
-            const int hi = ynew >= H - 1 ? a.lv[0].Ho : __builtin_amdgcn_readfirstlane(first_owned(ynew, syA, a.lv[0].Ho));
-            stream_emit<RA>(a.lv[0], ringA, dstA, row_wyA, row_y0A, 0, nextA, hi, 0, ngA, ncolsA, oxA0, xoffA, wxA,
-                            wckA, wave, lane, unit);
-            nextA = hi;
-        }
-        if constexpr (NL > 1) {
-            const int hi = ynew >= H - 1 ? a.lv[1].Ho : __builtin_amdgcn_readfirstlane(first_owned(ynew, syB, a.lv[1].Ho));
-            stream_emit<RB>(a.lv[1], ringB, dstB, row_wyB, row_y0B, 0, nextB, hi, 0, ngB, ncolsB, oxB0,
-                                           xoffB, wxB, wckB, wave, lane, unit);
-            nextB = hi;
-        }
+        const int ynew = y + K - 1 >= y_last ? (1 << 30) : y + K - 1;   // the last chunk emits whatever is left
+        nextA = stream_emit<RA>(a.lv[0], ringA, dstA, syA, nextA, endA, ynew, ya, ngA, ncolsA, oxA0, xoffA, wxA, wckA,
+                                wave, lane, unit);
+        if constexpr (NL > 1)
+            nextB = stream_emit<RB>(a.lv[1], ringB, dstB, syB, nextB, endB, ynew, ya, ngB, ncolsB, oxB0, xoffB, wxB,
+                                    wckB, wave, lane, unit);
+        if (kStreamRing < 2 * K + 1) __syncthreads();             // the next chunk's V rows overwrite rows read above
 #pragma unroll
         for (int i = 0; i < 2 * RM; i++) w[i] = w[K + i];
 #pragma unroll
@@ -913,8 +922,8 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
     // chip with full-height strips: one streaming pass over the source (k_pyramid_stream).
     // TDK_PYRAMID_STREAM=0 keeps them on the tiles below (bit-identical either way: tested).
     {
-        const char *env = getenv("TDK_PYRAMID_STREAM");       // 0 (default): never, 1: large batches, 2: always
-        const int use_stream = env ? atoi(env) : 0;
+        const char *env = getenv("TDK_PYRAMID_STREAM");       // 0: never, 1 (default): large batches, 2: always
+        const int use_stream = env ? atoi(env) : 1;
         auto fits = [&](int l, int R) {
             return l < n_out && !((skip_mask >> l) & 1u) && args.aa[l].Rr == R && args.aa[l].Rc == R &&
                    r.lv[l].Ho < H && r.lv[l].Wo < W;
@@ -927,16 +936,22 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
             for (int i = 0; i < 4; i++) sa.src[i] = r.src[i];
             sa.src_stride = src_stride; sa.H = H; sa.W = W; sa.n_arrays = n_arrays; sa.batch = batch;
             sa.n_strips = n_strips; sa.strip_w = strip_w;
+            // row segments: enough blocks for several full rounds of the 1024 resident ones (a segment pays
+            // 2 RM warm-up rows); TDK_STREAM_SEGS overrides
+            int n_segs = 1;
+            while (images * n_strips * n_segs < 8192 && H / (n_segs * 2) >= 48) n_segs *= 2;
+            if (const char *v = getenv("TDK_STREAM_SEGS")) n_segs = std::max(1, atoi(v));
+            sa.n_segs = n_segs; sa.seg_rows = (H + n_segs - 1) / n_segs;
+            sa.n_segs = (H + sa.seg_rows - 1) / sa.seg_rows;
             size_t lds = 0;
             for (int l = 0; l < 2; l++) {
                 const int k = l < nl ? l : 0;
                 for (int i = 0; i < 4; i++) sa.lv[l].dst[i] = r.lv[k].dst[i];
                 sa.lv[l].dst_stride = r.lv[k].stride; sa.lv[l].Ho = r.lv[k].Ho; sa.lv[l].Wo = r.lv[k].Wo;
                 sa.lv[l].wr = args.aa[k].wr; sa.lv[l].wc = args.aa[k].wc;
-                if (l < nl) lds += sizeof(double) * kStreamRing * kStreamSW + (size_t)r.lv[k].Ho * 12;
+                if (l < nl) lds += sizeof(double) * kStreamRing * kStreamSW;
             }
-            lds += 16;
-            const int64_t blocks = 8 * ((images + 7) / 8) * n_strips;
+            const int64_t blocks = 8 * ((images + 7) / 8) * n_strips * sa.n_segs;
             if (blocks < (1ll << 31) && lds <= 160 * 1024) {
                 static bool attr_set = false;
                 if (!attr_set) {   // > 64 KiB of dynamic LDS has to be asked for
