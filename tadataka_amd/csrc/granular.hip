@@ -643,8 +643,14 @@ __global__ __launch_bounds__(256) void k_rescale_aa_multi(AaMultiArgs m) {
 //     whose two V rows are now complete: horizontal Gaussian at the four taps from LDS,
 //     blend, store -- aa_tile_fixed's arithmetic, operation by operation (centre tap, pairs
 //     from the outermost inwards; top / bottom / rows), so the output is bit-identical.
-// V rows live in rings of 2 K + 1 rows: the rows a chunk's outputs read are not the ones the
-// next chunk overwrites, so ONE barrier per chunk orders everything.
+// V rows live in rings of K + 2 rows per level (two barriers per chunk): 35.8 KB of LDS for a VGA
+// strip, 4 blocks per CU.  Measured on 256 VGA pairs x 3 arrays (profiles/r04_pyramid.txt): rings of
+// 2 K + 1 rows with one barrier (2 blocks per CU) 1.44 ms, K + 2 rows 0.99, ring pitch = the strip's
+// columns instead of 256 0.91; K = 4 / 6 / 8 / 9 / 12: 1.31 / 1.09 / 0.91 / 0.90 / 0.95 (K >= 10 loses a
+// block per CU); the tiles above 1.035.  Timing-only ablations (-DTDK_STREAM_ABL_*): no emission 0.355
+// (the source streams at 5.3 TB/s), emission without LDS reads and stores 0.56, + LDS reads 0.68,
+// + stores 0.73, both 0.91 -- the phases add up instead of overlapping; conflict-free (wrong) tap
+// addresses 0.89, 16-byte stores by lane pairs 0.93, the second barrier nothing.
 // ---------------------------------------------------------------------------
 #ifndef TDK_STREAM_K
 #define TDK_STREAM_K 8
@@ -655,7 +661,6 @@ __global__ __launch_bounds__(256) void k_rescale_aa_multi(AaMultiArgs m) {
 constexpr int kStreamK = TDK_STREAM_K;            // source rows per chunk
 constexpr int kStreamRing = TDK_STREAM_RING;      // V rows per level ring (>= K + 2; < 2 K + 1: a second barrier per chunk)
 static_assert(kStreamRing >= kStreamK + 2 && kStreamK <= 32, "ring too small");
-constexpr int kStreamSW = 256;                    // ring row pitch = threads = columns incl. halo
 constexpr int kStreamMaxGroups = 4;               // 64-column groups of outputs per strip and level
 
 struct StreamLevel {
@@ -670,9 +675,12 @@ struct StreamArgs {
     int64_t src_stride;
     int H, W, n_arrays, batch;
     int n_strips, strip_w;                        // owned source columns per strip
+    int pitch;                                    // ring row pitch: strip_w + 2 RM + 1 columns, rounded up (<= 256 threads)
     int n_segs, seg_rows;                         // row segments: a block emits the outputs whose upper tap lies in its segment
     StreamLevel lv[2];
 };
+
+__device__ __forceinline__ double wx_fake(double a, int q) { return a + (double)q; }   // ablation builds only
 
 template <int R>
 __device__ __forceinline__ double stream_vtap(const double *w, int c, const double (&wk)[R + 1]) {
@@ -684,7 +692,7 @@ __device__ __forceinline__ double stream_vtap(const double *w, int c, const doub
 
 // the horizontal pass + blend of one level for the output rows [oy_lo, oy_hi) of this chunk
 template <int R>
-__device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *__restrict__ ring, double *dst,
+__device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *__restrict__ ring, int SW, double *dst,
                                            double sy, int oy_lo, int oy_end, int ynew, int ya, int n_groups,
                                            int ncols, int ox_first,
                                            const int (&xoff)[kStreamMaxGroups],
@@ -709,11 +717,15 @@ __device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *_
             const bool mine = ((unit++) & 3) == wave;             // units dealt round-robin to the waves
             if (!mine) continue;
             if (g * 64 + lane >= ncols) continue;
-            const double *p0 = ring + slot0 * kStreamSW + xoff[g];
-            const double *p1 = ring + slot1 * kStreamSW + xoff[g];
+            const double *p0 = ring + slot0 * SW + xoff[g];
+            const double *p1 = ring + slot1 * SW + xoff[g];
             double u[2][2 * R + 2];                               // V rows y0, y0 + 1, columns x0 - R .. x0 + 1 + R
 #pragma unroll
+#ifdef TDK_STREAM_ABL_NOLDSREAD
+            for (int q = 0; q < 2 * R + 2; q++) { u[0][q] = wx_fake(wxs[g], q); u[1][q] = wx_fake(wy, q); }
+#else
             for (int q = 0; q < 2 * R + 2; q++) { u[0][q] = p0[q - R]; u[1][q] = p1[q - R]; }
+#endif
             double f[2][2];
 #pragma unroll
             for (int ry = 0; ry < 2; ry++) {
@@ -728,6 +740,9 @@ __device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *_
             const double wx = wxs[g];
             const double top = f[0][0] * (1.0 - wx) + f[0][1] * wx;
             const double bot = f[1][0] * (1.0 - wx) + f[1][1] * wx;
+#ifdef TDK_STREAM_ABL_NOSTORE
+            if (wy == 12345.0)
+#endif
             (dst_row + g * 64)[lane] = top * (1.0 - wy) + bot * wy;
         }
     }
@@ -741,7 +756,8 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
     constexpr int K = kStreamK;
     extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
     double *ringA = reinterpret_cast<double *>(aa_smem);                    // [Ring][SW]
-    double *ringB = ringA + (NL > 1 ? kStreamRing * kStreamSW : 0);
+    const int SW = a.pitch;
+    double *ringB = ringA + (NL > 1 ? kStreamRing * SW : 0);
 
     // 1-D grid, XCD-major like k_rescale_aa_multi: XCD k takes images k, k + 8, ...; the strips of an
     // image are neighbours in dispatch order (their halo columns meet in one L2)
@@ -784,7 +800,7 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
             const double cx = ((double)(oxA0 + g * 64 + lane) + 0.5) * sx - 0.5;
             const double fx0 = floor(cx);
             wxA[g] = cx - fx0;
-            xoffA[g] = min(max((int)fx0 - (xa - RM), RA), kStreamSW - RA - 2);   // clamp: lanes beyond ncols
+            xoffA[g] = min(max((int)fx0 - (xa - RM), RA), SW - RA - 2);   // clamp: lanes beyond ncols
         }
     }
     if constexpr (NL > 1) {
@@ -801,7 +817,7 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
             const double cx = ((double)(oxB0 + g * 64 + lane) + 0.5) * sx - 0.5;
             const double fx0 = floor(cx);
             wxB[g] = cx - fx0;
-            xoffB[g] = min(max((int)fx0 - (xa - RM), RB), kStreamSW - RB - 2);
+            xoffB[g] = min(max((int)fx0 - (xa - RM), RB), SW - RB - 2);
         }
     }
     double *dstA = a.lv[0].dst[arr] + (int64_t)pair * a.lv[0].dst_stride;
@@ -835,18 +851,32 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
 #pragma unroll
         for (int j = 0; j < K; j++) {
             const int slot = (c * K + j) % kStreamRing;
-            ringA[slot * kStreamSW + threadIdx.x] = stream_vtap<RA>(w, j + RM, wkA);
-            if constexpr (NL > 1) ringB[slot * kStreamSW + threadIdx.x] = stream_vtap<RB>(w, j + RM, wkB);
+#ifdef TDK_STREAM_ABL_NOV
+            const double va = w[j + RM];
+            double vb = w[j + RM];
+#else
+            const double va = stream_vtap<RA>(w, j + RM, wkA);
+            double vb = 0.0;
+            if constexpr (NL > 1) vb = stream_vtap<RB>(w, j + RM, wkB);
+#endif
+            if ((int)threadIdx.x < SW) {                          // threads beyond the pitch hold a repeated column
+                ringA[slot * SW + threadIdx.x] = va;
+                if constexpr (NL > 1) ringB[slot * SW + threadIdx.x] = vb;
+            }
         }
         __syncthreads();
         // outputs whose lower row tap y0 + 1 is now in the ring: y0 + 1 <= y + K - 1
         const int ynew = y + K - 1 >= y_last ? (1 << 30) : y + K - 1;   // the last chunk emits whatever is left
-        nextA = stream_emit<RA>(a.lv[0], ringA, dstA, syA, nextA, endA, ynew, ya, ngA, ncolsA, oxA0, xoffA, wxA, wckA,
+#ifndef TDK_STREAM_ABL_NOEMIT
+        nextA = stream_emit<RA>(a.lv[0], ringA, SW, dstA, syA, nextA, endA, ynew, ya, ngA, ncolsA, oxA0, xoffA, wxA, wckA,
                                 wave, lane, unit);
         if constexpr (NL > 1)
-            nextB = stream_emit<RB>(a.lv[1], ringB, dstB, syB, nextB, endB, ynew, ya, ngB, ncolsB, oxB0, xoffB, wxB,
+            nextB = stream_emit<RB>(a.lv[1], ringB, SW, dstB, syB, nextB, endB, ynew, ya, ngB, ncolsB, oxB0, xoffB, wxB,
                                     wckB, wave, lane, unit);
+#endif
+#ifndef TDK_STREAM_ABL_NOBAR2
         if (kStreamRing < 2 * K + 1) __syncthreads();             // the next chunk's V rows overwrite rows read above
+#endif
 #pragma unroll
         for (int i = 0; i < 2 * RM; i++) w[i] = w[K + i];
 #pragma unroll
@@ -936,6 +966,7 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
             for (int i = 0; i < 4; i++) sa.src[i] = r.src[i];
             sa.src_stride = src_stride; sa.H = H; sa.W = W; sa.n_arrays = n_arrays; sa.batch = batch;
             sa.n_strips = n_strips; sa.strip_w = strip_w;
+            sa.pitch = std::min(256, (strip_w + 2 * 3 + 1 + 7) & ~7);
             // row segments: enough blocks for several full rounds of the 1024 resident ones (a segment pays
             // 2 RM warm-up rows); TDK_STREAM_SEGS overrides
             int n_segs = 1;
@@ -949,7 +980,7 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
                 for (int i = 0; i < 4; i++) sa.lv[l].dst[i] = r.lv[k].dst[i];
                 sa.lv[l].dst_stride = r.lv[k].stride; sa.lv[l].Ho = r.lv[k].Ho; sa.lv[l].Wo = r.lv[k].Wo;
                 sa.lv[l].wr = args.aa[k].wr; sa.lv[l].wc = args.aa[k].wc;
-                if (l < nl) lds += sizeof(double) * kStreamRing * kStreamSW;
+                if (l < nl) lds += sizeof(double) * kStreamRing * sa.pitch;
             }
             const int64_t blocks = 8 * ((images + 7) / 8) * n_strips * sa.n_segs;
             if (blocks < (1ll << 31) && lds <= 160 * 1024) {
