@@ -220,6 +220,12 @@ tdk_status tdk_dvo_get_profile(tdk_dvo *h, int64_t *launches, double *total_ms, 
  * returns), 1: only probes, 2: both kinds of pairs in one launch. */
 tdk_status tdk_dvo_get_profile_kind(tdk_dvo *h, int kind, int64_t *launches, double *total_ms,
                                     int64_t *pixels);
+/* tdk_dvo_set_profiling(h, 2) times the evaluation launches of EVERY pyramid level (1: the
+ * finest level only); this returns the buckets of one level (kinds as above; pixels = that
+ * level's source pixels x pairs evaluated).  Meant for a single batch alone on the device: with
+ * another batch's pyramid running beside it the coarse-level launches are stretched. */
+tdk_status tdk_dvo_get_profile_level(tdk_dvo *h, int level, int kind, int64_t *launches, double *total_ms,
+                                     int64_t *pixels);
 
 /* ---- least-squares pieces at the reference's own granularity -------------- */
 /* A^T W A (upper triangle, row-major, p(p+1)/2) and A^T W b (p) of an n x p

@@ -102,6 +102,7 @@ PROTOTYPES = {
     "tdk_dvo_set_profiling": [_vp, _i],
     "tdk_dvo_get_profile": [_vp, c_int64_p, _d, c_int64_p],
     "tdk_dvo_get_profile_kind": [_vp, _i, c_int64_p, _d, c_int64_p],
+    "tdk_dvo_get_profile_level": [_vp, _i, _i, c_int64_p, _d, c_int64_p],
     "tdk_weighted_normal_equations": [_d, _d, _d, _i64, _i, _d, _d],
     "tdk_dvo_pose_update": [_d, _d, _d, _d, _i, _i, _d, _i64, _i, _d, _d, _d, c_int64_p],
     "tdk_robust_weights": [_d, _i64, _i, _d],

@@ -2109,12 +2109,13 @@ struct tdk_dvo {
     double *d_tk_sample;           // [n][kTukeySample] sorted sample of the masked residuals
     unsigned int *d_tk_fallback;   // [1] pairs that took the exact radix path of k_tukey_finish (diagnostic)
     // profiling of the finest-level evaluation kernel (bench.py roofline leg)
-    bool profiling;
+    int profiling;               // 0 off, 1 the finest level's launches, 2 every level's (tdk_dvo_set_profiling)
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used;
     std::vector<int> ev_round;   // per event: [2 i] pairs evaluated in full, [2 i + 1] pairs probed by launch i
-    double prof_ms[3];           // buckets: full / probe / mixed launches (collect_profile)
-    int64_t prof_launches[3], prof_pixels[3];
+    double prof_ms[kMaxLevels][3];   // per level; buckets: full / probe / mixed launches (collect_profile)
+    int64_t prof_launches[kMaxLevels][3], prof_pixels[kMaxLevels][3];
+    std::vector<int> ev_level;   // level of each event pair
     std::vector<double> cams;   // cameras currently on the device: [cam0 (n x 4) | cam1 (n x 4)]
     hipStream_t copy_stream;    // tdk_dvo_upload_async: the library-wide copy stream (not owned)
     uint8_t *d_u8;              // staging for 8-bit frames (tdk_dvo_upload_async_u8), [n_pairs][N]
@@ -2410,13 +2411,15 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
     LevelPtrs P = ptrs_of(L);
     const size_t lds = sizeof(double) * (kWaves * kAccPad + (size_t)L.W + (size_t)L.H);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (h->profiling && level == 0) {
+    if (h->profiling && (level == 0 || h->profiling == 2)) {
         while (h->ev_pool.size() < h->ev_used + 2) {
             hipEvent_t e;
             TDK_HIP(hipEventCreate(&e));
             h->ev_pool.push_back(e);
             h->ev_round.push_back(0);
+            h->ev_level.push_back(0);
         }
+        h->ev_level[h->ev_used] = level;
         // until the device loop says otherwise: every pair, in full (tdk_dvo_evaluate)
         h->ev_round[h->ev_used] = h->n_pairs;
         h->ev_round[h->ev_used + 1] = 0;
@@ -2494,9 +2497,10 @@ tdk_status collect_profile(tdk_dvo *h) {
         TDK_HIP(hipEventElapsedTime(&ms, h->ev_pool[i], h->ev_pool[i + 1]));
         const int n_full = h->ev_round[i], n_probe = h->ev_round[i + 1];
         const int b = n_probe == 0 ? 0 : (n_full == 0 ? 1 : 2);
-        h->prof_ms[b] += ms;
-        h->prof_launches[b] += 1;
-        h->prof_pixels[b] += h->lv[0].N * (int64_t)(n_full + n_probe);
+        const int l = h->ev_level[i];
+        h->prof_ms[l][b] += ms;
+        h->prof_launches[l][b] += 1;
+        h->prof_pixels[l][b] += h->lv[l].N * (int64_t)(n_full + n_probe);
     }
     h->ev_used = 0;
     return TDK_OK;
@@ -2543,7 +2547,7 @@ static tdk_status queue_round(tdk_dvo *h, LevelRun &r, int weight_mode, int max_
 // the batch's stream has been waited for; true: another round is needed
 static bool after_round(tdk_dvo *h, LevelRun &r) {
     r.probe_only = ((volatile int *)h->h_flag)[8] == 0 && ((volatile int *)h->h_flag)[9] > 0;
-    if (h->profiling && r.level == 0 && h->ev_used >= 2) {   // what the launch just timed evaluated
+    if (h->profiling && (r.level == 0 || h->profiling == 2) && h->ev_used >= 2) {   // what the launch just timed evaluated
         h->ev_round[h->ev_used - 2] = ((volatile int *)h->h_flag)[4];
         h->ev_round[h->ev_used - 1] = ((volatile int *)h->h_flag)[5];
     }
@@ -2633,8 +2637,9 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
     h->max_blocks = 1024;
     h->d_rm = nullptr; h->d_wscale = nullptr; h->d_stat = nullptr; h->d_spartial = nullptr; h->d_st_pts = nullptr; h->d_st_redo = nullptr;
     h->d_count = nullptr; h->d_select = nullptr; h->d_hist = nullptr;
-    h->profiling = false; h->ev_used = 0;
-    for (int b = 0; b < 3; b++) { h->prof_ms[b] = 0; h->prof_launches[b] = 0; h->prof_pixels[b] = 0; }
+    h->profiling = 0; h->ev_used = 0;
+    memset(h->prof_ms, 0, sizeof(h->prof_ms)); memset(h->prof_launches, 0, sizeof(h->prof_launches));
+    memset(h->prof_pixels, 0, sizeof(h->prof_pixels));
     for (int l = 0; l < n_levels; l++) {
         tdk_dvo::Level &L = h->lv[l];
         L.scale = 1.0 / pow(ratio, (double)l);  // level_to_scale, vo/dvo/__init__.py:42-43
@@ -3017,7 +3022,7 @@ tdk_status tdk_dvo_photometric_error(tdk_dvo *h, int level, const double *camera
     TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * n, hipMemcpyHostToDevice, h->stream));
     // the error does not depend on the weights (metric.py:13-39): the unweighted kernel
     TDK_TRY(launch_eval(h, level, h->d_poses_in, nullptr, h->d_mode_probe, nullptr, TDK_W_NONE, true));
-    if (h->profiling && level == 0 && h->ev_used >= 2) {   // what the launch just timed evaluated: probes
+    if (h->profiling && (level == 0 || h->profiling == 2) && h->ev_used >= 2) {   // what the launch just timed evaluated: probes
         h->ev_round[h->ev_used - 2] = 0;
         h->ev_round[h->ev_used - 1] = n;
     }
@@ -3158,25 +3163,36 @@ tdk_status tdk_dvo_get_stream(tdk_dvo *h, void **stream_out) {
 
 tdk_status tdk_dvo_set_profiling(tdk_dvo *h, int enabled) {
     TDK_REQUIRE(h != nullptr, "handle is NULL");
-    h->profiling = enabled != 0;
+    h->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
     h->ev_used = 0;
-    for (int b = 0; b < 3; b++) { h->prof_ms[b] = 0; h->prof_launches[b] = 0; h->prof_pixels[b] = 0; }
+    memset(h->prof_ms, 0, sizeof(h->prof_ms)); memset(h->prof_launches, 0, sizeof(h->prof_launches));
+    memset(h->prof_pixels, 0, sizeof(h->prof_pixels));
     return TDK_OK;
 }
 
 tdk_status tdk_dvo_get_profile(tdk_dvo *h, int64_t *launches, double *total_ms, int64_t *pixels) {
     TDK_REQUIRE(h != nullptr, "handle is NULL");
-    if (launches) *launches = h->prof_launches[0];
-    if (total_ms) *total_ms = h->prof_ms[0];
-    if (pixels) *pixels = h->prof_pixels[0];
+    if (launches) *launches = h->prof_launches[0][0];
+    if (total_ms) *total_ms = h->prof_ms[0][0];
+    if (pixels) *pixels = h->prof_pixels[0][0];
     return TDK_OK;
 }
 
 tdk_status tdk_dvo_get_profile_kind(tdk_dvo *h, int kind, int64_t *launches, double *total_ms, int64_t *pixels) {
     TDK_REQUIRE(h != nullptr && kind >= 0 && kind <= 2, "bad argument");
-    if (launches) *launches = h->prof_launches[kind];
-    if (total_ms) *total_ms = h->prof_ms[kind];
-    if (pixels) *pixels = h->prof_pixels[kind];
+    if (launches) *launches = h->prof_launches[0][kind];
+    if (total_ms) *total_ms = h->prof_ms[0][kind];
+    if (pixels) *pixels = h->prof_pixels[0][kind];
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_get_profile_level(tdk_dvo *h, int level, int kind, int64_t *launches, double *total_ms,
+                                     int64_t *pixels) {
+    TDK_REQUIRE(h != nullptr && kind >= 0 && kind <= 2, "bad argument");
+    TDK_TRY(check_level(h, level));
+    if (launches) *launches = h->prof_launches[level][kind];
+    if (total_ms) *total_ms = h->prof_ms[level][kind];
+    if (pixels) *pixels = h->prof_pixels[level][kind];
     return TDK_OK;
 }
 

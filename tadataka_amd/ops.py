@@ -309,14 +309,15 @@ class DvoBatch(object):
         call("tdk_dvo_get_student_redos", self._h, C.byref(v))
         return int(v.value)
 
-    def set_profiling(self, enabled):
-        call("tdk_dvo_set_profiling", self._h, int(bool(enabled)))
+    def set_profiling(self, enabled, all_levels=False):
+        """HIP events around the evaluation launches of the finest level (all_levels: of every level)."""
+        call("tdk_dvo_set_profiling", self._h, 2 if (enabled and all_levels) else int(bool(enabled)))
 
-    def get_profile(self, kind="full"):
-        """Full-resolution evaluation launches since set_profiling(True): kind 'full' (only full
+    def get_profile(self, kind="full", level=0):
+        """Evaluation launches of a level since set_profiling(True): kind 'full' (only full
         evaluations), 'probe' (only error-only probes of candidates), 'mixed'."""
         n = C.c_int64(); ms = C.c_double(); px = C.c_int64()
-        call("tdk_dvo_get_profile_kind", self._h, {"full": 0, "probe": 1, "mixed": 2}[kind], C.byref(n),
+        call("tdk_dvo_get_profile_level", self._h, int(level), {"full": 0, "probe": 1, "mixed": 2}[kind], C.byref(n),
              C.byref(ms), C.byref(px))
         return dict(launches=int(n.value), total_ms=float(ms.value), pixels=int(px.value))
 
