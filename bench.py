@@ -81,10 +81,25 @@ def parse_args():
     ap.add_argument("--min-seconds", type=float, default=10.0,
                     help="repeat the timed block of --steps steps until this much timed work has run (default 10 s: a "
                          "GPU-busy sampler with a 5 s period cannot miss it; the headline is the LAST thing the run does)")
+    ap.add_argument("--config", choices=["cfg2", "cfg4"], default="cfg2",
+                    help="cfg2 (default, the headline): BASELINE configs[1], 640x480, 3 levels, max_iter 20.  cfg4: one "
+                         "GPU's shard of BASELINE configs[3] -- 64 pairs of 1280x720 per GPU, 1 level, 2 iterations -- "
+                         "so that a multi-GPU run can be quoted on the workload BASELINE names for it")
+    ap.add_argument("--dry-ranks", type=int, default=0,
+                    help="N worker processes that SHARE the visible GPU(s) and exchange through files instead of RCCL: "
+                         "the multi-rank bookkeeping of this script (sharded seeds, two batches in flight, the gather "
+                         "of step k collected after step k + 1, MAX / SUM reductions) runs end to end on a one-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-workloads", action="store_true", help="headline only")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.config == "cfg4":           # explicit --pairs / --height / ... still win (reduced smoke runs)
+        given = set(a.split("=")[0] for a in sys.argv[1:] if a.startswith("--"))
+        for flag, name, value in (("--pairs", "pairs", 64), ("--height", "height", 720), ("--width", "width", 1280),
+                                  ("--levels", "levels", 1), ("--max-iter", "max_iter", 2)):
+            if flag not in given:
+                setattr(args, name, value)
+    return args
 
 
 def true_poses(n, seed0):
@@ -625,7 +640,7 @@ def workload_ba(args):
 
 
 # ---------------------------------------------------------------------------
-def spawn_ranks(n):
+def spawn_ranks(n, dry=False):
     """`python bench.py --gpus N` by itself: one worker process per GPU with the
     environment torch.distributed.run would export; rank 0's JSON line is relayed."""
     import socket
@@ -636,6 +651,8 @@ def spawn_ranks(n):
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if dry:
+            env["TDK_BENCH_DRY"] = "1"
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
     out, _ = procs[0].communicate()
@@ -648,20 +665,42 @@ def spawn_ranks(n):
 
 def main():
     args = parse_args()
+    if args.dry_ranks > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.dry_ranks, dry=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("NCCL_DEBUG", "WARN")     # RCCL says on stderr why an init failed
 
     from tadataka_amd import _lib, ops, sharding, synthetic
     _lib.require_gpu()
     # one GPU per rank; on a box with fewer GPUs than ranks (only ever a smoke test) ranks share devices
-    _lib.call("tdk_set_device", local_rank % _lib.device_count())
+    _lib.call("tdk_set_device", local_rank % _lib.device_count())       # (= `device` below)
     # RCCL through the C ABI when WORLD_SIZE > 1.  Only where ranks have to SHARE a GPU (fewer GPUs than
     # ranks: the one-GPU smoke test of the multi-process path, RCCL refuses duplicate devices) may the few
     # bytes of poses and scalars go through files instead -- the JSON line says so ("exchange").  With a GPU
     # per rank a transport failure is an error: a scaling run must not "pass" without RCCL.
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
-    comm, comm_error = sharding.connect_or_fallback(allow_file_fallback=_lib.device_count() < local_world)
+    device = local_rank % _lib.device_count()
+    if os.environ.get("TDK_BENCH_DRY") == "1":
+        comm = sharding.FileComm(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
+        comm_error = "dry run (--dry-ranks): the ranks share the GPU, RCCL was not attempted"
+    else:
+        try:
+            comm, comm_error = sharding.connect_or_fallback(allow_file_fallback=_lib.device_count() < local_world)
+        except sharding.TransportUnavailable as e:
+            # a scaling run must not pass without RCCL: say where this rank stood, and fail
+            sys.stderr.write(
+                "bench.py rank %s (local rank %d): RCCL could not be brought up: %s\n"
+                "  device bound: %d of %d visible (%s); HIP_VISIBLE_DEVICES=%s ROCR_VISIBLE_DEVICES=%s "
+                "CUDA_VISIBLE_DEVICES=%s HSA_ENABLE_IPC_MODE_LEGACY=%s NCCL_DEBUG=%s\n"
+                "  (RCCL's own warnings are above this line on stderr)\n"
+                % (os.environ.get("RANK", "0"), local_rank, e, device, _lib.device_count(), _lib.device_name(),
+                   os.environ.get("HIP_VISIBLE_DEVICES"), os.environ.get("ROCR_VISIBLE_DEVICES"),
+                   os.environ.get("CUDA_VISIBLE_DEVICES"), os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                   os.environ.get("NCCL_DEBUG")))
+            sys.stderr.flush()
+            raise SystemExit(3)
     if comm_error:
         sys.stderr.write("bench.py: RCCL unavailable (%s); exchanging poses through files\n" % comm_error)
     world, rank = comm.world, comm.rank
@@ -793,7 +832,7 @@ def main():
     # pyramid kernel; these numbers are what each kernel takes by itself.
     by_level, pyramid_alone = {}, None
     if rank == 0:
-        fence()
+        _lib.call("tdk_sync")                       # (no collective here: only rank 0 takes this pass)
         solo = batches[0]
         solo.set_profiling(True, all_levels=True)
         for _ in range(3):
@@ -879,7 +918,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "DVO pose estimation (PoseChangeEstimator), batch of independent "
+            "config": {"name": args.config + (" (BASELINE configs[3]: one GPU's shard of the 512 x 1280x720 batch)"
+                                              if args.config == "cfg4" else " (BASELINE configs[1])"),
+                       "workload": "DVO pose estimation (PoseChangeEstimator), batch of independent "
                                    f"{W}x{H} frame pairs, {args.levels}-level pyramid ratio 1.5, "
                                    f"weights={args.weights}, max_iter={args.max_iter}",
                        "pairs_per_gpu": B, "batches_in_flight": n_batches,
@@ -894,7 +935,7 @@ def main():
             "max_translation_error": t_err,
             "rccl_ranks": world if (world > 1 and comm.kind == "rccl") else 0,
             "exchange": {"rccl": "ncclAllGather of the device-resident poses (tdk_comm, C ABI)",
-                         "file": "files in TMPDIR -- RCCL could not be initialised: %s" % comm_error,
+                         "file": "files in TMPDIR -- %s" % comm_error,
                          "local": "none (one process)"}[comm.kind],
             "roofline": rl,
         }

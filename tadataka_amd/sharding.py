@@ -155,6 +155,13 @@ def rendezvous_dir():
     """Private directory (0700) of this launch under TMPDIR."""
     d = os.path.join(os.environ.get("TMPDIR", "/tmp"), "tdk_rdv_%s" % launch_key())
     os.makedirs(d, mode=0o700, exist_ok=True)
+    # TMPDIR is world-writable and the name is predictable: somebody else's directory (or a symlink to
+    # one) under that name must not carry this launch's unique id
+    import stat
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.geteuid() or (st.st_mode & 0o077):
+        raise TransportUnavailable("rendezvous directory %s is not a private directory of this user "
+                                   "(owner %d, mode %o)" % (d, st.st_uid, st.st_mode & 0o7777))
     return d
 
 
@@ -181,7 +188,7 @@ def _collect(directory, names, timeout, what):
             except OSError:
                 pass
             if time.time() - t0 > timeout:
-                raise RuntimeError("%s: %s did not appear in %s within %.0f s" % (what, name, directory, timeout))
+                raise TransportUnavailable("%s: %s did not appear in %s within %.0f s" % (what, name, directory, timeout))
             time.sleep(0.005)
     return out
 
@@ -244,8 +251,8 @@ class FileComm(object):
         for r in range(self.world):
             path = os.path.join(self._dir, "%d_%d.npy" % (self._seq, r))
             while not os.path.exists(path):
-                if time.time() - t0 > 600.0:
-                    raise RuntimeError("file exchange: rank %d never arrived" % r)
+                if time.time() - t0 > float(os.environ.get("TDK_FILECOMM_TIMEOUT", "600")):
+                    raise RuntimeError("file exchange %d: rank %d never arrived" % (self._seq, r))
                 time.sleep(0.0005)
             parts.append(np.load(path))
         if self._seq > 2:                           # everybody has passed exchange seq - 2 by now
@@ -338,7 +345,7 @@ def _retire_after(directory, phases, rank, world, timeout):
     """On the failure paths there is no communicator to put a barrier behind the last read: one more file round does it."""
     try:
         _agree(directory, "bye", rank, world, None, b"", min(timeout, 60.0))
-    except RuntimeError:
+    except RuntimeError:                            # (TransportUnavailable is one)
         pass
     time.sleep(0.05)
     _retire(directory, tuple(phases) + ("bye",), rank, world)

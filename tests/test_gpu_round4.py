@@ -296,3 +296,76 @@ def test_streaming_pyramid_is_bit_identical(ops, orc, monkeypatch, shape, levels
         if l < levels:
             want = orc.rescale(pairs[i][n], 1 / 1.5 ** l, anti_aliasing=True)
             assert np.array_equal(got["2"][(l, i, n)], want), (l, i, n)
+
+
+# ---------------------------------------------------------------------------
+# multi-GPU path, as far as one GPU goes
+# ---------------------------------------------------------------------------
+def test_pose_gather_alternating_batches_with_host_collectives(ops):
+    """The ordering code of csrc/comm.hip that a real multi-GPU bench run takes, with a 1-rank RCCL
+    communicator: device-resident pose gathers queued on the streams of TWO batches in turn (bench.py
+    keeps two in flight), the gather of step k collected after step k + 1's estimation, and host-buffer
+    collectives (the bench's MAX / SUM reductions and its barrier) on the communicator's own stream in
+    between -- every gather must return the poses of the batch it was started on."""
+    from tadataka_amd import sharding, synthetic
+    comm = sharding.RcclComm(0, 1, sharding.RcclComm.unique_id())
+    B, H, W = 4, 60, 80
+    cam = synthetic.camera_for(W, H)
+    ident = np.tile(ops.pose12(np.eye(3), np.zeros(3)), (B, 1))
+    batches = []
+    for k in range(2):
+        bt = ops.DvoBatch(B, H, W, n_levels=2, ratio=1.5)
+        for i in range(B):
+            p = synthetic.make_pair(H, W, seed=200 + 10 * k + i)
+            bt.upload(i, p["I0"], p["D0"], p["I1"])
+        bt.build_pyramid()
+        batches.append(bt)
+    gather = sharding.PoseGather(B, comm)
+    gather.comm = comm                     # world 1 would take the local shortcut: force the RCCL path
+    expected, collected = [], []
+    for step in range(6):
+        bt = batches[step % 2]
+        poses, _ = bt.estimate(cam, cam, ident, ops.W_HUBER, 20)
+        if gather.pending:
+            collected.append(gather.finish())
+        assert np.array_equal(comm.all_reduce([float(step), 2.0], "max"), [float(step), 2.0])
+        gather.start(poses, bt)
+        expected.append(poses.copy())
+        comm.barrier()                     # a host-buffer collective while the gather is in flight
+        assert np.array_equal(comm.all_reduce([1.0], "sum"), [1.0])
+    collected.append(gather.finish())
+    assert len(collected) == len(expected) == 6
+    for got, want in zip(collected, expected):
+        assert got.shape == (B, 12) and np.array_equal(got, want)
+    assert not np.array_equal(expected[0], expected[1])          # the two batches hold different pairs
+    with pytest.raises(Exception):
+        comm.gather_poses_finish()                               # nothing in flight
+    for bt in batches:
+        bt.close()
+    comm.close()
+
+
+def test_bench_dry_ranks_runs_the_multi_rank_bookkeeping():
+    """bench.py --dry-ranks 3: three worker processes share the GPU and exchange through files; the
+    script's own step() / timed_block() / PoseGather run with world 3 (sharded seeds, two batches in
+    flight, gathered poses checked against the truth of every rank inside bench.py).  Also the
+    cfg4 workload definition (1280x720, 1 level, 2 iterations) at a reduced pair count."""
+    import json
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TDK_RENDEZVOUS_KEY="pytest_dry_%d" % os.getpid(), TDK_FILECOMM_TIMEOUT="60")
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--dry-ranks", "3", "--pairs", "6", "--steps", "3",
+                        "--warmup", "1", "--min-seconds", "0", "--no-cpu-baseline", "--no-workloads", "--height", "120",
+                        "--width", "160"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, timeout=180)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 3 and out["rccl_ranks"] == 0 and "dry run" in out["exchange"]
+    assert out["config"]["pairs_per_gpu"] == 6 and out["max_translation_error"] < 5e-3
+    assert abs(out["frame_pairs_per_s"] - 3 * 6 * out["steps"] * out["timed_blocks"] / out["timed_seconds"]) < 1e-6
+    p = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--config", "cfg4", "--pairs", "4", "--steps", "2",
+                        "--warmup", "1", "--min-seconds", "0", "--no-cpu-baseline", "--no-workloads"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["config"]["height"] == 720 and out["config"]["levels"] == 1 and out["config"]["max_iter"] == 2
+    assert out["config"]["name"].startswith("cfg4")
