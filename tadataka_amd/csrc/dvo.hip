@@ -776,6 +776,85 @@ __global__ void k_publish(LoopState ls, double *__restrict__ poses_out, int *__r
 }
 
 // ---------------------------------------------------------------------------
+// The speculative level chain of small batches (one pair: the drop-in PoseChangeEstimator call).
+//
+// A single pair's estimation is a chain of 10 - 30 us kernels; waiting on the host between the rounds
+// of a level and between levels cost four ~19 us round trips of a 265 us call.  Here the host queues
+// the whole coarse-to-fine chain at once -- per level the evaluations a level typically takes (3 on
+// the coarsest, 2 on the others), then a transition kernel -- and waits once.  What keeps a kernel
+// from running out of turn is the state array it is given: every level has its OWN state array,
+// RUNNING only while that level is being estimated, so k_dvo_eval / k_dvo_reduce launches of a level
+// whose turn has not come (the level above needed more rounds than were queued) return at once, as
+// they already do for pairs that have finished.  k_level_next moves on -- re-arming the loop state as
+// k_loop_init does and opening the next level's state array -- only if the level it closes is the
+// current one (gate) and has no pair left running; otherwise it leaves everything as it is, the host
+// reads the gate and queues more rounds for that level.  Evaluation kernels are untouched.
+// ---------------------------------------------------------------------------
+constexpr int kFlagGate = 12;          // host_flag[12]: the level being estimated, -1 when the call is complete
+constexpr int kFlagLevelEvals = 16;    // host_flag[16 + 4 l ...]: evaluations / updates (64 bit each) of level l
+
+__global__ void k_chain_init(LoopState ls, int *state_all, int *gate, int n, int n_levels, const double *poses_in) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        for (int k = 0; k < 12; k++) {
+            const double v = poses_in[12 * i + k];
+            ls.pose[12 * i + k] = v;
+            ls.cand[12 * i + k] = v;
+        }
+        ls.prev_err[i] = 0.0;
+        for (int l = 0; l < n_levels; l++) state_all[l * n + i] = l == n_levels - 1 ? ST_RUNNING : ST_DONE;
+        ls.stat_state[i] = ST_RUNNING;
+        ls.mode[i] = MODE_FULL0;
+        ls.tested[i] = 0;
+        ls.n_evals[i] = 0;
+        ls.warn[i] = 0;
+    }
+    if (threadIdx.x == 0) {
+        *ls.active = n;
+        *ls.ticket = 0;
+        ls.evals[0] = 0ull; ls.evals[1] = 0ull;
+        ls.round[0] = 0; ls.round[1] = 0;
+        ls.next[0] = 0; ls.next[1] = 0;
+        *gate = n_levels - 1;
+        ls.host_flag[kFlagGate] = n_levels - 1;
+    }
+}
+
+// closes level `from` (if it is the current one and nothing runs there any more) and opens from - 1;
+// after level 0 the poses and warnings go where the host reads them
+__global__ void k_level_next(LoopState ls, int *state_all, int *gate, int n, int from, double *__restrict__ poses_out,
+                             int *__restrict__ warn_out) {
+    __shared__ int go;
+    if (threadIdx.x == 0) go = (*gate == from && atomicAdd(ls.active, 0) == 0) ? 1 : 0;
+    __syncthreads();
+    if (!go) return;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        if (from > 0) {
+            for (int k = 0; k < 12; k++) ls.cand[12 * i + k] = ls.pose[12 * i + k];
+            ls.prev_err[i] = 0.0;
+            state_all[(from - 1) * n + i] = ST_RUNNING;
+            ls.stat_state[i] = ST_RUNNING;
+            ls.mode[i] = MODE_FULL0;
+            ls.tested[i] = 0;
+            ls.n_evals[i] = 0;
+        } else {
+            for (int k = 0; k < 12; k++) poses_out[12 * i + k] = ls.pose[12 * i + k];
+            warn_out[i] = ls.warn[i];
+        }
+    }
+    if (threadIdx.x == 0) {
+        *reinterpret_cast<volatile unsigned long long *>(ls.host_flag + kFlagLevelEvals + 4 * from) = ls.evals[0];
+        *reinterpret_cast<volatile unsigned long long *>(ls.host_flag + kFlagLevelEvals + 4 * from + 2) = ls.evals[1];
+        ls.evals[0] = 0ull; ls.evals[1] = 0ull;
+        ls.round[0] = 0; ls.round[1] = 0;
+        ls.next[0] = 0; ls.next[1] = 0;
+        if (from > 0) *ls.active = n;
+        *gate = from - 1;
+        ls.host_flag[kFlagGate] = from - 1;
+        __threadfence_system();
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Robust scale statistics per pair (Student-t, Tukey)
 // ---------------------------------------------------------------------------
 // 1 / a to the last bit or so: v_rcp_f64 and two Newton steps instead of the IEEE division sequence
@@ -2137,6 +2216,7 @@ struct tdk_dvo {
     tdk::PyramidSepPlan *sep_plan;   // tap lists of the separable pyramid kernel (created at the first build)
     double *d_aa_weights;       // its 1-D kernels, per level and axis (allocated on first use)
     int *h_flag;   // "pairs still running", written by k_dvo_reduce (mapped pinned host memory)
+    int *d_chain_state, *d_gate;   // the speculative level chain: [n_levels][n_pairs] state arrays, the current level
     // Prior poses in, final poses and warnings out of tdk_dvo_estimate*: mapped pinned host memory that the first /
     // last kernel of a call reads / writes directly.  As hipMemcpyAsync these few kilobytes queued behind whatever
     // bulk upload was in flight on the copy engine -- 1.4 ms per 78 MB of frames -- and with them the estimation.
@@ -2460,11 +2540,11 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
     return TDK_OK;
 }
 
-tdk_status launch_reduce(tdk_dvo *h, int level, int loop_mode, int max_iter) {
+tdk_status launch_reduce(tdk_dvo *h, int level, int loop_mode, int max_iter, const LoopState *ls = nullptr) {
     int nblk;
     int64_t chunk;
     plan_blocks(h, h->lv[level], &nblk, &chunk);
-    k_dvo_reduce<<<h->n_pairs, kBlock, 0, h->stream>>>(h->d_partials, nblk, h->d_results, h->ls,
+    k_dvo_reduce<<<h->n_pairs, kBlock, 0, h->stream>>>(h->d_partials, nblk, h->d_results, ls ? *ls : h->ls,
                                                            loop_mode, max_iter);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
@@ -2574,6 +2654,61 @@ tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64
     return TDK_OK;
 }
 
+// The whole coarse-to-fine estimation of a small batch with one host wait in the typical case (see
+// k_chain_init / k_level_next).  Weight modes without robust statistics only (their extra kernels per
+// full evaluation are decided on the host).
+static bool chain_applies(const tdk_dvo *h, int weight_mode) {
+    static const int enabled = [] { const char *v = getenv("TDK_DVO_CHAIN"); return v ? atoi(v) : 1; }();
+    return enabled && !h->profiling && (int64_t)h->n_pairs * h->lv[0].N <= (1ll << 22) &&
+           weight_mode != TDK_W_STUDENT_T && weight_mode != TDK_W_TUKEY;
+}
+
+static tdk_status chain_estimate(tdk_dvo *h, int weight_mode, int max_iter, double *poses12, int64_t *pixel_evals) {
+    const int n = h->n_pairs, L = h->n_levels;
+    volatile int *flag = (volatile int *)h->h_flag;
+    LoopState top = h->ls;
+    top.state = h->d_chain_state + (size_t)(L - 1) * n;
+    k_chain_init<<<1, 256, 0, h->stream>>>(top, h->d_chain_state, h->d_gate, n, L, h->d_io);
+    TDK_LAUNCH_CHECK();
+    int level = L - 1;
+    bool fresh = true;
+    // every host round makes progress (at least one more evaluation of the unfinished level), and a level takes
+    // at most 2 max_iter + 1 evaluations
+    for (int guard = 0; guard < (2 * max_iter + 2) * L + 2; guard++) {
+        for (int l = level; l >= 0; l--) {
+            LoopState ls = h->ls;
+            ls.state = h->d_chain_state + (size_t)l * n;
+            ls.fuse_first = l == L - 1;
+            const int burst = (l == L - 1 && (fresh || l != level)) ? 3 : 2;
+            for (int b = 0; b < burst; b++) {
+                TDK_TRY(launch_eval(h, l, h->ls.cand, ls.state, h->ls.mode, nullptr, weight_mode));
+                TDK_TRY(launch_reduce(h, l, 1, max_iter, &ls));
+            }
+            k_level_next<<<1, 256, 0, h->stream>>>(ls, h->d_chain_state, h->d_gate, n, l, h->d_io + 12 * (size_t)n,
+                                                  (int *)(h->d_io + 24 * (size_t)n));
+            TDK_LAUNCH_CHECK();
+        }
+        TDK_HIP(hipStreamSynchronize(h->stream));
+        const int g = flag[kFlagGate];
+        if (g < 0) {
+            for (int l = 0; l < L; l++) {
+                const int64_t evals = (int64_t)*(volatile unsigned long long *)(h->h_flag + kFlagLevelEvals + 4 * l);
+                const int64_t updates = (int64_t)*(volatile unsigned long long *)(h->h_flag + kFlagLevelEvals + 4 * l + 2);
+                if (pixel_evals) *pixel_evals += h->lv[l].N * evals;
+                h->count_error_px += h->lv[l].N * evals;
+                h->count_update_px += h->lv[l].N * updates;
+            }
+            memcpy(poses12, h->h_io + 12 * (size_t)n, sizeof(double) * 12 * n);
+            memcpy(h->host_warn.data(), h->h_io + 24 * (size_t)n, sizeof(int) * n);
+            return TDK_OK;
+        }
+        level = g;
+        fresh = false;
+    }
+    tdk::set_error("level chain did not terminate");
+    return TDK_ERR_HIP;
+}
+
 }  // namespace
 
 namespace tdk {
@@ -2681,7 +2816,9 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
     h->host_warn.assign((size_t)n_pairs, 0);
     TDK_HIP(hipHostMalloc((void **)&h->h_io, sizeof(double) * 24 * (size_t)n_pairs + sizeof(int) * (size_t)n_pairs, hipHostMallocMapped));
     TDK_HIP(hipHostGetDevicePointer((void **)&h->d_io, h->h_io, 0));
-    TDK_HIP(hipHostMalloc(&h->h_flag, 16 * sizeof(int), hipHostMallocMapped));
+    TDK_HIP(hipHostMalloc(&h->h_flag, (16 + 4 * kMaxLevels) * sizeof(int), hipHostMallocMapped));
+    TDK_HIP(hipMalloc(&h->d_chain_state, sizeof(int) * (size_t)n_pairs * n_levels));
+    TDK_HIP(hipMalloc(&h->d_gate, sizeof(int)));
     TDK_HIP(hipHostGetDevicePointer((void **)&h->ls.host_flag, h->h_flag, 0));
     return TDK_OK;
 }
@@ -2705,6 +2842,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     (void)hipFree(h->d_tk); (void)hipFree(h->d_tk_med); (void)hipFree(h->d_tk_dev); (void)hipFree(h->d_tk_sample); (void)hipFree(h->d_tk_fallback); (void)hipFree(h->d_tk_src);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->h_flag) (void)hipHostFree(h->h_flag);
+    (void)hipFree(h->d_chain_state); (void)hipFree(h->d_gate);
     if (h->h_io) (void)hipHostFree(h->h_io);
     if (h->d_aa_weights) (void)hipFree(h->d_aa_weights);
     (void)tdk::pyramid_sep_destroy(h->sep_plan);
@@ -3084,6 +3222,7 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
     memcpy(h->h_io, poses12, sizeof(double) * 12 * n);     // read by k_loop_init over the bus (see tdk_dvo::h_io)
     if (pixel_evals) *pixel_evals = 0;
     h->count_error_px = h->count_update_px = 0;
+    if (chain_applies(h, weight_mode)) return chain_estimate(h, weight_mode, max_iter, poses12, pixel_evals);
     TDK_HIP(hipMemsetAsync(h->ls.warn, 0, sizeof(int) * n, h->stream));
     for (int level = h->n_levels - 1; level >= 0; level--) {
         // the prior of a level is the result of the coarser one (:131-134), already in ls.pose
