@@ -557,9 +557,12 @@ __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairPara
     // 1-D grid.  Workgroups are dealt to the 8 XCDs round-robin, each XCD has its own L2: XCD k
     // takes pairs k, k + 8, ... one after the other, the blocks of a pair (whose tap halos and
     // stream lines overlap) consecutively -- so they meet in one L2, close in time.
+    // (n_pairs < 0: fewer than 8 pairs -- XCD-major order would leave 8 - n XCDs idle; the blocks of a pair
+    // are dealt to all XCDs instead, pair = blockIdx / nblk)
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int pair = (q / nblk) * 8 + xcd, blk = q - (q / nblk) * nblk;
-    if (pair >= n_pairs) return;
+    const int pair = n_pairs < 0 ? (int)blockIdx.x / nblk : (q / nblk) * 8 + xcd;
+    const int blk = n_pairs < 0 ? (int)blockIdx.x - pair * nblk : q - (q / nblk) * nblk;
+    if (pair >= (n_pairs < 0 ? -n_pairs : n_pairs)) return;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
     // block-uniform: a candidate pose is first PROBED -- error only, 50 of the 118 FP64 operations
     // and 4 of the 12 texels per pixel -- and evaluated in full only once it has been accepted
@@ -578,8 +581,9 @@ __global__ __launch_bounds__(kBlock) void k_dvo_probe(LevelPtrs L, const PairPar
                                                       const int *__restrict__ state, double scale, int64_t chunk,
                                                       int n_pairs, int nblk, double *__restrict__ partials) {
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int pair = (q / nblk) * 8 + xcd, blk = q - (q / nblk) * nblk;
-    if (pair >= n_pairs) return;
+    const int pair = n_pairs < 0 ? (int)blockIdx.x / nblk : (q / nblk) * 8 + xcd;
+    const int blk = n_pairs < 0 ? (int)blockIdx.x - pair * nblk : q - (q / nblk) * nblk;
+    if (pair >= (n_pairs < 0 ? -n_pairs : n_pairs)) return;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
     eval_body<TDK_W_NONE, true>(L, params, poses, nullptr, scale, chunk, pair, blk, nblk, partials);
 }
@@ -2487,7 +2491,10 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
     int nblk;
     int64_t chunk;
     plan_blocks(h, L, &nblk, &chunk);
-    dim3 grid(8u * (unsigned)((h->n_pairs + 7) / 8) * (unsigned)nblk);   // see k_dvo_eval: XCD-major order
+    // see k_dvo_eval: XCD-major order for batches, a pair's blocks over all XCDs for fewer than 8 pairs
+    const bool spread = h->n_pairs < 8;
+    const int n_pairs_arg = spread ? -h->n_pairs : h->n_pairs;
+    dim3 grid(spread ? (unsigned)h->n_pairs * (unsigned)nblk : 8u * (unsigned)((h->n_pairs + 7) / 8) * (unsigned)nblk);
     LevelPtrs P = ptrs_of(L);
     const size_t lds = sizeof(double) * (kWaves * kAccPad + (size_t)L.W + (size_t)L.H);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -2517,11 +2524,11 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
         TDK_HIP(hipFuncSetAttribute((const void *)k_dvo_eval<WM>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds));                                                         \
     k_dvo_eval<WM><<<grid, kBlock, lds, h->stream>>>(P, h->d_params, d_poses, d_state, d_mode, h->d_wscale, \
-                                                         L.scale, chunk, h->n_pairs, nblk, h->d_partials)
+                                                         L.scale, chunk, n_pairs_arg, nblk, h->d_partials)
     if (probe_only) {
         if (lds > 64 * 1024)
             TDK_HIP(hipFuncSetAttribute((const void *)k_dvo_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        k_dvo_probe<<<grid, kBlock, lds, h->stream>>>(P, h->d_params, d_poses, d_state, L.scale, chunk, h->n_pairs, nblk,
+        k_dvo_probe<<<grid, kBlock, lds, h->stream>>>(P, h->d_params, d_poses, d_state, L.scale, chunk, n_pairs_arg, nblk,
                                                       h->d_partials);
     } else
     switch (weight_mode) {
