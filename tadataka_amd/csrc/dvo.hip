@@ -640,21 +640,26 @@ struct LoopState {   // device arrays, one entry per pair
 
 // Fixed-order reduction of the per-block partials of one pair; in loop mode the
 // bookkeeping of _PoseChangeEstimator.__call__ (:92-111) follows.
+// NG groups of 32 lanes: group g adds the partials g, g + NG, ... of each accumulator, then the groups are added
+// in order.  8 groups for batches (a pair has ~32 partials there); 32 groups (1024 threads) for the few pairs
+// of a drop-in call, whose 60 - 300 partials per pair come from every XCD: ten dependent rounds of loads
+// instead of forty.
+template <int NG>
 __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials, int nblk,
                                             double *__restrict__ results, LoopState ls, int loop_mode, int max_iter) {
     const int pair = blockIdx.x;
-    __shared__ double red[kBlock / 32][kAccPad];
+    __shared__ double red[NG][kAccPad];
     __shared__ double solve_ws[108];   // workspace of the rank-deficient 6x6 solve (lane 0)
     const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
     double s = 0.0;
     if (k < kAcc)
-        for (int b = g; b < nblk; b += kBlock / 32) s += partials[((int64_t)pair * nblk + b) * kAccPad + k];
+        for (int b = g; b < nblk; b += NG) s += partials[((int64_t)pair * nblk + b) * kAccPad + k];
     red[g][k] = s;
     __syncthreads();
     if (threadIdx.x < kAccPad) {
         double t = 0.0;
 #pragma unroll
-        for (int i = 0; i < kBlock / 32; i++) t += red[i][threadIdx.x];
+        for (int i = 0; i < NG; i++) t += red[i][threadIdx.x];
         red[0][threadIdx.x] = t;
         results[(int64_t)pair * kAccPad + threadIdx.x] = (threadIdx.x < kAcc) ? t : 0.0;
     }
@@ -723,11 +728,12 @@ __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials,
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_dvo_reduce(const double *__restrict__ partials, int nblk,
-                                                       double *__restrict__ results, LoopState ls,
-                                                       int loop_mode, int max_iter) {
+template <int NG>
+__global__ __launch_bounds__(32 * NG) void k_dvo_reduce(const double *__restrict__ partials, int nblk,
+                                                        double *__restrict__ results, LoopState ls,
+                                                        int loop_mode, int max_iter) {
     const int pair = blockIdx.x;
-    if (!loop_mode || ls.state[pair] == ST_RUNNING) reduce_pair(partials, nblk, results, ls, loop_mode, max_iter);
+    if (!loop_mode || ls.state[pair] == ST_RUNNING) reduce_pair<NG>(partials, nblk, results, ls, loop_mode, max_iter);
     if (!loop_mode || threadIdx.x != 0) return;
     // the last block through publishes the number of running pairs to the host:
     // no copy kernel between the iterations, the host just waits for the stream
@@ -2551,8 +2557,12 @@ tdk_status launch_reduce(tdk_dvo *h, int level, int loop_mode, int max_iter, con
     int nblk;
     int64_t chunk;
     plan_blocks(h, h->lv[level], &nblk, &chunk);
-    k_dvo_reduce<<<h->n_pairs, kBlock, 0, h->stream>>>(h->d_partials, nblk, h->d_results, ls ? *ls : h->ls,
-                                                           loop_mode, max_iter);
+    if (h->n_pairs < 8 && nblk > 32)
+        k_dvo_reduce<32><<<h->n_pairs, 1024, 0, h->stream>>>(h->d_partials, nblk, h->d_results, ls ? *ls : h->ls,
+                                                               loop_mode, max_iter);
+    else
+        k_dvo_reduce<kBlock / 32><<<h->n_pairs, kBlock, 0, h->stream>>>(h->d_partials, nblk, h->d_results,
+                                                                         ls ? *ls : h->ls, loop_mode, max_iter);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
