@@ -728,10 +728,49 @@ __device__ __forceinline__ void reduce_pair(const double *__restrict__ partials,
     }
 }
 
+constexpr int kFlagGate = 12;          // host_flag[12]: the level being estimated, -1 when the call is complete
+constexpr int kFlagLevelEvals = 16;    // host_flag[16 + 4 l ...]: evaluations / updates (64 bit each) of level l
+
+// The speculative level chain of small batches (see k_chain_init below): what the last block of a reduce
+// launch needs to close its level and open the next one.  state_all == nullptr: not a chain launch.
+struct ChainArgs {
+    int *state_all;   // [n_levels][n] per-level state arrays
+    int *gate;        // [1] the level being estimated
+    int from, n;      // the level this launch belongs to; pairs
+    double *poses_out;
+    int *warn_out;    // where the host reads the result after level 0
+};
+
+// closes level `from` and opens from - 1 (one thread; the batches this runs for have a handful of pairs);
+// after level 0 the poses and warnings go where the host reads them
+__device__ __forceinline__ void chain_next_level(const LoopState &ls, const ChainArgs &c) {
+    const int from = c.from, n = c.n;
+    for (int i = 0; i < n; i++) {
+        if (from > 0) {
+            for (int k = 0; k < 12; k++) ls.cand[12 * i + k] = ls.pose[12 * i + k];
+            ls.prev_err[i] = 0.0;
+            c.state_all[(from - 1) * n + i] = ST_RUNNING;
+            ls.stat_state[i] = ST_RUNNING;
+            ls.mode[i] = MODE_FULL0;
+            ls.tested[i] = 0;
+            ls.n_evals[i] = 0;
+        } else {
+            for (int k = 0; k < 12; k++) c.poses_out[12 * i + k] = ls.pose[12 * i + k];
+            c.warn_out[i] = ls.warn[i];
+        }
+    }
+    *reinterpret_cast<volatile unsigned long long *>(ls.host_flag + kFlagLevelEvals + 4 * from) = atomicAdd(ls.evals, 0ull);
+    *reinterpret_cast<volatile unsigned long long *>(ls.host_flag + kFlagLevelEvals + 4 * from + 2) = atomicAdd(ls.evals + 1, 0ull);
+    ls.evals[0] = 0ull; ls.evals[1] = 0ull;
+    if (from > 0) *ls.active = n;
+    *c.gate = from - 1;
+    ls.host_flag[kFlagGate] = from - 1;
+}
+
 template <int NG>
 __global__ __launch_bounds__(32 * NG) void k_dvo_reduce(const double *__restrict__ partials, int nblk,
                                                         double *__restrict__ results, LoopState ls,
-                                                        int loop_mode, int max_iter) {
+                                                        int loop_mode, int max_iter, ChainArgs chain) {
     const int pair = blockIdx.x;
     if (!loop_mode || ls.state[pair] == ST_RUNNING) reduce_pair<NG>(partials, nblk, results, ls, loop_mode, max_iter);
     if (!loop_mode || threadIdx.x != 0) return;
@@ -746,7 +785,11 @@ __global__ __launch_bounds__(32 * NG) void k_dvo_reduce(const double *__restrict
         ls.host_flag[5] = atomicExch(&ls.round[1], 0);
         ls.host_flag[8] = atomicExch(&ls.next[0], 0);
         ls.host_flag[9] = atomicExch(&ls.next[1], 0);
-        *ls.host_flag = atomicAdd(ls.active, 0);
+        const int running = atomicAdd(ls.active, 0);
+        *ls.host_flag = running;
+        // chain launches: the level is done and it is the current one -> on to the next (the evaluation
+        // kernels queued behind this launch find their level's state array open)
+        if (chain.state_all != nullptr && running == 0 && *chain.gate == chain.from) chain_next_level(ls, chain);
         __threadfence_system();
     }
 }
@@ -795,14 +838,12 @@ __global__ void k_publish(LoopState ls, double *__restrict__ poses_out, int *__r
 // from running out of turn is the state array it is given: every level has its OWN state array,
 // RUNNING only while that level is being estimated, so k_dvo_eval / k_dvo_reduce launches of a level
 // whose turn has not come (the level above needed more rounds than were queued) return at once, as
-// they already do for pairs that have finished.  k_level_next moves on -- re-arming the loop state as
-// k_loop_init does and opening the next level's state array -- only if the level it closes is the
-// current one (gate) and has no pair left running; otherwise it leaves everything as it is, the host
-// reads the gate and queues more rounds for that level.  Evaluation kernels are untouched.
+// they already do for pairs that have finished.  The last block of a k_dvo_reduce launch moves on
+// (chain_next_level) -- re-arming the loop state as k_loop_init does and opening the next level's state
+// array -- only if its level is the current one (gate) and has no pair left running; otherwise everything
+// stays as it is, the host reads the gate and queues more rounds for that level.  Evaluation kernels are
+// untouched.
 // ---------------------------------------------------------------------------
-constexpr int kFlagGate = 12;          // host_flag[12]: the level being estimated, -1 when the call is complete
-constexpr int kFlagLevelEvals = 16;    // host_flag[16 + 4 l ...]: evaluations / updates (64 bit each) of level l
-
 __global__ void k_chain_init(LoopState ls, int *state_all, int *gate, int n, int n_levels, const double *poses_in) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         for (int k = 0; k < 12; k++) {
@@ -826,41 +867,6 @@ __global__ void k_chain_init(LoopState ls, int *state_all, int *gate, int n, int
         ls.next[0] = 0; ls.next[1] = 0;
         *gate = n_levels - 1;
         ls.host_flag[kFlagGate] = n_levels - 1;
-    }
-}
-
-// closes level `from` (if it is the current one and nothing runs there any more) and opens from - 1;
-// after level 0 the poses and warnings go where the host reads them
-__global__ void k_level_next(LoopState ls, int *state_all, int *gate, int n, int from, double *__restrict__ poses_out,
-                             int *__restrict__ warn_out) {
-    __shared__ int go;
-    if (threadIdx.x == 0) go = (*gate == from && atomicAdd(ls.active, 0) == 0) ? 1 : 0;
-    __syncthreads();
-    if (!go) return;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        if (from > 0) {
-            for (int k = 0; k < 12; k++) ls.cand[12 * i + k] = ls.pose[12 * i + k];
-            ls.prev_err[i] = 0.0;
-            state_all[(from - 1) * n + i] = ST_RUNNING;
-            ls.stat_state[i] = ST_RUNNING;
-            ls.mode[i] = MODE_FULL0;
-            ls.tested[i] = 0;
-            ls.n_evals[i] = 0;
-        } else {
-            for (int k = 0; k < 12; k++) poses_out[12 * i + k] = ls.pose[12 * i + k];
-            warn_out[i] = ls.warn[i];
-        }
-    }
-    if (threadIdx.x == 0) {
-        *reinterpret_cast<volatile unsigned long long *>(ls.host_flag + kFlagLevelEvals + 4 * from) = ls.evals[0];
-        *reinterpret_cast<volatile unsigned long long *>(ls.host_flag + kFlagLevelEvals + 4 * from + 2) = ls.evals[1];
-        ls.evals[0] = 0ull; ls.evals[1] = 0ull;
-        ls.round[0] = 0; ls.round[1] = 0;
-        ls.next[0] = 0; ls.next[1] = 0;
-        if (from > 0) *ls.active = n;
-        *gate = from - 1;
-        ls.host_flag[kFlagGate] = from - 1;
-        __threadfence_system();
     }
 }
 
@@ -2553,16 +2559,18 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
     return TDK_OK;
 }
 
-tdk_status launch_reduce(tdk_dvo *h, int level, int loop_mode, int max_iter, const LoopState *ls = nullptr) {
+tdk_status launch_reduce(tdk_dvo *h, int level, int loop_mode, int max_iter, const LoopState *ls = nullptr,
+                         const ChainArgs *chain = nullptr) {
     int nblk;
     int64_t chunk;
     plan_blocks(h, h->lv[level], &nblk, &chunk);
+    const ChainArgs ca = chain ? *chain : ChainArgs{nullptr, nullptr, 0, 0, nullptr, nullptr};
     if (h->n_pairs < 8 && nblk > 32)
         k_dvo_reduce<32><<<h->n_pairs, 1024, 0, h->stream>>>(h->d_partials, nblk, h->d_results, ls ? *ls : h->ls,
-                                                               loop_mode, max_iter);
+                                                               loop_mode, max_iter, ca);
     else
         k_dvo_reduce<kBlock / 32><<<h->n_pairs, kBlock, 0, h->stream>>>(h->d_partials, nblk, h->d_results,
-                                                                         ls ? *ls : h->ls, loop_mode, max_iter);
+                                                                         ls ? *ls : h->ls, loop_mode, max_iter, ca);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
@@ -2672,7 +2680,7 @@ tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64
 }
 
 // The whole coarse-to-fine estimation of a small batch with one host wait in the typical case (see
-// k_chain_init / k_level_next).  Weight modes without robust statistics only (their extra kernels per
+// k_chain_init / chain_next_level).  Weight modes without robust statistics only (their extra kernels per
 // full evaluation are decided on the host).
 static bool chain_applies(const tdk_dvo *h, int weight_mode) {
     static const int enabled = [] { const char *v = getenv("TDK_DVO_CHAIN"); return v ? atoi(v) : 1; }();
@@ -2697,13 +2705,11 @@ static tdk_status chain_estimate(tdk_dvo *h, int weight_mode, int max_iter, doub
             ls.state = h->d_chain_state + (size_t)l * n;
             ls.fuse_first = l == L - 1;
             const int burst = (l == L - 1 && (fresh || l != level)) ? 3 : 2;
+            const ChainArgs ca{h->d_chain_state, h->d_gate, l, n, h->d_io + 12 * (size_t)n, (int *)(h->d_io + 24 * (size_t)n)};
             for (int b = 0; b < burst; b++) {
                 TDK_TRY(launch_eval(h, l, h->ls.cand, ls.state, h->ls.mode, nullptr, weight_mode));
-                TDK_TRY(launch_reduce(h, l, 1, max_iter, &ls));
+                TDK_TRY(launch_reduce(h, l, 1, max_iter, &ls, &ca));
             }
-            k_level_next<<<1, 256, 0, h->stream>>>(ls, h->d_chain_state, h->d_gate, n, l, h->d_io + 12 * (size_t)n,
-                                                  (int *)(h->d_io + 24 * (size_t)n));
-            TDK_LAUNCH_CHECK();
         }
         TDK_HIP(hipStreamSynchronize(h->stream));
         const int g = flag[kFlagGate];

@@ -607,9 +607,12 @@ __global__ __launch_bounds__(256) void k_rescale_aa_multi(AaMultiArgs m) {
     // takes images k, k + 8, ... one after the other, all tiles of all levels of an image consecutively
     // -- so the halo rows that neighbouring tiles share and the second level's pass over the same
     // source (2.4 MB per VGA array, the L2 holds 4 MB) are L2 hits instead of fabric traffic.
+    // (fewer than 8 images -- a single pair's three arrays: their tiles go to all XCDs instead)
     const int tiles_total = m.tile_end[m.n - 1];
     const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-    const int image = (q / tiles_total) * 8 + xcd, t = q - (q / tiles_total) * tiles_total;
+    const bool few = m.n_arrays * m.batch < 8;
+    const int image = few ? (int)blockIdx.x / tiles_total : (q / tiles_total) * 8 + xcd;
+    const int t = few ? (int)blockIdx.x - image * tiles_total : q - (q / tiles_total) * tiles_total;
     if (image >= m.n_arrays * m.batch) return;
     const int pair = image / m.n_arrays, arr = image - pair * m.n_arrays;
     int l = 0;
@@ -1050,7 +1053,7 @@ tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int
         m.n_arrays = n_arrays;
         m.batch = batch;
         const int64_t images = (int64_t)n_arrays * batch;
-        const int64_t blocks = 8 * ((images + 7) / 8) * tiles_total;
+        const int64_t blocks = (images < 8 ? images : 8 * ((images + 7) / 8)) * tiles_total;
         if (blocks >= (1ll << 31)) {
             set_error("anti-aliased pyramid: %lld blocks exceed the grid limit", (long long)blocks);
             return TDK_ERR_INVALID_ARGUMENT;
