@@ -92,6 +92,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-workloads", action="store_true", help="headline only")
+    ap.add_argument("--no-solo-pass", action="store_true",
+                    help="skip the untimed single-batch pass behind roofline.by_level / pyramid_roofline (profiling runs)")
     args = ap.parse_args()
     if args.config == "cfg4":           # explicit --pairs / --height / ... still win (reduced smoke runs)
         given = set(a.split("=")[0] for a in sys.argv[1:] if a.startswith("--"))
@@ -315,6 +317,25 @@ def workload_dvo_single_pair(args, golden):
         out["roofline"] = roofline(BYTES_PER_PX_EVAL * prof["pixels"] / prof["launches"], kernel_ms,
                                    kernel="k_dvo_eval (full-resolution level, one pair: 300 blocks on 256 CUs)",
                                    bytes_per_px=BYTES_PER_PX_EVAL, launches=prof["launches"])
+        out["roofline"]["note"] = ("latency, not bandwidth: one pair is 300 blocks of one round; what matters here is "
+                                   "ms_per_call and its breakdown")
+    # where a call's time goes (C ABI, each part synchronised on its own): upload of the three host arrays,
+    # pyramid, estimation (the whole coarse-to-fine chain queued at once, one host wait)
+    from tadataka_amd import _lib, ops
+
+    def t_of(fn, n=100):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        return (time.perf_counter() - t0) / n * 1e3
+    ident = ops.pose12(np.eye(3), np.zeros(3))[None]
+    mode = ops.WEIGHT_MODES[weights]
+    out["breakdown_ms"] = {
+        "upload_3_host_arrays": t_of(lambda: batch.upload(0, pair["I0"], pair["D0"], pair["I1"])),
+        "pyramid": t_of(lambda: (batch.build_pyramid(), _lib.call("tdk_sync"))),
+        "estimation": t_of(lambda: batch.estimate(cam, cam, ident, mode, 20)),
+        "note": "7.4 MB over PCIe per call is the floor of the reference's signature (three fresh float64 arrays)"}
     return out
 
 
@@ -831,7 +852,7 @@ def main():
     # on its own.  With two batches in flight the coarse-level launches are stretched by the other batch's
     # pyramid kernel; these numbers are what each kernel takes by itself.
     by_level, pyramid_alone = {}, None
-    if rank == 0:
+    if rank == 0 and not args.no_solo_pass:
         _lib.call("tdk_sync")                       # (no collective here: only rank 0 takes this pass)
         solo = batches[0]
         solo.set_profiling(True, all_levels=True)

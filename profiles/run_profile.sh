@@ -9,10 +9,13 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-workloads --min-seconds 0.2 --steps 10 --warmup 2"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-workloads --no-solo-pass --min-seconds 0.2 --steps 10 --warmup 2"
 cd /tmp
-# 1) per-kernel time
+# 1) per-kernel time: (a) as the headline runs -- two batches in flight, one batch's pyramid beside the other's
+#    estimation, so every kernel but the full-resolution evaluations is stretched ("under overlap") --
+#    and (b) --single-buffer: one batch, every kernel alone on the device ("alone")
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o bench -- $BENCH > "$OUT/trace_stdout.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_single" -o bench -- $BENCH --single-buffer > "$OUT/trace_single_stdout.log" 2>&1
 # 2) HBM traffic, separate passes (FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o bench -- $BENCH > "$OUT/pmc_fetch_stdout.log" 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o bench -- $BENCH > "$OUT/pmc_write_stdout.log" 2>&1

@@ -26,17 +26,17 @@ def short(name):
     return name.split("(")[0]
 
 
-def kernel_stats(root):
+def kernel_stats(root, sub="trace"):
     rows = []
-    for f in find(os.path.join(root, "trace"), "*kernel_stats.csv"):
+    for f in find(os.path.join(root, sub), "*kernel_stats.csv"):
         rows += list(csv.DictReader(open(f)))
     return rows
 
 
-def trace_by_grid(root):
+def trace_by_grid(root, sub="trace"):
     """(kernel, grid) -> [durations ns]"""
     acc = defaultdict(list)
-    for f in find(os.path.join(root, "trace"), "*kernel_trace.csv"):
+    for f in find(os.path.join(root, sub), "*kernel_trace.csv"):
         for r in csv.DictReader(open(f)):
             grid = (int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
             acc[(short(r["Kernel_Name"]), grid)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
@@ -60,29 +60,42 @@ def main():
     root = sys.argv[1]
     px = float(sys.argv[2]) if len(sys.argv) > 2 else 256 * 480 * 640
     out = {"pixels_per_level0_launch": px}
-    print("== rocprofv3 --kernel-trace --stats ==")
-    print(f'{"kernel":42s} {"calls":>6s} {"avg_us":>10s} {"total_ms":>10s} {"pct":>7s}')
-    stats = []
-    for r in kernel_stats(root):
-        stats.append({"kernel": short(r["Name"]), "calls": int(r["Calls"]),
-                      "avg_us": float(r["AverageNs"]) / 1e3, "total_ms": float(r["TotalDurationNs"]) / 1e6,
-                      "pct": float(r["Percentage"])})
-        s = stats[-1]
-        print(f'{s["kernel"][:42]:42s} {s["calls"]:6d} {s["avg_us"]:10.1f} {s["total_ms"]:10.2f} {s["pct"]:7.2f}')
-    out["kernel_stats"] = stats
-
-    print("\n== k_dvo_eval / k_dvo_probe by grid (one grid per pyramid level; largest = full resolution) ==")
-    tr = trace_by_grid(root)
     is_eval = lambda name: name.startswith("k_dvo_eval") or name.startswith("k_dvo_probe")
-    evals = sorted([(k, v) for k, v in tr.items() if is_eval(k[0])],
-                   key=lambda kv: (-kv[0][1][0] * kv[0][1][1], kv[0][0]))
     levels = []
-    for (name, grid), durs in evals:
-        levels.append({"kernel": name, "grid": list(grid), "launches": len(durs), "avg_us": mean(durs) / 1e3,
-                       "min_us": min(durs) / 1e3, "max_us": max(durs) / 1e3})
-        print(f'{name:28s} grid={grid} launches={len(durs)} avg={mean(durs)/1e3:9.1f} us '
-              f'min={min(durs)/1e3:9.1f} max={max(durs)/1e3:9.1f}')
-    out["dvo_eval_levels"] = levels
+    for sub, label in (("trace", "UNDER OVERLAP: two batches in flight (the headline's mode); only the full-resolution "
+                                 "evaluation rows are kernel times, the others run beside the other batch's pyramid"),
+                       ("trace_single", "ALONE: --single-buffer, one batch, every kernel by itself on the device")):
+        rows = kernel_stats(root, sub)
+        if not rows:
+            continue
+        print(f"== rocprofv3 --kernel-trace --stats -- {label} ==")
+        print(f'{"kernel":42s} {"calls":>6s} {"avg_us":>10s} {"total_ms":>10s} {"pct":>7s}')
+        stats = []
+        for r in rows:
+            stats.append({"kernel": short(r["Name"]), "calls": int(r["Calls"]),
+                          "avg_us": float(r["AverageNs"]) / 1e3, "total_ms": float(r["TotalDurationNs"]) / 1e6,
+                          "pct": float(r["Percentage"])})
+            s = stats[-1]
+            print(f'{s["kernel"][:42]:42s} {s["calls"]:6d} {s["avg_us"]:10.1f} {s["total_ms"]:10.2f} {s["pct"]:7.2f}')
+        out["kernel_stats" if sub == "trace" else "kernel_stats_alone"] = stats
+        print(f"\n-- k_dvo_eval / k_dvo_probe by grid (one grid per pyramid level; largest = full resolution), "
+              f"{'under overlap' if sub == 'trace' else 'alone'}; HBM roofline on 24 B/px --")
+        tr = trace_by_grid(root, sub)
+        evals = sorted([(k, v) for k, v in tr.items() if is_eval(k[0])],
+                       key=lambda kv: (-kv[0][1][0] * kv[0][1][1], kv[0][0]))
+        lv = []
+        # pixels per launch of a level follow from the grid ratio to the finest level's (same pairs, px ~ blocks)
+        top_grid = max((g[0] * g[1] for (_, g), _ in evals), default=0)
+        for (name, grid), durs in evals:
+            rec = {"kernel": name, "grid": list(grid), "launches": len(durs), "avg_us": mean(durs) / 1e3,
+                   "min_us": min(durs) / 1e3, "max_us": max(durs) / 1e3}
+            lv.append(rec)
+            print(f'{name:28s} grid={grid} launches={len(durs)} avg={mean(durs)/1e3:9.1f} us '
+                  f'min={min(durs)/1e3:9.1f} max={max(durs)/1e3:9.1f}')
+        out["dvo_eval_levels" if sub == "trace" else "dvo_eval_levels_alone"] = lv
+        if sub == "trace":
+            levels = lv
+        print()
 
     fetch = pmc_by_grid(root, "pmc_fetch")
     write = pmc_by_grid(root, "pmc_write")
