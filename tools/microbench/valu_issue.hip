@@ -23,6 +23,7 @@ __global__ __launch_bounds__(1024) void k_issue(unsigned long long *ticks, doubl
     unsigned i0 = threadIdx.x, i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3, i4 = i0 + 4, i5 = i0 + 5, i6 = i0 + 6, i7 = i0 + 7;
     float f0 = threadIdx.x, f1 = f0 + 1, f2 = f0 + 2, f3 = f0 + 3, f4 = f0 + 4, f5 = f0 + 5, f6 = f0 + 6, f7 = f0 + 7;
     const unsigned k = 3;
+    double m2 = 1.0000001; unsigned k2 = 3;
     const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; it++) {
         if (KIND == 0) {   // v_fma_f64
@@ -60,7 +61,37 @@ __global__ __launch_bounds__(1024) void k_issue(unsigned long long *ticks, doubl
         } else if (KIND == 8) {   // v_cndmask_b32 (vcc)
             REP8(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
                               "v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc\n"
-                              : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(k) : "vcc");)
+                              : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(k));)
+        } else if (KIND == 13) {  // v_cndmask_b32_e64 with an SGPR-pair mask
+            unsigned long long msk = 0x5555555555555555ull;
+            REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n"
+                              "v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9\n"
+                              : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(k), "s"(msk));)
+        } else if (KIND == 14) {  // v_cmp_lt_f64 -> SGPR pair, then v_cndmask on it (compare + select pairs)
+            REP8(asm volatile("v_cmp_lt_f64_e64 s[40:41], %0, %8\n v_cndmask_b32_e64 %4, %4, %9, s[40:41]\n v_cmp_lt_f64_e64 s[42:43], %1, %8\n v_cndmask_b32_e64 %5, %5, %9, s[42:43]\n"
+                              "v_cmp_lt_f64_e64 s[44:45], %2, %8\n v_cndmask_b32_e64 %6, %6, %9, s[44:45]\n v_cmp_lt_f64_e64 s[46:47], %3, %8\n v_cndmask_b32_e64 %7, %7, %9, s[46:47]\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(m), "v"(k)
+                              : "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47");)
+        } else if (KIND == 15) {  // what hipcc emits for a select: v_cmp -> vcc, v_cndmask_b32_e32 reading vcc
+            REP8(asm volatile("v_cmp_lt_f64_e32 vcc, %0, %8\n v_cndmask_b32_e32 %4, %4, %9, vcc\n v_cmp_lt_f64_e32 vcc, %1, %8\n v_cndmask_b32_e32 %5, %5, %9, vcc\n"
+                              "v_cmp_lt_f64_e32 vcc, %2, %8\n v_cndmask_b32_e32 %6, %6, %9, vcc\n v_cmp_lt_f64_e32 vcc, %3, %8\n v_cndmask_b32_e32 %7, %7, %9, vcc\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3) : "v"(m), "v"(k) : "vcc");)
+        } else if (KIND == 16) {  // one compare, then eight selects on the same vcc
+            asm volatile("v_cmp_lt_f64_e32 vcc, %0, %1" :: "v"(a0), "v"(m) : "vcc");
+            REP8(asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e32 %3, %3, %8, vcc\n"
+                              "v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_cndmask_b32_e32 %6, %6, %8, vcc\n v_cndmask_b32_e32 %7, %7, %8, vcc\n"
+                              : "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3), "+v"(i4), "+v"(i5), "+v"(i6), "+v"(i7) : "v"(k));)
+        } else if (KIND == 17) {  // a select of a DOUBLE as hipcc emits it: one v_cmp -> vcc, two v_cndmask_b32_e32 on that vcc
+            REP8(asm volatile("v_cmp_lt_f64_e32 vcc, %0, %4\n v_cndmask_b32_e32 %1, %1, %5, vcc\n v_cndmask_b32_e32 %2, %2, %5, vcc\n"
+                              "v_cmp_lt_f64_e32 vcc, %3, %4\n v_cndmask_b32_e32 %6, %6, %5, vcc\n v_cndmask_b32_e32 %7, %7, %5, vcc\n"
+                              "v_cmp_lt_f64_e32 vcc, %0, %4\n v_cndmask_b32_e32 %8, %8, %5, vcc\n"
+                              : "+v"(a0), "+v"(i0), "+v"(i1), "+v"(a1), "+v"(m2), "+v"(k2), "+v"(i2), "+v"(i3), "+v"(i4) :: "vcc");)
+        } else if (KIND == 18) {  // the same select through an SGPR pair: v_cmp_e64 -> s[..], two v_cndmask_b32_e64
+            REP8(asm volatile("v_cmp_lt_f64_e64 s[40:41], %0, %4\n v_cndmask_b32_e64 %1, %1, %5, s[40:41]\n v_cndmask_b32_e64 %2, %2, %5, s[40:41]\n"
+                              "v_cmp_lt_f64_e64 s[42:43], %3, %4\n v_cndmask_b32_e64 %6, %6, %5, s[42:43]\n v_cndmask_b32_e64 %7, %7, %5, s[42:43]\n"
+                              "v_cmp_lt_f64_e64 s[44:45], %0, %4\n v_cndmask_b32_e64 %8, %8, %5, s[44:45]\n"
+                              : "+v"(a0), "+v"(i0), "+v"(i1), "+v"(a1), "+v"(m2), "+v"(k2), "+v"(i2), "+v"(i3), "+v"(i4)
+                              :: "s40", "s41", "s42", "s43", "s44", "s45");)
         } else if (KIND == 9) {   // v_lshl_add_u64 (64-bit address arithmetic)
             unsigned long long *p0 = (unsigned long long *)&a0, *p1 = (unsigned long long *)&a1;
             (void)p0; (void)p1;
@@ -84,7 +115,7 @@ __global__ __launch_bounds__(1024) void k_issue(unsigned long long *ticks, doubl
     const unsigned long long t1 = __builtin_readcyclecounter();
     if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
     sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (double)(i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7) +
-                                                  (double)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7);
+                                                  (double)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7) + m2 + (double)k2;
 }
 
 template <int KIND>
@@ -127,6 +158,6 @@ int main() {
     run<0>("v_fma_f64", 64); run<1>("v_add_f64", 64); run<2>("v_mul_f64", 64); run<3>("v_add_u32", 64);
     run<4>("v_mul_lo_u32", 64); run<5>("v_fma_f32", 64); run<6>("v_mov_b32", 64); run<7>("v_mov_b64", 64);
     run<8>("v_cndmask_b32", 64); run<9>("v_lshl_add_u64", 64); run<10>("v_pk_fma_f32", 64); run<11>("v_rcp_f64", 64);
-    run<12>("fma64+add32 1:1", 64);
+    run<12>("fma64+add32 1:1", 64); run<13>("v_cndmask_e64 sgpr", 64); run<14>("cmp_f64+cndmask", 64); run<15>("cmp->vcc+cndmask", 64); run<16>("cndmask_e32 vcc", 64); run<17>("cmp+2cndmask vcc", 64); run<18>("cmp+2cndmask sgpr", 64);
     return 0;
 }
