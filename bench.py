@@ -419,6 +419,7 @@ def workload_semi_dense(args, fixture):
         sd.step(T10s, T_wk, commit=False)
     dt_chain = time.perf_counter() - t0
     chain_ms = sd.timing()["step_ms"]
+    fallbacks = sd.warp_fallbacks()
     sd.close()
     warp_ms /= reps
     ud_ms /= reps
@@ -436,7 +437,9 @@ def workload_semi_dense(args, fixture):
            "roofline": roofline(bytes_ud * N * B, ud_ms, kernel="k_ud_classify + k_ud_estimate (update_depth)",
                                 bytes_per_px=bytes_ud, tracks=B),
            "roofline_warp": roofline(BYTES_PER_PX_WARP * N * B, warp_ms,
-                                     kernel="k_sd_scatter + k_sd_fold (increment_age + propagate)",
+                                     kernel="k_sd_targets + k_sd_gather (increment_age + propagate; slot path "
+                                            "k_sd_scatter + k_sd_fold for tracks whose displacement box is too large: "
+                                            "%d of this run)" % fallbacks,
                                      bytes_per_px=BYTES_PER_PX_WARP, tracks=B)}
     if not args.no_cpu_baseline:
         from oracle import oracle as orc             # the checker, here as the thing that is timed

@@ -125,6 +125,7 @@ PROTOTYPES = {
     "tdk_sd_create": [_i, _i, _i, _i, C.POINTER(_vp)],
     "tdk_sd_destroy": [_vp],
     "tdk_sd_set_age_policy": [_vp, _i],
+    "tdk_sd_get_warp_fallbacks": [_vp, c_int64_p],
     "tdk_sd_set_params": [_vp, C.POINTER(SemiDenseParams), C.c_double, C.c_double, C.c_double],
     "tdk_sd_set_maps": [_vp, _i, _d, _d, c_uint64_p],
     "tdk_sd_get_maps": [_vp, _i, _d, _d, c_uint64_p, c_int64_p],

@@ -134,27 +134,39 @@ __device__ __forceinline__ bool xcd_major_track(int nb, int n_tracks, int &track
 constexpr int kSlots = 4;
 struct WarpLists {
     int *cnt, *slots, *ovf, *next;
+    int *rng;   // [kRngStride n_tracks] displacement boxes of the gather path (k_sd_targets), a cache line per track
 };
-constexpr size_t kWarpListInts = 1 + kSlots + 1 + 1;   // ints per pixel and track behind a WarpLists (+ 16 of padding)
-inline size_t warp_list_bytes(int64_t stride, int n_tracks) { return sizeof(int) * (kWarpListInts * (size_t)(stride * n_tracks) + 16); }
+constexpr size_t kWarpListInts = 1 + kSlots + 1 + 1;   // ints per pixel and track behind a WarpLists
+constexpr int kRngStride = 32;                         // ints per track in WarpLists::rng (128 bytes: atomics of different tracks do not share a line)
+// one helper sizes what carve_lists carves: seven regions of m ints (m = stride * n_tracks rounded up to 4,
+// which keeps the slot rows 16-byte aligned), the boxes, 16 ints of padding
+__host__ __device__ inline int64_t warp_list_region(int64_t stride, int n_tracks) { return (stride * n_tracks + 3) & ~(int64_t)3; }
+inline size_t warp_list_bytes(int64_t stride, int n_tracks) {
+    return sizeof(int) * (kWarpListInts * (size_t)warp_list_region(stride, n_tracks) + kRngStride * (size_t)n_tracks + 16 + 32);
+}
 
 __host__ __device__ inline WarpLists carve_lists(int *buf, int64_t stride, int n_tracks) {
     WarpLists L;
-    const int64_t m = (stride * n_tracks + 3) & ~(int64_t)3;   // keeps the slot rows 16-byte aligned
+    const int64_t m = warp_list_region(stride, n_tracks);
     L.cnt = buf;
     L.slots = buf + m;
     L.ovf = buf + m * (1 + kSlots);
     L.next = buf + m * (2 + kSlots);
+    L.rng = buf + ((m * (3 + kSlots) + 31) & ~(int64_t)31);
     return L;
 }
+
+__device__ __forceinline__ bool slot_path_wanted(const int *__restrict__ rng, int track);   // (the gather path, below)
 
 // Forward warp of every source pixel of every track; an in-range source claims the next slot of its
 // target (one returning atomic), writes its index there, or joins the overflow chain.
 __global__ __launch_bounds__(kBlock) void k_sd_scatter(int H, int W, const TrackWarp *__restrict__ tw,
                                                        const double *__restrict__ depth0, int64_t stride,
-                                                       WarpLists lists, int nb, int n_tracks) {
+                                                       WarpLists lists, int nb, int n_tracks,
+                                                       const int *__restrict__ rng) {
     int track, blk;
     if (!xcd_major_track(nb, n_tracks, track, blk)) return;
+    if (!slot_path_wanted(rng, track)) return;
     const TrackWarp &t = tw[track];
     const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
     const int N = H * W;
@@ -194,9 +206,11 @@ __global__ __launch_bounds__(kBlock) void k_sd_fold(int H, int W, const TrackWar
                                                     const double *__restrict__ var0, int64_t stride,
                                                     double default_depth, double default_variance, double bias,
                                                     uint64_t *__restrict__ age1, double *__restrict__ depth1,
-                                                    double *__restrict__ var1, int nb, int n_tracks) {
+                                                    double *__restrict__ var1, int nb, int n_tracks,
+                                                    const int *__restrict__ rng) {
     int track, blk;
     if (!xcd_major_track(nb, n_tracks, track, blk)) return;
+    if (!slot_path_wanted(rng, track)) return;
     const TrackWarp &t = tw[track];
     const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
     const int N = H * W;
@@ -263,6 +277,227 @@ __global__ __launch_bounds__(kBlock) void k_sd_fold(int H, int W, const TrackWar
         }
         if (PROP) { depth1[base + tg] = d; var1[base + tg] = v; }
     }
+}
+
+// ---------------------------------------------------------------------------
+// The forward warp as a GATHER (round 4).  The scatter above is bound by its returning atomics
+// (19.7 M for 64 VGA tracks) and the fold by scattered slot reads.  But the displacement field of a
+// frame-to-frame warp is smooth: if every in-range source s lands on t(s) = s + d(s) with the integer
+// displacement d(s) inside a small box [dmin, dmax] (per track), then the sources of a target t are all
+// inside t - box, and scanning that box in raster order IS the reference's fold order -- no slots, no
+// chains, no atomics per pixel:
+//   k_sd_targets  one thread per source: warp, write the target index (4 B/px, coalesced; -1 = out of
+//                 range), and the track's displacement box by four atomic maxima per block;
+//   k_sd_gather   a block takes 64 x 4 targets; the (64 + rx) x (4 + ry) sources that can reach them vote into
+//                 per-target slots in LDS (LDS atomics; the slot algorithm of the scatter, but on chip), every
+//                 target orders its <= 4 sources and folds them exactly as k_sd_fold does (same order -> same
+//                 bits); the hypothesis (depth1, variance1a) of a source comes from k_sd_targets, where every
+//                 lane has one to compute -- in the fold the busiest target of a wave sets the pace.
+// A track whose box is too large (kGatherMaxRx x kGatherMaxRy, or too many candidates per target for the
+// rare plain scan) is left to the slot path: k_sd_gather returns at once for it, the scatter /
+// fold launches queued behind return at once for all the others -- decided on the device, no host wait;
+// the tracks that fell back are counted (tdk_sd_get_warp_fallbacks).
+// ---------------------------------------------------------------------------
+constexpr int kGatherTW = 64, kGatherTH = 4;              // targets per block tile (one per thread)
+constexpr int kGatherMaxRx = 64, kGatherMaxRy = 12;       // largest displacement spread the window holds
+constexpr int kGatherMaxCand = 320;                       // (rx + 1)(ry + 1): candidates scanned per target
+
+// rng[kRngStride track ..]: max(-dx), max(-dy), max(dx), max(dy) over the in-range sources (memset to 0x80808080 before)
+__device__ __forceinline__ bool gather_applies(const int *__restrict__ rng, int track, int &dxmin, int &dymin,
+                                               int &rx, int &ry) {
+    const int nx = rng[kRngStride * track], ny = rng[kRngStride * track + 1], mx = rng[kRngStride * track + 2],
+              my = rng[kRngStride * track + 3];
+    if (mx < -0x40000000) { dxmin = 0; dymin = 0; rx = -1; ry = -1; return true; }   // no source in range at all
+    dxmin = -nx; dymin = -ny;
+    rx = mx + nx; ry = my + ny;
+    return rx <= kGatherMaxRx && ry <= kGatherMaxRy && (rx + 1) * (ry + 1) <= kGatherMaxCand;
+}
+
+template <bool PROP>
+__global__ __launch_bounds__(kBlock) void k_sd_targets(int H, int W, const TrackWarp *__restrict__ tw,
+                                                       const double *__restrict__ depth0,
+                                                       const double *__restrict__ var0, double bias, int64_t stride,
+                                                       int *__restrict__ tgt, double2 *__restrict__ warped,
+                                                       int *__restrict__ rng, int nb, int n_tracks) {
+    int track, blk;
+    if (!xcd_major_track(nb, n_tracks, track, blk)) return;
+    const TrackWarp &t = tw[track];
+    const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
+    const double *__restrict__ d0 = depth0 + (int64_t)track * stride;
+    int *__restrict__ tg = tgt + (int64_t)track * stride;
+    const int tiles_x = (W + kGatherTW - 1) / kGatherTW, tiles_y = (H + kGatherTH - 1) / kGatherTH;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    int ndx = -0x7fffffff, ndy = -0x7fffffff, mdx = -0x7fffffff, mdy = -0x7fffffff;
+    for (int tile = blk; tile < tiles_x * tiles_y; tile += nb) {
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int x0 = txi * kGatherTW + lx, y0 = tyi * kGatherTH + ly;
+        if (x0 >= W || y0 >= H) continue;
+        const int i = y0 * W + x0;
+        double ux, uy, d1;
+        tdk::perspective_warp(t.T10, c0, c1, (double)x0, (double)y0, d0[i], ux, uy, d1);
+        int out = -1;
+        if (tdk::in_range(ux, uy, H, W)) {
+            const int tx = (int)ux, ty = (int)uy;   // `as usize`: truncation
+            out = ty * W + tx;
+            ndx = max(ndx, x0 - tx); mdx = max(mdx, tx - x0);
+            ndy = max(ndy, y0 - ty); mdy = max(mdy, ty - y0);
+            // propagate: the source's hypothesis in the new frame, computed HERE, where every lane has one --
+            // in the gather the targets of a wave have 1 - 4 sources each and the warp arithmetic would run
+            // for the busiest lane's count with most lanes idle
+            if (PROP) {
+                const double d0i = d0[i];
+                warped[(int64_t)track * stride + i] = make_double2(d1, propagate_variance(d0i, d1, var0[(int64_t)track * stride + i], bias));
+            }
+        }
+        tg[i] = out;
+    }
+    // the track's box: wave maxima, one atomic per wave and bound
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ndx = max(ndx, __shfl_xor(ndx, o)); ndy = max(ndy, __shfl_xor(ndy, o));
+        mdx = max(mdx, __shfl_xor(mdx, o)); mdy = max(mdy, __shfl_xor(mdy, o));
+    }
+    // ... block maxima through LDS, and an atomic only for a bound this block actually extends (after the
+    // first blocks of a track almost none does: 1.2 M atomics on the tracks' lines cost 4 ms, these cost nothing)
+    __shared__ int blk_rng[kBlock / 64][4];
+    if (lx == 0) { blk_rng[ly][0] = ndx; blk_rng[ly][1] = ndy; blk_rng[ly][2] = mdx; blk_rng[ly][3] = mdy; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        int m = blk_rng[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kBlock / 64; w++) m = max(m, blk_rng[w][threadIdx.x]);
+        int *dst = &rng[kRngStride * track + threadIdx.x];
+        if (m > -0x40000000 && m > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, m);
+    }
+}
+
+template <bool AGE, bool PROP>
+__global__ __launch_bounds__(kBlock) void k_sd_gather(int H, int W, const TrackWarp *__restrict__ tw,
+                                                      const int *__restrict__ tgt, const double2 *__restrict__ warped,
+                                                      const int *__restrict__ rng,
+                                                      const uint64_t *__restrict__ age0, int64_t stride,
+                                                      double default_depth, double default_variance, double bias,
+                                                      uint64_t *__restrict__ age1, double *__restrict__ depth1,
+                                                      double *__restrict__ var1, int nb, int n_tracks,
+                                                      unsigned int *__restrict__ fallbacks) {
+    // per target of the tile: how many sources of the window land on it, and the first four of them
+    __shared__ int cnt[kBlock];
+    __shared__ __attribute__((aligned(16))) int slot[kBlock * kSlots];
+    int track, blk;
+    if (!xcd_major_track(nb, n_tracks, track, blk)) return;
+    int dxmin, dymin, rx, ry;
+    if (!gather_applies(rng, track, dxmin, dymin, rx, ry)) {
+        if (blk == 0 && threadIdx.x == 0 && fallbacks) atomicAdd(fallbacks, 1u);
+        return;
+    }
+    const int dxmax = dxmin + rx, dymax = dymin + ry;
+    const TrackWarp &t = tw[track];
+    const int64_t base = (int64_t)track * stride;
+    const int *__restrict__ tg_all = tgt + base;
+    const int tiles_x = (W + kGatherTW - 1) / kGatherTW, tiles_y = (H + kGatherTH - 1) / kGatherTH;
+    const int lx = threadIdx.x & 63;
+    const int ly = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ww = kGatherTW + max(rx, 0), wh = kGatherTH + max(ry, 0);
+    for (int tile = blk; tile < tiles_x * tiles_y; tile += nb) {
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int tx0 = txi * kGatherTW, ty0 = tyi * kGatherTH;
+        const int wx0 = tx0 - dxmax, wy0 = ty0 - dymax;      // window origin in source coordinates
+        __syncthreads();                                      // the previous tile's folds are through
+        cnt[threadIdx.x] = 0;
+        __syncthreads();
+        // every source of the window votes: a wave per window row (coalesced reads of the target indices, no
+        // division); a source whose target lies in this tile claims one of the target's slots with an LDS atomic
+        if (rx >= 0) {
+            for (int r = ly; r < wh; r += kBlock / 64) {
+                const int sy = wy0 + r;
+                if ((unsigned)sy >= (unsigned)H) continue;
+                for (int c = lx; c < ww; c += 64) {
+                    const int sx = wx0 + c;
+                    if ((unsigned)sx >= (unsigned)W) continue;
+                    const int src = sy * W + sx;
+                    const int tg = tg_all[src];
+                    if (tg < 0) continue;
+                    const int ty = tg / W, tx = tg - ty * W;
+                    const unsigned ux = (unsigned)(tx - tx0), uy = (unsigned)(ty - ty0);
+                    if (ux >= (unsigned)kGatherTW || uy >= (unsigned)kGatherTH) continue;
+                    const int tl = (int)uy * kGatherTW + (int)ux;
+                    const int k = atomicAdd(&cnt[tl], 1);
+                    if (k < kSlots) slot[tl * kSlots + k] = src;
+                }
+            }
+        }
+        __syncthreads();
+        const int x = tx0 + lx, y = ty0 + ly;
+        if (x >= W || y >= H) continue;
+        const int me = y * W + x;
+        double d = default_depth, v = default_variance;
+        int last = -1;
+        bool have = false;
+        auto take = [&](int src) {      // the next source in raster order
+            if (PROP) {
+                const double2 w = warped[base + src];      // (depth1, variance1a) of the source, from k_sd_targets
+                if (!have) { d = w.x; v = w.y; have = true; }
+                else {
+                    double nd, nv;
+                    handle_collision(w.x, d, w.y, v, nd, nv);
+                    d = nd; v = nv;
+                }
+            }
+            last = src;
+        };
+        const int k = cnt[threadIdx.x];
+        if (k > 0) {
+            const int4 q = *reinterpret_cast<const int4 *>(slot + threadIdx.x * kSlots);
+            int s0 = q.x, s1 = k > 1 ? q.y : 0x7fffffff, s2 = k > 2 ? q.z : 0x7fffffff, s3 = k > 3 ? q.w : 0x7fffffff;
+            if (k <= kSlots) {
+                if (k > 1) {      // the votes arrive in any order: raster order by a five-exchange network
+                    sort2(s0, s1); sort2(s2, s3); sort2(s0, s2); sort2(s1, s3); sort2(s1, s2);
+                }
+                take(s0);
+                if (k > 1) take(s1);
+                if (k > 2) take(s2);
+                if (k > 3) take(s3);
+            } else {
+                // more than four sources on this target (a zoom-out inside the window): the plain scan of its
+                // candidates s = t - d, d in the box, in raster order
+                for (int cj = 0; cj <= ry; cj++) {
+                    const int sy = y - dymax + cj;
+                    if ((unsigned)sy >= (unsigned)H) continue;
+                    for (int ci = 0; ci <= rx; ci++) {
+                        const int sx = x - dxmax + ci;
+                        if ((unsigned)sx >= (unsigned)W) continue;
+                        if (tg_all[sy * W + sx] == me) take(sy * W + sx);
+                    }
+                }
+            }
+        }
+        if (AGE) {
+            uint64_t a = 0;
+            if (last >= 0) {
+                a = age0[base + last] + 1;
+                a = a > t.age_cap ? t.age_cap : a;
+            }
+            age1[base + me] = a;
+        }
+        if (PROP) { depth1[base + me] = d; var1[base + me] = v; }
+    }
+}
+
+// the slot path only where the gather did not apply (see above): the three launches of launch_warp_step
+// that follow k_sd_gather test this first
+__device__ __forceinline__ bool slot_path_wanted(const int *__restrict__ rng, int track) {
+    if (rng == nullptr) return true;
+    int a, b, c, d;
+    return !gather_applies(rng, track, a, b, c, d);
+}
+
+__global__ __launch_bounds__(kBlock) void k_sd_zero_counts(int *__restrict__ cnt, int64_t stride, int N,
+                                                           const int *__restrict__ rng, int nb, int n_tracks) {
+    int track, blk;
+    if (!xcd_major_track(nb, n_tracks, track, blk)) return;
+    if (!slot_path_wanted(rng, track)) return;
+    int *c = cnt + (int64_t)track * stride;
+    for (int i = blk * kBlock + threadIdx.x; i < N; i += nb * kBlock) c[i] = 0;
 }
 
 // ---- update_depth / estimate (src/semi_dense/semi_dense.rs) ----------------------
@@ -828,23 +1063,50 @@ void fill_track_warp(TrackWarp *tw, const double *T10, const double *cam0, const
     memcpy(tw->cam1, cam1, sizeof(double) * 4);
 }
 
-// scatter + fold for n_tracks maps laid out [track][stride]
+// forward warp (increment_age and / or propagate) for n_tracks maps laid out [track][stride]: the gather path
+// where a track's displacement box allows it, scatter + fold where not (both queued; the device decides)
 template <bool AGE, bool PROP>
 tdk_status launch_warp_step(int n_tracks, int H, int W, const TrackWarp *d_tw, const uint64_t *age0,
                             const double *depth0, const double *var0, int64_t stride, double default_depth,
                             double default_variance, double bias, int *list_buf, uint64_t *age1,
-                            double *depth1, double *var1, hipStream_t stream) {
+                            double *depth1, double *var1, hipStream_t stream, unsigned int *d_fallbacks = nullptr) {
     // list_buf: kWarpListInts * stride * n_tracks ints (carve_lists); stride must be even (16-byte slot rows)
     const int N = H * W;
     const WarpLists lists = carve_lists(list_buf, stride, n_tracks);
-    TDK_HIP(hipMemsetAsync(lists.cnt, 0, sizeof(int) * (size_t)stride * n_tracks, stream));
     const int nb = grid_for(N);
     const unsigned grid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)nb;
-    k_sd_scatter<<<grid, kBlock, 0, stream>>>(H, W, d_tw, depth0, stride, lists, nb, n_tracks);
+    const char *gv = getenv("TDK_SD_GATHER");   // (read per call: the tests switch it)
+    const int use_gather = gv ? atoi(gv) : 1;
+    // the target indices alias `next`, which the slot path only writes AFTER k_sd_gather has run (and only for
+    // the tracks that fell back); the boxes have their own 4 n_tracks ints behind the lists
+    int *rng = nullptr;
+    if (use_gather) {
+        rng = lists.rng;
+        TDK_HIP(hipMemsetAsync(rng, 0x80, sizeof(int) * kRngStride * (size_t)n_tracks, stream));
+        // (depth1, variance1a) of every source: 16 bytes per pixel in the `slots` region, like `next` free until
+        // the slot path runs
+        double2 *warped = reinterpret_cast<double2 *>(lists.slots);
+        // four 64 x 4 tiles per block (measured on 64 VGA tracks: 1 / 2 / 4 / 8 / 19 / 38 tiles per block
+        // 0.761 / 0.706 / 0.684 / 0.686 / 0.733 / 0.764 ms for the whole step)
+        const int n_tiles = ((W + kGatherTW - 1) / kGatherTW) * ((H + kGatherTH - 1) / kGatherTH);
+        int gnb = std::max(1, (n_tiles + 3) / 4);
+        if (const char *v = getenv("TDK_SD_GATHER_NB")) gnb = std::max(1, atoi(v));
+        const unsigned ggrid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)gnb;
+        k_sd_targets<PROP><<<ggrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, bias, stride, lists.next, warped, rng,
+                                                          gnb, n_tracks);
+        TDK_LAUNCH_CHECK();
+        k_sd_gather<AGE, PROP><<<ggrid, kBlock, 0, stream>>>(H, W, d_tw, lists.next, warped, rng, age0, stride,
+                                                              default_depth, default_variance, bias, age1, depth1,
+                                                              var1, gnb, n_tracks, d_fallbacks);
+        TDK_LAUNCH_CHECK();
+    }
+    k_sd_zero_counts<<<grid, kBlock, 0, stream>>>(lists.cnt, stride, N, rng, nb, n_tracks);
+    TDK_LAUNCH_CHECK();
+    k_sd_scatter<<<grid, kBlock, 0, stream>>>(H, W, d_tw, depth0, stride, lists, nb, n_tracks, rng);
     TDK_LAUNCH_CHECK();
     k_sd_fold<AGE, PROP><<<grid, kBlock, 0, stream>>>(H, W, d_tw, lists, age0, depth0, var0, stride,
                                                        default_depth, default_variance, bias, age1, depth1, var1,
-                                                       nb, n_tracks);
+                                                       nb, n_tracks, rng);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
@@ -1481,6 +1743,7 @@ struct tdk_sd {
     double default_depth, default_variance, bias;
     bool params_set, have_result, result_has_flag;
     bool saturate_age;       // tdk_sd_set_age_policy
+    unsigned int *d_warp_fallbacks;   // tracks x steps whose forward warp took the slot path (tdk_sd_get_warp_fallbacks)
     hipEvent_t ev[4];
     double ms[3];
 };
@@ -1510,6 +1773,7 @@ tdk_status tdk_sd_destroy(tdk_sd *h) {
     for (int k = 0; k < 2; k++) { (void)hipFree(h->age[k]); (void)hipFree(h->depth[k]); (void)hipFree(h->var[k]); }
     (void)hipFree(h->prior_depth); (void)hipFree(h->prior_var); (void)hipFree(h->flag);
     (void)hipFree(h->warp_lists); (void)hipFree(h->list); (void)hipFree(h->count);
+    (void)hipFree(h->d_warp_fallbacks);
     (void)hipFree(h->hist); (void)hipFree(h->d_tw); (void)hipFree(h->d_keys); (void)hipFree(h->d_refs);
     (void)hipFree((void *)h->d_img_ptrs);
     if (h->stage) (void)hipHostFree(h->stage);
@@ -1560,6 +1824,8 @@ tdk_status tdk_sd_create(int n_tracks, int height, int width, int max_refframes,
     SD_ALLOC(hipMalloc(&h->prior_var, 8 * m));
     SD_ALLOC(hipMalloc(&h->flag, 8 * m));
     SD_ALLOC(hipMalloc(&h->warp_lists, warp_list_bytes(h->stride, n_tracks)));
+    SD_ALLOC(hipMalloc(&h->d_warp_fallbacks, sizeof(unsigned int)));
+    SD_ALLOC(hipMemset(h->d_warp_fallbacks, 0, sizeof(unsigned int)));
     SD_ALLOC(hipMalloc(&h->list, 4 * m));
     SD_ALLOC(hipMalloc(&h->count, sizeof(int) * ((size_t)kCountStride * n_tracks + 1)));
     h->err = h->count + (size_t)kCountStride * n_tracks;
@@ -1594,6 +1860,15 @@ tdk_status tdk_sd_set_params(tdk_sd *h, const tdk_semi_dense_params *params, dou
 tdk_status tdk_sd_set_age_policy(tdk_sd *h, int saturate) {
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     h->saturate_age = saturate != 0;
+    return TDK_OK;
+}
+
+tdk_status tdk_sd_get_warp_fallbacks(tdk_sd *h, int64_t *tracks) {
+    TDK_REQUIRE(h && tracks, "null pointer");
+    unsigned int v = 0;
+    TDK_HIP(hipMemcpyAsync(&v, h->d_warp_fallbacks, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
+    *tracks = (int64_t)v;
     return TDK_OK;
 }
 
@@ -1778,7 +2053,7 @@ tdk_status tdk_sd_step(tdk_sd *h, const double *transforms10, const double *key_
     TDK_HIP(hipEventRecord(h->ev[0], s));
     TDK_TRY((launch_warp_step<true, true>(h->n, h->H, h->W, h->d_tw, h->age[c], h->depth[c], h->var[c], h->stride,
                                           h->default_depth, h->default_variance, h->bias, h->warp_lists,
-                                          h->age[o], h->prior_depth, h->prior_var, s)));
+                                          h->age[o], h->prior_depth, h->prior_var, s, h->d_warp_fallbacks)));
     TDK_HIP(hipEventRecord(h->ev[1], s));
     TDK_TRY(launch_update_depth(h->n, h->H, h->W, h->d_keys, h->d_refs, h->R, h->age[o], h->prior_depth,
                                 h->prior_var, h->stride, est_params(&h->params), h->list, h->count, h->err,
@@ -1797,7 +2072,7 @@ tdk_status tdk_sd_propagate(tdk_sd *h, const double *transforms10, int commit) {
     TDK_HIP(hipEventRecord(h->ev[0], s));
     TDK_TRY((launch_warp_step<true, true>(h->n, h->H, h->W, h->d_tw, h->age[c], h->depth[c], h->var[c], h->stride,
                                           h->default_depth, h->default_variance, h->bias, h->warp_lists,
-                                          h->age[o], h->depth[o], h->var[o], s)));
+                                          h->age[o], h->depth[o], h->var[o], s, h->d_warp_fallbacks)));
     TDK_HIP(hipEventRecord(h->ev[1], s));
     TDK_HIP(hipEventRecord(h->ev[2], s));
     return sd_finish(h, false, nullptr, o, commit);

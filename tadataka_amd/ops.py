@@ -853,6 +853,12 @@ class SemiDenseSession(object):
         TdkError(TDK_ERR_AGE_EXCEEDS_REFFRAMES) -- for good, so size the ring for the track."""
         call("tdk_sd_set_age_policy", self._h, int(bool(saturate)))
 
+    def warp_fallbacks(self):
+        """(track, step) forward warps of this session that took the slot path instead of the gather."""
+        v = C.c_int64()
+        call("tdk_sd_get_warp_fallbacks", self._h, C.byref(v))
+        return int(v.value)
+
     def set_params(self, params, default_depth, default_variance, uncertaintity_bias):
         call("tdk_sd_set_params", self._h, C.byref(params), float(default_depth), float(default_variance),
              float(uncertaintity_bias))

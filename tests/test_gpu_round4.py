@@ -369,3 +369,74 @@ def test_bench_dry_ranks_runs_the_multi_rank_bookkeeping():
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["config"]["height"] == 720 and out["config"]["levels"] == 1 and out["config"]["max_iter"] == 2
     assert out["config"]["name"].startswith("cfg4")
+
+
+# ---------------------------------------------------------------------------
+# the forward warp as a gather (k_sd_targets / k_sd_gather) against the slot path and the oracle
+# ---------------------------------------------------------------------------
+def _warp_case(H, W, seed, kind):
+    """Maps and a transform: 'stereo' = SURVEY cfg3's x-baseline (disparity spread ~20 px, no y motion),
+    'motion' = a small general motion (box of a few pixels in both axes), 'zoom' = a strong zoom-out that
+    folds many sources onto every target (box far beyond the gather's window: the slot path)."""
+    from tadataka_amd import synthetic
+    c = synthetic.make_semi_dense_case(H, W, seed=seed, valid_fraction=0.5)
+    rng = np.random.default_rng(seed)
+    T10 = np.eye(4)
+    if kind == "stereo":
+        T10 = np.linalg.inv(c["T_wr"]) @ c["T_wk"]
+    elif kind == "motion":
+        T10[:3, :3] = synthetic.rodrigues(rng.uniform(-0.01, 0.01, 3))
+        T10[:3, 3] = rng.uniform(-0.03, 0.03, 3)
+    else:
+        T10[2, 3] = 4.0
+    age0 = rng.integers(0, 4, (H, W)).astype(np.uint64)
+    var0 = rng.uniform(0.01, 0.2, (H, W))
+    return c, T10, age0, var0
+
+
+@pytest.mark.parametrize("kind", ["stereo", "motion", "zoom"])
+@pytest.mark.parametrize("shape", [(480, 640), (97, 131), (60, 64)])
+def test_forward_warp_gather_equals_slot_path_and_oracle(ops, orc, monkeypatch, kind, shape):
+    """increment_age and propagate: the gather path (default), the slot path (TDK_SD_GATHER=0) and the
+    oracle give the same bits -- for a stereo baseline, a small general motion and a zoom-out whose
+    displacement box exceeds the gather's window (there the default path IS the slot path: it falls back
+    on the device); frame sizes that are not multiples of the 64 x 4 tiles included."""
+    H, W = shape
+    c, T10, age0, var0 = _warp_case(H, W, 31, kind)
+    cam = c["cam"]
+    want_age = orc.increment_age(age0, cam, cam, T10, c["prior_depth"])
+    want_d, want_v = orc.propagate(T10, cam, cam, c["prior_depth"], var0, 1.0, 10.0, 0.01)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("TDK_SD_GATHER", mode)
+        got_age = ops.increment_age(age0, cam, cam, T10, c["prior_depth"])
+        got_d, got_v = ops.propagate(T10, cam, cam, c["prior_depth"], var0, 1.0, 10.0, 0.01)
+        assert np.array_equal(got_age, want_age), (mode, kind)
+        assert np.array_equal(got_d, want_d) and np.array_equal(got_v, want_v), (mode, kind)
+    assert int((want_age > 0).sum()) > 0
+
+
+def test_session_counts_warp_fallbacks(ops, orc, monkeypatch):
+    """The session's fused increment_age + propagate: tracks with a small displacement box take the gather,
+    a track with a zoom-out takes the slot path in the same launch; both bit-exact, the counter says which."""
+    monkeypatch.delenv("TDK_SD_GATHER", raising=False)
+    H, W, n = 96, 128, 3
+    pargs = (0.5, 10.0, 0.01, 0.01, 0.004, 0.01)
+    sd = ops.SemiDenseSession(n, H, W, max_refframes=2)
+    sd.set_age_policy(False)
+    sd.set_params(ops.make_params(*pargs), 1.0, 10.0, 0.01)
+    cases, T10s = [], []
+    for t, kind in enumerate(("stereo", "zoom", "motion")):
+        c, T10, age0, var0 = _warp_case(H, W, 40 + t, kind)
+        sd.push_frame(t, c["cam"], c["ref_image"], c["T_wr"])
+        sd.push_frame(t, c["cam"], c["key_image"], c["T_wk"])
+        sd.set_maps(t, c["prior_depth"], var0, age0)
+        cases.append((c, age0, var0)); T10s.append(T10)
+    assert sd.warp_fallbacks() == 0
+    sd.propagate(np.array(T10s), commit=False)
+    assert sd.warp_fallbacks() == 1                      # the zoom-out track
+    for t, (c, age0, var0) in enumerate(cases):
+        d1, v1, a1 = sd.get_results(t, with_flag=False)
+        assert np.array_equal(a1, orc.increment_age(age0, c["cam"], c["cam"], T10s[t], c["prior_depth"]))
+        od, ov = orc.propagate(T10s[t], c["cam"], c["cam"], c["prior_depth"], var0, 1.0, 10.0, 0.01)
+        assert np.array_equal(d1, od) and np.array_equal(v1, ov)
+    sd.close()
