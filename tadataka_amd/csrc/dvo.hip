@@ -1865,8 +1865,10 @@ __global__ __launch_bounds__(kBlock) void k_tukey_deviations(const double *__res
 // ---------------------------------------------------------------------------
 constexpr int kStudentPts = 9, kStudentSums = 3 * kStudentPts;
 constexpr int kStudentRow = kStudentPts + 1;   // expansion points of a pair + its "one more pass" flag
-// pass B moved a step's expansion point by more than this (relative): its remainder, at most (nu + 1) (d / v)^3,
-// may exceed 1e-14 -> the pair takes a third pass around the iterates of pass B.  Pass A lands within that
+// pass B moved a step's expansion point by more than this (relative): its remainder, bounded by
+// (nu + 1) (d / v)^3 = 6 * (1e-4)^3 = 6e-12 relative at the threshold (far below the 1e-6 bar on the pose, and
+// what the tests hold the variance to is 1e-12 at the d ~ 1e-5 that pass A actually leaves), may no longer be
+// negligible -> the pair takes a third pass around the iterates of pass B.  Pass A lands within the threshold
 // unless the sample estimate was more than ~8 % off.
 constexpr double kStudentRedo = 1e-4;
 
