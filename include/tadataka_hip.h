@@ -375,14 +375,16 @@ tdk_status tdk_rgb2gray_u8(const uint8_t *rgb, int height, int width, int channe
  * unused reference frames") while increment_age lets ages grow without bound (age.rs:28).  With
  * a bounded ring a pixel tracked for more than max_refframes steps would ask for a frame that is
  * gone.  tdk_sd_set_age_policy chooses what happens then:
- *   saturate = 1 (default)  increment_age saturates at the number of reference frames the next
- *                           update_depth will see, min(frames - 1, max_refframes): such a pixel
- *                           keeps using the OLDEST frame of the ring.  Identical to the reference
- *                           for every track of at most max_refframes + 1 frames.
- *   saturate = 0            ages are not limited; a step in which some age exceeds the ring fails
+ *   saturate = 0 (default since round 4: the reference's behaviour)
+ *                           ages are not limited; a step in which some age exceeds the ring fails
  *                           with TDK_ERR_AGE_EXCEEDS_REFFRAMES (what update_depth does when
  *                           age > len(refframes), semi_dense.rs:202-205) and commits nothing --
- *                           every later step fails too, so size max_refframes for the whole track. */
+ *                           every later step fails too, so size max_refframes for the whole track.
+ *   saturate = 1 (opt-in)   increment_age saturates at the number of reference frames the next
+ *                           update_depth will see, min(frames - 1, max_refframes): such a pixel
+ *                           keeps using the OLDEST frame of the ring -- results then differ from the
+ *                           reference's for tracks longer than max_refframes + 1 frames (identical
+ *                           up to there). */
 typedef struct tdk_sd tdk_sd;
 tdk_status tdk_sd_create(int n_tracks, int height, int width, int max_refframes, tdk_sd **out);
 tdk_status tdk_sd_set_age_policy(tdk_sd *h, int saturate);

@@ -45,7 +45,15 @@ tdk_status ensure_device() {
     return TDK_OK;
 }
 
+static void (*g_release_hooks[8])() = {};
+static int g_n_release_hooks = 0;
+
+void on_device_release(void (*hook)()) {
+    if (g_n_release_hooks < 8) g_release_hooks[g_n_release_hooks++] = hook;
+}
+
 static void release_pools() {
+    for (int i = 0; i < g_n_release_hooks; i++) g_release_hooks[i]();
     for (int i = 0; i < kScratchSlots; i++) {
         if (g_scratch[i]) (void)hipFree(g_scratch[i]);
         if (g_pinned[i]) (void)hipHostFree(g_pinned[i]);

@@ -1362,12 +1362,15 @@ struct MapPool {
 };
 MapPool g_map_pool;
 constexpr size_t kMapPoolMax = 48;
+constexpr size_t kMapPoolMaxBytes = (size_t)1 << 30;   // ... and at most 1 GiB parked (48 maps of a 4K frame would be 3 GB)
+size_t g_map_pool_bytes = 0;
 
 tdk_status map_alloc(size_t bytes, void **out) {
     for (size_t i = g_map_pool.free_list.size(); i-- > 0;)
         if (g_map_pool.free_list[i].first == bytes) {
             *out = g_map_pool.free_list[i].second;
             g_map_pool.free_list.erase(g_map_pool.free_list.begin() + (long)i);
+            g_map_pool_bytes -= bytes;
             return TDK_OK;
         }
     TDK_HIP(hipMalloc(out, bytes));
@@ -1375,8 +1378,9 @@ tdk_status map_alloc(size_t bytes, void **out) {
 }
 
 void map_release(size_t bytes, void *p) {
-    if (g_map_pool.free_list.size() < kMapPoolMax) {
+    if (g_map_pool.free_list.size() < kMapPoolMax && g_map_pool_bytes + bytes <= kMapPoolMaxBytes) {
         g_map_pool.free_list.emplace_back(bytes, p);
+        g_map_pool_bytes += bytes;
         return;
     }
     (void)hipStreamSynchronize(tdk::stream());
@@ -1394,6 +1398,26 @@ struct StageRing {
     int next = 0;
 };
 StageRing g_ring;
+
+// tdk_set_device leaves the device these belong to: parked maps are freed (a later map_alloc must not hand out a
+// buffer of the previous device), the ring's pinned block and events go (they were recorded on that device's stream)
+void release_map_state() {
+    (void)hipStreamSynchronize(tdk::stream());
+    for (auto &e : g_map_pool.free_list) (void)hipFree(e.second);
+    g_map_pool.free_list.clear();
+    g_map_pool_bytes = 0;
+    if (g_ring.base) {
+        for (int i = 0; i < kRingSlots; i++) {
+            if (g_ring.pending[i]) (void)hipEventSynchronize(g_ring.ev[i]);
+            (void)hipEventDestroy(g_ring.ev[i]);
+            g_ring.pending[i] = false;
+        }
+        (void)hipHostFree(g_ring.base);
+        g_ring.base = nullptr;
+        g_ring.next = 0;
+    }
+}
+const bool g_release_registered = (tdk::on_device_release(release_map_state), true);
 
 tdk_status h2d_small(int slot, const void *host, size_t bytes, void **dev) {
     if (bytes > kRingBytes) {   // e.g. thousands of reference frames: plain copy, then wait
@@ -1796,7 +1820,7 @@ tdk_status tdk_sd_create(int n_tracks, int height, int width, int max_refframes,
     h->stride = ((int64_t)h->N + 1) & ~1ll;
     h->cur = 0; h->result_buf = 0;
     h->params_set = false; h->have_result = false; h->result_has_flag = false;
-    h->saturate_age = true;   // see tdk_sd_set_age_policy
+    h->saturate_age = false;  // the reference's rule; saturation is opt-in (tdk_sd_set_age_policy)
     h->n_frames.assign((size_t)n_tracks, 0);
     h->cams.assign((size_t)n_tracks * (h->R + 1) * 4, 0.0);
     h->Twf.assign((size_t)n_tracks * (h->R + 1) * 16, 0.0);

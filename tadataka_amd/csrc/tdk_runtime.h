@@ -70,6 +70,10 @@ struct DvoLevel0 {
 };
 tdk_status dvo_level0(tdk_dvo *h, DvoLevel0 *out);
 
+// Other translation units keep process-wide device state of their own (the map pool and the staging ring of
+// semi_dense.hip); a hook registered here runs when tdk_set_device leaves a device, BEFORE its streams go away.
+void on_device_release(void (*hook)());
+
 }  // namespace tdk
 
 #define TDK_HIP(call)                                                                   \

@@ -846,11 +846,12 @@ class SemiDenseSession(object):
             pass
 
     def set_age_policy(self, saturate):
-        """True (default): ages saturate at the ring size (a pixel tracked for longer than
-        max_refframes steps keeps using the oldest retained frame; identical to the reference for
-        tracks of at most max_refframes + 1 frames).  False: ages grow without bound as in
+        """False (default, the reference's rule): ages grow without bound as in
         src/semi_dense/age.rs:28 and a step whose ages exceed the ring raises
-        TdkError(TDK_ERR_AGE_EXCEEDS_REFFRAMES) -- for good, so size the ring for the track."""
+        TdkError(TDK_ERR_AGE_EXCEEDS_REFFRAMES) -- for good, so size the ring for the track.
+        True (opt-in): ages saturate at the ring size (a pixel tracked for longer than
+        max_refframes steps keeps using the oldest retained frame; identical to the reference for
+        tracks of at most max_refframes + 1 frames, different beyond)."""
         call("tdk_sd_set_age_policy", self._h, int(bool(saturate)))
 
     def warp_fallbacks(self):
