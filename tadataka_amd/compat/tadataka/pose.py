@@ -15,14 +15,38 @@ min_correspondences = 6
 
 
 class Pose(object):
+    """`rotation` (a SciPy Rotation, as in the reference) is built on first access when the pose came
+    from a rotation MATRIX -- every result of the device loop does, and constructing a Rotation costs
+    ~25 us, a sixth of a 640x480 estimation."""
+
     def __init__(self, rotation, translation):
         assert(isinstance(rotation, Rotation))
-        self.rotation = rotation
+        self._rotation = rotation
+        self._R = None
         self.t = translation
+
+    @classmethod
+    def _from_R(cls, R, t):
+        obj = cls.__new__(cls)
+        obj._rotation = None
+        obj._R = R
+        obj.t = t
+        return obj
+
+    @property
+    def rotation(self):
+        if self._rotation is None:
+            self._rotation = Rotation.from_matrix(self._R)
+        return self._rotation
+
+    @rotation.setter
+    def rotation(self, value):
+        assert(isinstance(value, Rotation))
+        self._rotation, self._R = value, None
 
     @property
     def R(self):
-        return self.rotation.as_matrix()
+        return self._R.copy() if self._R is not None else self._rotation.as_matrix()
 
     @property
     def T(self):
@@ -35,7 +59,7 @@ class Pose(object):
 
     @classmethod
     def identity(cls):
-        return cls(Rotation.from_rotvec(np.zeros(3)), np.zeros(3))
+        return cls._from_R(np.eye(3), np.zeros(3))
 
     @classmethod
     def from_se3(cls, xi):
@@ -46,8 +70,8 @@ class Pose(object):
         """From a 4x4 (or 12-double {R, t}) rigid motion, e.g. a device result."""
         T = np.asarray(T, dtype=np.float64)
         if T.size == 12:
-            return cls(Rotation.from_matrix(T[:9].reshape(3, 3)), T[9:].copy())
-        return cls(Rotation.from_matrix(T[0:3, 0:3]), T[0:3, 3].copy())
+            return cls._from_R(T[:9].reshape(3, 3).copy(), T[9:].copy())
+        return cls._from_R(T[0:3, 0:3].copy(), T[0:3, 3].copy())
 
     def inv(self):
         return Pose(*convert_coordinate(self.rotation, self.t))

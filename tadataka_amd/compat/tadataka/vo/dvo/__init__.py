@@ -96,7 +96,12 @@ def _fused_mode(weights):
     return ops.WEIGHT_MODES[weights]      # None / "huber" / "student-t" / "tukey"
 
 
+_IDENTITY12 = ops.pose12(np.eye(3), np.zeros(3))[None]
+
+
 def _pose12(pose):
+    if pose is None:
+        return _IDENTITY12
     return ops.pose12(pose.R, pose.t)[None]
 
 
@@ -179,7 +184,6 @@ class PoseChangeEstimator(object):
         assert(np.ndim(D0) == 2)
         assert(np.ndim(I1) == 2)
         _check_weights_name(weights)
-        pose10 = Pose.identity() if pose10 is None else pose10
         has_map = _is_map(weights)
         batch = _batch_for(I0.shape, self.n_coarse_to_fine, self.layer_size_ratio, has_map)
         batch.upload(0, I0, D0, I1, weights if has_map else None)

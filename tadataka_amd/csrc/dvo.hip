@@ -2259,7 +2259,8 @@ void plan_blocks(const tdk_dvo *h, const tdk_dvo::Level &L, int *nblk, int64_t *
     // flat (+-0.5 %) from 12 to 40 pixels per thread on the bench workload
     // -- unless the batch is so small that this would leave CUs without a block
     // (a single pair): then down to 4 pixels per thread, aiming at >= 512 blocks
-    int64_t px_per_thread = L.N * h->n_pairs / (512 * (int64_t)kBlock);
+    static const int64_t target_blocks = [] { const char *v = getenv("TDK_DVO_TARGET_BLOCKS"); return v && atoll(v) > 0 ? atoll(v) : 512ll; }();
+    int64_t px_per_thread = L.N * h->n_pairs / (target_blocks * (int64_t)kBlock);
     static const int64_t min_px = [] { const char *v = getenv("TDK_DVO_MIN_PX"); return v ? atoll(v) : 4ll; }();
     px_per_thread = px_per_thread < min_px ? min_px : (px_per_thread > 16 ? 16 : px_per_thread);
     int64_t per_block = (int64_t)kBlock * px_per_thread;
