@@ -328,28 +328,43 @@ __global__ __launch_bounds__(kBlock) void k_sd_targets(int H, int W, const Track
     const int tiles_x = (W + kGatherTW - 1) / kGatherTW, tiles_y = (H + kGatherTH - 1) / kGatherTH;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     int ndx = -0x7fffffff, ndy = -0x7fffffff, mdx = -0x7fffffff, mdy = -0x7fffffff;
-    for (int tile = blk; tile < tiles_x * tiles_y; tile += nb) {
-        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-        const int x0 = txi * kGatherTW + lx, y0 = tyi * kGatherTH + ly;
-        if (x0 >= W || y0 >= H) continue;
-        const int i = y0 * W + x0;
-        double ux, uy, d1;
-        tdk::perspective_warp(t.T10, c0, c1, (double)x0, (double)y0, d0[i], ux, uy, d1);
-        int out = -1;
-        if (tdk::in_range(ux, uy, H, W)) {
-            const int tx = (int)ux, ty = (int)uy;   // `as usize`: truncation
-            out = ty * W + tx;
-            ndx = max(ndx, x0 - tx); mdx = max(mdx, tx - x0);
-            ndy = max(ndy, y0 - ty); mdy = max(mdy, ty - y0);
-            // propagate: the source's hypothesis in the new frame, computed HERE, where every lane has one --
-            // in the gather the targets of a wave have 1 - 4 sources each and the warp arithmetic would run
-            // for the busiest lane's count with most lanes idle
-            if (PROP) {
-                const double d0i = d0[i];
-                warped[(int64_t)track * stride + i] = make_double2(d1, propagate_variance(d0i, d1, var0[(int64_t)track * stride + i], bias));
-            }
+    const double *__restrict__ v0 = var0 + (int64_t)track * stride;
+    const int n_tiles = tiles_x * tiles_y;
+    // four tiles per round: their eight loads are issued before the first warp is computed
+    for (int tile0 = blk; tile0 < n_tiles; tile0 += 4 * nb) {
+        int xs[4], ys[4];
+        double dd[4], vv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int tile = tile0 + k * nb;
+            const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+            xs[k] = txi * kGatherTW + lx; ys[k] = tyi * kGatherTH + ly;
+            const bool ok = tile < n_tiles && xs[k] < W && ys[k] < H;
+            if (!ok) xs[k] = -1;
+            const int i = ok ? ys[k] * W + xs[k] : 0;
+            dd[k] = d0[i];
+            vv[k] = PROP ? v0[i] : 0.0;
         }
-        tg[i] = out;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (xs[k] < 0) continue;
+            const int x0 = xs[k], y0 = ys[k], i = y0 * W + x0;
+            double ux, uy, d1;
+            tdk::perspective_warp(t.T10, c0, c1, (double)x0, (double)y0, dd[k], ux, uy, d1);
+            int out = -1;
+            if (tdk::in_range(ux, uy, H, W)) {
+                const int tx = (int)ux, ty = (int)uy;   // `as usize`: truncation
+                out = ty * W + tx;
+                ndx = max(ndx, x0 - tx); mdx = max(mdx, tx - x0);
+                ndy = max(ndy, y0 - ty); mdy = max(mdy, ty - y0);
+                // propagate: the source's hypothesis in the new frame, computed HERE, where every lane has one --
+                // in the gather the targets of a wave have 1 - 4 sources each and the warp arithmetic would run
+                // for the busiest lane's count with most lanes idle
+                if (PROP)
+                    warped[(int64_t)track * stride + i] = make_double2(d1, propagate_variance(dd[k], d1, vv[k], bias));
+            }
+            tg[i] = out;
+        }
     }
     // the track's box: wave maxima, one atomic per wave and bound
 #pragma unroll
