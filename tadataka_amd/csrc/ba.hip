@@ -338,9 +338,43 @@ __global__ __launch_bounds__(kBlock) void k_ba_point_sums(const int64_t *__restr
     }
 }
 
-// inverse of the damped symmetric 3x3 V (upper triangle in, upper triangle out)
+// W_ij = A_ij^T B_ij from the parameters instead of from memory (round 4).  The Schur complement and the
+// back-substitution used to READ W (18 doubles per observation, written by the block reduce): 58 MB written
+// and twice 58 MB read per damping trial of the 8 x 50 000 window, ~35 us of a 120 us trial at HBM speed --
+// while recomputing the two Jacobians of an observation is ~300 FP64 operations, 3 us for all 400 000.  So the
+// reduce stores only B (for the per-point sums) and these kernels rebuild W where they need it, with the
+// pose-only part of the Rodrigues formula precomputed per pose (rod8: A, B, dA, dB, th[3]) by the first block
+// of k_ba_invert_V, which runs before both.  TDK_BA_W=stored keeps the stored W (and is what the pair-wise
+// and general Schur kernels always use).
+__device__ __forceinline__ void recompute_W(const double *__restrict__ poses, const double *__restrict__ rod8, int j,
+                                            const double *__restrict__ points, int64_t i, double *W) {
+    double pose[6], p[3], x[2], A[12], B[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) pose[k] = poses[6 * j + k];
+    Rod c;
+    c.A = rod8[8 * j]; c.B = rod8[8 * j + 1]; c.dA = rod8[8 * j + 2]; c.dB = rod8[8 * j + 3];
+    c.th[0] = rod8[8 * j + 4]; c.th[1] = rod8[8 * j + 5]; c.th[2] = rod8[8 * j + 6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) p[k] = points[3 * i + k];
+    project_observation<true>(pose, c, p, x, A, B);
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) W[3 * a + b] = A[a] * B[b] + A[6 + a] * B[3 + b];
+}
+
+// inverse of the damped symmetric 3x3 V (upper triangle in, upper triangle out); block 0 also leaves the
+// pose-only Rodrigues coefficients of the CURRENT poses for the kernels that rebuild W (rod8 != nullptr)
 __global__ __launch_bounds__(kBlock) void k_ba_invert_V(const double *__restrict__ V, double mu, int64_t n_points,
-                                                        double *__restrict__ Vinv) {
+                                                        double *__restrict__ Vinv, const double *__restrict__ poses,
+                                                        int n_poses, double *__restrict__ rod8) {
+    if (rod8 != nullptr && blockIdx.x == 0 && (int)threadIdx.x < n_poses) {
+        double w[3] = {poses[6 * threadIdx.x], poses[6 * threadIdx.x + 1], poses[6 * threadIdx.x + 2]};
+        Rod c;
+        rodrigues_coeffs(w, c);
+        double *o = rod8 + 8 * threadIdx.x;
+        o[0] = c.A; o[1] = c.B; o[2] = c.dA; o[3] = c.dB; o[4] = c.th[0]; o[5] = c.th[1]; o[6] = c.th[2]; o[7] = 0.0;
+    }
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n_points; i += (int64_t)gridDim.x * kBlock) {
         const int64_t Q = n_points;
         double a = V[i] + mu, b = V[Q + i], c = V[2 * Q + i];
@@ -468,13 +502,16 @@ constexpr int kSchurK = 3 * kSchurPC;          // columns of Z per chunk
 constexpr int kSchurPitch = kSchurK + 4;       // 100 doubles: the 64 operand lanes spread over all banks, 2 per bank
 typedef double schur_acc_t __attribute__((ext_vector_type(4)));
 
-template <int RB>
+template <int RB, bool RECOMP>
 __global__ __launch_bounds__(kBlock) void k_ba_schur_mfma(const int *__restrict__ obs_at,
                                                           const double *__restrict__ Wobs,
                                                           const double *__restrict__ Vinv,
                                                           const double *__restrict__ eb, int64_t n,
                                                           int64_t n_points, int n_poses, int n_chunks,
-                                                          double *__restrict__ partials) {
+                                                          double *__restrict__ partials,
+                                                          const double *__restrict__ poses,
+                                                          const double *__restrict__ rod8,
+                                                          const double *__restrict__ points) {
     constexpr int kTiles = RB * (RB + 1) / 2;
     constexpr int kRows = 16 * RB;
     __shared__ double Zs[kRows * kSchurPitch];
@@ -505,9 +542,13 @@ __global__ __launch_bounds__(kBlock) void k_ba_schur_mfma(const int *__restrict_
                 const double u0 = v00 * b0 + v01 * b1 + v02 * b2;   // V*^-1 e_b
                 const double u1 = v01 * b0 + v11 * b1 + v12 * b2;
                 const double u2 = v02 * b0 + v12 * b1 + v22 * b2;
+                double Wr[18];
+                if (RECOMP) recompute_W(poses, rod8, j, points, i, Wr);
 #pragma unroll
                 for (int a = 0; a < 6; a++) {
-                    const double w0 = Wobs[(3 * a) * n + ko], w1 = Wobs[(3 * a + 1) * n + ko], w2 = Wobs[(3 * a + 2) * n + ko];
+                    const double w0 = RECOMP ? Wr[3 * a] : Wobs[(3 * a) * n + ko];
+                    const double w1 = RECOMP ? Wr[3 * a + 1] : Wobs[(3 * a + 1) * n + ko];
+                    const double w2 = RECOMP ? Wr[3 * a + 2] : Wobs[(3 * a + 2) * n + ko];
                     double *z = &Zs[(6 * j + a) * kSchurPitch + 3 * il];
                     z[0] = w0 * l00 + w1 * l10 + w2 * l20;
                     z[1] = w1 * l11 + w2 * l21;
@@ -663,6 +704,7 @@ __global__ __launch_bounds__(kBlock) void k_ba_schur(const int64_t *__restrict__
     }
 }
 
+template <bool RECOMP>
 __global__ __launch_bounds__(kBlock) void k_ba_backsub(const int64_t *__restrict__ row_ptr,
                                                        const int64_t *__restrict__ obs_of_point,
                                                        const int64_t *__restrict__ vp,
@@ -671,18 +713,32 @@ __global__ __launch_bounds__(kBlock) void k_ba_backsub(const int64_t *__restrict
                                                        const double *__restrict__ eb,
                                                        const double *__restrict__ da, int64_t n,
                                                        int64_t n_points, const double *__restrict__ points,
-                                                       double *__restrict__ db, double *__restrict__ cpoints) {
+                                                       double *__restrict__ db, double *__restrict__ cpoints,
+                                                       const double *__restrict__ poses,
+                                                       const double *__restrict__ rod8) {
     const int64_t Q = n_points;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n_points; i += (int64_t)gridDim.x * kBlock) {
         double g[3] = {eb[i], eb[Q + i], eb[2 * Q + i]};
         for (int64_t pa = row_ptr[i]; pa < row_ptr[i + 1]; pa++) {
             const int64_t k = obs_of_point[pa];
-            const double *d = da + 6 * vp[k];
+            const int jp = (int)vp[k];
+            const double *d = da + 6 * jp;
+            if (RECOMP) {
+                double Wr[18];
+                recompute_W(poses, rod8, jp, points, i, Wr);
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
-                g[0] -= Wobs[(3 * r) * n + k] * d[r];
-                g[1] -= Wobs[(3 * r + 1) * n + k] * d[r];
-                g[2] -= Wobs[(3 * r + 2) * n + k] * d[r];
+                for (int r = 0; r < 6; r++) {
+                    g[0] -= Wr[3 * r] * d[r];
+                    g[1] -= Wr[3 * r + 1] * d[r];
+                    g[2] -= Wr[3 * r + 2] * d[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+                    g[0] -= Wobs[(3 * r) * n + k] * d[r];
+                    g[1] -= Wobs[(3 * r + 1) * n + k] * d[r];
+                    g[2] -= Wobs[(3 * r + 2) * n + k] * d[r];
+                }
             }
         }
         const double v[6] = {Vinv[i], Vinv[Q + i], Vinv[2 * Q + i], Vinv[3 * Q + i], Vinv[4 * Q + i], Vinv[5 * Q + i]};
@@ -928,6 +984,7 @@ struct tdk_ba {
     int *d_obs_at;      // [n_poses][n_points] observation index or -1; NULL -> atomics fallback
     double *d_spart;    // [pairs][point chunks][kSchurAccPad]
     double *d_mpart;    // [mfma_blocks][tiles * 256 + 64] partials of k_ba_schur_mfma (NULL: more than 8 poses)
+    double *d_rod;      // [n_poses][8] pose-only Rodrigues coefficients of the current poses (recompute_W)
     int mfma_blocks;
     int64_t pchunk, npchunks;
 };
@@ -968,6 +1025,15 @@ void ba_collect_profile(tdk_ba *h) {
     h->ev_used = 0;
 }
 
+// W_ij rebuilt from the parameters by the Schur / back-substitution kernels instead of stored by the reduce:
+// whenever the MFMA Schur kernel applies (windows of up to 8 poses with a dense observation table), unless
+// TDK_BA_W=stored or TDK_BA_SCHUR=pairs ask for the stored form (the other Schur kernels read W from memory)
+bool ba_recompute_w(const tdk_ba *h) {
+    static const bool stored = [] { const char *v = getenv("TDK_BA_W"); return v && !strcmp(v, "stored"); }();
+    static const bool no_mfma = [] { const char *v = getenv("TDK_BA_SCHUR"); return v && !strcmp(v, "pairs"); }();
+    return !stored && !no_mfma && h->d_obs_at != nullptr && h->d_mpart != nullptr;
+}
+
 // what a reduce computes at parameters that are already on the device
 enum { REDUCE_ERROR = 0, REDUCE_SUMS = 1, REDUCE_STEP = 2 };
 //   REDUCE_ERROR: the residual sum only
@@ -984,6 +1050,7 @@ tdk_status ba_reduce_launch(tdk_ba *h, const double *d_poses, const double *d_po
                             h->d_ticket, into.U, into.ea, h->d_err, tdk::stream())
         if (what == REDUCE_ERROR) BA_LAUNCH(MODE_ERROR);
         else if (what == REDUCE_SUMS) BA_LAUNCH(MODE_STORE_B);
+        else if (ba_recompute_w(h)) BA_LAUNCH(MODE_STORE_B);   // W is rebuilt where it is needed (recompute_W)
         else BA_LAUNCH(MODE_STORE_BW);
 #undef BA_LAUNCH
         TDK_LAUNCH_CHECK();
@@ -1366,10 +1433,12 @@ __global__ void k_ba_add(const double *__restrict__ a, const double *__restrict_
 tdk_status ba_update_launch(tdk_ba *h, double mu) {
     const int dim = (int)(6 * h->n_poses);
     const int gp = grid_for(h->n_points);
-    k_ba_invert_V<<<gp, kBlock, 0, tdk::stream()>>>(h->cur.V, mu, h->n_points, h->d_Vinv);
-    TDK_LAUNCH_CHECK();
     static const bool no_mfma = [] { const char *v = getenv("TDK_BA_SCHUR"); return v && !strcmp(v, "pairs"); }();
     const bool mfma = h->d_obs_at != nullptr && h->d_mpart != nullptr && !no_mfma;
+    const bool recomp = ba_recompute_w(h);
+    k_ba_invert_V<<<gp, kBlock, 0, tdk::stream()>>>(h->cur.V, mu, h->n_points, h->d_Vinv, h->d_poses, (int)h->n_poses,
+                                                    recomp ? h->d_rod : nullptr);
+    TDK_LAUNCH_CHECK();
     if (!mfma) {   // the other kernels accumulate into S and e; the MFMA finish writes every entry
         TDK_HIP(hipMemsetAsync(h->d_S, 0, (size_t)dim * dim * 8, tdk::stream()));
         TDK_HIP(hipMemsetAsync(h->d_e, 0, (size_t)dim * 8, tdk::stream()));
@@ -1383,8 +1452,12 @@ tdk_status ba_update_launch(tdk_ba *h, double mu) {
         const int nb = n_chunks < h->mfma_blocks ? n_chunks : h->mfma_blocks;
 #define BA_SCHUR_MFMA(RBV)                                                                                         \
     do {                                                                                                           \
-        k_ba_schur_mfma<RBV><<<nb, kBlock, 0, tdk::stream()>>>(h->d_obs_at, h->cur.W, h->d_Vinv, h->cur.eb, h->n,   \
-                                                               h->n_points, (int)h->n_poses, n_chunks, h->d_mpart); \
+        if (recomp)                                                                                               \
+            k_ba_schur_mfma<RBV, true><<<nb, kBlock, 0, tdk::stream()>>>(h->d_obs_at, h->cur.W, h->d_Vinv, h->cur.eb, \
+                h->n, h->n_points, (int)h->n_poses, n_chunks, h->d_mpart, h->d_poses, h->d_rod, h->d_points);      \
+        else                                                                                                      \
+            k_ba_schur_mfma<RBV, false><<<nb, kBlock, 0, tdk::stream()>>>(h->d_obs_at, h->cur.W, h->d_Vinv, h->cur.eb, \
+                h->n, h->n_points, (int)h->n_poses, n_chunks, h->d_mpart, nullptr, nullptr, nullptr);              \
         constexpr int per = RBV * (RBV + 1) / 2 * 256 + 64;                                                        \
         k_ba_schur_mfma_finish<RBV><<<(per + 31) / 32, kBlock, 0, tdk::stream()>>>(h->d_mpart, nb, dim,           \
                                                                                               h->d_S, h->d_e);    \
@@ -1455,8 +1528,14 @@ tdk_status ba_update_launch(tdk_ba *h, double mu) {
     }
     {
         BaTimer t(h, BA_K_BACKSUB);
-        k_ba_backsub<<<gp, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->cur.W, h->d_Vinv, h->cur.eb,
-                                                       h->d_da, h->n, h->n_points, h->d_points, h->d_db, h->d_cpoints);
+        if (recomp)
+            k_ba_backsub<true><<<gp, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->cur.W, h->d_Vinv,
+                                                                 h->cur.eb, h->d_da, h->n, h->n_points, h->d_points,
+                                                                 h->d_db, h->d_cpoints, h->d_poses, h->d_rod);
+        else
+            k_ba_backsub<false><<<gp, kBlock, 0, tdk::stream()>>>(h->d_row_ptr, h->d_obs, h->d_vp, h->cur.W, h->d_Vinv,
+                                                                  h->cur.eb, h->d_da, h->n, h->n_points, h->d_points,
+                                                                  h->d_db, h->d_cpoints, nullptr, nullptr);
     }
     TDK_LAUNCH_CHECK();
     return TDK_OK;
@@ -1563,6 +1642,7 @@ static tdk_status ba_allocate(tdk_ba *h, int64_t n_poses, int64_t n_points, cons
     // dense (pose, point) -> observation table for the pair-wise Schur kernel:
     // only when it is small (local BA windows) and no observation is repeated
     h->d_obs_at = nullptr; h->d_spart = nullptr; h->d_mpart = nullptr; h->mfma_blocks = 0;
+    TDK_HIP(hipMalloc(&h->d_rod, (size_t)n_poses * 8 * 8));
     h->pchunk = 2048;
     h->npchunks = (n_points + h->pchunk - 1) / h->pchunk;
     const char *force = getenv("TDK_BA_SCHUR");   // "atomics": always take the general kernel (tests)
@@ -1581,6 +1661,7 @@ static tdk_status ba_allocate(tdk_ba *h, int64_t n_poses, int64_t n_points, cons
             TDK_HIP(hipMalloc(&h->d_spart, (size_t)(pairs * h->npchunks) * kSchurAccPad * 8));
             if (n_poses <= 8) {   // 6 P <= 48 rows = three 16-row blocks of the FP64 MFMA tile
                 h->mfma_blocks = 768;   // 3 resident blocks per CU (50 KB of LDS each), ~2 chunks of 32 points per block at 50 000 points
+                if (const char *v = getenv("TDK_BA_MFMA_BLOCKS")) h->mfma_blocks = std::max(1, std::min(768, atoi(v)));
                 TDK_HIP(hipMalloc(&h->d_mpart, (size_t)h->mfma_blocks * (6 * 256 + 64) * 8));
             }
             TDK_HIP(hipMemcpy(h->d_obs_at, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1601,7 +1682,7 @@ tdk_status tdk_ba_destroy(tdk_ba *h) {
     void *ptrs[] = {h->d_poses, h->d_points, h->d_xt, h->d_vp, h->d_pt, h->d_row_ptr, h->d_obs, h->cur.U, h->cur.ea,
                     h->cur.V, h->cur.eb, h->d_part, h->d_err, h->cur.W, h->d_Vinv, h->d_S, h->d_e, h->d_da, h->d_db,
                     h->d_Be, h->d_obs_at, h->d_spart, h->d_mpart, h->d_cposes, h->d_cpoints, h->d_obs_sorted, h->d_pt32,
-                    h->d_segs, h->d_seg_ptr, h->d_ticket, h->alt.U, h->alt.ea, h->alt.V, h->alt.eb, h->alt.W};
+                    h->d_segs, h->d_seg_ptr, h->d_ticket, h->alt.U, h->alt.ea, h->alt.V, h->alt.eb, h->alt.W, h->d_rod};
     for (void *p : ptrs) (void)hipFree(p);
     for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
     delete h;
