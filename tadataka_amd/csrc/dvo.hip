@@ -2511,6 +2511,9 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
     const int n_pairs_arg = spread ? -h->n_pairs : h->n_pairs;
     dim3 grid(spread ? (unsigned)h->n_pairs * (unsigned)nblk : 8u * (unsigned)((h->n_pairs + 7) / 8) * (unsigned)nblk);
     LevelPtrs P = ptrs_of(L);
+    // (Capping the evaluation at 2 blocks per CU by padding this request, so that the other batch's pyramid
+    // blocks -- 36 KB of LDS, 121 VGPRs -- co-reside on the same SIMDs: full evaluation 0.55 -> 0.65 ms, bench
+    // step 2.73 -> 2.92 ms.  The two kernels do not fill each other's issue gaps; measured in round 4, not kept.)
     const size_t lds = sizeof(double) * (kWaves * kAccPad + (size_t)L.W + (size_t)L.H);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling && (level == 0 || h->profiling == 2)) {
