@@ -117,8 +117,10 @@ __device__ __forceinline__ void handle_collision(double depth_a, double depth_b,
 // 1-D grids of 8 ceil(n_tracks / 8) nb blocks: workgroups are dealt to the 8 XCDs round-robin, so XCD k
 // takes tracks k, k + 8, ... one after the other and all blocks of a track share one L2 (the
 // list walk of the fold and the forward warp of the scatter touch neighbouring lines).
-__device__ __forceinline__ bool xcd_major_track(int nb, int n_tracks, int &track, int &blk) {
-    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+__device__ __forceinline__ bool xcd_major_track(int nb, int n_tracks, int &track, int &blk,
+                                                unsigned b = 0xffffffffu) {
+    if (b == 0xffffffffu) b = blockIdx.x;
+    const int xcd = b & 7, q = b >> 3;
     track = (q / nb) * 8 + xcd;
     blk = q - (q / nb) * nb;
     return track < n_tracks;
@@ -157,16 +159,19 @@ __host__ __device__ inline WarpLists carve_lists(int *buf, int64_t stride, int n
 }
 
 __device__ __forceinline__ bool slot_path_wanted(const int *__restrict__ rng, int track);   // (the gather path, below)
+__device__ __forceinline__ bool any_slot_track(const int *__restrict__ rng, int n_tracks);
 
 // Forward warp of every source pixel of every track; an in-range source claims the next slot of its
 // target (one returning atomic), writes its index there, or joins the overflow chain.
 __global__ __launch_bounds__(kBlock) void k_sd_scatter(int H, int W, const TrackWarp *__restrict__ tw,
                                                        const double *__restrict__ depth0, int64_t stride,
                                                        WarpLists lists, int nb, int n_tracks,
-                                                       const int *__restrict__ rng) {
+                                                       const int *__restrict__ rng, unsigned vgrid) {
+    if (!any_slot_track(rng, n_tracks)) return;
+    for (unsigned vb = blockIdx.x; vb < vgrid; vb += gridDim.x) {
     int track, blk;
-    if (!xcd_major_track(nb, n_tracks, track, blk)) return;
-    if (!slot_path_wanted(rng, track)) return;
+    if (!xcd_major_track(nb, n_tracks, track, blk, vb)) continue;
+    if (!slot_path_wanted(rng, track)) continue;
     const TrackWarp &t = tw[track];
     const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
     const int N = H * W;
@@ -184,6 +189,7 @@ __global__ __launch_bounds__(kBlock) void k_sd_scatter(int H, int W, const Track
         const int k = atomicAdd(&cn[tg], 1);
         if (k < kSlots) sl[(int64_t)tg * kSlots + k] = i;
         else nx[i] = atomicExch(&oh[tg], i);
+    }
     }
 }
 
@@ -207,10 +213,12 @@ __global__ __launch_bounds__(kBlock) void k_sd_fold(int H, int W, const TrackWar
                                                     double default_depth, double default_variance, double bias,
                                                     uint64_t *__restrict__ age1, double *__restrict__ depth1,
                                                     double *__restrict__ var1, int nb, int n_tracks,
-                                                    const int *__restrict__ rng) {
+                                                    const int *__restrict__ rng, unsigned vgrid) {
+    if (!any_slot_track(rng, n_tracks)) return;
+    for (unsigned vb = blockIdx.x; vb < vgrid; vb += gridDim.x) {
     int track, blk;
-    if (!xcd_major_track(nb, n_tracks, track, blk)) return;
-    if (!slot_path_wanted(rng, track)) return;
+    if (!xcd_major_track(nb, n_tracks, track, blk, vb)) continue;
+    if (!slot_path_wanted(rng, track)) continue;
     const TrackWarp &t = tw[track];
     const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
     const int N = H * W;
@@ -277,6 +285,7 @@ __global__ __launch_bounds__(kBlock) void k_sd_fold(int H, int W, const TrackWar
         }
         if (PROP) { depth1[base + tg] = d; var1[base + tg] = v; }
     }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -313,7 +322,9 @@ __device__ __forceinline__ bool gather_applies(const int *__restrict__ rng, int 
     return rx <= kGatherMaxRx && ry <= kGatherMaxRy && (rx + 1) * (ry + 1) <= kGatherMaxCand;
 }
 
-template <bool PROP>
+// PX = pixels per lane: 2 where W is even (16-byte loads of depth0 / var0 and a 8-byte store of the two target
+// indices; a wave covers 128 columns), 1 otherwise.  (8-byte accesses run at 0.54 - 0.70 of the 16-byte rate.)
+template <bool PROP, int PX>
 __global__ __launch_bounds__(kBlock) void k_sd_targets(int H, int W, const TrackWarp *__restrict__ tw,
                                                        const double *__restrict__ depth0,
                                                        const double *__restrict__ var0, double bias, int64_t stride,
@@ -325,7 +336,8 @@ __global__ __launch_bounds__(kBlock) void k_sd_targets(int H, int W, const Track
     const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
     const double *__restrict__ d0 = depth0 + (int64_t)track * stride;
     int *__restrict__ tg = tgt + (int64_t)track * stride;
-    const int tiles_x = (W + kGatherTW - 1) / kGatherTW, tiles_y = (H + kGatherTH - 1) / kGatherTH;
+    constexpr int TW = kGatherTW * PX;
+    const int tiles_x = (W + TW - 1) / TW, tiles_y = (H + kGatherTH - 1) / kGatherTH;
     const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
     int ndx = -0x7fffffff, ndy = -0x7fffffff, mdx = -0x7fffffff, mdy = -0x7fffffff;
     const double *__restrict__ v0 = var0 + (int64_t)track * stride;
@@ -333,37 +345,53 @@ __global__ __launch_bounds__(kBlock) void k_sd_targets(int H, int W, const Track
     // four tiles per round: their eight loads are issued before the first warp is computed
     for (int tile0 = blk; tile0 < n_tiles; tile0 += 4 * nb) {
         int xs[4], ys[4];
-        double dd[4], vv[4];
+        double dd[4][PX], vv[4][PX];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int tile = tile0 + k * nb;
             const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-            xs[k] = txi * kGatherTW + lx; ys[k] = tyi * kGatherTH + ly;
-            const bool ok = tile < n_tiles && xs[k] < W && ys[k] < H;
+            xs[k] = txi * TW + lx * PX; ys[k] = tyi * kGatherTH + ly;
+            const bool ok = tile < n_tiles && xs[k] < W && ys[k] < H;      // (PX = 2: W even, both or neither)
             if (!ok) xs[k] = -1;
             const int i = ok ? ys[k] * W + xs[k] : 0;
-            dd[k] = d0[i];
-            vv[k] = PROP ? v0[i] : 0.0;
+            if (PX == 2) {
+                const double2 a = *reinterpret_cast<const double2 *>(d0 + i);
+                dd[k][0] = a.x; dd[k][PX - 1] = a.y;
+                if (PROP) {
+                    const double2 b = *reinterpret_cast<const double2 *>(v0 + i);
+                    vv[k][0] = b.x; vv[k][PX - 1] = b.y;
+                }
+            } else {
+                dd[k][0] = d0[i];
+                if (PROP) vv[k][0] = v0[i];
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (xs[k] < 0) continue;
-            const int x0 = xs[k], y0 = ys[k], i = y0 * W + x0;
-            double ux, uy, d1;
-            tdk::perspective_warp(t.T10, c0, c1, (double)x0, (double)y0, dd[k], ux, uy, d1);
-            int out = -1;
-            if (tdk::in_range(ux, uy, H, W)) {
-                const int tx = (int)ux, ty = (int)uy;   // `as usize`: truncation
-                out = ty * W + tx;
-                ndx = max(ndx, x0 - tx); mdx = max(mdx, tx - x0);
-                ndy = max(ndy, y0 - ty); mdy = max(mdy, ty - y0);
-                // propagate: the source's hypothesis in the new frame, computed HERE, where every lane has one --
-                // in the gather the targets of a wave have 1 - 4 sources each and the warp arithmetic would run
-                // for the busiest lane's count with most lanes idle
-                if (PROP)
-                    warped[(int64_t)track * stride + i] = make_double2(d1, propagate_variance(dd[k], d1, vv[k], bias));
+            int out[PX];
+#pragma unroll
+            for (int e = 0; e < PX; e++) {
+                const int x0 = xs[k] + e, y0 = ys[k], i = y0 * W + x0;
+                double ux, uy, d1;
+                tdk::perspective_warp(t.T10, c0, c1, (double)x0, (double)y0, dd[k][e], ux, uy, d1);
+                out[e] = -1;
+                if (tdk::in_range(ux, uy, H, W)) {
+                    const int tx = (int)ux, ty = (int)uy;   // `as usize`: truncation
+                    out[e] = ty * W + tx;
+                    ndx = max(ndx, x0 - tx); mdx = max(mdx, tx - x0);
+                    ndy = max(ndy, y0 - ty); mdy = max(mdy, ty - y0);
+                    // propagate: the source's hypothesis in the new frame, computed HERE, where every lane has
+                    // one -- in the gather the targets of a wave have 1 - 4 sources each and the warp arithmetic
+                    // would run for the busiest lane's count with most lanes idle
+                    if (PROP)
+                        warped[(int64_t)track * stride + i] =
+                            make_double2(d1, propagate_variance(dd[k][e], d1, PROP ? vv[k][e] : 0.0, bias));
+                }
             }
-            tg[i] = out;
+            const int i0 = ys[k] * W + xs[k];
+            if (PX == 2) *reinterpret_cast<int2 *>(tg + i0) = make_int2(out[0], out[PX - 1]);
+            else tg[i0] = out[0];
         }
     }
     // the track's box: wave maxima, one atomic per wave and bound
@@ -498,6 +526,160 @@ __global__ __launch_bounds__(kBlock) void k_sd_gather(int H, int W, const TrackW
     }
 }
 
+// The same gather with the memory latencies of a tile taken together instead of one after the other
+// (k_sd_gather above: up to four dependent rounds of target-index loads per tile, then hypothesis, then age --
+// six latencies per 256 targets at full occupancy, 0.47 ms for 64 VGA tracks):
+//   * a tile is 64 x 8 targets, two per thread (rows ly and ly + 4);
+//   * the window is walked FLAT (index -> row, column by a multiply-shift), all of a thread's target-index
+//     loads are issued before the first vote;
+//   * after the votes a thread knows, for both its targets, the first source (whose hypothesis starts the
+//     fold) and the last one (whose age is the writer's): those four loads are issued together.  Targets with
+//     two to four sources load the rest in the fold; more than four: the plain scan, as above.
+// Same sources in the same order as k_sd_gather and k_sd_fold -> same bits.
+constexpr int kG2Batch = 4;                                 // target-index loads in flight per thread
+
+template <bool AGE, bool PROP, int kG2Rows>
+__global__ __launch_bounds__(kBlock) void k_sd_gather2(int H, int W, const TrackWarp *__restrict__ tw,
+                                                       const int *__restrict__ tgt, const double2 *__restrict__ warped,
+                                                       const int *__restrict__ rng,
+                                                       const uint64_t *__restrict__ age0, int64_t stride,
+                                                       double default_depth, double default_variance, double bias,
+                                                       uint64_t *__restrict__ age1, double *__restrict__ depth1,
+                                                       double *__restrict__ var1, int nb, int n_tracks,
+                                                       unsigned int *__restrict__ fallbacks) {
+    constexpr int kG2TH = kGatherTH * kG2Rows;                  // tile height
+    __shared__ int cnt[kBlock * kG2Rows];
+    __shared__ __attribute__((aligned(16))) int slot[kBlock * kG2Rows * kSlots];
+    int track, blk;
+    if (!xcd_major_track(nb, n_tracks, track, blk)) return;
+    int dxmin, dymin, rx, ry;
+    if (!gather_applies(rng, track, dxmin, dymin, rx, ry)) {
+        if (blk == 0 && threadIdx.x == 0 && fallbacks) atomicAdd(fallbacks, 1u);
+        return;
+    }
+    const int dxmax = dxmin + rx, dymax = dymin + ry;
+    const TrackWarp &t = tw[track];
+    const int64_t base = (int64_t)track * stride;
+    const int *__restrict__ tg_all = tgt + base;
+    const int tiles_x = (W + kGatherTW - 1) / kGatherTW, tiles_y = (H + kG2TH - 1) / kG2TH;
+    const int lx = threadIdx.x & 63;
+    const int ly = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ww = kGatherTW + max(rx, 0), wh = kG2TH + max(ry, 0);
+    const int n_win = rx >= 0 ? ww * wh : 0;                        // <= 128 x 20
+    const unsigned m_ww = ((1u << 24) + ww - 1) / ww;               // idx / ww = idx m_ww >> 24 (idx < 4096, ww <= 128)
+    const unsigned m_W = (unsigned)std::min<uint64_t>(0x100000000ull / (unsigned)W, 0xffffffffull);  // tg / W: low by at most one
+#pragma unroll
+    for (int e = 0; e < kG2Rows; e++) cnt[threadIdx.x + e * kBlock] = 0;
+    for (int tile = blk; tile < tiles_x * tiles_y; tile += nb) {
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int tx0 = txi * kGatherTW, ty0 = tyi * kG2TH;
+        const int wx0 = tx0 - dxmax, wy0 = ty0 - dymax;      // window origin in source coordinates
+        __syncthreads();                                      // the previous tile's folds are through, counts zero
+        for (int i0 = 0; i0 < n_win; i0 += kG2Batch * kBlock) {
+            int src[kG2Batch], tg[kG2Batch];
+#pragma unroll
+            for (int j = 0; j < kG2Batch; j++) {
+                const int idx = i0 + j * kBlock + (int)threadIdx.x;
+                const int r = (int)(((unsigned)idx * m_ww) >> 24), c = idx - r * ww;
+                const int sy = wy0 + r, sx = wx0 + c;
+                const bool ok = idx < n_win && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+                src[j] = ok ? sy * W + sx : -1;
+                tg[j] = -1;
+                if (i0 + j * kBlock < n_win) tg[j] = tg_all[max(src[j], 0)];      // (uniform test: a whole round or none)
+            }
+#pragma unroll
+            for (int j = 0; j < kG2Batch; j++) {
+                if (src[j] < 0 || tg[j] < 0) continue;
+                unsigned ty = __umulhi((unsigned)tg[j], m_W);
+                unsigned tx = (unsigned)tg[j] - ty * (unsigned)W;
+                if (tx >= (unsigned)W) { ty++; tx -= (unsigned)W; }
+                const unsigned ux = tx - (unsigned)tx0, uy = ty - (unsigned)ty0;
+                if (ux >= (unsigned)kGatherTW || uy >= (unsigned)kG2TH) continue;
+                const int tl = (int)uy * kGatherTW + (int)ux;
+                const int k = atomicAdd(&cnt[tl], 1);
+                if (k < kSlots) slot[tl * kSlots + k] = src[j];
+            }
+        }
+        __syncthreads();
+        const int x = tx0 + lx;
+        int kk[kG2Rows], me[kG2Rows], s[kG2Rows][kSlots], last[kG2Rows];
+        double2 w0[kG2Rows];
+        uint64_t a0[kG2Rows];
+#pragma unroll
+        for (int e = 0; e < kG2Rows; e++) {
+            const int tl = (ly + e * kGatherTH) * kGatherTW + lx, y = ty0 + ly + e * kGatherTH;
+            me[e] = (x < W && y < H) ? y * W + x : -1;
+            kk[e] = cnt[tl];
+            cnt[tl] = 0;                                      // for the next tile (this thread is the only reader)
+            const int4 q = *reinterpret_cast<const int4 *>(slot + tl * kSlots);
+            const int k = kk[e];
+            s[e][0] = q.x; s[e][1] = k > 1 ? q.y : 0x7fffffff; s[e][2] = k > 2 ? q.z : 0x7fffffff;
+            s[e][3] = k > 3 ? q.w : 0x7fffffff;
+            if (k > 1 && k <= kSlots) {   // the votes arrive in any order: raster order by a five-exchange network
+                sort2(s[e][0], s[e][1]); sort2(s[e][2], s[e][3]); sort2(s[e][0], s[e][2]); sort2(s[e][1], s[e][3]);
+                sort2(s[e][1], s[e][2]);
+            }
+            const bool fast = me[e] >= 0 && k > 0 && k <= kSlots;
+            last[e] = fast ? (k > 3 ? s[e][3] : k > 2 ? s[e][2] : k > 1 ? s[e][1] : s[e][0]) : -1;
+            const int f = fast ? s[e][0] : max(me[e], 0);
+            if (PROP) w0[e] = warped[base + f];
+            if (AGE) a0[e] = age0[base + (fast ? last[e] : max(me[e], 0))];
+        }
+#pragma unroll
+        for (int e = 0; e < kG2Rows; e++) {
+            if (me[e] < 0) continue;
+            const int k = kk[e];
+            double d = default_depth, v = default_variance;
+            int lastw = -1;
+            bool have = false;
+            auto fold = [&](const double2 w) {
+                if (!have) { d = w.x; v = w.y; have = true; }
+                else {
+                    double nd, nv;
+                    handle_collision(w.x, d, w.y, v, nd, nv);
+                    d = nd; v = nv;
+                }
+            };
+            uint64_t a = 0;
+            if (k > 0 && k <= kSlots) {
+                if (PROP) {
+                    fold(w0[e]);
+                    if (k > 1) fold(warped[base + s[e][1]]);
+                    if (k > 2) fold(warped[base + s[e][2]]);
+                    if (k > 3) fold(warped[base + s[e][3]]);
+                }
+                lastw = last[e];
+                if (AGE) a = a0[e];
+            } else if (k > kSlots) {
+                // more than four sources on this target (a zoom-out inside the window): the plain scan of its
+                // candidates s = t - d, d in the box, in raster order
+                const int y = ty0 + ly + e * kGatherTH;
+                for (int cj = 0; cj <= ry; cj++) {
+                    const int sy = y - dymax + cj;
+                    if ((unsigned)sy >= (unsigned)H) continue;
+                    for (int ci = 0; ci <= rx; ci++) {
+                        const int sx = x - dxmax + ci;
+                        if ((unsigned)sx >= (unsigned)W) continue;
+                        if (tg_all[sy * W + sx] == me[e]) {
+                            if (PROP) fold(warped[base + sy * W + sx]);
+                            lastw = sy * W + sx;
+                        }
+                    }
+                }
+                if (AGE && lastw >= 0) a = age0[base + lastw];
+            }
+            if (AGE) {
+                if (lastw >= 0) {
+                    a = a + 1;
+                    a = a > t.age_cap ? t.age_cap : a;
+                } else a = 0;
+                age1[base + me[e]] = a;
+            }
+            if (PROP) { depth1[base + me[e]] = d; var1[base + me[e]] = v; }
+        }
+    }
+}
+
 // the slot path only where the gather did not apply (see above): the three launches of launch_warp_step
 // that follow k_sd_gather test this first
 __device__ __forceinline__ bool slot_path_wanted(const int *__restrict__ rng, int track) {
@@ -506,13 +688,29 @@ __device__ __forceinline__ bool slot_path_wanted(const int *__restrict__ rng, in
     return !gather_applies(rng, track, a, b, c, d);
 }
 
+// Does ANY track of the step need the slot path?  Asked once per block of the three slot-path launches, which
+// run on a capped grid (kSlotGrid blocks, each walking its share of the virtual grid): when the gather took
+// every track -- the normal case -- they cost a few microseconds each instead of the 26 us that 77 000
+// blocks needed just to start and return (measured, 64 VGA tracks).
+constexpr unsigned kSlotGrid = 2048;
+__device__ __forceinline__ bool any_slot_track(const int *__restrict__ rng, int n_tracks) {
+    if (rng == nullptr) return true;
+    int want = 0;
+    for (int t = threadIdx.x; t < n_tracks; t += kBlock) want |= slot_path_wanted(rng, t) ? 1 : 0;
+    return __syncthreads_or(want) != 0;
+}
+
 __global__ __launch_bounds__(kBlock) void k_sd_zero_counts(int *__restrict__ cnt, int64_t stride, int N,
-                                                           const int *__restrict__ rng, int nb, int n_tracks) {
+                                                           const int *__restrict__ rng, int nb, int n_tracks,
+                                                           unsigned vgrid) {
+    if (!any_slot_track(rng, n_tracks)) return;
+    for (unsigned vb = blockIdx.x; vb < vgrid; vb += gridDim.x) {
     int track, blk;
-    if (!xcd_major_track(nb, n_tracks, track, blk)) return;
-    if (!slot_path_wanted(rng, track)) return;
+    if (!xcd_major_track(nb, n_tracks, track, blk, vb)) continue;
+    if (!slot_path_wanted(rng, track)) continue;
     int *c = cnt + (int64_t)track * stride;
     for (int i = blk * kBlock + threadIdx.x; i < N; i += nb * kBlock) c[i] = 0;
+    }
 }
 
 // ---- update_depth / estimate (src/semi_dense/semi_dense.rs) ----------------------
@@ -1107,21 +1305,44 @@ tdk_status launch_warp_step(int n_tracks, int H, int W, const TrackWarp *d_tw, c
         int gnb = std::max(1, (n_tiles + 3) / 4);
         if (const char *v = getenv("TDK_SD_GATHER_NB")) gnb = std::max(1, atoi(v));
         const unsigned ggrid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)gnb;
-        k_sd_targets<PROP><<<ggrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, bias, stride, lists.next, warped, rng,
-                                                          gnb, n_tracks);
+        if (W % 2 == 0 && !getenv("TDK_SD_TARGETS_PX1")) {
+            const int n_tiles2 = ((W + 2 * kGatherTW - 1) / (2 * kGatherTW)) * ((H + kGatherTH - 1) / kGatherTH);
+            const int tnb = std::max(1, (n_tiles2 + 3) / 4);
+            const unsigned tgrid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)tnb;
+            k_sd_targets<PROP, 2><<<tgrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, bias, stride, lists.next,
+                                                                 warped, rng, tnb, n_tracks);
+        } else
+            k_sd_targets<PROP, 1><<<ggrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, bias, stride, lists.next,
+                                                                 warped, rng, gnb, n_tracks);
         TDK_LAUNCH_CHECK();
-        k_sd_gather<AGE, PROP><<<ggrid, kBlock, 0, stream>>>(H, W, d_tw, lists.next, warped, rng, age0, stride,
-                                                              default_depth, default_variance, bias, age1, depth1,
-                                                              var1, gnb, n_tracks, d_fallbacks);
+        if (use_gather == 3)
+            k_sd_gather<AGE, PROP><<<ggrid, kBlock, 0, stream>>>(H, W, d_tw, lists.next, warped, rng, age0, stride,
+                                                                  default_depth, default_variance, bias, age1, depth1,
+                                                                  var1, gnb, n_tracks, d_fallbacks);
+        else {
+            const int rows = getenv("TDK_SD_GATHER_ROWS") ? atoi(getenv("TDK_SD_GATHER_ROWS")) : 2;
+            const int th = kGatherTH * rows;
+            const int n_tiles8 = ((W + kGatherTW - 1) / kGatherTW) * ((H + th - 1) / th);
+            int g2nb = std::max(1, (n_tiles8 + 1) / 2);
+            if (const char *v = getenv("TDK_SD_GATHER_NB")) g2nb = std::max(1, atoi(v));
+            const unsigned g2grid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)g2nb;
+            auto kern = rows == 4 ? k_sd_gather2<AGE, PROP, 4> : rows == 1 ? k_sd_gather2<AGE, PROP, 1> : k_sd_gather2<AGE, PROP, 2>;
+            kern<<<g2grid, kBlock, 0, stream>>>(H, W, d_tw, lists.next, warped, rng, age0, stride,
+                                                                    default_depth, default_variance, bias, age1,
+                                                                    depth1, var1, g2nb, n_tracks, d_fallbacks);
+        }
         TDK_LAUNCH_CHECK();
     }
-    k_sd_zero_counts<<<grid, kBlock, 0, stream>>>(lists.cnt, stride, N, rng, nb, n_tracks);
+    // with the gather queued the slot path is the exception: a capped grid whose blocks ask first whether any
+    // track needs them (any_slot_track); without it, the full grid
+    const unsigned sgrid = rng ? std::min(grid, kSlotGrid) : grid;
+    k_sd_zero_counts<<<sgrid, kBlock, 0, stream>>>(lists.cnt, stride, N, rng, nb, n_tracks, grid);
     TDK_LAUNCH_CHECK();
-    k_sd_scatter<<<grid, kBlock, 0, stream>>>(H, W, d_tw, depth0, stride, lists, nb, n_tracks, rng);
+    k_sd_scatter<<<sgrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, stride, lists, nb, n_tracks, rng, grid);
     TDK_LAUNCH_CHECK();
-    k_sd_fold<AGE, PROP><<<grid, kBlock, 0, stream>>>(H, W, d_tw, lists, age0, depth0, var0, stride,
+    k_sd_fold<AGE, PROP><<<sgrid, kBlock, 0, stream>>>(H, W, d_tw, lists, age0, depth0, var0, stride,
                                                        default_depth, default_variance, bias, age1, depth1, var1,
-                                                       nb, n_tracks, rng);
+                                                       nb, n_tracks, rng, grid);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
