@@ -158,7 +158,8 @@ __host__ __device__ inline WarpLists carve_lists(int *buf, int64_t stride, int n
     return L;
 }
 
-__device__ __forceinline__ bool slot_path_wanted(const int *__restrict__ rng, int track);   // (the gather path, below)
+// (the gather path, below; rng[kRngStride track + 4] holds the window limit of the gather kernel that ran)
+__device__ __forceinline__ bool slot_path_wanted(const int *__restrict__ rng, int track);
 __device__ __forceinline__ bool any_slot_track(const int *__restrict__ rng, int n_tracks);
 
 // Forward warp of every source pixel of every track; an in-range source claims the next slot of its
@@ -297,13 +298,13 @@ __global__ __launch_bounds__(kBlock) void k_sd_fold(int H, int W, const TrackWar
 // chains, no atomics per pixel:
 //   k_sd_targets  one thread per source: warp, write the target index (4 B/px, coalesced; -1 = out of
 //                 range), and the track's displacement box by four atomic maxima per block;
-//   k_sd_gather   a block takes 64 x 4 targets; the (64 + rx) x (4 + ry) sources that can reach them vote into
+//   k_sd_gather2  a block takes 64 x 8 targets; the (64 + rx) x (8 + ry) sources that can reach them vote into
 //                 per-target slots in LDS (LDS atomics; the slot algorithm of the scatter, but on chip), every
 //                 target orders its <= 4 sources and folds them exactly as k_sd_fold does (same order -> same
 //                 bits); the hypothesis (depth1, variance1a) of a source comes from k_sd_targets, where every
 //                 lane has one to compute -- in the fold the busiest target of a wave sets the pace.
 // A track whose box is too large (kGatherMaxRx x kGatherMaxRy, or too many candidates per target for the
-// rare plain scan) is left to the slot path: k_sd_gather returns at once for it, the scatter /
+// rare plain scan) is left to the slot path: k_sd_gather2 returns at once for it, the scatter /
 // fold launches queued behind return at once for all the others -- decided on the device, no host wait;
 // the tracks that fell back are counted (tdk_sd_get_warp_fallbacks).
 // ---------------------------------------------------------------------------
@@ -312,24 +313,29 @@ constexpr int kGatherMaxRx = 64, kGatherMaxRy = 12;       // largest displacemen
 constexpr int kGatherMaxCand = 320;                       // (rx + 1)(ry + 1): candidates scanned per target
 
 // rng[kRngStride track ..]: max(-dx), max(-dy), max(dx), max(dy) over the in-range sources (memset to 0x80808080 before)
+constexpr int kFusedTH = 8;                                 // target rows per tile of the fused gather
+constexpr int kFusedMaxWin = 1024;                          // window sources it keeps in LDS
 __device__ __forceinline__ bool gather_applies(const int *__restrict__ rng, int track, int &dxmin, int &dymin,
-                                               int &rx, int &ry) {
+                                               int &rx, int &ry, int max_win = 0) {
     const int nx = rng[kRngStride * track], ny = rng[kRngStride * track + 1], mx = rng[kRngStride * track + 2],
               my = rng[kRngStride * track + 3];
     if (mx < -0x40000000) { dxmin = 0; dymin = 0; rx = -1; ry = -1; return true; }   // no source in range at all
     dxmin = -nx; dymin = -ny;
     rx = mx + nx; ry = my + ny;
+    if (max_win > 0 && (kGatherTW + rx) * (kFusedTH + ry) > max_win) return false;
     return rx <= kGatherMaxRx && ry <= kGatherMaxRy && (rx + 1) * (ry + 1) <= kGatherMaxCand;
 }
 
 // PX = pixels per lane: 2 where W is even (16-byte loads of depth0 / var0 and a 8-byte store of the two target
 // indices; a wave covers 128 columns), 1 otherwise.  (8-byte accesses run at 0.54 - 0.70 of the 16-byte rate.)
-template <bool PROP, int PX>
+// STORE = false: only the track's box (the fused gather below warps its window itself); max_win is left in
+// rng[.. + 4] for gather_applies of the launches that follow.
+template <bool PROP, int PX, bool STORE>
 __global__ __launch_bounds__(kBlock) void k_sd_targets(int H, int W, const TrackWarp *__restrict__ tw,
                                                        const double *__restrict__ depth0,
                                                        const double *__restrict__ var0, double bias, int64_t stride,
                                                        int *__restrict__ tgt, double2 *__restrict__ warped,
-                                                       int *__restrict__ rng, int nb, int n_tracks) {
+                                                       int *__restrict__ rng, int nb, int n_tracks, int max_win) {
     int track, blk;
     if (!xcd_major_track(nb, n_tracks, track, blk)) return;
     const TrackWarp &t = tw[track];
@@ -384,12 +390,13 @@ __global__ __launch_bounds__(kBlock) void k_sd_targets(int H, int W, const Track
                     // propagate: the source's hypothesis in the new frame, computed HERE, where every lane has
                     // one -- in the gather the targets of a wave have 1 - 4 sources each and the warp arithmetic
                     // would run for the busiest lane's count with most lanes idle
-                    if (PROP)
+                    if (PROP && STORE)
                         warped[(int64_t)track * stride + i] =
                             make_double2(d1, propagate_variance(dd[k][e], d1, PROP ? vv[k][e] : 0.0, bias));
                 }
             }
             const int i0 = ys[k] * W + xs[k];
+            if (!STORE) continue;
             if (PX == 2) *reinterpret_cast<int2 *>(tg + i0) = make_int2(out[0], out[PX - 1]);
             else tg[i0] = out[0];
         }
@@ -412,130 +419,19 @@ __global__ __launch_bounds__(kBlock) void k_sd_targets(int H, int W, const Track
         int *dst = &rng[kRngStride * track + threadIdx.x];
         if (m > -0x40000000 && m > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, m);
     }
+    if (blk == 0 && threadIdx.x == 4) rng[kRngStride * track + 4] = max_win;
 }
 
-template <bool AGE, bool PROP>
-__global__ __launch_bounds__(kBlock) void k_sd_gather(int H, int W, const TrackWarp *__restrict__ tw,
-                                                      const int *__restrict__ tgt, const double2 *__restrict__ warped,
-                                                      const int *__restrict__ rng,
-                                                      const uint64_t *__restrict__ age0, int64_t stride,
-                                                      double default_depth, double default_variance, double bias,
-                                                      uint64_t *__restrict__ age1, double *__restrict__ depth1,
-                                                      double *__restrict__ var1, int nb, int n_tracks,
-                                                      unsigned int *__restrict__ fallbacks) {
-    // per target of the tile: how many sources of the window land on it, and the first four of them
-    __shared__ int cnt[kBlock];
-    __shared__ __attribute__((aligned(16))) int slot[kBlock * kSlots];
-    int track, blk;
-    if (!xcd_major_track(nb, n_tracks, track, blk)) return;
-    int dxmin, dymin, rx, ry;
-    if (!gather_applies(rng, track, dxmin, dymin, rx, ry)) {
-        if (blk == 0 && threadIdx.x == 0 && fallbacks) atomicAdd(fallbacks, 1u);
-        return;
-    }
-    const int dxmax = dxmin + rx, dymax = dymin + ry;
-    const TrackWarp &t = tw[track];
-    const int64_t base = (int64_t)track * stride;
-    const int *__restrict__ tg_all = tgt + base;
-    const int tiles_x = (W + kGatherTW - 1) / kGatherTW, tiles_y = (H + kGatherTH - 1) / kGatherTH;
-    const int lx = threadIdx.x & 63;
-    const int ly = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int ww = kGatherTW + max(rx, 0), wh = kGatherTH + max(ry, 0);
-    for (int tile = blk; tile < tiles_x * tiles_y; tile += nb) {
-        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-        const int tx0 = txi * kGatherTW, ty0 = tyi * kGatherTH;
-        const int wx0 = tx0 - dxmax, wy0 = ty0 - dymax;      // window origin in source coordinates
-        __syncthreads();                                      // the previous tile's folds are through
-        cnt[threadIdx.x] = 0;
-        __syncthreads();
-        // every source of the window votes: a wave per window row (coalesced reads of the target indices, no
-        // division); a source whose target lies in this tile claims one of the target's slots with an LDS atomic
-        if (rx >= 0) {
-            for (int r = ly; r < wh; r += kBlock / 64) {
-                const int sy = wy0 + r;
-                if ((unsigned)sy >= (unsigned)H) continue;
-                for (int c = lx; c < ww; c += 64) {
-                    const int sx = wx0 + c;
-                    if ((unsigned)sx >= (unsigned)W) continue;
-                    const int src = sy * W + sx;
-                    const int tg = tg_all[src];
-                    if (tg < 0) continue;
-                    const int ty = tg / W, tx = tg - ty * W;
-                    const unsigned ux = (unsigned)(tx - tx0), uy = (unsigned)(ty - ty0);
-                    if (ux >= (unsigned)kGatherTW || uy >= (unsigned)kGatherTH) continue;
-                    const int tl = (int)uy * kGatherTW + (int)ux;
-                    const int k = atomicAdd(&cnt[tl], 1);
-                    if (k < kSlots) slot[tl * kSlots + k] = src;
-                }
-            }
-        }
-        __syncthreads();
-        const int x = tx0 + lx, y = ty0 + ly;
-        if (x >= W || y >= H) continue;
-        const int me = y * W + x;
-        double d = default_depth, v = default_variance;
-        int last = -1;
-        bool have = false;
-        auto take = [&](int src) {      // the next source in raster order
-            if (PROP) {
-                const double2 w = warped[base + src];      // (depth1, variance1a) of the source, from k_sd_targets
-                if (!have) { d = w.x; v = w.y; have = true; }
-                else {
-                    double nd, nv;
-                    handle_collision(w.x, d, w.y, v, nd, nv);
-                    d = nd; v = nv;
-                }
-            }
-            last = src;
-        };
-        const int k = cnt[threadIdx.x];
-        if (k > 0) {
-            const int4 q = *reinterpret_cast<const int4 *>(slot + threadIdx.x * kSlots);
-            int s0 = q.x, s1 = k > 1 ? q.y : 0x7fffffff, s2 = k > 2 ? q.z : 0x7fffffff, s3 = k > 3 ? q.w : 0x7fffffff;
-            if (k <= kSlots) {
-                if (k > 1) {      // the votes arrive in any order: raster order by a five-exchange network
-                    sort2(s0, s1); sort2(s2, s3); sort2(s0, s2); sort2(s1, s3); sort2(s1, s2);
-                }
-                take(s0);
-                if (k > 1) take(s1);
-                if (k > 2) take(s2);
-                if (k > 3) take(s3);
-            } else {
-                // more than four sources on this target (a zoom-out inside the window): the plain scan of its
-                // candidates s = t - d, d in the box, in raster order
-                for (int cj = 0; cj <= ry; cj++) {
-                    const int sy = y - dymax + cj;
-                    if ((unsigned)sy >= (unsigned)H) continue;
-                    for (int ci = 0; ci <= rx; ci++) {
-                        const int sx = x - dxmax + ci;
-                        if ((unsigned)sx >= (unsigned)W) continue;
-                        if (tg_all[sy * W + sx] == me) take(sy * W + sx);
-                    }
-                }
-            }
-        }
-        if (AGE) {
-            uint64_t a = 0;
-            if (last >= 0) {
-                a = age0[base + last] + 1;
-                a = a > t.age_cap ? t.age_cap : a;
-            }
-            age1[base + me] = a;
-        }
-        if (PROP) { depth1[base + me] = d; var1[base + me] = v; }
-    }
-}
-
-// The same gather with the memory latencies of a tile taken together instead of one after the other
-// (k_sd_gather above: up to four dependent rounds of target-index loads per tile, then hypothesis, then age --
-// six latencies per 256 targets at full occupancy, 0.47 ms for 64 VGA tracks):
+// The gather.  Its first form (a wave per window row, one 64 x 4 tile at a time: up to four dependent rounds of
+// target-index loads per tile, then the hypothesis, then the age -- six latencies per 256 targets at full
+// occupancy) took 0.47 ms for 64 VGA tracks; with the latencies of a tile taken together, 0.35 ms:
 //   * a tile is 64 x 8 targets, two per thread (rows ly and ly + 4);
 //   * the window is walked FLAT (index -> row, column by a multiply-shift), all of a thread's target-index
 //     loads are issued before the first vote;
 //   * after the votes a thread knows, for both its targets, the first source (whose hypothesis starts the
 //     fold) and the last one (whose age is the writer's): those four loads are issued together.  Targets with
 //     two to four sources load the rest in the fold; more than four: the plain scan, as above.
-// Same sources in the same order as k_sd_gather and k_sd_fold -> same bits.
+// Same sources in the same order as k_sd_fold -> same bits.
 constexpr int kG2Batch = 4;                                 // target-index loads in flight per thread
 
 template <bool AGE, bool PROP, int kG2Rows>
@@ -680,12 +576,182 @@ __global__ __launch_bounds__(kBlock) void k_sd_gather2(int H, int W, const Track
     }
 }
 
+// The gather FUSED with the warp (round 4, second step).  k_sd_targets + k_sd_gather2 move 89 bytes per pixel:
+// the target index and the warped hypothesis of every source are written (20 B) and read back (21 B) only to
+// carry them from one kernel to the next.  Here a block warps the sources of its window ITSELF (depth0 and
+// var0, 16 B x the window overlap of about 1.3, mostly L2 hits) and keeps target and hypothesis in LDS:
+//   k_sd_targets<.., STORE = false>   the box only (8 B/px read, nothing written)
+//   k_sd_gather_fused                 per 64 x 8 tile: window sources -> warp -> vote (LDS) -> fold from LDS;
+//                                     one global gather left, the age of the last writer
+// 8 + 21 + 8 + 24 = 61 bytes per pixel.  The window must fit kFusedMaxWin sources (rx <= 20 with ry <= 4, say);
+// a track beyond that goes the slot path.  Same warp arithmetic (perspective_warp, propagate_variance), same
+// sources in the same order -> same bits as every other path.
+template <bool AGE, bool PROP>
+__global__ __launch_bounds__(kBlock) void k_sd_gather_fused(int H, int W, const TrackWarp *__restrict__ tw,
+                                                            const double *__restrict__ depth0,
+                                                            const double *__restrict__ var0,
+                                                            const int *__restrict__ rng,
+                                                            const uint64_t *__restrict__ age0, int64_t stride,
+                                                            double default_depth, double default_variance, double bias,
+                                                            uint64_t *__restrict__ age1, double *__restrict__ depth1,
+                                                            double *__restrict__ var1, int nb, int n_tracks,
+                                                            unsigned int *__restrict__ fallbacks) {
+    constexpr int kRows = kFusedTH / kGatherTH;              // targets per thread
+    constexpr int kBatch = kFusedMaxWin / kBlock;            // window sources per thread
+    __shared__ int cnt[kBlock * kRows];
+    __shared__ __attribute__((aligned(16))) int slot[kBlock * kRows * kSlots];   // window indices
+    __shared__ short wtl[kFusedMaxWin];                      // window source -> target of this tile, or -1
+    __shared__ __attribute__((aligned(16))) double hyp_raw[2 * (PROP ? kFusedMaxWin : 1)];
+    double2 *hyp = reinterpret_cast<double2 *>(hyp_raw);      // window source -> (depth1, variance1a)
+    int track, blk;
+    if (!xcd_major_track(nb, n_tracks, track, blk)) return;
+    int dxmin, dymin, rx, ry;
+    if (!gather_applies(rng, track, dxmin, dymin, rx, ry, kFusedMaxWin)) {
+        if (blk == 0 && threadIdx.x == 0 && fallbacks) atomicAdd(fallbacks, 1u);
+        return;
+    }
+    const int dxmax = dxmin + rx, dymax = dymin + ry;
+    const TrackWarp &t = tw[track];
+    const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
+    const int64_t base = (int64_t)track * stride;
+    const double *__restrict__ d0 = depth0 + base;
+    const double *__restrict__ v0 = var0 + base;
+    const int tiles_x = (W + kGatherTW - 1) / kGatherTW, tiles_y = (H + kFusedTH - 1) / kFusedTH;
+    const int lx = threadIdx.x & 63;
+    const int ly = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int ww = kGatherTW + max(rx, 0), wh = kFusedTH + max(ry, 0);
+    const int n_win = rx >= 0 ? ww * wh : 0;                        // <= kFusedMaxWin
+    const unsigned m_ww = ((1u << 24) + ww - 1) / ww;               // idx / ww = idx m_ww >> 24 (idx < 4096, ww <= 128)
+#pragma unroll
+    for (int e = 0; e < kRows; e++) cnt[threadIdx.x + e * kBlock] = 0;
+    for (int tile = blk; tile < tiles_x * tiles_y; tile += nb) {
+        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
+        const int tx0 = txi * kGatherTW, ty0 = tyi * kFusedTH;
+        const int wx0 = tx0 - dxmax, wy0 = ty0 - dymax;      // window origin in source coordinates
+        __syncthreads();                                      // the previous tile's folds are through, counts zero
+        {
+            int sxs[kBatch], sys[kBatch];
+            double dd[kBatch], vv[kBatch];
+#pragma unroll
+            for (int j = 0; j < kBatch; j++) {
+                const int idx = j * kBlock + (int)threadIdx.x;
+                const int r = (int)(((unsigned)idx * m_ww) >> 24), c = idx - r * ww;
+                const int sy = wy0 + r, sx = wx0 + c;
+                const bool ok = idx < n_win && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
+                sxs[j] = ok ? sx : -1; sys[j] = sy;
+                dd[j] = 0.0; vv[j] = 0.0;
+                if (j * kBlock < n_win) {                     // (uniform: a whole round or none)
+                    const int i = ok ? sy * W + sx : 0;
+                    dd[j] = d0[i];
+                    if (PROP) vv[j] = v0[i];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kBatch; j++) {
+                if (j * kBlock >= n_win) continue;
+                const int idx = j * kBlock + (int)threadIdx.x;
+                int tl = -1;
+                if (sxs[j] >= 0) {
+                    double ux, uy, d1;
+                    tdk::perspective_warp(t.T10, c0, c1, (double)sxs[j], (double)sys[j], dd[j], ux, uy, d1);
+                    if (tdk::in_range(ux, uy, H, W)) {
+                        const unsigned qx = (unsigned)((int)ux - tx0), qy = (unsigned)((int)uy - ty0);   // `as usize`
+                        if (qx < (unsigned)kGatherTW && qy < (unsigned)kFusedTH) {
+                            tl = (int)qy * kGatherTW + (int)qx;
+                            const int k = atomicAdd(&cnt[tl], 1);
+                            if (k < kSlots) slot[tl * kSlots + k] = idx;
+                            if (PROP) hyp[idx] = make_double2(d1, propagate_variance(dd[j], d1, vv[j], bias));
+                        }
+                    }
+                }
+                if (idx < n_win) wtl[idx] = (short)tl;
+            }
+        }
+        __syncthreads();
+        const int x = tx0 + lx;
+        int kk[kRows], me[kRows], s[kRows][kSlots], lastw[kRows];
+        uint64_t a0[kRows];
+#pragma unroll
+        for (int e = 0; e < kRows; e++) {
+            const int tl = (ly + e * kGatherTH) * kGatherTW + lx, y = ty0 + ly + e * kGatherTH;
+            me[e] = (x < W && y < H) ? y * W + x : -1;
+            const int k = kk[e] = cnt[tl];
+            cnt[tl] = 0;                                      // for the next tile (this thread is the only reader)
+            const int4 q = *reinterpret_cast<const int4 *>(slot + tl * kSlots);
+            s[e][0] = q.x; s[e][1] = k > 1 ? q.y : 0x7fffffff; s[e][2] = k > 2 ? q.z : 0x7fffffff;
+            s[e][3] = k > 3 ? q.w : 0x7fffffff;
+            if (k > 1 && k <= kSlots) {   // votes arrive in any order; window order IS raster order
+                sort2(s[e][0], s[e][1]); sort2(s[e][2], s[e][3]); sort2(s[e][0], s[e][2]); sort2(s[e][1], s[e][3]);
+                sort2(s[e][1], s[e][2]);
+            }
+            int li = -1;                                      // window index of the last writer
+            if (me[e] >= 0 && k > 0) {
+                if (k <= kSlots) li = k > 3 ? s[e][3] : k > 2 ? s[e][2] : k > 1 ? s[e][1] : s[e][0];
+                else {
+                    // more than four sources on this target: its candidates s = t - d, d in the box, in raster
+                    // order; the last one that lands here
+                    for (int cj = 0; cj <= ry; cj++)
+                        for (int ci = 0; ci <= rx; ci++) {
+                            const int wi = (ly + e * kGatherTH + cj) * ww + lx + ci;
+                            if (wtl[wi] == tl) li = wi;
+                        }
+                }
+            }
+            lastw[e] = -1;
+            if (li >= 0) {
+                const int r = (int)(((unsigned)li * m_ww) >> 24), c = li - r * ww;
+                lastw[e] = (wy0 + r) * W + wx0 + c;
+            }
+            if (AGE) a0[e] = age0[base + max(lastw[e], 0)];
+        }
+#pragma unroll
+        for (int e = 0; e < kRows; e++) {
+            if (me[e] < 0) continue;
+            const int k = kk[e];
+            double d = default_depth, v = default_variance;
+            if (PROP && k > 0) {
+                bool have = false;
+                auto fold = [&](const double2 w) {
+                    if (!have) { d = w.x; v = w.y; have = true; }
+                    else {
+                        double nd, nv;
+                        handle_collision(w.x, d, w.y, v, nd, nv);
+                        d = nd; v = nv;
+                    }
+                };
+                if (k <= kSlots) {
+                    fold(hyp[s[e][0]]);
+                    if (k > 1) fold(hyp[s[e][1]]);
+                    if (k > 2) fold(hyp[s[e][2]]);
+                    if (k > 3) fold(hyp[s[e][3]]);
+                } else {
+                    const int tl = (ly + e * kGatherTH) * kGatherTW + lx;
+                    for (int cj = 0; cj <= ry; cj++)
+                        for (int ci = 0; ci <= rx; ci++) {
+                            const int wi = (ly + e * kGatherTH + cj) * ww + lx + ci;
+                            if (wtl[wi] == tl) fold(hyp[wi]);
+                        }
+                }
+            }
+            if (AGE) {
+                uint64_t a = 0;
+                if (lastw[e] >= 0) {
+                    a = a0[e] + 1;
+                    a = a > t.age_cap ? t.age_cap : a;
+                }
+                age1[base + me[e]] = a;
+            }
+            if (PROP) { depth1[base + me[e]] = d; var1[base + me[e]] = v; }
+        }
+    }
+}
+
 // the slot path only where the gather did not apply (see above): the three launches of launch_warp_step
-// that follow k_sd_gather test this first
+// that follow k_sd_gather2 test this first
 __device__ __forceinline__ bool slot_path_wanted(const int *__restrict__ rng, int track) {
     if (rng == nullptr) return true;
     int a, b, c, d;
-    return !gather_applies(rng, track, a, b, c, d);
+    return !gather_applies(rng, track, a, b, c, d, rng[kRngStride * track + 4]);
 }
 
 // Does ANY track of the step need the slot path?  Asked once per block of the three slot-path launches, which
@@ -1290,7 +1356,7 @@ tdk_status launch_warp_step(int n_tracks, int H, int W, const TrackWarp *d_tw, c
     const unsigned grid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)nb;
     const char *gv = getenv("TDK_SD_GATHER");   // (read per call: the tests switch it)
     const int use_gather = gv ? atoi(gv) : 1;
-    // the target indices alias `next`, which the slot path only writes AFTER k_sd_gather has run (and only for
+    // the target indices alias `next`, which the slot path only writes AFTER k_sd_gather2 has run (and only for
     // the tracks that fell back); the boxes have their own 4 n_tracks ints behind the lists
     int *rng = nullptr;
     if (use_gather) {
@@ -1305,33 +1371,46 @@ tdk_status launch_warp_step(int n_tracks, int H, int W, const TrackWarp *d_tw, c
         int gnb = std::max(1, (n_tiles + 3) / 4);
         if (const char *v = getenv("TDK_SD_GATHER_NB")) gnb = std::max(1, atoi(v));
         const unsigned ggrid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)gnb;
-        if (W % 2 == 0 && !getenv("TDK_SD_TARGETS_PX1")) {
-            const int n_tiles2 = ((W + 2 * kGatherTW - 1) / (2 * kGatherTW)) * ((H + kGatherTH - 1) / kGatherTH);
-            const int tnb = std::max(1, (n_tiles2 + 3) / 4);
-            const unsigned tgrid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)tnb;
-            k_sd_targets<PROP, 2><<<tgrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, bias, stride, lists.next,
-                                                                 warped, rng, tnb, n_tracks);
-        } else
-            k_sd_targets<PROP, 1><<<ggrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, bias, stride, lists.next,
-                                                                 warped, rng, gnb, n_tracks);
+        const bool px2 = W % 2 == 0;
+        const int n_tiles2 = ((W + 2 * kGatherTW - 1) / (2 * kGatherTW)) * ((H + kGatherTH - 1) / kGatherTH);
+        const int tnb = px2 ? std::max(1, (n_tiles2 + 3) / 4) : gnb;
+        const unsigned tgrid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)tnb;
+        if (use_gather == 2) {
+            // fused (opt-in): the box, then warp + vote + fold per tile (k_sd_gather_fused)
+            if (px2)
+                k_sd_targets<false, 2, false><<<tgrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, bias, stride, nullptr,
+                                                                             nullptr, rng, tnb, n_tracks, kFusedMaxWin);
+            else
+                k_sd_targets<false, 1, false><<<tgrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, bias, stride, nullptr,
+                                                                             nullptr, rng, tnb, n_tracks, kFusedMaxWin);
+            TDK_LAUNCH_CHECK();
+            const int n_tiles8 = ((W + kGatherTW - 1) / kGatherTW) * ((H + kFusedTH - 1) / kFusedTH);
+            int fnb = std::max(1, (n_tiles8 + 1) / 2);
+            if (const char *v = getenv("TDK_SD_GATHER_NB")) fnb = std::max(1, atoi(v));
+            const unsigned fgrid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)fnb;
+            k_sd_gather_fused<AGE, PROP><<<fgrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, rng, age0, stride,
+                                                                        default_depth, default_variance, bias, age1,
+                                                                        depth1, var1, fnb, n_tracks, d_fallbacks);
+            TDK_LAUNCH_CHECK();
+        } else {
+        if (px2)
+            k_sd_targets<PROP, 2, true><<<tgrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, bias, stride, lists.next,
+                                                                       warped, rng, tnb, n_tracks, 0);
+        else
+            k_sd_targets<PROP, 1, true><<<tgrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, bias, stride, lists.next,
+                                                                       warped, rng, tnb, n_tracks, 0);
         TDK_LAUNCH_CHECK();
-        if (use_gather == 3)
-            k_sd_gather<AGE, PROP><<<ggrid, kBlock, 0, stream>>>(H, W, d_tw, lists.next, warped, rng, age0, stride,
-                                                                  default_depth, default_variance, bias, age1, depth1,
-                                                                  var1, gnb, n_tracks, d_fallbacks);
-        else {
-            const int rows = getenv("TDK_SD_GATHER_ROWS") ? atoi(getenv("TDK_SD_GATHER_ROWS")) : 2;
-            const int th = kGatherTH * rows;
-            const int n_tiles8 = ((W + kGatherTW - 1) / kGatherTW) * ((H + th - 1) / th);
+        {
+            const int n_tiles8 = ((W + kGatherTW - 1) / kGatherTW) * ((H + 2 * kGatherTH - 1) / (2 * kGatherTH));
             int g2nb = std::max(1, (n_tiles8 + 1) / 2);
             if (const char *v = getenv("TDK_SD_GATHER_NB")) g2nb = std::max(1, atoi(v));
             const unsigned g2grid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)g2nb;
-            auto kern = rows == 4 ? k_sd_gather2<AGE, PROP, 4> : rows == 1 ? k_sd_gather2<AGE, PROP, 1> : k_sd_gather2<AGE, PROP, 2>;
-            kern<<<g2grid, kBlock, 0, stream>>>(H, W, d_tw, lists.next, warped, rng, age0, stride,
-                                                                    default_depth, default_variance, bias, age1,
-                                                                    depth1, var1, g2nb, n_tracks, d_fallbacks);
+            k_sd_gather2<AGE, PROP, 2><<<g2grid, kBlock, 0, stream>>>(H, W, d_tw, lists.next, warped, rng, age0, stride,
+                                                                       default_depth, default_variance, bias, age1,
+                                                                       depth1, var1, g2nb, n_tracks, d_fallbacks);
         }
         TDK_LAUNCH_CHECK();
+        }
     }
     // with the gather queued the slot path is the exception: a capped grid whose blocks ask first whether any
     // track needs them (any_slot_track); without it, the full grid

@@ -406,13 +406,59 @@ def test_forward_warp_gather_equals_slot_path_and_oracle(ops, orc, monkeypatch, 
     cam = c["cam"]
     want_age = orc.increment_age(age0, cam, cam, T10, c["prior_depth"])
     want_d, want_v = orc.propagate(T10, cam, cam, c["prior_depth"], var0, 1.0, 10.0, 0.01)
-    for mode in ("1", "0"):
+    # 1 = k_sd_targets + k_sd_gather2 (default), 2 = box pass + k_sd_gather_fused (opt-in), 0 = slots
+    for mode in ("1", "2", "0"):
         monkeypatch.setenv("TDK_SD_GATHER", mode)
         got_age = ops.increment_age(age0, cam, cam, T10, c["prior_depth"])
         got_d, got_v = ops.propagate(T10, cam, cam, c["prior_depth"], var0, 1.0, 10.0, 0.01)
         assert np.array_equal(got_age, want_age), (mode, kind)
         assert np.array_equal(got_d, want_d) and np.array_equal(got_v, want_v), (mode, kind)
     assert int((want_age > 0).sum()) > 0
+
+
+def test_forward_warp_more_than_four_sources_inside_the_window(ops, orc, monkeypatch):
+    """A zoom-out by 0.47 on an 8 x 32 frame: the displacement box still fits every gather kernel's window,
+    but most targets collect five or more sources -- the plain-scan branch of the gathers (more sources than
+    slots) against the oracle.  The test counts the sources per target itself to be sure the branch runs."""
+    from tadataka_amd import synthetic
+    H, W = 8, 32
+    c = synthetic.make_semi_dense_case(H, W, seed=77, valid_fraction=0.5)
+    rng = np.random.default_rng(77)
+    cam = c["cam"]
+    d0 = np.full((H, W), 2.0) * rng.uniform(0.98, 1.02, (H, W))
+    T10 = np.eye(4)
+    T10[2, 3] = 2.0 * (1.0 / 0.47 - 1.0)
+    fx, fy, ox, oy = [float(v) for v in np.asarray(cam).ravel()[:4]]
+    ys, xs = np.mgrid[0:H, 0:W].astype(float)
+    z1 = d0 + T10[2, 3]
+    u = ((xs - ox) / fx * d0) / z1 * fx + ox
+    v = ((ys - oy) / fy * d0) / z1 * fy + oy
+    ok = (u >= 0) & (u <= W - 1) & (v >= 0) & (v <= H - 1)
+    tg = (v[ok].astype(int) * W + u[ok].astype(int))
+    assert np.bincount(tg).max() >= 5, "the case no longer folds more than four sources onto a target"
+    age0 = rng.integers(0, 4, (H, W)).astype(np.uint64)
+    var0 = rng.uniform(0.01, 0.2, (H, W))
+    want_age = orc.increment_age(age0, cam, cam, T10, d0)
+    want_d, want_v = orc.propagate(T10, cam, cam, d0, var0, 1.0, 10.0, 0.01)
+    sd = ops.SemiDenseSession(1, H, W, max_refframes=2)
+    sd.set_age_policy(False)
+    sd.set_params(ops.make_params(0.5, 10.0, 0.01, 0.01, 0.004, 0.01), 1.0, 10.0, 0.01)
+    sd.push_frame(0, cam, c["ref_image"], c["T_wr"])
+    sd.push_frame(0, cam, c["key_image"], c["T_wk"])
+    for mode in ("1", "2", "0"):
+        monkeypatch.setenv("TDK_SD_GATHER", mode)
+        got_age = ops.increment_age(age0, cam, cam, T10, d0)
+        got_d, got_v = ops.propagate(T10, cam, cam, d0, var0, 1.0, 10.0, 0.01)
+        assert np.array_equal(got_age, want_age), mode
+        assert np.array_equal(got_d, want_d) and np.array_equal(got_v, want_v), mode
+        sd.set_maps(0, d0, var0, age0)
+        before = sd.warp_fallbacks()
+        sd.propagate(T10[None], commit=False)
+        if mode != "0":
+            assert sd.warp_fallbacks() == before, f"mode {mode}: the box left the gather's window"
+        d1, v1, a1 = sd.get_results(0, with_flag=False)
+        assert np.array_equal(a1, want_age) and np.array_equal(d1, want_d) and np.array_equal(v1, want_v), mode
+    sd.close()
 
 
 def test_session_counts_warp_fallbacks(ops, orc, monkeypatch):
