@@ -933,18 +933,84 @@ __device__ __forceinline__ void band_flush(const double *buf, const unsigned int
     }
 }
 
+// Student-t, Taylor scheme (see k_student_taylor below): nine expansion points per pair, three sums per point
+constexpr int kStudentPts = 9, kStudentSums = 3 * kStudentPts;
+constexpr int kStudentRow = kStudentPts + 1;   // expansion points of a pair + its "one more pass" flag
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Pass A of the scheme in packed FP32: its only product is the next set of expansion points, for which 1e-5 is
+// plenty.  The two residuals of a 16-byte load ride in the two halves of v_pk_add/mul/fma_f32 (two FP32 lanes per
+// FP64 issue slot) and v_rcp_f32 needs no Newton steps.  s' is capped at 1e4 so that the product of nine factors
+// stays inside FP32 (a = s' / (c' + s') is 0.9999 there; the few pixels beyond it shift the predicted points by
+// less than 1e-4 of their share of the sum).  Rides in the mask pass (k_robust_mask<.., TAYLOR>): the residuals are
+// in registers there and the pass waits for HBM.
+struct StudentF32 {
+    float c[kStudentPts];            // p_k / p_9 (block-uniform)
+    f32x2 acc[kStudentSums];
+    double inv_ref;
+    __device__ __forceinline__ void init(const double *__restrict__ pts, int pair) {
+        const double p_ref = pts[(size_t)pair * kStudentRow + kStudentPts - 1];
+        inv_ref = 1.0 / (kStudentNu * p_ref);
+        const double inv_p = 1.0 / p_ref;
+#pragma unroll
+        for (int k = 0; k < kStudentPts; k++) c[k] = (float)(pts[(size_t)pair * kStudentRow + k] * inv_p);
+#pragma unroll
+        for (int j = 0; j < kStudentSums; j++) acc[j] = f32x2{0.0f, 0.0f};
+    }
+    // s' in FP64 (r^2 may leave the FP32 range), then capped; NaN (outside the mask): adds nothing
+    __device__ __forceinline__ float scaled_square(double x) const {
+        const double sd = (x * x) * inv_ref;
+        return x == x ? (float)(sd < 1e4 ? sd : 1e4) : 0.0f;
+    }
+    __device__ __forceinline__ void add(double x0, double x1) {
+        const f32x2 s_ = {scaled_square(x0), scaled_square(x1)};
+        f32x2 u[kStudentPts], q[kStudentPts];
+#pragma unroll
+        for (int k = 0; k < kStudentPts; k++) u[k] = s_ + c[k];
+        q[0] = u[0];
+#pragma unroll
+        for (int k = 1; k < kStudentPts; k++) q[k] = q[k - 1] * u[k];
+        f32x2 inv = {__builtin_amdgcn_rcpf(q[kStudentPts - 1].x), __builtin_amdgcn_rcpf(q[kStudentPts - 1].y)};
+#pragma unroll
+        for (int k = kStudentPts - 1; k >= 0; k--) {
+            const f32x2 t = k > 0 ? inv * q[k > 0 ? k - 1 : 0] : inv;
+            if (k > 0) inv *= u[k];
+            const f32x2 a = s_ * t, at = a * t;
+            acc[3 * k + 0] += a;
+            acc[3 * k + 1] = __builtin_elementwise_fma(a, a, acc[3 * k + 1]);
+            acc[3 * k + 2] = __builtin_elementwise_fma(a, at, acc[3 * k + 2]);
+        }
+    }
+    // block partials, [kStudentSums] doubles at `out` (red: [kWaves][kStudentSums] in LDS)
+    __device__ __forceinline__ void store(double (*red)[kStudentSums], double *__restrict__ out) {
+#pragma unroll
+        for (int j = 0; j < kStudentSums; j++) {
+            double v = (double)acc[j].x + (double)acc[j].y;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < kStudentSums)
+            out[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
+};
+
 struct TukeyArgs {            // TUKEY: brackets of every pair and the band the pass collects into (see k_tukey_sample)
     TukeyBracket *brackets;
     double *med_bands;
     unsigned int cap;         // doubles per pair in a band
 };
 
-template <bool STUDENT, bool FAST, bool TUKEY>
+// TAYLOR (with STUDENT): pass A of the Taylor scheme around `pts` rides along (StudentF32); its block partials go
+// to partial_a[pair][block][kStudentSums].
+template <bool STUDENT, bool FAST, bool TUKEY, bool TAYLOR>
 __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairParams *__restrict__ params,
                                                         const double *__restrict__ poses,
                                                         const int *__restrict__ state, double scale,
                                                         double *__restrict__ rm, int *__restrict__ count,
-                                                        double *__restrict__ partial, TukeyArgs tka) {
+                                                        double *__restrict__ partial, TukeyArgs tka,
+                                                        const double *__restrict__ pts, double *__restrict__ partial_a) {
     const int pair = blockIdx.y;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
     BlockSetup b;
@@ -962,6 +1028,8 @@ __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairP
     unsigned int tk_below = 0;
     double *med_band = nullptr;
     TukeyBracket *tg = nullptr;
+    StudentF32 ta;
+    if (TAYLOR) ta.init(pts, pair);
     if (TUKEY) {
         tb = tka.brackets[pair];
         tg = tka.brackets + pair;
@@ -1004,6 +1072,7 @@ __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairP
         __builtin_nontemporal_store(r, reinterpret_cast<double2_u *>(out + i));     // read next by another kernel, from HBM
         term(r.x, in0);
         term(r.y, in1);
+        if (TAYLOR) ta.add(r.x, r.y);
         local += (in0 ? 1 : 0) + (in1 ? 1 : 0);
         x += step_x;
         y += step_y;
@@ -1020,6 +1089,7 @@ __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairP
             r = I0[i] - I1[i];
             out[i] = in ? r : nan;
             local += in ? 1 : 0;
+            if (TAYLOR) ta.add(in ? r : nan, nan);
         }
         if (TUKEY || tail) term(r, in);
     }
@@ -1036,6 +1106,10 @@ __global__ __launch_bounds__(kBlock) void k_robust_mask(LevelPtrs L, const PairP
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
         __syncthreads();
         if (threadIdx.x == 0) partial[(int64_t)pair * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+    if (TAYLOR) {
+        __shared__ double red_a[kWaves][kStudentSums];
+        ta.store(red_a, partial_a + ((int64_t)pair * gridDim.x + blockIdx.x) * kStudentSums);
     }
 }
 
@@ -1863,8 +1937,7 @@ __global__ __launch_bounds__(kBlock) void k_tukey_deviations(const double *__res
 // tdk_dvo_set_student_passes / TDK_STUDENT=sequential keep the nine passes, TDK_STUDENT_EXACT=1 the nine passes
 // with IEEE divisions.
 // ---------------------------------------------------------------------------
-constexpr int kStudentPts = 9, kStudentSums = 3 * kStudentPts;
-constexpr int kStudentRow = kStudentPts + 1;   // expansion points of a pair + its "one more pass" flag
+// (kStudentPts, kStudentSums, kStudentRow: above k_robust_mask, whose Student-t form carries pass A)
 // pass B moved a step's expansion point by more than this (relative): its remainder, bounded by
 // (nu + 1) (d / v)^3 = 6 * (1e-4)^3 = 6e-12 relative at the threshold (far below the 1e-6 bar on the pose, and
 // what the tests hold the variance to is 1e-12 at the d ~ 1e-5 that pass A actually leaves), may no longer be
@@ -1874,27 +1947,63 @@ constexpr double kStudentRedo = 1e-4;
 
 // the fixed-point sequence v_1 .. v_9 of a sample of the pair's masked residuals: kStudentSample entries of the
 // residual map, spread over the frame (all of a small level)
+// DIRECT: the sample's residuals are computed here (masked_residual: the mask pass has not run yet -- pass A rides
+// in it and needs these points); otherwise read from the residual map.
 constexpr int kStudentSample = 2048;
+template <bool DIRECT>
 __global__ __launch_bounds__(kBlock) void k_student_predict(const double *__restrict__ rm, int64_t stride, int N,
-                                                            const int *__restrict__ state, double *__restrict__ pts) {
+                                                            const int *__restrict__ state, double *__restrict__ pts,
+                                                            LevelPtrs L, const PairParams *__restrict__ params,
+                                                            const double *__restrict__ poses, double scale) {
     __shared__ double red[kWaves];
     __shared__ int red_n[kWaves];
     const int pair = blockIdx.x;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
-    const double *__restrict__ r = rm + (int64_t)pair * stride;
+    const double *__restrict__ r = DIRECT ? nullptr : rm + (int64_t)pair * stride;
+    BlockSetup b;
+    const double *__restrict__ tab = nullptr;
+    if (DIRECT) {
+        load_setup(b, params, poses, pair, scale);
+        tab = L.tab + (size_t)pair * (L.W + L.H);
+    }
     const int m = N < kStudentSample ? N : kStudentSample;
     constexpr int kPer = kStudentSample / kBlock;
     double sq[kPer];
     int valid = 0;
+    if (DIRECT) {
+        // the five loads of every sample first (addresses depend on the sample's index only), then the warps: one
+        // round of latency instead of kPer (44 -> ~25 us for 256 pairs)
+        const int W = L.W, H = L.H;
+        const int64_t base = (int64_t)pair * L.stride;
+        double tx[kPer], ty[kPer], dd[kPer], ra[kPer], rc[kPer];
 #pragma unroll
-    for (int j = 0; j < kPer; j++) {
-        const int k = threadIdx.x + j * kBlock;
-        double x = 0.0;
-        if (k < m) {
-            x = r[sample_position(k, m, N, pair)];
-            if (x == x) valid++; else x = 0.0;
+        for (int j = 0; j < kPer; j++) {
+            const int k = threadIdx.x + j * kBlock;
+            const int i = sample_position(k < m ? k : 0, m, N, pair);
+            const int y = i / W, x = i - y * W;
+            tx[j] = tab[x]; ty[j] = tab[W + y];
+            dd[j] = L.D0[base + i]; ra[j] = L.I0[base + i]; rc[j] = L.I1[base + i];
         }
-        sq[j] = x * x;                                  // outside the mask or the sample: adds nothing to the sum
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const int k = threadIdx.x + j * kBlock;
+            Pixel p;
+            sp_warp(p, true, tx[j], ty[j], dd[j], H, W, b.P, b.c);      // (masked_residual's arithmetic)
+            double x = ra[j] - rc[j];
+            if (k < m && p.mask == 2 && x == x) valid++; else x = 0.0;
+            sq[j] = x * x;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kPer; j++) {
+            const int k = threadIdx.x + j * kBlock;
+            double x = 0.0;
+            if (k < m) {
+                x = r[sample_position(k, m, N, pair)];
+                if (x == x) valid++; else x = 0.0;
+            }
+            sq[j] = x * x;                              // outside the mask or the sample: adds nothing to the sum
+        }
     }
     for (int off = 32; off > 0; off >>= 1) valid += __shfl_down(valid, off, 64);
     if ((threadIdx.x & 63) == 0) red_n[threadIdx.x >> 6] = valid;
@@ -1987,12 +2096,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// Pass A in packed FP32: its only product is the next set of expansion points, for which 1e-5 is plenty.  The two
-// residuals of a 16-byte load ride in the two halves of v_pk_add/mul/fma_f32 (two FP32 lanes per FP64 issue
-// slot) and v_rcp_f32 needs no Newton steps: 165 us instead of 320 at 256 x 640x480.  s' is capped at 1e4 so that
-// the product of nine factors stays inside FP32 (a = s' / (c' + s') is 0.9999 there; the few pixels beyond it
-// shift the predicted points by less than 1e-4 of their share of the sum).
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+// Pass A on its own (TDK_STUDENT_FUSED=0; by default it rides in the mask pass): StudentF32 over the residual map,
+// 165 us instead of 320 in FP64 at 256 x 640x480.
 __global__ __launch_bounds__(kBlock) void k_student_taylor_f32(const double *__restrict__ rm, int64_t stride, int N,
                                                                const int *__restrict__ state,
                                                                const double *__restrict__ pts,
@@ -2000,37 +2105,9 @@ __global__ __launch_bounds__(kBlock) void k_student_taylor_f32(const double *__r
     const int pair = blockIdx.y;
     if (state != nullptr && state[pair] != ST_RUNNING) return;
     if (pts[(size_t)pair * kStudentRow + kStudentPts] == 0.0) return;
-    const double p_ref = pts[(size_t)pair * kStudentRow + kStudentPts - 1];
-    const double inv_ref = 1.0 / (kStudentNu * p_ref), inv_p = 1.0 / p_ref;
-    float c[kStudentPts];
-#pragma unroll
-    for (int k = 0; k < kStudentPts; k++) c[k] = (float)(pts[(size_t)pair * kStudentRow + k] * inv_p);
-    f32x2 acc[kStudentSums];
-#pragma unroll
-    for (int j = 0; j < kStudentSums; j++) acc[j] = f32x2{0.0f, 0.0f};
+    StudentF32 ta;
+    ta.init(pts, pair);
     const double *r = rm + (int64_t)pair * stride;
-#define TDK_SCALED_SQUARE(X, OUT)  /* s' in FP64 (r^2 may leave the FP32 range), then capped */                    \
-    {                                                                                                                \
-        const double x_ = (X), sd_ = (x_ * x_) * inv_ref;                                                            \
-        OUT = x_ == x_ ? (float)(sd_ < 1e4 ? sd_ : 1e4) : 0.0f;                                                      \
-    }
-#define TDK_STUDENT_TERM(S)                                                                                          \
-    {                                                                                                                \
-        const f32x2 s_ = (S);                                                                                        \
-        f32x2 u[kStudentPts], q[kStudentPts];                                                                        \
-        _Pragma("unroll") for (int k = 0; k < kStudentPts; k++) u[k] = s_ + c[k];                                    \
-        q[0] = u[0];                                                                                                 \
-        _Pragma("unroll") for (int k = 1; k < kStudentPts; k++) q[k] = q[k - 1] * u[k];                              \
-        f32x2 inv = {__builtin_amdgcn_rcpf(q[kStudentPts - 1].x), __builtin_amdgcn_rcpf(q[kStudentPts - 1].y)};      \
-        _Pragma("unroll") for (int k = kStudentPts - 1; k >= 0; k--) {                                               \
-            const f32x2 t = k > 0 ? inv * q[k > 0 ? k - 1 : 0] : inv;                                                \
-            if (k > 0) inv *= u[k];                                                                                  \
-            const f32x2 a = s_ * t, at = a * t;                                                                      \
-            acc[3 * k + 0] += a;                                                                                     \
-            acc[3 * k + 1] = __builtin_elementwise_fma(a, a, acc[3 * k + 1]);                                        \
-            acc[3 * k + 2] = __builtin_elementwise_fma(a, at, acc[3 * k + 2]);                                       \
-        }                                                                                                            \
-    }
     const int N2 = N >> 1;
     const int step = gridDim.x * kBlock;
     const double nan = __longlong_as_double(0x7ff8000000000000ll);
@@ -2050,31 +2127,12 @@ __global__ __launch_bounds__(kBlock) void k_student_taylor_f32(const double *__r
         for (int d = 0; d < kDeep; d++) {
             const double2_u v = ring[d];
             ring[d] = fetch(i + (kDeep + d) * step);
-            f32x2 s2;
-            TDK_SCALED_SQUARE(v.x, s2.x)
-            TDK_SCALED_SQUARE(v.y, s2.y)
-            TDK_STUDENT_TERM(s2)
+            ta.add(v.x, v.y);
         }
     }
-    if ((N & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        f32x2 s2 = {0.0f, 0.0f};
-        TDK_SCALED_SQUARE(r[N - 1], s2.x)
-        TDK_STUDENT_TERM(s2)
-    }
-#undef TDK_STUDENT_TERM
-#undef TDK_SCALED_SQUARE
+    if ((N & 1) && blockIdx.x == 0 && threadIdx.x == 0) ta.add(r[N - 1], nan);
     __shared__ double red[kWaves][kStudentSums];
-#pragma unroll
-    for (int j = 0; j < kStudentSums; j++) {
-        double v = (double)acc[j].x + (double)acc[j].y;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][j] = v;
-    }
-    __syncthreads();
-    if (threadIdx.x < kStudentSums)
-        partial[((int64_t)pair * gridDim.x + blockIdx.x) * kStudentSums + threadIdx.x] =
-            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    ta.store(red, partial + ((int64_t)pair * gridDim.x + blockIdx.x) * kStudentSums);
 }
 
 // one wave per pair: block partials -> sums (fixed order), then the chain v_1 -> v_10 through the nine Taylor
@@ -2192,7 +2250,7 @@ struct tdk_dvo {
     double *d_rm;         // [n][stride0] masked residual map
     double *d_wscale;     // [n] variance (student-t) / sigma_mad (tukey)
     double *d_stat;       // [n][4]: lo, hi, median, spare
-    double *d_spartial;   // [n][kStatBlocks][kStudentSums] block partials of the statistics passes
+    double *d_spartial;   // [n][kStatBlocks][kStudentSums] block partials of the statistics passes | [n][kStatBlocks] of the first step (fused pass A)
     double *d_st_pts;     // [n][kStudentRow] Student-t: expansion points of the Taylor passes, redo flag
     unsigned int *d_st_redo;   // pairs that took a third Taylor pass (diagnostics)
     int *d_count;         // [n]
@@ -2330,7 +2388,7 @@ tdk_status ensure_robust_buffers(tdk_dvo *h) {
     TDK_HIP(hipMalloc(&h->d_rm, sizeof(double) * (size_t)h->lv[0].stride * n));
     TDK_HIP(hipMalloc(&h->d_wscale, sizeof(double) * n));
     TDK_HIP(hipMalloc(&h->d_stat, sizeof(double) * 4 * n));
-    TDK_HIP(hipMalloc(&h->d_spartial, sizeof(double) * kStatBlocks * kStudentSums * n));
+    TDK_HIP(hipMalloc(&h->d_spartial, sizeof(double) * kStatBlocks * (kStudentSums + 1) * n));   // + the first step's partials
     TDK_HIP(hipMalloc(&h->d_st_pts, sizeof(double) * kStudentRow * n));
     TDK_HIP(hipMalloc(&h->d_st_redo, sizeof(unsigned int)));
     TDK_HIP(hipMemsetAsync(h->d_st_redo, 0, sizeof(unsigned int), h->stream));
@@ -2417,13 +2475,25 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
                                                            h->d_tk_sample);
         TDK_LAUNCH_CHECK();
     }
-#define TDK_MASK(ST, FA, TK)                                                                                          \
-    k_robust_mask<ST, FA, TK><<<grid, kBlock, 0, h->stream>>>(ptrs_of(L), h->d_params, d_poses, d_state, L.scale, h->d_rm, \
-                                                              h->d_count, h->d_spartial, tka)
-    if (brackets) TDK_MASK(false, false, true);
-    else if (weight_mode != TDK_W_STUDENT_T) TDK_MASK(false, false, false);
-    else if (exact) TDK_MASK(true, false, false);
-    else TDK_MASK(true, true, false);
+    // Student-t, Taylor scheme: pass A rides in the mask pass (TDK_STUDENT_FUSED=0: on its own, after it), so the
+    // sample's fixed-point sequence comes first, from residuals computed on the spot
+    static const bool fused_env = [] { const char *v = getenv("TDK_STUDENT_FUSED"); return !(v && v[0] == '0'); }();
+    const bool fused_a = taylor && fused_env;
+    double *partial_v1 = fused_a ? h->d_spartial + (size_t)kStatBlocks * kStudentSums * n : h->d_spartial;
+    if (fused_a) {
+        k_student_predict<true><<<n, kBlock, 0, h->stream>>>(nullptr, L.stride, (int)L.N, d_state, h->d_st_pts, ptrs_of(L),
+                                                             h->d_params, d_poses, L.scale);
+        TDK_LAUNCH_CHECK();
+    }
+#define TDK_MASK(ST, FA, TK, TA)                                                                                      \
+    k_robust_mask<ST, FA, TK, TA><<<grid, kBlock, 0, h->stream>>>(ptrs_of(L), h->d_params, d_poses, d_state, L.scale, \
+                                                                  h->d_rm, h->d_count, partial_v1, tka, h->d_st_pts,  \
+                                                                  h->d_spartial)
+    if (brackets) TDK_MASK(false, false, true, false);
+    else if (weight_mode != TDK_W_STUDENT_T) TDK_MASK(false, false, false, false);
+    else if (exact) TDK_MASK(true, false, false, false);
+    else if (fused_a) TDK_MASK(true, true, false, true);
+    else TDK_MASK(true, true, false, false);
 #undef TDK_MASK
     TDK_LAUNCH_CHECK();
     if (brackets) {
@@ -2451,17 +2521,26 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
     }
     if (weight_mode == TDK_W_STUDENT_T) {
         // the mask pass has left the partial sums of the first step (variance 1, weights.py:10-13)
-        k_robust_student_update<<<n, 64, 0, h->stream>>>(h->d_spartial, nb, h->d_count, d_state,
+        k_robust_student_update<<<n, 64, 0, h->stream>>>(partial_v1, nb, h->d_count, d_state,
                                                          h->d_wscale, n, 0);
         TDK_LAUNCH_CHECK();
         if (taylor) {   // steps 2 .. 10 from two passes (see k_student_taylor); a third one for flagged pairs only
-            k_student_predict<<<n, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, h->d_st_pts);
-            TDK_LAUNCH_CHECK();
+            if (!fused_a) {
+                k_student_predict<false><<<n, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, h->d_st_pts,
+                                                                      ptrs_of(L), h->d_params, d_poses, L.scale);
+                TDK_LAUNCH_CHECK();
+            }
             // one round of resident blocks (4 per CU at 128 VGPRs): a block ends with 36 wave reductions -- the price of
             // ~10 loop iterations -- so it should run many (150 at 256 x 640x480), and a second, partial round would idle CUs
             const int nbt = std::max(1, std::min(nb, 4 * h->n_cu / n));
             dim3 tgrid(nbt, n);
             for (int pass = 0; pass < 3; pass++) {
+                if (pass == 0 && fused_a) {     // the sums of pass A are where the mask pass left them, nb blocks per pair
+                    k_student_chain<<<n, 64, 0, h->stream>>>(h->d_spartial, nb, h->d_count, d_state, h->d_st_pts,
+                                                             h->d_wscale, pass, h->d_st_redo);
+                    TDK_LAUNCH_CHECK();
+                    continue;
+                }
                 if (pass == 0)
                     k_student_taylor_f32<<<tgrid, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, d_state, h->d_st_pts,
                                                                           h->d_spartial);
