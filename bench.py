@@ -92,6 +92,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-workloads", action="store_true", help="headline only")
+    ap.add_argument("--no-traffic-pass", action="store_true",
+                    help="skip the two child runs under rocprofv3 --pmc that measure roofline.traffic in this run")
     ap.add_argument("--no-solo-pass", action="store_true",
                     help="skip the untimed single-batch pass behind roofline.by_level / pyramid_roofline (profiling runs)")
     args = ap.parse_args()
@@ -159,6 +161,71 @@ def load_profile_json(name):
         return json.load(open(path))
     except (ValueError, OSError):
         return None
+
+
+def measure_traffic_in_run(argv):
+    """HBM bytes per full-resolution evaluation launch, measured NOW: two child runs of this script (headline
+    only, a few steps) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, KiB units,
+    read side doubled on gfx950, exactly as /opt/skills/guides/MI355X_MICROARCH.md prescribes (and as
+    profiles/summarize.py does for the committed profile).  Returns (dict | None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    if any(k in os.environ for k in ("ROCPROF_OUTPUT_PATH", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_SDK_TOOL_LIBRARIES")):
+        return None, "this run is itself under a profiler"
+    keep = []
+    skip_next = False
+    for a in argv:                       # the workload flags of this run; its length flags are replaced
+        if skip_next:
+            skip_next = False
+            continue
+        if a in ("--gpus", "--steps", "--warmup", "--min-seconds", "--cpu-seconds", "--dry-ranks"):
+            skip_next = True
+            continue
+        if a.split("=")[0] in ("--gpus", "--steps", "--warmup", "--min-seconds", "--cpu-seconds", "--dry-ranks"):
+            continue
+        keep.append(a)
+    child = [sys.executable, os.path.abspath(__file__)] + keep + [
+        "--no-cpu-baseline", "--no-workloads", "--no-solo-pass", "--no-traffic-pass", "--min-seconds", "0.2",
+        "--steps", "6", "--warmup", "2"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    raw = {}
+    tmp = tempfile.mkdtemp(prefix="tdk_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            try:
+                subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=240, check=True)
+            except (subprocess.SubprocessError, OSError) as e:
+                return None, "rocprofv3 --pmc %s failed: %r" % (ctr, e)
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    name = r["Kernel_Name"]
+                    if r["Counter_Name"] != ctr or not ("k_dvo_eval" in name or "k_dvo_probe" in name):
+                        continue
+                    per.setdefault(int(r["Grid_Size"]), []).append(float(r["Counter_Value"]))
+            if not per:
+                return None, "no k_dvo_eval / k_dvo_probe rows in the %s pass" % ctr
+            top = max(per)               # the full-resolution launches
+            raw[ctr] = (sum(per[top]) / len(per[top]), len(per[top]))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    fetch_kib, n_f = raw["FETCH_SIZE"]
+    write_kib, n_w = raw["WRITE_SIZE"]
+    return ({"hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0, "FETCH_SIZE_KiB_raw": fetch_kib,
+             "WRITE_SIZE_KiB_raw": write_kib, "launches_counted": [n_f, n_w], "seconds": time.perf_counter() - t0},
+            "two child runs of this command (headline only, 6 steps) under rocprofv3 --pmc FETCH_SIZE / --pmc "
+            "WRITE_SIZE during this run; full-resolution k_dvo_eval + k_dvo_probe launches, launch-weighted; "
+            "read side doubled (gfx950 FETCH_SIZE correction)")
 
 
 def roofline_fp64(prof_kind):
@@ -437,7 +504,7 @@ def workload_semi_dense(args, fixture):
            "roofline": roofline(bytes_ud * N * B, ud_ms, kernel="k_ud_classify + k_ud_estimate (update_depth)",
                                 bytes_per_px=bytes_ud, tracks=B),
            "roofline_warp": roofline(BYTES_PER_PX_WARP * N * B, warp_ms,
-                                     kernel="k_sd_targets + k_sd_gather (increment_age + propagate; slot path "
+                                     kernel="k_sd_targets + k_sd_gather2 (increment_age + propagate; slot path "
                                             "k_sd_scatter + k_sd_fold for tracks whose displacement box is too large: "
                                             "%d of this run)" % fallbacks,
                                      bytes_per_px=BYTES_PER_PX_WARP, tracks=B)}
@@ -754,6 +821,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         hp = synthetic.make_pair(H, W, seed=0)
         early["cpu_baselines"] = dvo_cpu_baselines(hp["I0"], hp["D0"], hp["I1"], cam, args.cpu_seconds)
+    if rank == 0 and world == 1 and not args.no_traffic_pass and os.environ.get("TDK_BENCH_DRY") != "1":
+        early["traffic"] = measure_traffic_in_run(sys.argv[1:])
     if rank == 0 and world == 1 and not args.no_workloads:
         fixture = None
         fpath = os.path.join(REPO, "tests", "golden", "semi_dense_cfg3.npz")
@@ -910,15 +979,21 @@ def main():
         kernel_ms = prof["total_ms"] / max(prof["launches"], 1)
         pmc = load_profile_json("pmc_dvo_eval.json") or {}
         traffic = pmc.get("hbm_bytes_per_launch")
+        measured, measured_note = early.get("traffic", (None, "not attempted (--no-traffic-pass, or more than one rank)"))
         rl = roofline(BYTES_PER_PX_EVAL * prof["pixels"] / max(prof["launches"], 1), kernel_ms,
                       kernel=f"k_dvo_eval<{args.weights}> + k_dvo_probe, every full-resolution launch (by_mode: the two kernels on their own)",
                       bytes_per_px=BYTES_PER_PX_EVAL,
                       px_per_launch=prof["pixels"] / max(prof["launches"], 1), launches=prof["launches"],
                       limiter="full evaluations: FP64 issue at the package power cap (DESIGN.md 5.1); "
                               "probes (error only): HBM")
-        rl["traffic"] = traffic
-        rl["traffic_source"] = ("profiles/pmc_dvo_eval.json (%s): separate rocprofv3 --pmc passes over this command, "
-                                "not measured in this run" % pmc.get("source", "?")) if traffic else None
+        if measured:
+            rl["traffic"] = measured["hbm_bytes_per_launch"]
+            rl["traffic_source"] = "measured in this run: " + measured_note
+            rl["traffic_detail"] = dict(measured, committed_profile_bytes_per_launch=traffic)
+        else:
+            rl["traffic"] = traffic
+            rl["traffic_source"] = ("profiles/pmc_dvo_eval.json (%s): separate rocprofv3 --pmc passes over this command, "
+                                    "not measured in this run (%s)" % (pmc.get("source", "?"), measured_note)) if traffic else None
         rl["timing_note"] = ("kernel_ms: HIP events recorded on the batch's own stream around every full-resolution "
                              "launch INSIDE the timed region (one event pair + one host wait per launch: the headline "
                              "is measured with that overhead, i.e. conservatively)")
@@ -1005,7 +1080,7 @@ def main():
         batches = []
         if "workloads" in early:
             out["workloads"] = early["workloads"]
-        out["run_order"] = "cpu baselines, other workloads, headline (timed region last)"
+        out["run_order"] = "cpu baselines, HBM-traffic passes (child runs under rocprofv3 --pmc), other workloads, headline (timed region last)"
         print(json.dumps(out))
     for bt in batches:
         bt.close()

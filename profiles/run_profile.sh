@@ -9,7 +9,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline --no-workloads --no-solo-pass --min-seconds 0.2 --steps 10 --warmup 2"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-workloads --no-solo-pass --no-traffic-pass --min-seconds 0.2 --steps 10 --warmup 2"
 cd /tmp
 # 1) per-kernel time: (a) as the headline runs -- two batches in flight, one batch's pyramid beside the other's
 #    estimation, so every kernel but the full-resolution evaluations is stretched ("under overlap") --
