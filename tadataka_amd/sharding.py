@@ -274,23 +274,30 @@ class FileComm(object):
         self._exchange(np.zeros(1))
 
     def close(self):
-        """Two closing barriers: after the first everybody has read everything that mattered, after
-        the second everybody has read the first's files -- then each rank removes what it wrote and the
-        last one out removes the directories."""
+        """A closing barrier, then every rank leaves a `bye` marker -- written only after it has READ the barrier's
+        files -- and goes; rank 0 waits for all markers (bounded) and removes what is left.  No rank deletes a file
+        a slower peer may still be waiting for."""
         try:
-            self.barrier()
             self.barrier()
         except RuntimeError:
             pass
-        for seq in range(max(1, self._seq - 3), self._seq):
-            try:
-                os.unlink(os.path.join(self._dir, "%d_%d.npy" % (seq, self.rank)))
-            except OSError:
-                pass
-        # the last barrier's own file may still be read by a slower peer: leave it to the last one out
-        time.sleep(0.05)
         try:
-            os.unlink(os.path.join(self._dir, "%d_%d.npy" % (self._seq, self.rank)))
+            open(os.path.join(self._dir, "bye_%d" % self.rank), "wb").close()
+        except OSError:
+            pass
+        if self.rank != 0:
+            return
+        t0 = time.time()
+        while time.time() - t0 < 30.0:
+            if all(os.path.exists(os.path.join(self._dir, "bye_%d" % r)) for r in range(self.world)):
+                break
+            time.sleep(0.002)
+        try:
+            for name in os.listdir(self._dir):
+                try:
+                    os.unlink(os.path.join(self._dir, name))
+                except OSError:
+                    pass
         except OSError:
             pass
         for d in (self._dir, os.path.dirname(self._dir)):
