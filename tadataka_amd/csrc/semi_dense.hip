@@ -1365,12 +1365,11 @@ tdk_status launch_warp_step(int n_tracks, int H, int W, const TrackWarp *d_tw, c
         // (depth1, variance1a) of every source: 16 bytes per pixel in the `slots` region, like `next` free until
         // the slot path runs
         double2 *warped = reinterpret_cast<double2 *>(lists.slots);
-        // four 64 x 4 tiles per block (measured on 64 VGA tracks: 1 / 2 / 4 / 8 / 19 / 38 tiles per block
-        // 0.761 / 0.706 / 0.684 / 0.686 / 0.733 / 0.764 ms for the whole step)
+        // pass 1: four tiles of 64 (or 128: two pixels per lane where W is even) x 4 sources per block and round
+        // (measured on 64 VGA tracks: 1 / 2 / 4 / 8 / 19 / 38 tiles per block 0.761 / 0.706 / 0.684 / 0.686 / 0.733 /
+        // 0.764 ms for the whole step)
         const int n_tiles = ((W + kGatherTW - 1) / kGatherTW) * ((H + kGatherTH - 1) / kGatherTH);
-        int gnb = std::max(1, (n_tiles + 3) / 4);
-        if (const char *v = getenv("TDK_SD_GATHER_NB")) gnb = std::max(1, atoi(v));
-        const unsigned ggrid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)gnb;
+        const int gnb = std::max(1, (n_tiles + 3) / 4);
         const bool px2 = W % 2 == 0;
         const int n_tiles2 = ((W + 2 * kGatherTW - 1) / (2 * kGatherTW)) * ((H + kGatherTH - 1) / kGatherTH);
         const int tnb = px2 ? std::max(1, (n_tiles2 + 3) / 4) : gnb;
