@@ -913,6 +913,37 @@ __device__ int estimate_gate(double ukx, double uky, double prior_id, double pri
     return 0;
 }
 
+// n / d for several n and one d, bit for bit what the compiler's FP64 division gives.  Its sequence is
+//   d' = v_div_scale(d), n' = v_div_scale(n); r = v_rcp(d'); two Newton steps on r; q = n' r; e = fma(-d', q, n');
+//   v_div_fmas(e, r, q); v_div_fixup
+// and v_div_scale / v_div_fmas / v_div_fixup leave their operands alone unless an exponent is extreme (a numerator
+// below 2^-969, a denormal divisor or quotient, exponents ~768 apart) or an operand is 0, Inf or NaN.  Here the
+// numerators are the five samples of a search window and the divisor the root of the sum of their squares: if
+// every sample is "plain" -- zero, or of magnitude in [2^-401, 2^400) -- the divisor (non-zero: checked by the
+// caller) lies in [2^-401, 2^402), every quotient in [2^-803, 1], no scaling or fix-up applies and the result IS
+// fma(e, r, q) with an r that depends on the divisor alone: refined once, three operations per quotient instead of
+// eleven (-8 % of the instructions of k_ud_estimate, which is FP64-issue bound: profiles/r04_update_depth.txt).
+// A zero numerator gives +-0 either way (the sign of a zero cannot reach the error: (+-0 - k)^2).  Inf / NaN
+// samples count as plain too (v_frexp_exp returns 0 for them): they make the window's error NaN on both paths.
+// Anything else -- denormals, |w| outside the range -- takes the division.  tests/test_gpu_round4.py feeds such
+// frames through both and compares with the oracle's IEEE divisions.
+__device__ __forceinline__ bool plain_numerator(double w) {
+    return (unsigned)(__builtin_amdgcn_frexp_exp(w) + 400) <= 800u;
+}
+
+__device__ __forceinline__ double refined_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+__device__ __forceinline__ double shared_quotient(double n, double d, double r) {
+    const double q = n * r;
+    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+
 // Second half: the search along the epipolar line, depth and variance of the best match, final range check.
 __device__ int estimate_search(const SearchState &st, double ukx, double uky, const Cam &kc,
                                const double *__restrict__ key_image, const RefConst &rf, int H, int W,
@@ -939,16 +970,24 @@ __device__ int estimate_search(const SearchState &st, double ukx, double uky, co
     double w0 = 0, w1 = 0, w2 = 0, w3 = 0, w4 = 0;
     double min_err = INFINITY;
     int argmin = 0;
+    int plain_run = 5;          // samples up to and including w4 that are plain numerators (the initial zeros are)
     for (int i = 0; i < n; i++) {
         double s = (double)i * pr.ref_step, ux, uy;
         tdk::unnormalize(rc, xmin_x + s * dirx, xmin_y + s * diry, ux, uy);
         w0 = w1; w1 = w2; w2 = w3; w3 = w4;
         w4 = sample(rf.image, H, W, ux, uy);
+        plain_run = plain_numerator(w4) ? plain_run + 1 : 0;
         if (i < 4) continue;
         double q = ((((w0 * w0 + w1 * w1) + w2 * w2) + w3 * w3) + w4 * w4);
         double sn = sqrt(q);
         double a0 = w0, a1 = w1, a2 = w2, a3 = w3, a4 = w4;
-        if (sn != 0.) { a0 = w0 / sn; a1 = w1 / sn; a2 = w2 / sn; a3 = w3 / sn; a4 = w4 / sn; }
+        if (sn != 0.) {
+            if (plain_run >= 5) {       // the five IEEE quotients from one refinement of 1 / sn (shared_quotient)
+                const double r = refined_rcp(sn);
+                a0 = shared_quotient(w0, sn, r); a1 = shared_quotient(w1, sn, r); a2 = shared_quotient(w2, sn, r);
+                a3 = shared_quotient(w3, sn, r); a4 = shared_quotient(w4, sn, r);
+            } else { a0 = w0 / sn; a1 = w1 / sn; a2 = w2 / sn; a3 = w3 / sn; a4 = w4 / sn; }
+        }
         double d0 = a0 - kn[0], d1 = a1 - kn[1], d2 = a2 - kn[2], d3 = a3 - kn[3], d4 = a4 - kn[4];
         double e = ((((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3) + d4 * d4);
         if (e < min_err) { min_err = e; argmin = i - 4; }

@@ -486,3 +486,34 @@ def test_session_counts_warp_fallbacks(ops, orc, monkeypatch):
         od, ov = orc.propagate(T10s[t], c["cam"], c["cam"], c["prior_depth"], var0, 1.0, 10.0, 0.01)
         assert np.array_equal(d1, od) and np.array_equal(v1, ov)
     sd.close()
+
+
+# ---------------------------------------------------------------------------
+# the search's five quotients by one refined reciprocal (shared_quotient, csrc/semi_dense.hip) against IEEE divisions
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("special", ["finite", "inf_nan"])
+def test_update_depth_mixed_magnitude_reference_frames(ops, orc, special):
+    """Reference frames whose texels mix ordinary intensities with zeros, negative zeros, denormals, values far
+    outside [2^-401, 2^400) and (second case) Inf / NaN, texel by texel, so that search windows hold every mixture
+    of "plain" and other numerators: flags, depths and variances equal the oracle's (IEEE divisions on the CPU)."""
+    from tadataka_amd import synthetic
+    H, W = 96, 128
+    c = synthetic.make_semi_dense_case(H, W, seed=5)
+    pg, po = ops.make_params(0.5, 10.0, 0.01, 0.01, 0.004, 0.01), orc.make_params(0.5, 10.0, 0.01, 0.01, 0.004, 0.01)
+    age = np.ones((H, W), dtype=np.uint64)
+    rng = np.random.default_rng(9)
+    scales = [1.0, 1.0, 1.0, 1e-130, 1e-200, 1e-310, 0.0, -0.0, 1e150, -1.0, 3e-122, 2.6e120]
+    if special == "inf_nan":
+        scales += [np.inf, np.nan, -np.inf]
+    with np.errstate(all="ignore"):
+        for density in (0.02, 0.3, 1.0):
+            pick = rng.integers(0, len(scales), (H, W))
+            mult = np.asarray(scales)[pick]
+            mult = np.where(rng.uniform(size=(H, W)) < density, mult, 1.0)
+            ref_image = np.ascontiguousarray(c["ref_image"] * mult)
+            key = (c["cam"], c["key_image"], c["T_wk"]); ref = (c["cam"], ref_image, c["T_wr"])
+            d, v, f = ops.update_depth(key, [ref], age, c["prior_depth"], c["prior_variance"], pg)
+            od, ov, of = orc.update_depth(key, [ref], age, c["prior_depth"], c["prior_variance"], po)
+            assert np.array_equal(f, of), (special, density, int((f != of).sum()))
+            assert np.array_equal(d, od, equal_nan=True) and np.array_equal(v, ov, equal_nan=True), (special, density)
+            assert int((of == 0).sum()) > 0 or density == 1.0
