@@ -203,7 +203,7 @@ def measure_traffic_in_run(argv):
             try:
                 subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
                                cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
-                               timeout=240, check=True)
+                               timeout=120, check=True)
             except (subprocess.SubprocessError, OSError) as e:
                 return None, "rocprofv3 --pmc %s failed: %r" % (ctr, e)
             per = {}
