@@ -389,7 +389,7 @@ typedef struct tdk_sd tdk_sd;
 tdk_status tdk_sd_create(int n_tracks, int height, int width, int max_refframes, tdk_sd **out);
 tdk_status tdk_sd_set_age_policy(tdk_sd *h, int saturate);
 /* The forward warp of a step (increment_age + propagate) runs as a gather over a small window of sources
- * where the track's displacement field fits one (see csrc/semi_dense.hip: k_sd_targets / k_sd_gather) and
+ * where the track's displacement field fits one (see csrc/semi_dense.hip: k_sd_targets / k_sd_gather2) and
  * through per-target slot lists where it does not; same results either way.  tracks: how many (track, step)
  * warps of this session have taken the slot path so far.  TDK_SD_GATHER=0 disables the gather. */
 tdk_status tdk_sd_get_warp_fallbacks(tdk_sd *h, int64_t *tracks);
