@@ -238,6 +238,99 @@ def rescale(image, scale, anti_aliasing=False):
     return out
 
 
+# ---------------------------------------------------------------------------
+# skimage.transform.rescale, faithfully (scikit-image 0.18.3; orc_rescale_skimage in
+# tdk_oracle.c).  The two interpreter-dependent ingredients -- the affine map that
+# resize() ESTIMATES by SVD and scipy.ndimage's Gaussian kernels -- are computed here
+# with the very NumPy calls skimage / scipy make (so on any interpreter they are what
+# skimage would get there), or come from a fixture that recorded the generator's.
+# ---------------------------------------------------------------------------
+def _center_and_normalize_points(points):
+    """skimage/transform/_geometric.py:18-69 (Hartley normalisation), call for call."""
+    import math
+    centroid = np.mean(points, axis=0)
+    rms = math.sqrt(np.sum((points - centroid) ** 2) / points.shape[0])
+    norm_factor = math.sqrt(2) / rms
+    matrix = np.array([[norm_factor, 0, -norm_factor * centroid[0]],
+                       [0, norm_factor, -norm_factor * centroid[1]],
+                       [0, 0, 1]])
+    pointsh = np.vstack([points.T, np.ones((points.shape[0]),)])
+    new_pointsh = (matrix @ pointsh).T
+    new_points = new_pointsh[:, :2]
+    new_points[:, 0] /= new_pointsh[:, 2]
+    new_points[:, 1] /= new_pointsh[:, 2]
+    return matrix, new_points
+
+
+def skimage_resize_map(in_shape, out_shape):
+    """(ax, bx, ay, by) of skimage.transform.resize's warp: _warps.py:156-176 (three corner
+    correspondences, AffineTransform.estimate, off-diagonals zeroed) with
+    ProjectiveTransform.estimate (_geometric.py:652-702) restated call for call."""
+    rows, cols = float(out_shape[0]), float(out_shape[1])
+    factors = np.asarray(in_shape, dtype=float) / np.asarray([rows, cols], dtype=float)
+    if rows == 1 and cols == 1:
+        return np.array([1.0, in_shape[1] / 2.0 - 0.5, 1.0, in_shape[0] / 2.0 - 0.5])
+    src = np.array([[1, 1], [1, rows], [cols, rows]]) - 1
+    dst = np.zeros(src.shape, dtype=np.double)
+    dst[:, 0] = factors[1] * (src[:, 0] + 0.5) - 0.5
+    dst[:, 1] = factors[0] * (src[:, 1] + 0.5) - 0.5
+    src_matrix, s = _center_and_normalize_points(src)
+    dst_matrix, d = _center_and_normalize_points(dst)
+    xs, ys, xd, yd = s[:, 0], s[:, 1], d[:, 0], d[:, 1]
+    n = s.shape[0]
+    A = np.zeros((n * 2, 9))
+    A[:n, 0] = xs; A[:n, 1] = ys; A[:n, 2] = 1; A[:n, 6] = -xd * xs; A[:n, 7] = -xd * ys
+    A[n:, 3] = xs; A[n:, 4] = ys; A[n:, 5] = 1; A[n:, 6] = -yd * xs; A[n:, 7] = -yd * ys
+    A[:n, 8] = xd; A[n:, 8] = yd
+    coeffs = list(range(6))                      # AffineTransform._coeffs
+    A = A[:, coeffs + [8]]
+    _, _, V = np.linalg.svd(A)
+    Hm = np.zeros((3, 3))
+    Hm.flat[coeffs + [8]] = -V[-1, :-1] / V[-1, -1]
+    Hm[2, 2] = 1
+    Hm = np.linalg.inv(dst_matrix) @ Hm @ src_matrix
+    return np.array([Hm[0, 0], Hm[0, 2], Hm[1, 1], Hm[1, 2]])
+
+
+def scipy_gaussian_kernel(sigma):
+    """scipy.ndimage gaussian_filter1d's kernel (truncate 4), or None where gaussian_filter skips the axis."""
+    if not sigma > 1e-15:
+        return None
+    radius = int(4.0 * float(sigma) + 0.5)
+    sigma2 = sigma * sigma
+    x = np.arange(-radius, radius + 1)
+    phi_x = np.exp(-0.5 / sigma2 * x ** 2)
+    return np.ascontiguousarray((phi_x / phi_x.sum())[::-1])
+
+
+def skimage_plan(in_shape, out_shape, anti_aliasing=True):
+    """Everything of resize() that depends on shapes only: {'map', 'wr', 'wc'}."""
+    factors = np.asarray(in_shape, dtype=float) / np.asarray(out_shape, dtype=float)
+    sigma = np.maximum(0, (factors - 1) / 2)
+    return {"map": skimage_resize_map(in_shape, out_shape),
+            "wr": scipy_gaussian_kernel(sigma[0]) if anti_aliasing else None,
+            "wc": scipy_gaussian_kernel(sigma[1]) if anti_aliasing else None}
+
+
+def rescale_skimage(image, scale, plan=None, anti_aliasing=True, clip=True):
+    """skimage.transform.rescale(image, scale) of a 2-D float64 image, to the bit given the plan."""
+    image, p = _d(image)
+    Ho, Wo = rescale_shape(image.shape, scale)
+    if plan is None:
+        plan = skimage_plan(image.shape, (Ho, Wo), anti_aliasing)
+    out = np.empty((Ho, Wo))
+    m = np.ascontiguousarray(plan["map"], dtype=np.float64)
+    wr = None if plan.get("wr") is None or len(plan["wr"]) == 0 else np.ascontiguousarray(plan["wr"], dtype=np.float64)
+    wc = None if plan.get("wc") is None or len(plan["wc"]) == 0 else np.ascontiguousarray(plan["wc"], dtype=np.float64)
+    lib().orc_rescale_skimage(
+        p, C.c_int(image.shape[0]), C.c_int(image.shape[1]), out.ctypes.data_as(_dp), C.c_int(Ho), C.c_int(Wo),
+        m.ctypes.data_as(_dp),
+        None if wr is None else wr.ctypes.data_as(_dp), C.c_int(0 if wr is None else len(wr) // 2),
+        None if wc is None else wc.ctypes.data_as(_dp), C.c_int(0 if wc is None else len(wc) // 2),
+        C.c_int(1 if clip else 0))
+    return out
+
+
 def gaussian_weights(sigma, radius=None):
     radius = lib().orc_gaussian_radius(C.c_double(sigma)) if radius is None else radius
     w = np.empty(2 * radius + 1)
@@ -326,12 +419,23 @@ def dvo_estimate_level(I0, D0, I1, cam0, cam1, rotation, t, weights=None,
 
 
 def dvo_estimate(I0, D0, I1, cam0, cam1, weights=None, n_coarse_to_fine=5,
-                 max_iter=20, layer_size_ratio=1.5, rotation=None, t=None, anti_aliasing=False):
-    """PoseChangeEstimator.__call__ (tadataka/vo/dvo/__init__.py:125-150) with
-    the build's own pyramid (plain bilinear, or with skimage's anti-aliasing prefilter)
-    in place of skimage.rescale."""
-    def rescale(image, scale, _aa=anti_aliasing):
-        return globals()["rescale"](image, scale, anti_aliasing=_aa)
+                 max_iter=20, layer_size_ratio=1.5, rotation=None, t=None, anti_aliasing=False,
+                 pyramid=None, plans=None, level_poses=None):
+    """PoseChangeEstimator.__call__ (tadataka/vo/dvo/__init__.py:125-150).
+
+    pyramid="skimage": every level -- level 0 / scale 1.0 included, as the reference does -- through
+    rescale_skimage (scikit-image 0.18.3 to the bit, given the plans: a callable (in_shape, out_shape)
+    -> plan, or None for this interpreter's own).  Otherwise the idealised readings of earlier rounds:
+    level 0 is the input itself, the others sample at (i + 0.5) * factor - 0.5, plain bilinear or
+    (anti_aliasing=True) behind the Gaussian prefilter."""
+    if pyramid == "skimage":
+        def rescale(image, scale):
+            out_shape = rescale_shape(image.shape, scale)
+            plan = plans(image.shape, out_shape) if plans is not None else None
+            return rescale_skimage(image, scale, plan)
+    else:
+        def rescale(image, scale, _aa=anti_aliasing):
+            return globals()["rescale"](image, scale, anti_aliasing=_aa)
     rotation = Rotation.from_rotvec(np.zeros(3)) if rotation is None else rotation
     t = np.zeros(3) if t is None else t
     cam0 = np.asarray(cam0, dtype=np.float64); cam1 = np.asarray(cam1, dtype=np.float64)
@@ -341,7 +445,17 @@ def dvo_estimate(I0, D0, I1, cam0, cam1, weights=None, n_coarse_to_fine=5,
         rotation, t = dvo_estimate_level(
             rescale(I0, scale), rescale(D0, scale), rescale(I1, scale),
             cam0 * scale, cam1 * scale, rotation, t, W0, max_iter)
+        if level_poses is not None:
+            level_poses.append(np.concatenate([rotation.as_rotvec(), t]))
     return rotation, t
+
+
+def fixture_plans(npz):
+    """(in_shape, out_shape) -> plan from the plan_* records of a tests/golden/skimage_*.npz."""
+    def get(in_shape, out_shape):
+        key = f"plan_{in_shape[0]}x{in_shape[1]}_{out_shape[0]}x{out_shape[1]}"
+        return {"map": npz[key + "_map"], "wr": npz[key + "_wr"], "wc": npz[key + "_wc"]}
+    return get
 
 
 # ---- semi-dense ------------------------------------------------------------

@@ -494,6 +494,92 @@ void orc_rescale_anti_aliased(const double *src, int H, int W, double *dst, int 
     free(f); free(wr); free(wc);
 }
 
+/* ------------------------------------------------------------------------
+ * skimage.transform.rescale as scikit-image 0.18.3 executes it for a 2-D float64
+ * image (order 1, mode 'reflect', clip=True: what tadataka/vo/dvo/__init__.py:
+ * 144-148 calls for EVERY level, level 0 / scale 1.0 included), restated from the
+ * installed package's sources (transform/_warps.py resize() :91-185, warp()
+ * :826-930, _clip_warp_output; transform/_warps_cy.pyx _warp_fast /
+ * _transform_metric; _shared/interpolation.pxd bilinear_interpolation /
+ * coord_map mode 'R') and PINNED against that package run in the build container
+ * (tests/golden/generate_golden_skimage.py -> tests/golden/skimage_*.npz).
+ *
+ * Two quantities in that pipeline are products of the interpreter's NumPy /
+ * LAPACK / libm rather than of the algorithm, so they are INPUTS here:
+ *   map = (ax, bx, ay, by): resize() ESTIMATES its affine map from three corner
+ *         correspondences (AffineTransform.estimate: Hartley normalisation,
+ *         numpy.linalg.svd, numpy.linalg.inv) instead of using
+ *         factor, factor/2 - 1/2; the estimate is a few ulp off in the scale and
+ *         ~1e-13 off in the offset, differently on every LAPACK build.  Sample
+ *         positions are col = ax * ox + bx, row = ay * oy + by (a product and a
+ *         sum, each rounded: _transform_metric).
+ *   wr / wc: scipy.ndimage's Gaussian kernels, numpy.exp(-0.5 / sigma^2 * x^2)
+ *         normalised by their numpy sum (2 R + 1 entries; NULL = that axis has
+ *         sigma <= 1e-15 and is not filtered).  numpy's SIMD exp and pairwise
+ *         sum differ from libm's exp and a sequential sum in the last bit.
+ * oracle.py (skimage_plan) and the product's host code (tadataka_amd/
+ * rescale_plan.py) compute both with the same NumPy calls skimage / scipy make,
+ * or take them from a fixture that recorded what the generating interpreter got.
+ * --------------------------------------------------------------------- */
+
+/* _shared/interpolation.pxd coord_map, mode 'R' ("reflect" = numpy.pad 'reflect':
+ * d c b | a b c d | c b a) */
+static inline int64_t skimage_reflect(int64_t dim, int64_t coord) {
+    int64_t cmax = dim - 1;
+    if (dim == 1) return 0;
+    if (coord < 0) {
+        if (((-coord) / cmax) % 2 != 0) return cmax - ((-coord) % cmax);
+        return (-coord) % cmax;
+    }
+    if (coord > cmax) {
+        if ((coord / cmax) % 2 != 0) return cmax - (coord % cmax);
+        return coord % cmax;
+    }
+    return coord;
+}
+
+/* numpy.clip(x, lo, hi) == minimum(maximum(x, lo), hi), NaN-propagating */
+static inline double np_clip(double x, double lo, double hi) {
+    double m = (x != x || lo != lo) ? NAN : (x > lo ? x : lo);
+    return (m != m || hi != hi) ? NAN : (m < hi ? m : hi);
+}
+
+void orc_rescale_skimage(const double *src, int H, int W, double *dst, int Ho, int Wo, const double *map,
+                         const double *wr, int Rr, const double *wc, int Rc, int clip) {
+    /* resize(): image = ndi.gaussian_filter(image, sigma, mode='mirror') -- a plain copy when no axis is filtered */
+    double *f = (double *)malloc(sizeof(double) * (size_t)H * W);
+    orc_gaussian_filter_mirror(src, H, W, wr, Rr, wc, Rc, f);
+    const double ax = map[0], bx = map[1], ay = map[2], by = map[3];
+    /* _clip_warp_output: bounds are the min / max of the image handed to warp(), i.e. of the FILTERED image
+     * (ndarray.min / .max: NaN if any element is NaN) */
+    double lo = f[0], hi = f[0];
+    int has_nan = 0;
+    for (int64_t i = 0; i < (int64_t)H * W; i++) {
+        if (f[i] != f[i]) has_nan = 1;
+        if (f[i] < lo) lo = f[i];
+        if (f[i] > hi) hi = f[i];
+    }
+    if (has_nan) lo = hi = NAN;
+    for (int oy = 0; oy < Ho; oy++) {
+        const double r = ay * (double)oy + by;                 /* _transform_metric: y_ = H[4] * y + H[5] */
+        const int64_t minr = (int64_t)floor(r), maxr = (int64_t)ceil(r);
+        const double dr = r - (double)minr;
+        const int64_t r0 = skimage_reflect(H, minr), r1 = skimage_reflect(H, maxr);
+        for (int ox = 0; ox < Wo; ox++) {
+            const double c = ax * (double)ox + bx;             /* x_ = H[0] * x + H[2] */
+            const int64_t minc = (int64_t)floor(c), maxc = (int64_t)ceil(c);
+            const double dc = c - (double)minc;
+            const int64_t c0 = skimage_reflect(W, minc), c1 = skimage_reflect(W, maxc);
+            /* bilinear_interpolation */
+            const double top = (1 - dc) * f[r0 * W + c0] + dc * f[r0 * W + c1];
+            const double bottom = (1 - dc) * f[r1 * W + c0] + dc * f[r1 * W + c1];
+            const double v = (1 - dr) * top + dr * bottom;
+            dst[(int64_t)oy * Wo + ox] = clip ? np_clip(v, lo, hi) : v;
+        }
+    }
+    free(f);
+}
+
 /* ========================================================================
  * Semi-dense (src/semi_dense/ *.rs)
  * ===================================================================== */

@@ -74,6 +74,10 @@ int orc_gaussian_radius(double sigma);
 void orc_gaussian_filter_mirror(const double *src, int H, int W, const double *wr, int Rr,
                                 const double *wc, int Rc, double *dst);
 void orc_rescale_anti_aliased(const double *src, int H, int W, double *dst, int Ho, int Wo);
+/* skimage.transform.rescale (0.18.3) with the interpreter-dependent constants as inputs: map = (ax, bx, ay, by) the
+ * estimated affine map, wr / wc scipy's Gaussian kernels (2 R + 1 entries, NULL = axis not filtered), clip as clip=True */
+void orc_rescale_skimage(const double *src, int H, int W, double *dst, int Ho, int Wo, const double *map,
+                         const double *wr, int Rr, const double *wc, int Rc, int clip);
 
 /* ---- semi-dense ---------------------------------------------------------- */
 typedef struct {
