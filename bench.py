@@ -75,9 +75,14 @@ def parse_args():
                          "but the NEXT batch's pyramid is queued on that batch's own stream and runs under the current "
                          "batch's estimation")
     ap.set_defaults(double_buffer=True)
-    ap.add_argument("--pyramid", choices=["anti-aliased", "bilinear"],
-                    default="anti-aliased" if tadataka_amd.PYRAMID_ANTI_ALIASING else "bilinear",
-                    help="anti-aliased = what skimage.rescale builds by default (the reference-equivalent one)")
+    ap.add_argument("--pyramid", choices=["skimage", "skimage-depth-level0", "ideal", "bilinear"], default="skimage",
+                    help="skimage = every level as skimage.transform.rescale returns it, to the bit, level 0 through "
+                         "rescale(., 1.0) and clip=True included -- what the reference builds (for 640x480 x 3 levels with "
+                         "the plans of tests/golden/skimage_dvo.npz, so that pair 0 can be held against the reference "
+                         "run on the real scikit-image; else with this interpreter's own plans); skimage-depth-level0 = "
+                         "the same, but only the depth map gets a level 0 of its own (the images' level 0 is the frame: "
+                         "1e-13 from skimage's, poses unchanged at 1e-16); ideal = ideal sample positions, libm "
+                         "kernels, level 0 = the frame, no clip (rounds 1-4); bilinear = ideal without the prefilter")
     ap.add_argument("--min-seconds", type=float, default=10.0,
                     help="repeat the timed block of --steps steps until this much timed work has run (default 10 s: a "
                          "GPU-busy sampler with a 5 s period cannot miss it; the headline is the LAST thing the run does)")
@@ -350,6 +355,17 @@ def workload_dvo_single_pair(args, golden):
     cm = CameraModel(CameraParameters(cam[0:2], cam[2:4]), distortion_model=None)
     est = dvo.PoseChangeEstimator(cm, cm, n_coarse_to_fine=3, max_iter=20)
     weights = None if args.weights == "none" else args.weights
+    if golden is not None and "plan_480x640_480x640_map" in golden:
+        # the plans of the interpreter the fixture's reference run used (the default: this interpreter's own)
+        def fixture_plans(shape, n_levels, ratio):
+            from tadataka_amd import rescale_plan
+            plans = []
+            for lv in range(n_levels):
+                ho, wo = rescale_plan.rescale_shape(shape, 1 / ratio ** lv)
+                key = f"plan_{shape[0]}x{shape[1]}_{ho}x{wo}"
+                plans.append({"map": golden[key + "_map"], "wr": golden[key + "_wr"], "wc": golden[key + "_wc"]})
+            return plans
+        dvo.PYRAMID_PLANS = fixture_plans
     pose = est(pair["I0"], pair["D0"], pair["I1"], weights)          # creates the device batch
     n_calls = 100
     t0 = time.perf_counter()
@@ -357,7 +373,7 @@ def workload_dvo_single_pair(args, golden):
         pose = est(pair["I0"], pair["D0"], pair["I1"], weights)
     dt = time.perf_counter() - t0
     # kernel times in a second, profiled loop (profiling records events and waits once per launch)
-    batch = dvo._batch_for((480, 640), 3, 1.5, False)
+    batch = dvo._batch_for((480, 640), 3, 1.5, False, dvo.PYRAMID)
     batch.set_profiling(True)
     for _ in range(20):
         est(pair["I0"], pair["D0"], pair["I1"], weights)
@@ -367,7 +383,7 @@ def workload_dvo_single_pair(args, golden):
                      "640x480 pair per call, host arrays in, Pose out (PCIe and launch latency included)",
            "ms_per_call": dt / n_calls * 1e3, "frame_pairs_per_s": n_calls / dt,
            "h2d_bytes_per_call": 3 * 480 * 640 * 8}
-    tag = ("pyr_aa_" if dvo.ANTI_ALIASING else "pyr_") + str(weights)
+    tag = "v3_" + str(weights)
     if golden is not None and f"{tag}_t" in golden:
         from scipy.spatial.transform import Rotation
         err = max(float(np.max(np.abs(pose.R - Rotation.from_rotvec(golden[f"{tag}_rotvec"]).as_matrix()))),
@@ -775,7 +791,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("NCCL_DEBUG", "WARN")     # RCCL says on stderr why an init failed
 
-    from tadataka_amd import _lib, ops, sharding, synthetic
+    from tadataka_amd import _lib, ops, rescale_plan, sharding, synthetic
     _lib.require_gpu()
     # one GPU per rank; on a box with fewer GPUs than ranks (only ever a smoke test) ranks share devices
     _lib.call("tdk_set_device", local_rank % _lib.device_count())       # (= `device` below)
@@ -815,9 +831,23 @@ def main():
     # BASELINE configs -- so that the tail of the run is the timed GPU work of the headline.
     early = {}
     golden_early = None
-    gpath = os.path.join(REPO, "tests", "golden", "dvo_vga_pyramid.npz")
-    if rank == 0 and (H, W, args.levels, args.max_iter) == (480, 640, 3, 20) and os.path.exists(gpath):
+    skimage_mode = args.pyramid.startswith("skimage")
+    gpath = os.path.join(REPO, "tests", "golden", "skimage_dvo.npz" if skimage_mode else "dvo_vga_pyramid.npz")
+    is_cfg2 = (H, W, args.levels, args.max_iter) == (480, 640, 3, 20)
+    if is_cfg2 and os.path.exists(gpath):
         golden_early = np.load(gpath)
+    # the plans of the pyramid: the fixture's for configs[1] (every rank: pair 0's assertion is against the reference
+    # run on that interpreter's scikit-image), this interpreter's own otherwise
+    fixture_plans = None
+    if skimage_mode and golden_early is not None:
+        fixture_plans = []
+        for lv in range(args.levels):
+            ho, wo = rescale_plan.rescale_shape((H, W), 1 / 1.5 ** lv)
+            key = f"plan_{H}x{W}_{ho}x{wo}"
+            fixture_plans.append({"map": golden_early[key + "_map"], "wr": golden_early[key + "_wr"],
+                                  "wc": golden_early[key + "_wc"]})
+    if rank != 0:
+        golden_early = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         hp = synthetic.make_pair(H, W, seed=0)
         early["cpu_baselines"] = dvo_cpu_baselines(hp["I0"], hp["D0"], hp["I1"], cam, args.cpu_seconds)
@@ -843,15 +873,18 @@ def main():
                 wl[name] = {"error": repr(e)}
         early["workloads"] = wl
     mode = ops.WEIGHT_MODES[weights]
-    anti_aliasing = args.pyramid == "anti-aliased"
+    anti_aliasing = args.pyramid != "bilinear"
     n_batches = 2 if args.double_buffer else 1
     # this rank's shard of the pair ids: n_batches consecutive blocks of B pairs
     seeds = [sharding.batch_seed0(rank, n_batches, B, k) for k in range(n_batches)]
     batches = []
     for seed0 in seeds:
         bt = ops.DvoBatch(B, H, W, n_levels=args.levels, ratio=1.5)
+        if skimage_mode:
+            bt.set_skimage_pyramid(fixture_plans, level0="all" if args.pyramid == "skimage" else ["D0"])
+        else:
+            bt.set_anti_aliasing(anti_aliasing)
         bt.fill_synthetic(cam, true_poses(B, seed0), seed0=seed0, noise=0.02)
-        bt.set_anti_aliasing(anti_aliasing)
         batches.append(bt)
     batch = batches[0]
     # pair 0 of the whole job = the pair the reference's own PoseChangeEstimator was run on
@@ -955,7 +988,7 @@ def main():
             h_l, w_l = solo.level_shape(lv)
             by_level[f"level{lv}_{w_l}x{h_l}"] = entry
         solo.set_profiling(False)
-        if args.levels > 1:
+        if args.levels > 1 or solo.level0_mask:
             _lib.call("tdk_sync")
             n_builds = 20
             t0 = time.perf_counter()
@@ -964,10 +997,12 @@ def main():
             _lib.call("tdk_sync")
             pms = (time.perf_counter() - t0) / n_builds * 1e3
             out_px = sum(solo.level_shape(lv)[0] * solo.level_shape(lv)[1] for lv in range(1, args.levels))
-            pbytes = 8.0 * 3 * B * (H * W + out_px)           # I0, D0, I1: level 0 read once, the levels written
+            n_l0 = bin(solo.level0_mask & 7).count("1")       # arrays whose level 0 is a rescale of its own: + one write each
+            pbytes = 8.0 * B * (3 * (H * W + out_px) + n_l0 * H * W)   # I0, D0, I1: frame read once, the levels written
             pyramid_alone = roofline(pbytes, pms, kernel="pyramid build of one batch alone (k_pyramid_stream / "
                                      "k_rescale_aa_multi for anti-aliased levels), host-timed over %d builds" % n_builds,
-                                     bytes_note="compulsory traffic: 3 arrays x (level 0 read once + levels written)")
+                                     bytes_note="compulsory traffic: 3 arrays x (frame read once + levels written), "
+                                                "+ one frame written per array whose level 0 is a rescale of its own")
     pixels_all, error_px_all, update_px_all = (float(v) for v in sharding.reduce_scalars(
         [float(pixels), float(work_px[0]), float(work_px[1])], "sum", comm))
 
@@ -1035,8 +1070,13 @@ def main():
                                    f"{W}x{H} frame pairs, {args.levels}-level pyramid ratio 1.5, "
                                    f"weights={args.weights}, max_iter={args.max_iter}",
                        "pairs_per_gpu": B, "batches_in_flight": n_batches,
-                       "pyramid": "anti-aliased (gaussian prefilter + bilinear, skimage.rescale's default)"
-                                  if anti_aliasing else "bilinear",
+                       "pyramid": {"skimage": "skimage.transform.rescale to the bit, every level incl. level 0 (rescale(., 1.0)), "
+                                              "clip=True; plans (estimated affine maps, scipy kernels): " +
+                                              ("tests/golden/skimage_dvo.npz (scikit-image 0.18.3 / numpy 1.26.4)"
+                                               if fixture_plans else "this interpreter's"),
+                                   "skimage-depth-level0": "as skimage, level 0 of its own for the depth map only",
+                                   "ideal": "anti-aliased at the ideal sample positions, level 0 = the frame, no clip",
+                                   "bilinear": "bilinear at the ideal sample positions"}[args.pyramid],
                        "height": H, "width": W, "levels": args.levels,
                        "weights": args.weights, "max_iter": args.max_iter,
                        "parallelism": f"pair-shard x{world}, RCCL all-gather of poses" if world > 1 else "single GPU"},
@@ -1058,13 +1098,17 @@ def main():
 
         if golden is not None and pair0_pose[0] is not None:
             from scipy.spatial.transform import Rotation
-            tag = ("pyr_aa_" if anti_aliasing else "pyr_") + str(weights)
+            tag = ("v3_" if skimage_mode else ("pyr_aa_" if anti_aliasing else "pyr_")) + str(weights)
             if f"{tag}_t" in golden:
                 p0 = pair0_pose[0]                      # pair 0 of batch 0, from the last step that ran it
                 err = max(float(np.max(np.abs(p0[:9].reshape(3, 3) -
                                               Rotation.from_rotvec(golden[f"{tag}_rotvec"]).as_matrix()))),
                           float(np.max(np.abs(p0[9:] - golden[f"{tag}_t"]))))
                 out["pair0_pose_error_vs_reference_loop"] = err
+                out["pair0_reference"] = ("the reference's own PoseChangeEstimator on the REAL skimage.transform.rescale "
+                                          "(scikit-image 0.18.3; tests/golden/skimage_dvo.npz)" if skimage_mode else
+                                          "the reference's own PoseChangeEstimator on the ideal-constants stand-in rescale "
+                                          "(tests/golden/dvo_vga_pyramid.npz)")
                 assert err < 1e-6, f"pair 0 differs from the reference's PoseChangeEstimator by {err}"
         if "cpu_baselines" in early:
             cb = early["cpu_baselines"]

@@ -79,15 +79,26 @@ tdk_status tdk_interpolation(const double *image, int height, int width,
 tdk_status tdk_calc_depth0(const double *transform10, const double *x0, const double *x1, double *depth);
 /* tadataka.vo.dvo.jacobian.calc_image_gradient = np.gradient (jacobian.py:27-29); out (DX, DY) */
 tdk_status tdk_image_gradient(const double *image, int height, int width, double *gx, double *gy);
-/* Pyramid level: bilinear rescale to (out_height, out_width) (stand-in for
- * skimage.transform.rescale, tadataka/vo/dvo/__init__.py:144-148) */
+/* skimage.transform.rescale(image, scale) / resize(image, (out_height, out_width)) of a 2-D float64 image as
+ * the reference calls it for every pyramid level (tadataka/vo/dvo/__init__.py:144-148; order 1, mode 'reflect',
+ * anti_aliasing and clip as given), bit for bit what scikit-image 0.18.3 returns -- pinned against that package
+ * run in the build container (tests/golden/skimage_rescale.npz).  Two ingredients of skimage's pipeline are
+ * products of the caller's NumPy / LAPACK rather than of the algorithm and are therefore ARGUMENTS:
+ *   map[4] = (ax, bx, ay, by): output (row oy, column ox) samples the filtered image at (ay * oy + by, ax * ox + bx);
+ *            resize() estimates this map by SVD from three corner correspondences (skimage/transform/_warps.py:156-176),
+ *            a few ulp / 1e-13 off factor and factor / 2 - 1 / 2, differently on every LAPACK build;
+ *   w_rows / w_cols: scipy.ndimage's Gaussian kernels (2 * radius + 1 doubles, numpy.exp(-0.5 / sigma^2 * x^2) / sum);
+ *            radius 0 = that axis is not filtered (sigma <= 1e-15, or anti_aliasing=False).
+ * tadataka_amd/rescale_plan.py computes both with the NumPy calls skimage and scipy make.  clip: skimage's
+ * clip=True (outputs clipped to the extremes of the filtered image). */
+tdk_status tdk_rescale_skimage(const double *image, int height, int width, double *out, int out_height, int out_width,
+                               const double *map, const double *w_rows, int radius_rows, const double *w_cols,
+                               int radius_cols, int clip);
+/* The same pipeline with the IDEAL constants instead of a plan -- sample positions (i + 0.5) * factor - 0.5,
+ * kernels from libm's exp, no clip -- without (tdk_rescale) and with (tdk_rescale_anti_aliased) the Gaussian
+ * prefilter.  What a caller without NumPy gets; within ~1e-13 of skimage, not bit-identical with it. */
 tdk_status tdk_rescale(const double *image, int height, int width, double *out,
                        int out_height, int out_width);
-/* The same with the anti-aliasing prefilter skimage.transform.rescale applies by
- * default (0.15+) when it shrinks an image: scipy.ndimage.gaussian_filter(image,
- * sigma = (factor - 1) / 2 per axis, mode='mirror', truncate=4), then the
- * bilinear warp.  Third-party behaviour restated from its published algorithm
- * (skimage is not importable in the build container): "parity unpinned". */
 tdk_status tdk_rescale_anti_aliased(const double *image, int height, int width, double *out,
                                     int out_height, int out_width);
 
@@ -132,24 +143,28 @@ tdk_status tdk_dvo_upload_async_u8(tdk_dvo *h, int which, int first_pair, int n_
  * poses12[i] as ground truth and seed seed0+i for the noise. */
 tdk_status tdk_dvo_fill_synthetic(tdk_dvo *h, const double *camera, const double *poses12,
                                   uint64_t seed0, double noise);
-/* Builds pyramid levels 1..n_levels-1 on the device from level 0. */
+/* Builds pyramid levels 1..n_levels-1 (and level 0 of the arrays of tdk_dvo_set_rescale_options) on the device
+ * from the uploaded frames. */
 tdk_status tdk_dvo_build_pyramid(tdk_dvo *h);
 /* The same for a subset of the arrays: bit 0 I0, bit 1 D0, bit 2 I1, bit 3 W0.  A consumer of a stream of frames
  * that replaces only I1 of every pair per step (tdk_dvo_upload_async*) rebuilds a third of the pyramid. */
 tdk_status tdk_dvo_build_pyramid_arrays(tdk_dvo *h, unsigned int arrays);
 /* Device -> host copy of one array of one pair/level: which = 0 I0, 1 D0, 2 I1, 3 W0. */
 tdk_status tdk_dvo_download(tdk_dvo *h, int pair, int level, int which, double *out);
-/* Pyramid levels with (1, the default) or without (0) the anti-aliasing prefilter of
- * tdk_rescale_anti_aliased.  The default is what the reference builds:
- * skimage.transform.rescale(image, scale) (tadataka/vo/dvo/__init__.py:144-148, scikit-image
- * 0.16.2) low-pass filters with a Gaussian, sigma = (1/scale - 1)/2, before it resamples
- * bilinearly.  0 = plain bilinear resampling (SURVEY 8(d) cfg2's wording).
- *   1, 2  the filter in scipy.ndimage's operation order (vertical correlate1d, horizontal
- *         correlate1d, blend): bit-identical with tdk_rescale_anti_aliased and the CPU restatement;
- *   3     opt-in experiment: I0 / I1 / W0 through one folded tap list per axis evaluated as FMA
- *         chains (csrc/pyramid_sep.hip; the same linear map, last-bit differences), D0 as in 1.
- *         Measured slower than 1 on the MI355X (1.39 vs 1.10 ms per 256-pair VGA batch). */
+/* Levels WITHOUT a plan (below): with (1, the default) or without (0) the anti-aliasing prefilter, at the
+ * ideal sample positions (tdk_rescale_anti_aliased / tdk_rescale). */
 tdk_status tdk_dvo_set_anti_aliasing(tdk_dvo *h, int enabled);
+/* skimage.transform.rescale to the bit for pyramid level `level` (0 .. n_levels - 1): the map and kernels of
+ * tdk_rescale_skimage for (full-resolution shape -> shape of that level).  map == NULL removes the plan.
+ * Takes effect at the next tdk_dvo_build_pyramid*. */
+tdk_status tdk_dvo_set_level_plan(tdk_dvo *h, int level, const double *map, const double *w_rows, int radius_rows,
+                                  const double *w_cols, int radius_cols);
+/* level0_arrays (bit 0 I0, bit 1 D0, bit 2 I1, bit 3 W0): the arrays whose LEVEL 0 is built by the pyramid too --
+ * the reference sends level 0 through rescale(image, 1.0) like every other level, and skimage's estimated map
+ * for scale 1.0 is a few ulp from the identity, so that level differs from the frame by ~1e-13 at almost every
+ * pixel (the uploaded frames are then kept beside level 0).  clip: skimage's clip=True for every level.
+ * Defaults: 0, 0 (level 0 is the uploaded frame itself, nothing is clipped). */
+tdk_status tdk_dvo_set_rescale_options(tdk_dvo *h, unsigned int level0_arrays, int clip);
 tdk_status tdk_dvo_level_shape(tdk_dvo *h, int level, int *height, int *width);
 
 /* One evaluation per pair at `level`:

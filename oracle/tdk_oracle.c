@@ -377,53 +377,65 @@ int64_t orc_photometric_error(const double *I0, const double *D0,
     return count;
 }
 
-/* Bilinear rescale with reflect ('symmetric') boundary, sample positions
- * src = (dst + 0.5) * (in/out) - 0.5.  Stand-in for skimage.transform.rescale
- * (tadataka/vo/dvo/__init__.py:144-148) -- third-party, absent here, PARITY
- * UNPINNED; the same function is used on both sides of every comparison. */
-static inline int reflect_idx(int64_t i, int n) {
-    if (n == 1) return 0;
-    int64_t p = 2 * (int64_t)n;
-    i %= p;
-    if (i < 0) i += p;
-    if (i >= n) i = p - 1 - i;
-    return (int)i;
+/* _shared/interpolation.pxd coord_map, mode 'R' ("reflect" = numpy.pad 'reflect':
+ * d c b | a b c d | c b a) */
+static inline int64_t skimage_reflect(int64_t dim, int64_t coord) {
+    int64_t cmax = dim - 1;
+    if (dim == 1) return 0;
+    if (coord < 0) {
+        if (((-coord) / cmax) % 2 != 0) return cmax - ((-coord) % cmax);
+        return (-coord) % cmax;
+    }
+    if (coord > cmax) {
+        if ((coord / cmax) % 2 != 0) return cmax - (coord % cmax);
+        return coord % cmax;
+    }
+    return coord;
 }
 
-void orc_rescale_bilinear(const double *src, int H, int W, double *dst, int Ho,
-                          int Wo) {
-    double sy = (double)H / (double)Ho, sx = (double)W / (double)Wo;
+/* skimage's warp of an (already filtered) image f: _warp_fast / bilinear_interpolation
+ * (transform/_warps_cy.pyx, _shared/interpolation.pxd).  Sample positions: map != NULL
+ * -> col = ax * ox + bx, row = ay * oy + by (_transform_metric: a product and a sum);
+ * map == NULL -> the IDEAL positions (o + 0.5) * (in / out) - 0.5. */
+static void warp_bilinear(const double *f, int H, int W, double *dst, int Ho, int Wo, const double *map) {
+    const double sy = (double)H / (double)Ho, sx = (double)W / (double)Wo;
     for (int oy = 0; oy < Ho; oy++) {
-        double cy = ((double)oy + 0.5) * sy - 0.5;
-        double fy0 = floor(cy);
-        double wy = cy - fy0;
-        int y0 = reflect_idx((int64_t)fy0, H), y1 = reflect_idx((int64_t)fy0 + 1, H);
+        const double r = map ? map[2] * (double)oy + map[3] : ((double)oy + 0.5) * sy - 0.5;
+        const int64_t minr = (int64_t)floor(r), maxr = (int64_t)ceil(r);
+        const double dr = r - (double)minr;
+        const int64_t r0 = skimage_reflect(H, minr), r1 = skimage_reflect(H, maxr);
         for (int ox = 0; ox < Wo; ox++) {
-            double cx = ((double)ox + 0.5) * sx - 0.5;
-            double fx0 = floor(cx);
-            double wx = cx - fx0;
-            int x0 = reflect_idx((int64_t)fx0, W), x1 = reflect_idx((int64_t)fx0 + 1, W);
-            double top = src[(int64_t)y0 * W + x0] * (1.0 - wx) + src[(int64_t)y0 * W + x1] * wx;
-            double bot = src[(int64_t)y1 * W + x0] * (1.0 - wx) + src[(int64_t)y1 * W + x1] * wx;
-            dst[(int64_t)oy * Wo + ox] = top * (1.0 - wy) + bot * wy;
+            const double c = map ? map[0] * (double)ox + map[1] : ((double)ox + 0.5) * sx - 0.5;
+            const int64_t minc = (int64_t)floor(c), maxc = (int64_t)ceil(c);
+            const double dc = c - (double)minc;
+            const int64_t c0 = skimage_reflect(W, minc), c1 = skimage_reflect(W, maxc);
+            const double top = (1 - dc) * f[r0 * W + c0] + dc * f[r0 * W + c1];
+            const double bottom = (1 - dc) * f[r1 * W + c0] + dc * f[r1 * W + c1];
+            dst[(int64_t)oy * Wo + ox] = (1 - dr) * top + dr * bottom;
         }
     }
 }
 
+/* rescale(image, scale, anti_aliasing=False) at the ideal sample positions, no clip */
+void orc_rescale_bilinear(const double *src, int H, int W, double *dst, int Ho,
+                          int Wo) {
+    warp_bilinear(src, H, W, dst, Ho, Wo, NULL);
+}
+
 /* ------------------------------------------------------------------------
- * Anti-aliased rescale: what skimage.transform.rescale (== 0.16.2, setup.py:117)
- * does with its defaults when it shrinks an image (tadataka/vo/dvo/__init__.py:
- * 144-148 calls it as rescale(image, scale)).  Third-party code that is not
- * under /root/reference and not importable here, restated from its published
- * algorithm (skimage/transform/_warps.py: resize()):
+ * Anti-aliased rescale with the IDEAL constants (sample positions, libm kernels, no
+ * clip): what skimage.transform.rescale does with its defaults (tadataka/vo/dvo/
+ * __init__.py:144-148 calls it as rescale(image, scale)) up to the interpreter-
+ * dependent last bits that orc_rescale_skimage below takes as inputs
+ * (skimage/transform/_warps.py: resize()):
  *     factors = input_shape / output_shape            (per axis)
  *     sigma   = max(0, (factors - 1) / 2)
  *     image   = scipy.ndimage.gaussian_filter(image, sigma, mode='mirror')
  *               (skimage mode 'reflect' -> ndimage 'mirror'; truncate = 4)
  *     out     = bilinear warp with dst -> src: (i + 0.5) * factor - 0.5
- * The Gaussian part is pinned against scipy.ndimage itself (which IS
- * importable) in tests/test_oracle_golden.py; whether 0.16.2 really defaults to
- * anti_aliasing=True is from memory of that release -- "parity unpinned".
+ * The Gaussian part is pinned against scipy.ndimage itself in
+ * tests/test_oracle_golden.py, the whole pipeline against scikit-image 0.18.3 in
+ * tests/test_oracle_skimage.py.
  * --------------------------------------------------------------------- */
 
 /* scipy.ndimage._filters._gaussian_kernel1d, order 0: exp(-0.5 / sigma^2 * x^2) / sum */
@@ -490,7 +502,7 @@ void orc_rescale_anti_aliased(const double *src, int H, int W, double *dst, int 
     if (sc > 1e-15) { wc = (double *)malloc(sizeof(double) * (2 * Rc + 1)); orc_gaussian_weights(sc, Rc, wc); }
     double *f = (double *)malloc(sizeof(double) * (size_t)H * W);
     orc_gaussian_filter_mirror(src, H, W, wr, Rr, wc, Rc, f);
-    orc_rescale_bilinear(f, H, W, dst, Ho, Wo);
+    warp_bilinear(f, H, W, dst, Ho, Wo, NULL);
     free(f); free(wr); free(wc);
 }
 
@@ -522,22 +534,6 @@ void orc_rescale_anti_aliased(const double *src, int H, int W, double *dst, int 
  * or take them from a fixture that recorded what the generating interpreter got.
  * --------------------------------------------------------------------- */
 
-/* _shared/interpolation.pxd coord_map, mode 'R' ("reflect" = numpy.pad 'reflect':
- * d c b | a b c d | c b a) */
-static inline int64_t skimage_reflect(int64_t dim, int64_t coord) {
-    int64_t cmax = dim - 1;
-    if (dim == 1) return 0;
-    if (coord < 0) {
-        if (((-coord) / cmax) % 2 != 0) return cmax - ((-coord) % cmax);
-        return (-coord) % cmax;
-    }
-    if (coord > cmax) {
-        if ((coord / cmax) % 2 != 0) return cmax - (coord % cmax);
-        return coord % cmax;
-    }
-    return coord;
-}
-
 /* numpy.clip(x, lo, hi) == minimum(maximum(x, lo), hi), NaN-propagating */
 static inline double np_clip(double x, double lo, double hi) {
     double m = (x != x || lo != lo) ? NAN : (x > lo ? x : lo);
@@ -549,7 +545,6 @@ void orc_rescale_skimage(const double *src, int H, int W, double *dst, int Ho, i
     /* resize(): image = ndi.gaussian_filter(image, sigma, mode='mirror') -- a plain copy when no axis is filtered */
     double *f = (double *)malloc(sizeof(double) * (size_t)H * W);
     orc_gaussian_filter_mirror(src, H, W, wr, Rr, wc, Rc, f);
-    const double ax = map[0], bx = map[1], ay = map[2], by = map[3];
     /* _clip_warp_output: bounds are the min / max of the image handed to warp(), i.e. of the FILTERED image
      * (ndarray.min / .max: NaN if any element is NaN) */
     double lo = f[0], hi = f[0];
@@ -560,23 +555,9 @@ void orc_rescale_skimage(const double *src, int H, int W, double *dst, int Ho, i
         if (f[i] > hi) hi = f[i];
     }
     if (has_nan) lo = hi = NAN;
-    for (int oy = 0; oy < Ho; oy++) {
-        const double r = ay * (double)oy + by;                 /* _transform_metric: y_ = H[4] * y + H[5] */
-        const int64_t minr = (int64_t)floor(r), maxr = (int64_t)ceil(r);
-        const double dr = r - (double)minr;
-        const int64_t r0 = skimage_reflect(H, minr), r1 = skimage_reflect(H, maxr);
-        for (int ox = 0; ox < Wo; ox++) {
-            const double c = ax * (double)ox + bx;             /* x_ = H[0] * x + H[2] */
-            const int64_t minc = (int64_t)floor(c), maxc = (int64_t)ceil(c);
-            const double dc = c - (double)minc;
-            const int64_t c0 = skimage_reflect(W, minc), c1 = skimage_reflect(W, maxc);
-            /* bilinear_interpolation */
-            const double top = (1 - dc) * f[r0 * W + c0] + dc * f[r0 * W + c1];
-            const double bottom = (1 - dc) * f[r1 * W + c0] + dc * f[r1 * W + c1];
-            const double v = (1 - dr) * top + dr * bottom;
-            dst[(int64_t)oy * Wo + ox] = clip ? np_clip(v, lo, hi) : v;
-        }
-    }
+    warp_bilinear(f, H, W, dst, Ho, Wo, map);
+    if (clip)
+        for (int64_t i = 0; i < (int64_t)Ho * Wo; i++) dst[i] = np_clip(dst[i], lo, hi);
     free(f);
 }
 

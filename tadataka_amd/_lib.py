@@ -79,7 +79,10 @@ PROTOTYPES = {
     "tdk_image_gradient": [_d, _i, _i, _d, _d],
     "tdk_rescale": [_d, _i, _i, _d, _i, _i],
     "tdk_rescale_anti_aliased": [_d, _i, _i, _d, _i, _i],
+    "tdk_rescale_skimage": [_d, _i, _i, _d, _i, _i, _d, _d, _i, _d, _i, _i],
     "tdk_dvo_set_anti_aliasing": [_vp, _i],
+    "tdk_dvo_set_level_plan": [_vp, _i, _d, _d, _i, _d, _i],
+    "tdk_dvo_set_rescale_options": [_vp, C.c_uint, _i],
     "tdk_dvo_create": [_i, _i, _i, _i, C.c_double, _i, C.POINTER(_vp)],
     "tdk_dvo_destroy": [_vp],
     "tdk_dvo_upload": [_vp, _i, _d, _d, _d, _d],

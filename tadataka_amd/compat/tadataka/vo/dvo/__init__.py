@@ -105,16 +105,21 @@ def _pose12(pose):
     return ops.pose12(pose.R, pose.t)[None]
 
 
-# The reference builds its pyramid with skimage.transform.rescale(image, scale)
-# (:144-148; scikit-image pinned to 0.16.2, setup.py:117).  Since 0.15 that call
-# anti-aliases by default when it shrinks: a Gaussian prefilter with
-# sigma = (1 / scale - 1) / 2 before the bilinear resampling.  scikit-image cannot
-# be imported where this package was built, so the behaviour is restated from its
-# published algorithm (Gaussian part checked against scipy.ndimage bit for bit);
-# set this to False for the plain bilinear pyramid.  The default is the package-wide
-# constant bench.py measures with as well.
+# The reference builds its pyramid with skimage.transform.rescale(image, scale) -- every level, level 0
+# at scale 1.0 included (:144-148; scikit-image pinned to 0.16.2, setup.py:117).  PYRAMID selects what the
+# device builds:
+#   "skimage"  (default) what scikit-image returns on THIS interpreter, to the bit: anti-aliasing prefilter,
+#              the affine map resize() estimates by SVD, scipy's Gaussian kernels, clip=True, level 0 through
+#              rescale(., 1.0) -- tadataka_amd/rescale_plan.py makes skimage's own NumPy calls; pinned against
+#              scikit-image 0.18.3 (tests/golden/skimage_*.npz).  PYRAMID_PLANS, if set, is a callable
+#              (shape, n_levels, ratio) -> list of plans recorded on another interpreter (the fixtures').
+#   "ideal"    the same pipeline with ideal constants (sample positions (i + 0.5) * factor - 0.5, libm
+#              kernels, level 0 = the frame itself, no clip): platform-independent, within the spread that
+#              two NumPy builds show between themselves, not bit-identical with any of them.
+#   "bilinear" ideal constants without the prefilter (anti_aliasing=False).
 import tadataka_amd
-ANTI_ALIASING = tadataka_amd.PYRAMID_ANTI_ALIASING
+PYRAMID = "skimage" if tadataka_amd.PYRAMID_ANTI_ALIASING else "bilinear"
+PYRAMID_PLANS = None
 
 
 # Device batches are kept between calls (one per shape / pyramid / weight-map
@@ -124,12 +129,17 @@ ANTI_ALIASING = tadataka_amd.PYRAMID_ANTI_ALIASING
 _BATCHES = {}
 
 
-def _batch_for(shape, n_levels, ratio, with_weight_map):
-    key = (int(shape[0]), int(shape[1]), int(n_levels), float(ratio), bool(with_weight_map))
+def _batch_for(shape, n_levels, ratio, with_weight_map, pyramid=None):
+    key = (int(shape[0]), int(shape[1]), int(n_levels), float(ratio), bool(with_weight_map), pyramid,
+           PYRAMID_PLANS)
     batch = _BATCHES.pop(key, None)
     if batch is None:
         batch = ops.DvoBatch(1, key[0], key[1], n_levels=key[2], ratio=key[3], with_weight_map=key[4])
-    batch.set_anti_aliasing(ANTI_ALIASING)
+        if pyramid == "skimage":
+            plans = PYRAMID_PLANS(shape, n_levels, ratio) if PYRAMID_PLANS is not None else None
+            batch.set_skimage_pyramid(plans)
+        else:
+            batch.set_anti_aliasing(pyramid != "bilinear")
     _BATCHES[key] = batch          # most recently used last
     while len(_BATCHES) > 2:
         _BATCHES.pop(next(iter(_BATCHES))).close()
@@ -185,7 +195,7 @@ class PoseChangeEstimator(object):
         assert(np.ndim(I1) == 2)
         _check_weights_name(weights)
         has_map = _is_map(weights)
-        batch = _batch_for(I0.shape, self.n_coarse_to_fine, self.layer_size_ratio, has_map)
+        batch = _batch_for(I0.shape, self.n_coarse_to_fine, self.layer_size_ratio, has_map, PYRAMID)
         batch.upload(0, I0, D0, I1, weights if has_map else None)
         batch.build_pyramid()
         cam0 = ops.camera_vec(self.camera_model0)

@@ -2285,12 +2285,23 @@ struct tdk_dvo {
     bool uploads_pending;
     int *d_mode_probe;          // [n] MODE_PROBE (tdk_dvo_photometric_error), allocated on first use
     int64_t count_error_px, count_update_px;   // tdk_dvo_get_counts: source pixels of the last estimate call
-    bool anti_aliasing;         // pyramid levels get skimage's Gaussian prefilter (tdk_dvo_set_anti_aliasing)
+    bool anti_aliasing;         // levels without a plan get skimage's Gaussian prefilter (tdk_dvo_set_anti_aliasing)
+    // skimage.transform.rescale to the bit (pyramid.hip): per-level plans from the host (tdk_dvo_set_level_plan),
+    // the identity-scale level 0 the reference also sends through rescale, clip=True (tdk_dvo_set_rescale_options)
+    struct Plan {
+        bool set;
+        double map[4];
+        std::vector<double> wr, wc;
+    } plan[kMaxLevels];
+    double *raw[4];             // the uploaded frames of the arrays whose level 0 is a rescale of its own (else null:
+                                // lv[0] IS the upload)
+    unsigned level0_mask;       // bit k: array k (I0, D0, I1, W0) gets rescale(., 1.0) as its level 0
+    bool clip;                  // clip=True: outputs clipped to the extremes of the filtered image
+    void *d_clip;               // ClipSlot[n_pairs * 4 * n_levels]
+    bool weights_dirty;         // the device copy of the kernels is stale (a plan changed)
     int n_cu, device;           // compute units and index of the batch's device
     int student_mode;           // Student-t variance: 0 two Taylor passes, 1 nine sequential passes, 2 ... with IEEE divisions
-    bool aa_taplists;           // ... evaluated as folded tap lists (mode 3, pyramid_sep.hip) instead of in ndimage's operation order
-    tdk::PyramidSepPlan *sep_plan;   // tap lists of the separable pyramid kernel (created at the first build)
-    double *d_aa_weights;       // its 1-D kernels, per level and axis (allocated on first use)
+    double *d_aa_weights;       // the pyramid's 1-D kernels, per level and axis (allocated on first use)
     int *h_flag;   // "pairs still running", written by k_dvo_reduce (mapped pinned host memory)
     int *d_chain_state, *d_gate;   // the speculative level chain: [n_levels][n_pairs] state arrays, the current level
     // Prior poses in, final poses and warnings out of tdk_dvo_estimate*: mapped pinned host memory that the first /
@@ -2819,12 +2830,20 @@ static tdk_status chain_estimate(tdk_dvo *h, int weight_mode, int max_iter, doub
 
 }  // namespace
 
+// where the frames of array k (0 I0, 1 D0, 2 I1, 3 W0) arrive: level 0 itself, unless that array's level 0 is a
+// rescale of its own (tdk_dvo_set_rescale_options)
+static double *upload_ptr(const tdk_dvo *h, int k) {
+    if (h->raw[k]) return h->raw[k];
+    const tdk_dvo::Level &L = h->lv[0];
+    return k == 0 ? L.I0 : k == 1 ? L.D0 : k == 2 ? L.I1 : L.W0;
+}
+
 namespace tdk {
 
 tdk_status dvo_level0(tdk_dvo *h, DvoLevel0 *out) {
     TDK_REQUIRE(h != nullptr && out != nullptr, "null pointer");
     const tdk_dvo::Level &L = h->lv[0];
-    out->I0 = L.I0; out->D0 = L.D0; out->I1 = L.I1; out->W0 = L.W0;
+    out->I0 = upload_ptr(h, 0); out->D0 = upload_ptr(h, 1); out->I1 = upload_ptr(h, 2); out->W0 = upload_ptr(h, 3);
     out->stride = L.stride; out->H = L.H; out->W = L.W; out->n_pairs = h->n_pairs;
     out->stream = h->stream;
     out->poses = h->ls.pose;
@@ -2865,7 +2884,12 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
     h->n_pairs = n_pairs; h->H = height; h->W = width; h->n_levels = n_levels;
     h->ratio = ratio; h->with_w = with_weight_map != 0;
     h->anti_aliasing = true;   // the reference-equivalent pyramid (skimage.transform.rescale's default)
-    h->aa_taplists = false;
+    for (int l = 0; l < kMaxLevels; l++) h->plan[l].set = false;
+    for (int k = 0; k < 4; k++) h->raw[k] = nullptr;
+    h->level0_mask = 0u;
+    h->clip = false;
+    h->d_clip = nullptr;
+    h->weights_dirty = true;
     {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess ||
@@ -2953,7 +2977,8 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
     (void)hipFree(h->d_chain_state); (void)hipFree(h->d_gate);
     if (h->h_io) (void)hipHostFree(h->h_io);
     if (h->d_aa_weights) (void)hipFree(h->d_aa_weights);
-    (void)tdk::pyramid_sep_destroy(h->sep_plan);
+    for (int k = 0; k < 4; k++) (void)hipFree(h->raw[k]);
+    (void)hipFree(h->d_clip);
     if (h->d_u8) (void)hipFree(h->d_u8);
     if (h->uploads_pending && h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
     if (h->ev_copy) (void)hipEventDestroy(h->ev_copy);
@@ -2973,11 +2998,11 @@ tdk_status tdk_dvo_upload(tdk_dvo *h, int pair, const double *I0, const double *
     size_t bytes = (size_t)L.N * sizeof(double);
     int64_t off = (int64_t)pair * L.stride;
     TDK_TRY(after_uploads(h));
-    TDK_HIP(hipMemcpyAsync(L.I0 + off, I0, bytes, hipMemcpyHostToDevice, h->stream));
-    TDK_HIP(hipMemcpyAsync(L.D0 + off, D0, bytes, hipMemcpyHostToDevice, h->stream));
-    TDK_HIP(hipMemcpyAsync(L.I1 + off, I1, bytes, hipMemcpyHostToDevice, h->stream));
+    TDK_HIP(hipMemcpyAsync(upload_ptr(h, 0) + off, I0, bytes, hipMemcpyHostToDevice, h->stream));
+    TDK_HIP(hipMemcpyAsync(upload_ptr(h, 1) + off, D0, bytes, hipMemcpyHostToDevice, h->stream));
+    TDK_HIP(hipMemcpyAsync(upload_ptr(h, 2) + off, I1, bytes, hipMemcpyHostToDevice, h->stream));
     if (weight_map)
-        TDK_HIP(hipMemcpyAsync(L.W0 + off, weight_map, bytes, hipMemcpyHostToDevice, h->stream));
+        TDK_HIP(hipMemcpyAsync(upload_ptr(h, 3) + off, weight_map, bytes, hipMemcpyHostToDevice, h->stream));
     TDK_HIP(hipStreamSynchronize(h->stream));
     return TDK_OK;
 }
@@ -2989,7 +3014,8 @@ tdk_status tdk_dvo_upload_mixed(tdk_dvo *h, int pair, const double *const *host4
     const tdk_dvo::Level &L = h->lv[0];
     const size_t bytes = (size_t)L.N * sizeof(double);
     const int64_t off = (int64_t)pair * L.stride;
-    double *dst[4] = {L.I0 + off, L.D0 + off, L.I1 + off, L.W0 ? L.W0 + off : nullptr};
+    double *dst[4] = {upload_ptr(h, 0) + off, upload_ptr(h, 1) + off, upload_ptr(h, 2) + off,
+                      L.W0 ? upload_ptr(h, 3) + off : nullptr};
     TDK_TRY(after_uploads(h));
     bool any_device = false, any_host = false;
     for (int k = 0; k < 4; k++) any_device |= device4[k] != nullptr;
@@ -3038,7 +3064,7 @@ tdk_status tdk_dvo_upload_async(tdk_dvo *h, int which, int first_pair, int n_pai
     TDK_REQUIRE(which >= 0 && which <= 3 && (which != 3 || h->with_w), "no such array");
     TDK_REQUIRE(first_pair >= 0 && n_pairs >= 1 && first_pair + n_pairs <= h->n_pairs, "pair range out of bounds");
     const tdk_dvo::Level &L = h->lv[0];
-    double *base = which == 0 ? L.I0 : which == 1 ? L.D0 : which == 2 ? L.I1 : L.W0;
+    double *base = upload_ptr(h, which);
     TDK_TRY(ensure_copy_stream(h));
     // after what the batch's own stream still does with the old frames ...
     TDK_HIP(hipEventRecord(h->ev_copy, h->stream));
@@ -3061,7 +3087,7 @@ tdk_status tdk_dvo_upload_async_u8(tdk_dvo *h, int which, int first_pair, int n_
     TDK_REQUIRE(which >= 0 && which <= 2, "8-bit frames: I0, D0 (rarely) or I1");
     TDK_REQUIRE(first_pair >= 0 && n_pairs >= 1 && first_pair + n_pairs <= h->n_pairs, "pair range out of bounds");
     const tdk_dvo::Level &L = h->lv[0];
-    double *base = which == 0 ? L.I0 : which == 1 ? L.D0 : L.I1;
+    double *base = upload_ptr(h, which);
     TDK_TRY(ensure_copy_stream(h));
     const size_t need = (size_t)h->n_pairs * (size_t)L.N;
     if (h->u8_bytes < need) {
@@ -3093,103 +3119,71 @@ tdk_status tdk_dvo_fill_synthetic(tdk_dvo *h, const double *camera, const double
     int gx = (int)((L.N + kBlock * 4 - 1) / (kBlock * 4));
     dim3 grid(gx < 1 ? 1 : gx, h->n_pairs);
     Cam cam{camera[0], camera[1], camera[2], camera[3]};
-    k_fill_synthetic<<<grid, kBlock, 0, h->stream>>>(L.I0, L.D0, L.I1, L.W0, L.stride, L.H, L.W, cam,
+    k_fill_synthetic<<<grid, kBlock, 0, h->stream>>>(upload_ptr(h, 0), upload_ptr(h, 1), upload_ptr(h, 2),
+                                                         L.W0 ? upload_ptr(h, 3) : nullptr, L.stride, L.H, L.W, cam,
                                                          h->d_poses_in, seed0, noise);
     TDK_LAUNCH_CHECK();
     TDK_HIP(hipStreamSynchronize(h->stream));
     return TDK_OK;
 }
 
-// arrays: bit 0 I0, bit 1 D0, bit 2 I1, bit 3 W0 -- the arrays whose levels 1 .. n_levels - 1 are (re)built
+// arrays: bit 0 I0, bit 1 D0, bit 2 I1, bit 3 W0 -- the arrays whose levels are (re)built: levels 1 .. n_levels - 1
+// and, for the arrays of level0_mask, level 0 (rescale(., 1.0), tadataka/vo/dvo/__init__.py:144-148).  Every level
+// is resampled from the full-resolution frame, exactly as _estimate_at rescales the ORIGINAL I0/D0/I1/W0.
 static tdk_status build_pyramid_of(tdk_dvo *h, unsigned arrays) {
     const tdk_dvo::Level &S = h->lv[0];
     if (!h->with_w) arrays &= 7u;
     TDK_TRY(after_uploads(h));
-    if (arrays == 0u || h->n_levels <= 1) return TDK_OK;
-    const int n_out = h->n_levels - 1;
-    // the selected arrays, in the fixed order I0, D0, I1, W0
-    int sel[4], n_sel = 0;
-    for (int k = 0; k < 4; k++)
-        if ((arrays >> k) & 1u) sel[n_sel++] = k;
-    auto src_of = [&](const tdk_dvo::Level &L, int k) -> double * { return k == 0 ? L.I0 : k == 1 ? L.D0 : k == 2 ? L.I1 : L.W0; };
-    // sources and per-level destinations of a subset `idx` of the arrays
-    auto describe = [&](const int *idx, int n, const double **srcs, tdk::PyramidLevelDesc *lv) {
-        for (int k = 0; k < 4; k++) srcs[k] = k < n ? src_of(S, idx[k]) : nullptr;
-        for (int l = 1; l < h->n_levels; l++) {
-            const tdk_dvo::Level &L = h->lv[l];
-            for (int k = 0; k < 4; k++) lv[l - 1].dst[k] = k < n ? src_of(L, idx[k]) : nullptr;
-            lv[l - 1].stride = L.stride; lv[l - 1].H = L.H; lv[l - 1].W = L.W;
+    if (arrays == 0u) return TDK_OK;
+    auto dst_of = [&](const tdk_dvo::Level &L, int k) -> double * { return k == 0 ? L.I0 : k == 1 ? L.D0 : k == 2 ? L.I1 : L.W0; };
+    std::vector<double> storage((size_t)kMaxLevels * 2 * (2 * tdk::pyramid_max_radius() + 1));
+    // a level's description for a subset `idx` of the arrays
+    auto describe = [&](int l, const int *idx, int n, tdk::PyramidLevelDesc *d) {
+        const tdk_dvo::Level &L = h->lv[l];
+        for (int k = 0; k < 4; k++) d->dst[k] = k < n ? dst_of(L, idx[k]) : nullptr;
+        d->stride = L.stride; d->H = L.H; d->W = L.W;
+        const tdk_dvo::Plan &P = h->plan[l];
+        if (P.set) {
+            d->mx = tdk::affine_axis(P.map[0], P.map[1]);
+            d->my = tdk::affine_axis(P.map[2], P.map[3]);
+            d->wr = P.wr.empty() ? nullptr : P.wr.data(); d->Rr = (int)(P.wr.size() / 2);
+            d->wc = P.wc.empty() ? nullptr : P.wc.data(); d->Rc = (int)(P.wc.size() / 2);
+        } else {
+            tdk::ideal_level_plan(d, S.H, S.W, h->anti_aliasing && l > 0,
+                                  storage.data() + (size_t)l * 2 * (2 * tdk::pyramid_max_radius() + 1));
         }
     };
-    // every level is resampled from the full-resolution frame, exactly as
-    // _estimate_at rescales the original I0/D0/I1/W0 (vo/dvo/__init__.py:144-148).
-    // Default: one launch, levels of one image dispatched together so the
-    // re-reads of level 0 stay on die.  TDK_PYRAMID=lds stages level-0 tiles in
-    // LDS (one read, slower as measured), TDK_PYRAMID=levels runs one k_rescale
-    // per (array, level).  All three are bit-identical.
-    if (h->anti_aliasing) {
-        const double *srcs[4];
-        tdk::PyramidLevelDesc lv[kMaxLevels];
-        describe(sel, n_sel, srcs, lv);
-        const bool first = h->d_aa_weights == nullptr;
-        if (first)
-            TDK_HIP(hipMalloc(&h->d_aa_weights, tdk::pyramid_aa_weight_doubles(h->n_levels - 1) * sizeof(double)));
-        if (!h->aa_taplists)
-            return tdk::launch_pyramid_aa(srcs, n_sel, S.H, S.W, S.stride, n_out, lv, h->n_pairs, h->d_aa_weights,
-                                          first, h->stream);
-        // Mode 3 (opt-in; measured slower, see pyramid_sep.hip).  The images (and the weight map) go through the separable tap-list kernel
-        // (pyramid_sep.hip) for every level it can take.  The DEPTH map stays on the ndimage-order
-        // kernels: at the identity prior the whole right / bottom border of a level projects exactly
-        // onto the inclusive mask boundary and the last bit of D0 decides on which side a border pixel
-        // falls (a few hundred pixels, 1e-5 in the pose) -- the depth levels are kept bit-identical with
-        // the CPU restatement so that poses are reproducible to 1e-15, the images only enter smoothly.
-        if (!tdk::pyramid_sep_matches(h->sep_plan, S.H, S.W, n_out, lv)) {
-            (void)tdk::pyramid_sep_destroy(h->sep_plan);
-            h->sep_plan = nullptr;
-            int Ho[kMaxLevels], Wo[kMaxLevels];
-            for (int l = 0; l < n_out; l++) { Ho[l] = lv[l].H; Wo[l] = lv[l].W; }
-            TDK_TRY(tdk::pyramid_sep_create(S.H, S.W, n_out, Ho, Wo, h->stream, &h->sep_plan, nullptr));
+    if (h->d_aa_weights == nullptr) {
+        TDK_HIP(hipMalloc(&h->d_aa_weights, tdk::pyramid_weight_doubles(h->n_levels) * sizeof(double)));
+        h->weights_dirty = true;
+    }
+    if (h->clip && h->d_clip == nullptr)
+        TDK_HIP(hipMalloc(&h->d_clip, tdk::pyramid_clip_bytes((int64_t)h->n_pairs * 4, h->n_levels)));
+    const char *env = getenv("TDK_PYRAMID_STREAM");           // 0: never, 1 (default): large batches, 2: always
+    const int use_stream = env ? atoi(env) : 1;
+    // two groups of arrays: those with a level 0 of their own (sources: the uploads, levels 0 .. n - 1) and the rest
+    // (sources: level 0 = the upload, levels 1 .. n - 1); the device kernels are stored per level: slot l of the
+    // weight buffer is level l in both groups
+    for (int group = 0; group < 2; group++) {
+        int sel[4], n_sel = 0;
+        for (int k = 0; k < 4; k++) {
+            if (!((arrays >> k) & 1u)) continue;
+            const bool own0 = ((h->level0_mask >> k) & 1u) != 0;
+            if (own0 == (group == 0)) sel[n_sel++] = k;
         }
-        const unsigned sep_mask = tdk::pyramid_sep_mask(h->sep_plan), all = (1u << n_out) - 1u;
-        int img[4], n_img = 0;
-        for (int k = 0; k < n_sel; k++)
-            if (sel[k] != 1) img[n_img++] = sel[k];
-        const int depth_idx[1] = {1};
-        const bool depth = (arrays >> 1) & 1u;
-        const double *img_srcs[4], *depth_srcs[4];
-        tdk::PyramidLevelDesc img_lv[kMaxLevels], depth_lv[kMaxLevels];
-        describe(img, n_img, img_srcs, img_lv);
-        describe(depth_idx, 1, depth_srcs, depth_lv);
-        bool weights_up = first;
-        if (n_img > 0) TDK_TRY(tdk::launch_pyramid_sep(h->sep_plan, img_srcs, n_img, S.stride, img_lv, h->n_pairs, h->stream));
-        if (depth) {
-            // (deep levels whose tiles exceed LDS are skipped here and built with every array below)
-            TDK_TRY(tdk::launch_pyramid_aa(depth_srcs, 1, S.H, S.W, S.stride, n_out, depth_lv, h->n_pairs, h->d_aa_weights,
-                                           weights_up, h->stream, all & ~sep_mask));
-            weights_up = false;
-        }
-        if (sep_mask == all) return TDK_OK;
-        return tdk::launch_pyramid_aa(srcs, n_sel, S.H, S.W, S.stride, n_out, lv, h->n_pairs, h->d_aa_weights, weights_up,
-                                      h->stream, sep_mask);
-    }
-    static const int mode = [] {
-        const char *v = getenv("TDK_PYRAMID");
-        if (v && !strcmp(v, "lds")) return 1;
-        if (v && !strcmp(v, "levels")) return 2;
-        return 0;
-    }();
-    if (mode != 2) {
+        if (n_sel == 0) continue;
+        const int first = group == 0 ? 0 : 1;
+        const int n_out = h->n_levels - first;
+        if (n_out <= 0) continue;
         const double *srcs[4];
+        for (int k = 0; k < 4; k++) srcs[k] = k < n_sel ? upload_ptr(h, sel[k]) : nullptr;
         tdk::PyramidLevelDesc lv[kMaxLevels];
-        describe(sel, n_sel, srcs, lv);
-        return tdk::launch_pyramid(srcs, n_sel, S.H, S.W, S.stride, n_out, lv, h->n_pairs, mode, h->stream);
+        for (int l = first; l < h->n_levels; l++) describe(l, sel, n_sel, &lv[l - first]);
+        double *weights = h->d_aa_weights + tdk::pyramid_weight_doubles(first);
+        TDK_TRY(tdk::launch_pyramid(srcs, n_sel, S.H, S.W, S.stride, n_out, lv, h->n_pairs, weights, h->weights_dirty,
+                                    h->clip ? h->d_clip : nullptr, use_stream, h->stream));
     }
-    for (int l = 1; l < h->n_levels; l++) {
-        const tdk_dvo::Level &L = h->lv[l];
-        for (int k = 0; k < n_sel; k++)
-            TDK_TRY(tdk::launch_rescale(src_of(S, sel[k]), S.H, S.W, src_of(L, sel[k]), L.H, L.W, h->n_pairs, S.stride,
-                                        L.stride, h->stream));
-    }
+    h->weights_dirty = false;
     return TDK_OK;
 }
 
@@ -3396,9 +3390,56 @@ tdk_status tdk_dvo_get_warnings(tdk_dvo *h, int *too_large) {
 
 tdk_status tdk_dvo_set_anti_aliasing(tdk_dvo *h, int enabled) {
     TDK_REQUIRE(h != nullptr, "handle is NULL");
-    TDK_REQUIRE(enabled >= 0 && enabled <= 3, "mode must be 0 ... 3");
+    TDK_REQUIRE(enabled == 0 || enabled == 1, "enabled must be 0 or 1");
     h->anti_aliasing = enabled != 0;
-    h->aa_taplists = enabled == 3;
+    h->weights_dirty = true;
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_set_level_plan(tdk_dvo *h, int level, const double *map, const double *w_rows, int radius_rows,
+                                  const double *w_cols, int radius_cols) {
+    TDK_TRY(check_level(h, level));
+    tdk_dvo::Plan &P = h->plan[level];
+    h->weights_dirty = true;
+    if (map == nullptr) {
+        P.set = false;
+        P.wr.clear(); P.wc.clear();
+        return TDK_OK;
+    }
+    TDK_REQUIRE(radius_rows >= 0 && radius_cols >= 0 && radius_rows <= tdk::pyramid_max_radius() &&
+                radius_cols <= tdk::pyramid_max_radius(), "kernel radius out of range");
+    TDK_REQUIRE((radius_rows == 0 || w_rows) && (radius_cols == 0 || w_cols), "kernel is NULL");
+    TDK_REQUIRE(map[0] > 0.0 && map[2] > 0.0, "the map's scales must be positive");
+    for (int k = 0; k < 4; k++) P.map[k] = map[k];
+    P.wr.assign(w_rows, w_rows + (radius_rows > 0 ? 2 * radius_rows + 1 : 0));
+    P.wc.assign(w_cols, w_cols + (radius_cols > 0 ? 2 * radius_cols + 1 : 0));
+    P.set = true;
+    return TDK_OK;
+}
+
+tdk_status tdk_dvo_set_rescale_options(tdk_dvo *h, unsigned int level0_arrays, int clip) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    TDK_REQUIRE(level0_arrays <= 15u, "level0_arrays: bit 0 I0, bit 1 D0, bit 2 I1, bit 3 W0");
+    if (!h->with_w) level0_arrays &= 7u;
+    TDK_TRY(after_uploads(h));
+    const tdk_dvo::Level &L = h->lv[0];
+    const size_t bytes = ((size_t)L.stride * h->n_pairs + 4 * kBlock) * sizeof(double);
+    for (int k = 0; k < 4; k++) {
+        double *lvl0 = k == 0 ? L.I0 : k == 1 ? L.D0 : k == 2 ? L.I1 : L.W0;
+        const bool want = ((level0_arrays >> k) & 1u) != 0;
+        if (want && !h->raw[k]) {
+            // frames uploaded so far move to the new upload array
+            TDK_HIP(hipMalloc(&h->raw[k], bytes));
+            TDK_HIP(hipMemcpyAsync(h->raw[k], lvl0, bytes, hipMemcpyDeviceToDevice, h->stream));
+        } else if (!want && h->raw[k]) {
+            TDK_HIP(hipMemcpyAsync(lvl0, h->raw[k], bytes, hipMemcpyDeviceToDevice, h->stream));
+            TDK_HIP(hipStreamSynchronize(h->stream));
+            (void)hipFree(h->raw[k]);
+            h->raw[k] = nullptr;
+        }
+    }
+    h->level0_mask = level0_arrays;
+    h->clip = clip != 0;
     return TDK_OK;
 }
 

@@ -1,0 +1,1240 @@
+// pyramid.hip -- skimage.transform.rescale on the device: the pyramid of the DVO batch and the
+// host-pointer tdk_rescale* entries.
+//
+// What the reference calls (tadataka/vo/dvo/__init__.py:144-148, for EVERY level, level 0 at scale 1.0
+// included): skimage.transform.rescale(image, scale) == resize(image, round(shape * scale)):
+//     1. scipy.ndimage.gaussian_filter(image, sigma = max(0, (factor - 1) / 2) per axis, mode='mirror'),
+//        axis 0 first; an axis with sigma <= 1e-15 is skipped
+//     2. warp(): bilinear, sample position of output (oy, ox) = (ay * oy + by, ax * ox + bx) with an affine map
+//        that resize() ESTIMATES from three corner correspondences (SVD), taps floor / ceil of the position,
+//        boundary 'reflect' (d c b | a b c d | c b a)
+//     3. clip=True: numpy.clip to the minimum / maximum of the FILTERED image.
+// Pinned against scikit-image 0.18.3 run in the build container (tests/golden/skimage_*.npz; the tests hold a
+// CPU restatement of the same pipeline beside it).  The map and the Gaussian kernels are products of the caller's
+// NumPy / LAPACK / libm (a few ulp / 1e-13 from their ideal values, differently on every build), so they come
+// in from the host: tdk_rescale_skimage, tdk_dvo_set_level_plan (tadataka_amd/rescale_plan.py makes the same
+// NumPy calls skimage and scipy make).  Without a plan a level uses the IDEAL map (i + 0.5) * factor - 0.5 and
+// kernels from libm's exp -- the reading of rounds 1-4, kept for tdk_rescale / tdk_rescale_anti_aliased.
+//
+// Compiled with -ffp-contract=off: every product and sum is one IEEE rounding, in scipy's / skimage's order.
+//
+// Kernels:
+//   k_rescale_generic     any radii, any map, taps outside the image reflected: one level of one image per
+//                         (blockIdx.x range, y, z); (2 Rr + 1)(2 Rc + 1) loads per tap -- small images, deep
+//                         levels, enlargements, level 0 of small batches
+//   k_rescale_aa_multi    LDS tiles (vertical Gaussian once per tile, horizontal at the taps), all tiled levels
+//                         of a batch in one launch, XCD-major
+//   k_pyramid_stream      one pass over the source for the first TWO shrinking levels (radii 1 and 3: ratio 1.5):
+//                         full-height strips, one source column per thread, V rows in per-level LDS rings
+//   k_level0_rows         the identity-scale level (no filter): a row per wave, 4 cached loads per output
+//   k_clip_bounds / k_clip_apply   step 3, see "clip" below
+#include "tdk_runtime.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+namespace {
+
+using tdk::AxisMap;
+using tdk::PyramidLevelDesc;
+
+constexpr int kMaxGaussRadius = 64;
+constexpr int kMaxOut = 16;          // levels per launch (level 0 + 15)
+
+// sample position of output index o along one axis
+__host__ __device__ __forceinline__ double axis_pos(const AxisMap &m, int o) {
+    return m.ideal ? ((double)o + 0.5) * m.s - 0.5 : m.a * (double)o + m.b;
+}
+
+// skimage _shared/interpolation.pxd coord_map, mode 'R'
+__host__ __device__ __forceinline__ int skimage_reflect(int coord, int dim) {
+    if ((unsigned)coord < (unsigned)dim) return coord;
+    if (dim == 1) return 0;
+    const int cmax = dim - 1;
+    if (coord < 0) {
+        const int n = -coord;
+        return ((n / cmax) & 1) ? cmax - (n % cmax) : n % cmax;
+    }
+    return ((coord / cmax) & 1) ? cmax - (coord % cmax) : coord % cmax;
+}
+
+// ndimage 'mirror': d c b | a b c d | c b a
+__device__ __forceinline__ int mirror_idx(int i, int n) {
+    if ((unsigned)i < (unsigned)n) return i;
+    if (n == 1) return 0;
+    const int p = 2 * (n - 1);
+    i %= p;
+    if (i < 0) i += p;
+    if (i >= n) i = p - i;
+    return i;
+}
+
+// ---------------------------------------------------------------------------
+// clip=True.  The bounds are the extremes of the filtered image, which no kernel here ever forms.  But an
+// output is a rounded convex combination of four filtered values (its taps), so it can leave [lo, hi] only
+// by rounding, and only if its taps sit within an ulp of an extreme -- a plateau (a constant depth plane,
+// a saturated region).  Every kernel therefore tracks, per (image, level), the extremes of its outputs and
+// of the taps it evaluated (all of them elements of the filtered image):
+//     out_max <= tap_max (<= hi)  and  out_min >= tap_min (>= lo)  and  no NaN output   =>   clip is a no-op.
+// Otherwise (rare; decided on the device) k_clip_bounds evaluates the whole filtered image of that
+// (image, level) for its true extremes -- numpy's: NaN if any element is NaN -- and k_clip_apply applies
+// numpy.clip.  Both launches return at once for every (image, level) that is not flagged.
+// ---------------------------------------------------------------------------
+struct ClipSlot {
+    unsigned long long out_max, out_min, tap_max, tap_min;   // order-preserving keys (enc)
+    unsigned long long lo, hi;                               // true bounds, by k_clip_bounds
+    unsigned int nan_out, nan_img;
+};
+
+__device__ __forceinline__ unsigned long long enc(double x) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dec(unsigned long long k) {
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_min(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmin(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+// Per thread only the running extremes of the taps live in registers.  An output that could leave the GLOBAL tap
+// range must leave the thread's running range first, so only such outputs (rare: a plateau at an extreme, a NaN)
+// are recorded -- straight into the slot, behind a plain load that drops what would not move it.
+struct ClipTrack {
+    double tmax, tmin;
+    __device__ __forceinline__ void init() {
+        tmax = -INFINITY;
+        tmin = INFINITY;
+    }
+    __device__ __forceinline__ void add(ClipSlot *slot, double out, double f00, double f01, double f10, double f11) {
+        tmax = fmax(tmax, fmax(fmax(f00, f01), fmax(f10, f11)));
+        tmin = fmin(tmin, fmin(fmin(f00, f01), fmin(f10, f11)));
+        if (!(out <= tmax && out >= tmin)) record(slot, out);     // also taken by a NaN
+    }
+    __device__ __noinline__ static void record(ClipSlot *slot, double out) {
+        if (out != out) {
+            if (!*(volatile unsigned int *)&slot->nan_out) atomicOr(&slot->nan_out, 1u);
+            return;
+        }
+        const unsigned long long k = enc(out);
+        if (k > *(volatile unsigned long long *)&slot->out_max) atomicMax(&slot->out_max, k);
+        if (k < *(volatile unsigned long long *)&slot->out_min) atomicMin(&slot->out_min, k);
+    }
+    // every lane of the wave must call this
+    __device__ __forceinline__ void flush(ClipSlot *slot) {
+        const double c = wave_max(tmax), d = wave_min(tmin);
+        if ((threadIdx.x & 63) == 0 && (c != -INFINITY || d != INFINITY)) {
+            atomicMax(&slot->tap_max, enc(c));
+            atomicMin(&slot->tap_min, enc(d));
+        }
+    }
+};
+
+// (the untouched keys 0 / ~0 decode to NaNs: every comparison with them is false)
+__device__ __forceinline__ bool clip_needed(const ClipSlot &s) {
+    if (s.nan_out) return true;
+    return dec(s.out_max) > dec(s.tap_max) || dec(s.out_min) < dec(s.tap_min);
+}
+
+__global__ void k_clip_reset(ClipSlot *slots, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    ClipSlot s;
+    s.out_max = 0ull; s.tap_max = 0ull; s.hi = 0ull;
+    s.out_min = ~0ull; s.tap_min = ~0ull; s.lo = ~0ull;
+    s.nan_out = 0u; s.nan_img = 0u;
+    slots[i] = s;
+}
+
+struct AaLevel {
+    const double *wr, *wc;   // device: 2 R + 1 weights each (a one-tap kernel {1} for an unfiltered axis)
+    int Rr, Rc;
+};
+
+// correlate1d with a symmetric kernel along a column of the source image: centre tap first, then the pairs
+// from the outermost inwards (scipy ni_filters.c, the `symmetric > 0` branch)
+__device__ __forceinline__ double column_tap(const double *__restrict__ s, int H, int W, int y, int x,
+                                             const double *__restrict__ w, int R) {
+    if (R == 0) return s[(int64_t)y * W + x];                      // gaussian_filter skips the axis
+    double tmp = s[(int64_t)y * W + x] * w[R];
+    for (int j = -R; j < 0; j++)
+        tmp += (s[(int64_t)mirror_idx(y + j, H) * W + x] + s[(int64_t)mirror_idx(y - j, H) * W + x]) * w[R + j];
+    return tmp;
+}
+
+// ... and along a row of the vertically filtered image
+__device__ __forceinline__ double filtered_tap(const double *__restrict__ s, int H, int W, int y, int x,
+                                               const AaLevel &a) {
+    if (a.Rc == 0) return column_tap(s, H, W, y, x, a.wr, a.Rr);
+    double tmp = column_tap(s, H, W, y, x, a.wr, a.Rr) * a.wc[a.Rc];
+    for (int j = -a.Rc; j < 0; j++)
+        tmp += (column_tap(s, H, W, y, mirror_idx(x + j, W), a.wr, a.Rr) +
+                column_tap(s, H, W, y, mirror_idx(x - j, W), a.wr, a.Rr)) * a.wc[a.Rc + j];
+    return tmp;
+}
+
+struct DevLevel {
+    double *dst[4];
+    int64_t stride;
+    int Ho, Wo;
+    AxisMap mx, my;
+    AaLevel aa;
+};
+
+struct GenericArgs {
+    const double *src[4];
+    int64_t src_stride;
+    int H, W, n;
+    int lvl[kMaxOut];        // index of the level (slot numbering)
+    int blk_end[kMaxOut];    // cumulative block count per entry
+    DevLevel lv[kMaxOut];
+    ClipSlot *slots;         // [image][n_out] or null
+    int n_arrays, n_out;
+};
+
+// One output row per wave, lanes along the row: the general form of skimage's warp (ceil taps, reflected
+// coordinates), every tap evaluated from global memory.
+__global__ __launch_bounds__(256) void k_rescale_generic(GenericArgs a) {
+    int e = 0;
+    while (e + 1 < a.n && (int)blockIdx.x >= a.blk_end[e]) e++;
+    const DevLevel &L = a.lv[e];
+    const int arr = blockIdx.y, pair = blockIdx.z;
+    const int oy = (((int)blockIdx.x - (e ? a.blk_end[e - 1] : 0)) << 2) + (int)(threadIdx.x >> 6);
+    const int H = a.H, W = a.W;
+    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    ClipSlot *slot = a.slots ? a.slots + ((int64_t)pair * a.n_arrays + arr) * a.n_out + a.lvl[e] : nullptr;
+    ClipTrack tr;
+    tr.init();
+    if (oy < L.Ho) {
+        const double r = axis_pos(L.my, oy);
+        const double fr = floor(r);
+        const double dr = r - fr;
+        const int y0 = skimage_reflect((int)fr, H), y1 = skimage_reflect((int)ceil(r), H);
+        double *d = L.dst[arr] + (int64_t)pair * L.stride + (int64_t)oy * L.Wo;
+        for (int ox = threadIdx.x & 63; ox < L.Wo; ox += 64) {
+            const double c = axis_pos(L.mx, ox);
+            const double fc = floor(c);
+            const double dc = c - fc;
+            const int x0 = skimage_reflect((int)fc, W), x1 = skimage_reflect((int)ceil(c), W);
+            const double f00 = filtered_tap(s, H, W, y0, x0, L.aa), f01 = filtered_tap(s, H, W, y0, x1, L.aa);
+            const double f10 = filtered_tap(s, H, W, y1, x0, L.aa), f11 = filtered_tap(s, H, W, y1, x1, L.aa);
+            const double top = (1.0 - dc) * f00 + dc * f01;
+            const double bot = (1.0 - dc) * f10 + dc * f11;
+            const double v = (1.0 - dr) * top + dr * bot;
+            d[ox] = v;
+            if (slot) tr.add(slot, v, f00, f01, f10, f11);
+        }
+    }
+    if (slot) tr.flush(slot);
+}
+
+// The identity-scale level (rescale(image, 1.0): no filter, a map a few ulp from the identity): the same
+// arithmetic as k_rescale_generic with Rr = Rc = 0, organised for bandwidth -- a wave takes kL0Rows
+// consecutive output rows of a 64-column group, the row terms are wave-uniform, the column terms per lane,
+// the four taps are plain loads (three of them cache hits).
+constexpr int kL0Rows = 8;
+struct Level0Args {
+    const double *src[4];
+    double *dst[4];
+    int64_t src_stride, dst_stride;
+    int H, W, n_arrays, batch, lvl, n_out;
+    AxisMap mx, my;
+    ClipSlot *slots;
+};
+
+__global__ __launch_bounds__(256) void k_level0_rows(Level0Args a) {
+    const int H = a.H, W = a.W;
+    const int gx = (W + 63) >> 6, gy = (H + 4 * kL0Rows - 1) / (4 * kL0Rows);
+    const int per_image = gx * gy;
+    // XCD-major: XCD k takes images k, k + 8, ...
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int images = a.n_arrays * a.batch;
+    const bool few = images < 8;
+    const int image = few ? (int)blockIdx.x / per_image : (q / per_image) * 8 + xcd;
+    const int part = few ? (int)blockIdx.x - image * per_image : q - (q / per_image) * per_image;
+    if (image >= images) return;
+    const int pair = image / a.n_arrays, arr = image - pair * a.n_arrays;
+    const int by = part / gx, bx = part - by * gx;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ox = bx * 64 + lane;
+    const int oy0 = (by * 4 + wave) * kL0Rows;
+    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    double *d = a.dst[arr] + (int64_t)pair * a.dst_stride;
+    ClipSlot *slot = a.slots ? a.slots + ((int64_t)pair * a.n_arrays + arr) * a.n_out + a.lvl : nullptr;
+    ClipTrack tr;
+    tr.init();
+    if (ox < W) {
+        const double c = axis_pos(a.mx, ox);
+        const double fc = floor(c);
+        const double dc = c - fc;
+        const int x0 = skimage_reflect((int)fc, W), x1 = skimage_reflect((int)ceil(c), W);
+#pragma unroll
+        for (int i = 0; i < kL0Rows; i++) {
+            const int oy = oy0 + i;
+            if (oy >= H) break;
+            const double r = axis_pos(a.my, oy);
+            const double fr = floor(r);
+            const double dr = r - fr;
+            const int y0 = skimage_reflect((int)fr, H), y1 = skimage_reflect((int)ceil(r), H);
+            const double *r0 = s + (int64_t)y0 * W, *r1 = s + (int64_t)y1 * W;
+            const double f00 = r0[x0], f01 = r0[x1], f10 = r1[x0], f11 = r1[x1];
+            const double top = (1.0 - dc) * f00 + dc * f01;
+            const double bot = (1.0 - dc) * f10 + dc * f11;
+            const double v = (1.0 - dr) * top + dr * bot;
+            d[(int64_t)oy * W + ox] = v;
+            if (slot) tr.add(slot, v, f00, f01, f10, f11);
+        }
+    }
+    if (slot) tr.flush(slot);
+}
+
+// ---------------------------------------------------------------------------
+// LDS tiles.  A block produces tile_rows x kAaCols output pixels of a SHRINKING level (all four taps inside
+// the image, x1 = x0 + 1, y1 = y0 + 1 -- checked on the host with the level's own map):
+//   1. the vertical Gaussian is evaluated once per (row, column) its taps and their horizontal support touch
+//      (mirror boundary), from global memory into an LDS tile V -- ndimage filters axis 0 first, so V is
+//      rounded exactly like its intermediate image,
+//   2. every thread evaluates the horizontal Gaussian of V at its four taps and blends.
+// Same operations in the same order as filtered_tap(): bit-identical with k_rescale_generic.
+// ---------------------------------------------------------------------------
+constexpr int kAaCols = 64;
+
+struct AaTileArgs {
+    const double *src[4];
+    double *dst[4];
+    int64_t src_stride, dst_stride;
+    int H, W, Ho, Wo;
+    AxisMap mx, my;
+    AaLevel aa;
+    int lvl;
+    int tile_rows;              // output rows per block
+    int max_v_rows, max_cols;   // LDS tile bounds, computed on the host from the map
+};
+
+// Any radii (from the arguments): the levels aa_tile_fixed<R> has no instantiation for.
+__device__ __forceinline__ void aa_tile_generic(const AaTileArgs &a, int tile, int arr, int pair,
+                                                unsigned char *aa_smem, ClipTrack &tr, ClipSlot *slot) {
+    const int Rr = a.aa.Rr, Rc = a.aa.Rc;
+    const int SC = a.max_cols;
+    double *V = reinterpret_cast<double *>(aa_smem);           // [max_v_rows][SC] vertically filtered
+    double *wr = V + (size_t)a.max_v_rows * SC;                 // [2 Rr + 1] kernel weights, LDS copies
+    double *wc = wr + 2 * Rr + 1;                               // [2 Rc + 1]
+    for (int k = threadIdx.x; k < 2 * Rr + 1; k += 256) wr[k] = a.aa.wr[k];
+    for (int k = threadIdx.x; k < 2 * Rc + 1; k += 256) wc[k] = a.aa.wc[k];
+    const int tiles_x = (a.Wo + kAaCols - 1) / kAaCols;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int H = a.H, W = a.W;
+    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    const int oy0 = ty * a.tile_rows, oy1 = min(oy0 + a.tile_rows, a.Ho);
+    const int ox0 = tx * kAaCols, ox1 = min(ox0 + kAaCols, a.Wo);
+    const int yv0 = (int)floor(axis_pos(a.my, oy0));
+    const int yv1 = min((int)floor(axis_pos(a.my, oy1 - 1)) + 1, H - 1);
+    const int xv0 = (int)floor(axis_pos(a.mx, ox0));
+    const int xv1 = min((int)floor(axis_pos(a.mx, ox1 - 1)) + 1, W - 1);
+    const int nv = yv1 - yv0 + 1;                                // V rows
+    const int nc = xv1 - xv0 + 1 + 2 * Rc;                       // columns incl. the horizontal support
+    const int xs0 = xv0 - Rc;
+    __syncthreads();                                             // weights in place
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < nv; r += 4) {
+        const int y = yv0 + r;
+        for (int c = lane; c < nc; c += 64) {
+            const double *col = s + mirror_idx(xs0 + c, W);
+            double tmp;
+            if (Rr == 0) tmp = col[(int64_t)y * W];
+            else {
+                tmp = col[(int64_t)y * W] * wr[Rr];
+                for (int j = -Rr; j < 0; j++)
+                    tmp += (col[(int64_t)mirror_idx(y + j, H) * W] + col[(int64_t)mirror_idx(y - j, H) * W]) * wr[Rr + j];
+            }
+            V[r * SC + c] = tmp;
+        }
+    }
+    __syncthreads();
+    const int ox = ox0 + (int)(threadIdx.x & 63);
+    if (ox >= ox1) return;
+    const double cx = axis_pos(a.mx, ox);
+    const double fx0 = floor(cx);
+    const double wx = cx - fx0;
+    const int x0 = (int)fx0;
+    for (int oy = oy0 + (int)(threadIdx.x >> 6); oy < oy1; oy += 4) {
+        const double cy = axis_pos(a.my, oy);
+        const double fy0 = floor(cy);
+        const double wy = cy - fy0;
+        const int y0 = (int)fy0;
+        double f[2][2];
+#pragma unroll
+        for (int ry = 0; ry < 2; ry++) {
+#pragma unroll
+            for (int rx = 0; rx < 2; rx++) {
+                const double *row = V + (y0 + ry - yv0) * SC + (x0 + rx - xs0);
+                double tmp;
+                if (Rc == 0) tmp = row[0];
+                else {
+                    tmp = row[0] * wc[Rc];
+                    for (int j = -Rc; j < 0; j++) tmp += (row[j] + row[-j]) * wc[Rc + j];
+                }
+                f[ry][rx] = tmp;
+            }
+        }
+        const double top = (1.0 - wx) * f[0][0] + wx * f[0][1];
+        const double bot = (1.0 - wx) * f[1][0] + wx * f[1][1];
+        const double v = (1.0 - wy) * top + wy * bot;
+        a.dst[arr][(int64_t)pair * a.dst_stride + (int64_t)oy * a.Wo + ox] = v;
+        if (slot) tr.add(slot, v, f[0][0], f[0][1], f[1][0], f[1][1]);
+    }
+}
+
+// The tile for a compile-time radius R (both axes): the pyramid levels of the bench (R = 1, 3, 5 at ratio
+// 1.5).  Same products and sums in the same order as aa_tile_generic / filtered_tap(), so bit-identical; what
+// differs is the bookkeeping around them -- on this kernel 70 % of the issued VALU work was integer address
+// arithmetic and predication, not the FP64 filter:
+//   * the wave index is made scalar (readfirstlane), so row numbers, boundary reflection of rows and row base
+//     pointers live in SGPRs: a source load is `global_load v, voff, s[row]` with one per-lane column offset;
+//   * a wave loads the CH + 2 R source rows of its column walk unconditionally (rows beyond the wave's share
+//     are clamped to the last one and unused): no per-load exec masking;
+//   * x1 = x0 + 1 and y1 = y0 + 1, so the two horizontal filters of a V row share 2 R of their 2 R + 1 LDS reads;
+//   * the per-row terms (wy and the V offset of the upper tap) are computed once per tile into LDS.
+template <int R>
+__device__ __forceinline__ void aa_tile_fixed(const AaTileArgs &a, int tile, int arr, int pair,
+                                              unsigned char *aa_smem, ClipTrack &tr, ClipSlot *slot) {
+    static_assert(R > 0, "compile-time radius");
+    constexpr int CH = 8;                                         // V rows per wave held in registers
+    const int SC = a.max_cols;
+    double *V = reinterpret_cast<double *>(aa_smem);              // [max_v_rows][SC] vertically filtered
+    double *row_wy = V + (size_t)a.max_v_rows * SC;               // [tile_rows] weight of the lower row tap
+    int *row_off = reinterpret_cast<int *>(row_wy + a.tile_rows); // [tile_rows] V offset of the upper row tap
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tiles_x = (a.Wo + kAaCols - 1) / kAaCols;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int H = a.H, W = a.W;
+    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    const int oy0 = ty * a.tile_rows, oy1 = min(oy0 + a.tile_rows, a.Ho);
+    const int ox0 = tx * kAaCols, ox1 = min(ox0 + kAaCols, a.Wo);
+    const int yv0 = (int)floor(axis_pos(a.my, oy0));
+    const int yv1 = min((int)floor(axis_pos(a.my, oy1 - 1)) + 1, H - 1);
+    const int xv0 = (int)floor(axis_pos(a.mx, ox0));
+    const int xv1 = min((int)floor(axis_pos(a.mx, ox1 - 1)) + 1, W - 1);
+    const int nv = yv1 - yv0 + 1;                                // V rows
+    const int nc = xv1 - xv0 + 1 + 2 * R;                        // columns incl. the horizontal support
+    const int xs0 = xv0 - R;
+    double wk[R + 1], wck[R + 1];                                // kernel halves (uniform: scalar loads)
+#pragma unroll
+    for (int k = 0; k <= R; k++) { wk[k] = a.aa.wr[k]; wck[k] = a.aa.wc[k]; }
+    if ((int)threadIdx.x < oy1 - oy0) {                          // per-row terms of the blend
+        const double cy = axis_pos(a.my, oy0 + (int)threadIdx.x);
+        const double fy0 = floor(cy);
+        row_wy[threadIdx.x] = cy - fy0;
+        row_off[threadIdx.x] = ((int)fy0 - yv0) * SC;
+    }
+    {
+        const int chunk = (nv + 3) >> 2;
+        const int r0 = wave * chunk, r1 = min(r0 + chunk, nv);
+        const int rows = r1 - r0;                                // wave-uniform
+        const int ytop = yv0 + r0 - R;
+        const bool inside = ytop >= 0 && yv0 + r1 - 1 + R <= H - 1;   // no reflection needed
+        if (rows > 0 && rows <= CH) {
+            const double *rowp[CH + 2 * R];                      // uniform row base pointers
+#pragma unroll
+            for (int k = 0; k < CH + 2 * R; k++) {
+                const int y = ytop + (k < rows + 2 * R ? k : rows + 2 * R - 1);
+                rowp[k] = s + (int64_t)(inside ? y : mirror_idx(y, H)) * W;
+            }
+            for (int c = lane; c < nc; c += 64) {
+                const unsigned xs = (unsigned)mirror_idx(xs0 + c, W);
+                double v[CH + 2 * R];
+#pragma unroll
+                for (int k = 0; k < CH + 2 * R; k++) v[k] = rowp[k][xs];
+#pragma unroll
+                for (int i = 0; i < CH; i++) {
+                    if (i < rows) {                              // uniform
+                        double tmp = v[i + R] * wk[R];
+#pragma unroll
+                        for (int j = -R; j < 0; j++) tmp += (v[i + R + j] + v[i + R - j]) * wk[R + j];
+                        V[(r0 + i) * SC + c] = tmp;
+                    }
+                }
+            }
+        } else if (rows > 0) {                                   // taller tiles: sliding window
+            for (int c = lane; c < nc; c += 64) {
+                const double *col = s + mirror_idx(xs0 + c, W);
+                double win[2 * R + 1];
+#pragma unroll
+                for (int k = 0; k < 2 * R; k++) {
+                    const int y = ytop + k;
+                    win[k + 1] = col[(int64_t)(inside ? y : mirror_idx(y, H)) * W];
+                }
+                for (int r = r0; r < r1; r++) {
+#pragma unroll
+                    for (int k = 0; k < 2 * R; k++) win[k] = win[k + 1];
+                    const int y = yv0 + r + R;
+                    win[2 * R] = col[(int64_t)(inside ? y : mirror_idx(y, H)) * W];
+                    double tmp = win[R] * wk[R];
+#pragma unroll
+                    for (int j = -R; j < 0; j++) tmp += (win[R + j] + win[R - j]) * wk[R + j];
+                    V[r * SC + c] = tmp;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int ox = ox0 + lane;
+    if (ox >= ox1) return;
+    const double cx = axis_pos(a.mx, ox);
+    const double fx0 = floor(cx);
+    const double wx = cx - fx0;
+    const double *Vx = V + ((int)fx0 - xs0);                     // the lane's left tap in V row 0
+    double *dst = a.dst[arr] + (int64_t)pair * a.dst_stride;
+    for (int i = wave; i < oy1 - oy0; i += 4) {                  // i is wave-uniform
+        const double wy = row_wy[i];
+        const double *p = Vx + row_off[i];
+        double u[2][2 * R + 2];                                  // V rows y0, y0 + 1, columns x0 - R .. x0 + 1 + R
+#pragma unroll
+        for (int ry = 0; ry < 2; ry++)
+#pragma unroll
+            for (int q = 0; q < 2 * R + 2; q++) u[ry][q] = p[ry * SC + q - R];
+        double f[2][2];
+#pragma unroll
+        for (int ry = 0; ry < 2; ry++) {
+#pragma unroll
+            for (int rx = 0; rx < 2; rx++) {
+                double tmp = u[ry][R + rx] * wck[R];
+#pragma unroll
+                for (int j = -R; j < 0; j++) tmp += (u[ry][R + rx + j] + u[ry][R + rx - j]) * wck[R + j];
+                f[ry][rx] = tmp;
+            }
+        }
+        const double top = (1.0 - wx) * f[0][0] + wx * f[0][1];
+        const double bot = (1.0 - wx) * f[1][0] + wx * f[1][1];
+        const double v = (1.0 - wy) * top + wy * bot;
+        dst[(int64_t)(oy0 + i) * a.Wo + ox] = v;
+        if (slot) tr.add(slot, v, f[0][0], f[0][1], f[1][0], f[1][1]);
+    }
+}
+
+// Every tiled level of the pyramid in ONE launch: the tiles of level 1, then level 2, ... of one (array, pair)
+// are consecutive work items of ONE XCD, so the coarser levels of an image are produced right after the finer
+// ones and find the full-resolution source in that L2.
+constexpr int kAaMaxFused = 4;
+struct AaMultiArgs {
+    int n, n_arrays, batch, n_out;
+    int tile_end[kAaMaxFused];
+    AaTileArgs lv[kAaMaxFused];
+    ClipSlot *slots;
+};
+
+__global__ __launch_bounds__(256) void k_rescale_aa_multi(AaMultiArgs m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
+    // 1-D grid.  Workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2: XCD k takes
+    // images k, k + 8, ... one after the other, all tiles of all levels of an image consecutively
+    // (fewer than 8 images -- a single pair's three arrays: their tiles go to all XCDs instead)
+    const int tiles_total = m.tile_end[m.n - 1];
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const bool few = m.n_arrays * m.batch < 8;
+    const int image = few ? (int)blockIdx.x / tiles_total : (q / tiles_total) * 8 + xcd;
+    const int t = few ? (int)blockIdx.x - image * tiles_total : q - (q / tiles_total) * tiles_total;
+    if (image >= m.n_arrays * m.batch) return;
+    const int pair = image / m.n_arrays, arr = image - pair * m.n_arrays;
+    int l = 0;
+    while (l + 1 < m.n && t >= m.tile_end[l]) l++;
+    const int tile = t - (l ? m.tile_end[l - 1] : 0);
+    const AaTileArgs &a = m.lv[l];
+    const int R = a.aa.Rr == a.aa.Rc ? a.aa.Rr : 0;
+    ClipTrack tr;
+    tr.init();
+    ClipSlot *slot = m.slots ? m.slots + ((int64_t)pair * m.n_arrays + arr) * m.n_out + a.lvl : nullptr;
+    switch (R) {      // block-uniform
+        case 1: aa_tile_fixed<1>(a, tile, arr, pair, aa_smem, tr, slot); break;   // ratio 1.5, level 1
+        case 3: aa_tile_fixed<3>(a, tile, arr, pair, aa_smem, tr, slot); break;   // level 2
+        case 5: aa_tile_fixed<5>(a, tile, arr, pair, aa_smem, tr, slot); break;   // level 3
+        default: aa_tile_generic(a, tile, arr, pair, aa_smem, tr, slot); break;
+    }
+    // (lanes that returned early from the tile functions rejoin here: the returns are inlined branches)
+    if (slot) tr.flush(slot);
+}
+
+// first output index o in [0, n_out] whose lower tap max(floor(pos(o)), 0) is >= s0 (pos is increasing)
+__device__ __forceinline__ int first_owned(int s0, const AxisMap &m, int n_out) {
+    const double guess = m.ideal ? ((double)s0 + 0.5) / m.s - 0.5 : ((double)s0 - m.b) / m.a;
+    int o = (int)ceil(guess);
+    o = max(0, min(o, n_out));
+    while (o > 0 && max((int)floor(axis_pos(m, o - 1)), 0) >= s0) o--;
+    while (o < n_out && max((int)floor(axis_pos(m, o)), 0) < s0) o++;
+    return o;
+}
+
+// ---------------------------------------------------------------------------
+// Row-streaming form of the anti-aliased pyramid: one pass over the source for up to TWO levels.
+//
+// A block owns a full-height strip of source columns, one column per thread, and walks DOWN it:
+//   * every source texel is loaded exactly once (rows of the strip are contiguous: coalesced 8-byte loads),
+//     the loads of chunk c + 1 are issued before chunk c is computed (software prefetch in registers);
+//   * the thread keeps the last 2 RM rows of its column in registers, so the vertical Gaussians of BOTH
+//     levels (radius RA and RB) come from the same registers: K new V rows per level per chunk, written to
+//     per-level LDS rings;
+//   * after a barrier the waves take (output row, 64-column group) units of both levels whose two V rows are
+//     now complete: horizontal Gaussian at the four taps from LDS, blend, store -- aa_tile_fixed's arithmetic,
+//     operation by operation, so the output is bit-identical.
+// V rows live in rings of K + 2 rows per level (two barriers per chunk): 35.8 KB of LDS for a VGA strip,
+// 4 blocks per CU.  Measured on 256 VGA pairs x 3 arrays (profiles/r04_pyramid.txt): rings of 2 K + 1 rows
+// with one barrier (2 blocks per CU) 1.44 ms, K + 2 rows 0.99, ring pitch = the strip's columns instead of
+// 256 0.91; K = 4 / 6 / 8 / 9 / 12: 1.31 / 1.09 / 0.91 / 0.90 / 0.95; the tiles above 1.035.
+// ---------------------------------------------------------------------------
+constexpr int kStreamK = 8;                       // source rows per chunk
+constexpr int kStreamRing = kStreamK + 2;         // V rows per level ring (>= K + 2; < 2 K + 1: a second barrier per chunk)
+constexpr int kStreamMaxGroups = 3;               // 64-column groups of outputs per strip and level (checked on the host)
+
+struct StreamLevel {
+    double *dst[4];
+    int64_t dst_stride;
+    int Ho, Wo;
+    AxisMap mx, my;
+    const double *wr, *wc;                        // device: kernel halves incl. centre (R + 1 used)
+    int lvl;
+};
+
+struct StreamArgs {
+    const double *src[4];
+    int64_t src_stride;
+    int H, W, n_arrays, batch, n_out;
+    int n_strips, strip_w;                        // owned source columns per strip
+    int pitch;                                    // ring row pitch: strip_w + 2 RM + 1 columns, rounded up (<= 256 threads)
+    int n_segs, seg_rows;                         // row segments: a block emits the outputs whose upper tap lies in its segment
+    StreamLevel lv[2];
+    ClipSlot *slots;
+};
+
+template <int R>
+__device__ __forceinline__ double stream_vtap(const double *w, int c, const double (&wk)[R + 1]) {
+    double tmp = w[c] * wk[R];
+#pragma unroll
+    for (int j = -R; j < 0; j++) tmp += (w[c + j] + w[c - j]) * wk[R + j];
+    return tmp;
+}
+
+// the horizontal pass + blend of one level for the output rows [oy_lo, oy_hi) of this chunk
+template <int R>
+__device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *__restrict__ ring, int SW, double *dst,
+                                           int oy_lo, int oy_end, int ynew, int ya, int n_groups,
+                                           int ncols, int ox_first,
+                                           const int (&xoff)[kStreamMaxGroups],
+                                           const double (&wxs)[kStreamMaxGroups], const double (&wck)[R + 1],
+                                           int wave, int lane, int &unit, ClipTrack &tr, ClipSlot *slot) {
+    // the row terms of the next rows: lane i computes those of row oy_lo + i, the rows read them by lane;
+    // the rows to emit now are those whose lower tap y0 + 1 is in the ring (a prefix: y0 is monotone)
+    const double my_cy = axis_pos(L.my, oy_lo + lane);
+    const double my_fy = floor(my_cy);
+    const double my_wy = my_cy - my_fy;
+    const int my_y0 = (int)my_fy;
+    const int n_rows = __builtin_popcountll(__ballot(oy_lo + lane < oy_end && my_y0 + 1 <= ynew));
+    for (int i = 0; i < n_rows; i++) {                            // wave-uniform
+        const int y0 = __builtin_amdgcn_readlane(my_y0, i);
+        const double wy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_wy), i),
+                                           __builtin_amdgcn_readlane(__double2loint(my_wy), i));
+        const int slot0 = (y0 - ya) % kStreamRing, slot1 = (y0 + 1 - ya) % kStreamRing;
+        double *dst_row = dst + (int64_t)(oy_lo + i) * L.Wo + ox_first;   // uniform base, the lane is the offset
+#pragma unroll
+        for (int g = 0; g < kStreamMaxGroups; g++) {
+            if (g >= n_groups) break;
+            const bool mine = ((unit++) & 3) == wave;             // units dealt round-robin to the waves
+            if (!mine) continue;
+            if (g * 64 + lane >= ncols) continue;
+            const double *p0 = ring + slot0 * SW + xoff[g];
+            const double *p1 = ring + slot1 * SW + xoff[g];
+            double u[2][2 * R + 2];                               // V rows y0, y0 + 1, columns x0 - R .. x0 + 1 + R
+#pragma unroll
+            for (int q = 0; q < 2 * R + 2; q++) { u[0][q] = p0[q - R]; u[1][q] = p1[q - R]; }
+            double f[2][2];
+#pragma unroll
+            for (int ry = 0; ry < 2; ry++) {
+#pragma unroll
+                for (int rx = 0; rx < 2; rx++) {
+                    double tmp = u[ry][R + rx] * wck[R];
+#pragma unroll
+                    for (int j = -R; j < 0; j++) tmp += (u[ry][R + rx + j] + u[ry][R + rx - j]) * wck[R + j];
+                    f[ry][rx] = tmp;
+                }
+            }
+            const double wx = wxs[g];
+            const double top = (1.0 - wx) * f[0][0] + wx * f[0][1];
+            const double bot = (1.0 - wx) * f[1][0] + wx * f[1][1];
+            const double v = (1.0 - wy) * top + wy * bot;
+            (dst_row + g * 64)[lane] = v;
+            if (slot) tr.add(slot, v, f[0][0], f[0][1], f[1][0], f[1][1]);
+        }
+    }
+    return oy_lo + n_rows;
+}
+
+template <int RA, int RB>
+__global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
+    constexpr int RM = RA > RB ? RA : RB;
+    constexpr int NL = RB > 0 ? 2 : 1;
+    constexpr int K = kStreamK;
+    extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
+    double *ringA = reinterpret_cast<double *>(aa_smem);                    // [Ring][SW]
+    const int SW = a.pitch;
+    double *ringB = ringA + (NL > 1 ? kStreamRing * SW : 0);
+
+    // 1-D grid, XCD-major like k_rescale_aa_multi: XCD k takes images k, k + 8, ...; the strips of an
+    // image are neighbours in dispatch order (their halo columns meet in one L2)
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int per_image = a.n_strips * a.n_segs;
+    const int image = (q / per_image) * 8 + xcd, part = q - (q / per_image) * per_image;
+    const int seg = part / a.n_strips, strip = part - seg * a.n_strips;
+    if (image >= a.n_arrays * a.batch) return;
+    const int pair = image / a.n_arrays, arr = image - pair * a.n_arrays;
+    const int H = a.H, W = a.W;
+    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int xa = strip * a.strip_w, xb = min(xa + a.strip_w, W);
+    const int ya = seg * a.seg_rows, yb = min(ya + a.seg_rows, H);   // V rows ya .. min(yb, H - 1) are needed
+    // this thread's source column; threads beyond the strip's support (owned columns + RM on the left,
+    // RM + 1 on the right) repeat its last column
+    const unsigned xcol = (unsigned)mirror_idx(xa - RM + min((int)threadIdx.x, xb - xa + 2 * RM), W);
+
+    // per level: the strip's output columns (those whose left tap lies in [xa, xb)), per 64-column
+    // group the lane's left tap as a ring column and its blend weight
+    double wkA[RA + 1], wckA[RA + 1];
+    double wkB[RB + 1], wckB[RB + 1];
+    int oxA0, ncolsA, ngA, xoffA[kStreamMaxGroups];
+    double wxA[kStreamMaxGroups];
+    int oxB0 = 0, ncolsB = 0, ngB = 0, xoffB[kStreamMaxGroups];
+    double wxB[kStreamMaxGroups];
+    {
+        const StreamLevel &L = a.lv[0];
+#pragma unroll
+        for (int k = 0; k <= RA; k++) { wkA[k] = L.wr[k]; wckA[k] = L.wc[k]; }
+        oxA0 = first_owned(xa, L.mx, L.Wo);
+        ncolsA = (xb >= W ? L.Wo : first_owned(xb, L.mx, L.Wo)) - oxA0;
+        ngA = (ncolsA + 63) >> 6;
+#pragma unroll
+        for (int g = 0; g < kStreamMaxGroups; g++) {
+            const double cx = axis_pos(L.mx, oxA0 + g * 64 + lane);
+            const double fx0 = floor(cx);
+            wxA[g] = cx - fx0;
+            xoffA[g] = min(max((int)fx0 - (xa - RM), RA), SW - RA - 2);   // clamp: lanes beyond ncols
+        }
+    }
+    if constexpr (NL > 1) {
+        const StreamLevel &L = a.lv[1];
+#pragma unroll
+        for (int k = 0; k <= RB; k++) { wkB[k] = L.wr[k]; wckB[k] = L.wc[k]; }
+        oxB0 = first_owned(xa, L.mx, L.Wo);
+        ncolsB = (xb >= W ? L.Wo : first_owned(xb, L.mx, L.Wo)) - oxB0;
+        ngB = (ncolsB + 63) >> 6;
+#pragma unroll
+        for (int g = 0; g < kStreamMaxGroups; g++) {
+            const double cx = axis_pos(L.mx, oxB0 + g * 64 + lane);
+            const double fx0 = floor(cx);
+            wxB[g] = cx - fx0;
+            xoffB[g] = min(max((int)fx0 - (xa - RM), RB), SW - RB - 2);
+        }
+    }
+    double *dstA = a.lv[0].dst[arr] + (int64_t)pair * a.lv[0].dst_stride;
+    double *dstB = NL > 1 ? a.lv[1].dst[arr] + (int64_t)pair * a.lv[1].dst_stride : nullptr;
+    ClipTrack trA, trB;
+    trA.init();
+    trB.init();
+    ClipSlot *slotA = a.slots ? a.slots + ((int64_t)pair * a.n_arrays + arr) * a.n_out + a.lv[0].lvl : nullptr;
+    ClipSlot *slotB = a.slots && NL > 1 ? a.slots + ((int64_t)pair * a.n_arrays + arr) * a.n_out + a.lv[1].lvl : nullptr;
+
+    // the column's window: w[i] = source row (y - RM + i) for the chunk that starts at V row y
+    double w[K + 2 * RM], nxt[K];
+#pragma unroll
+    for (int i = 0; i < 2 * RM; i++) w[i] = s[(int64_t)mirror_idx(ya + i - RM, H) * W + xcol];
+#pragma unroll
+    for (int i = 0; i < K; i++) w[2 * RM + i] = s[(int64_t)mirror_idx(ya + RM + i, H) * W + xcol];
+    const bool last_seg = yb >= H;
+    int nextA = first_owned(ya, a.lv[0].my, a.lv[0].Ho), nextB = NL > 1 ? first_owned(ya, a.lv[1].my, a.lv[1].Ho) : 0, unit = 0;
+    const int endA = last_seg ? a.lv[0].Ho : first_owned(yb, a.lv[0].my, a.lv[0].Ho);
+    const int endB = NL > 1 ? (last_seg ? a.lv[1].Ho : first_owned(yb, a.lv[1].my, a.lv[1].Ho)) : 0;
+    const int y_last = min(yb, H - 1);                            // last V row this block needs
+    const int n_chunks = (y_last - ya + K) / K;
+    for (int c = 0; c < n_chunks; c++) {
+        const int y = ya + c * K;                                 // first V row of this chunk
+        if (c + 1 < n_chunks) {                                   // prefetch the next chunk's K rows
+            const int r0 = y + K + RM;
+            if (r0 + K - 1 <= H - 1) {                            // inside the image: uniform row bases, the column is the offset
+#pragma unroll
+                for (int i = 0; i < K; i++) nxt[i] = (s + (int64_t)(r0 + i) * W)[xcol];
+            } else {
+#pragma unroll
+                for (int i = 0; i < K; i++) nxt[i] = s[(int64_t)mirror_idx(r0 + i, H) * W + xcol];
+            }
+        }
+        // vertical Gaussians of both levels at V rows y .. y + K - 1 (rows >= H: computed, never read)
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            const int slot = (c * K + j) % kStreamRing;
+            const double va = stream_vtap<RA>(w, j + RM, wkA);
+            double vb = 0.0;
+            if constexpr (NL > 1) vb = stream_vtap<RB>(w, j + RM, wkB);
+            if ((int)threadIdx.x < SW) {                          // threads beyond the pitch hold a repeated column
+                ringA[slot * SW + threadIdx.x] = va;
+                if constexpr (NL > 1) ringB[slot * SW + threadIdx.x] = vb;
+            }
+        }
+        __syncthreads();
+        // outputs whose lower row tap y0 + 1 is now in the ring: y0 + 1 <= y + K - 1
+        const int ynew = y + K - 1 >= y_last ? (1 << 30) : y + K - 1;   // the last chunk emits whatever is left
+        nextA = stream_emit<RA>(a.lv[0], ringA, SW, dstA, nextA, endA, ynew, ya, ngA, ncolsA, oxA0, xoffA, wxA, wckA,
+                                wave, lane, unit, trA, slotA);
+        if constexpr (NL > 1)
+            nextB = stream_emit<RB>(a.lv[1], ringB, SW, dstB, nextB, endB, ynew, ya, ngB, ncolsB, oxB0, xoffB, wxB,
+                                    wckB, wave, lane, unit, trB, slotB);
+        if (kStreamRing < 2 * K + 1) __syncthreads();             // the next chunk's V rows overwrite rows read above
+#pragma unroll
+        for (int i = 0; i < 2 * RM; i++) w[i] = w[K + i];
+#pragma unroll
+        for (int i = 0; i < K; i++) w[2 * RM + i] = nxt[i];
+    }
+    if (slotA) trA.flush(slotA);
+    if constexpr (NL > 1)
+        if (slotB) trB.flush(slotB);
+}
+
+// ---------------------------------------------------------------------------
+// clip: true bounds of a flagged (image, level) and numpy.clip
+// ---------------------------------------------------------------------------
+struct ClipArgs {
+    const double *src[4];
+    int64_t src_stride;
+    int H, W, n_arrays, batch, n_out;
+    DevLevel lv[kMaxOut];
+    ClipSlot *slots;
+};
+
+constexpr int kClipTileRows = 16, kClipTileCols = 64;
+
+// grid: (tiles of the SOURCE image, n_out, images).  A tile's filtered values: vertical pass into LDS
+// (columns + 2 Rc of halo), horizontal pass from LDS -- scipy's order, as everywhere in this file.
+__global__ __launch_bounds__(256) void k_clip_bounds(ClipArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
+    const int image = blockIdx.z, l = blockIdx.y;
+    ClipSlot *slot = a.slots + (int64_t)image * a.n_out + l;
+    if (!clip_needed(*slot)) return;
+    const int pair = image / a.n_arrays, arr = image - pair * a.n_arrays;
+    const DevLevel &L = a.lv[l];
+    const int H = a.H, W = a.W, Rr = L.aa.Rr, Rc = L.aa.Rc;
+    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    const int tiles_x = (W + kClipTileCols - 1) / kClipTileCols, tiles_y = (H + kClipTileRows - 1) / kClipTileRows;
+    const int SC = kClipTileCols + 2 * Rc;
+    double *V = reinterpret_cast<double *>(aa_smem);
+    double vmax = -INFINITY, vmin = INFINITY;
+    bool nan = false;
+    for (int t = blockIdx.x; t < tiles_x * tiles_y; t += gridDim.x) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int y0 = ty * kClipTileRows, x0 = tx * kClipTileCols;
+        const int nr = min(kClipTileRows, H - y0), nc = min(kClipTileCols, W - x0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * (nc + 2 * Rc); i += 256) {
+            const int r = i / (nc + 2 * Rc), c = i - r * (nc + 2 * Rc);
+            V[r * SC + c] = column_tap(s, H, W, y0 + r, mirror_idx(x0 - Rc + c, W), L.aa.wr, Rr);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * nc; i += 256) {
+            const int r = i / nc, c = i - r * nc;
+            const double *row = V + r * SC + c + Rc;
+            double tmp;
+            if (Rc == 0) tmp = row[0];
+            else {
+                tmp = row[0] * L.aa.wc[Rc];
+                for (int j = -Rc; j < 0; j++) tmp += (row[j] + row[-j]) * L.aa.wc[Rc + j];
+            }
+            vmax = fmax(vmax, tmp);
+            vmin = fmin(vmin, tmp);
+            nan |= tmp != tmp;
+        }
+    }
+    vmax = wave_max(vmax);
+    vmin = wave_min(vmin);
+    const bool any_nan = __ballot(nan) != 0ull;
+    if ((threadIdx.x & 63) == 0) {
+        if (vmax != -INFINITY || vmin != INFINITY) {
+            atomicMax(&slot->hi, enc(vmax));
+            atomicMin(&slot->lo, enc(vmin));
+        }
+        if (any_nan) atomicOr(&slot->nan_img, 1u);
+    }
+}
+
+// grid: (blocks over the level's outputs, n_out, images)
+__global__ __launch_bounds__(256) void k_clip_apply(ClipArgs a) {
+    const int image = blockIdx.z, l = blockIdx.y;
+    const ClipSlot slot = a.slots[(int64_t)image * a.n_out + l];
+    if (!clip_needed(slot)) return;
+    const int pair = image / a.n_arrays, arr = image - pair * a.n_arrays;
+    const DevLevel &L = a.lv[l];
+    double *d = L.dst[arr] + (int64_t)pair * L.stride;
+    const int64_t n = (int64_t)L.Ho * L.Wo;
+    // ndarray.min() / .max() of an image with a NaN are NaN, and numpy.clip with a NaN bound returns NaN
+    const double lo = slot.nan_img ? NAN : dec(slot.lo), hi = slot.nan_img ? NAN : dec(slot.hi);
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const double x = d[i];
+        const double m = (x != x || lo != lo) ? NAN : (x > lo ? x : lo);
+        const double v = (m != m || hi != hi) ? NAN : (m < hi ? m : hi);
+        if (__double_as_longlong(v) != __double_as_longlong(x)) d[i] = v;
+    }
+}
+
+// scipy.ndimage._filters._gaussian_kernel1d (order 0) with libm's exp and a sequential sum: the kernels of a
+// level without a plan (the ideal reading; a plan brings the caller's NumPy kernels)
+void gaussian_weights(double sigma, int radius, double *w) {
+    const double sigma2 = sigma * sigma;
+    double sum = 0.0;
+    for (int i = -radius; i <= radius; i++) {
+        w[i + radius] = exp(-0.5 / sigma2 * (double)(i * i));
+        sum += w[i + radius];
+    }
+    for (int i = 0; i <= 2 * radius; i++) w[i] = w[i] / sum;
+}
+
+// all four taps of every output inside the image, so that x1 = x0 + 1 / y1 = y0 + 1 hold (tiles, stream)
+bool taps_inside(const AxisMap &m, int n_in, int n_out) {
+    if (n_out >= n_in) return false;
+    const double p0 = axis_pos(m, 0), p1 = axis_pos(m, n_out - 1);
+    if (!(p0 >= 0.0) || !(p1 > p0)) return false;
+    return (int)floor(p1) + 1 <= n_in - 1;
+}
+
+}  // namespace
+
+namespace tdk {
+
+AxisMap ideal_axis(int n_in, int n_out) {
+    AxisMap m;
+    m.a = 0.0; m.b = 0.0; m.s = (double)n_in / (double)n_out; m.ideal = 1;
+    return m;
+}
+
+AxisMap affine_axis(double a, double b) {
+    AxisMap m;
+    m.a = a; m.b = b; m.s = 0.0; m.ideal = 0;
+    return m;
+}
+
+void ideal_level_plan(PyramidLevelDesc *lv, int H, int W, bool anti_aliasing, double *storage) {
+    lv->mx = ideal_axis(W, lv->W);
+    lv->my = ideal_axis(H, lv->H);
+    lv->wr = lv->wc = nullptr;
+    lv->Rr = lv->Rc = 0;
+    if (!anti_aliasing) return;
+    // sigma = max(0, (factor - 1) / 2) per axis; an axis with sigma <= 1e-15 is not filtered
+    const double sg[2] = {((double)H / (double)lv->H - 1.0) / 2.0, ((double)W / (double)lv->W - 1.0) / 2.0};
+    for (int ax = 0; ax < 2; ax++) {
+        if (!(sg[ax] > 1e-15)) continue;
+        const int R = (int)(4.0 * sg[ax] + 0.5);
+        if (R > kMaxGaussRadius) {      // reported by launch_pyramid
+            (ax ? lv->Rc : lv->Rr) = R;
+            continue;
+        }
+        double *w = storage + (size_t)ax * (2 * kMaxGaussRadius + 1);
+        gaussian_weights(sg[ax], R, w);
+        if (ax == 0) { lv->wr = w; lv->Rr = R; }
+        else { lv->wc = w; lv->Rc = R; }
+    }
+}
+
+size_t pyramid_weight_doubles(int n_out) { return (size_t)n_out * 2 * (2 * kMaxGaussRadius + 1); }
+size_t pyramid_clip_bytes(int64_t n_images, int n_out) { return sizeof(ClipSlot) * (size_t)n_images * (size_t)n_out; }
+int pyramid_max_radius() { return kMaxGaussRadius; }
+
+// Every level in `levels` (n_out of them; a level-0 entry has H x W = the source's) of `n_arrays` arrays of
+// `batch` images.  `weights` is a device buffer of pyramid_weight_doubles(n_out) doubles owned by the caller;
+// the kernels of every level are copied into it when upload_weights is set (they depend on shapes and plans
+// only).  `clip_slots`: a device buffer of pyramid_clip_bytes(batch * n_arrays, n_out) bytes, or null for
+// clip=False.  stream_mode: 0 never the streaming kernel, 1 for batches that fill the chip, 2 always.
+tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride, int n_out,
+                          const PyramidLevelDesc *levels, int batch, double *weights, bool upload_weights,
+                          void *clip_slots, int stream_mode, hipStream_t stream) {
+    if (n_out <= 0) return TDK_OK;
+    if (n_out > kMaxOut || n_arrays > 4) {
+        set_error("pyramid too deep");
+        return TDK_ERR_INVALID_ARGUMENT;
+    }
+    constexpr int kSlot = 2 * kMaxGaussRadius + 1;
+    std::vector<double> host((size_t)n_out * 2 * kSlot, 0.0);
+    DevLevel dv[kMaxOut];
+    bool done[kMaxOut] = {};
+    for (int l = 0; l < n_out; l++) {
+        const PyramidLevelDesc &P = levels[l];
+        if (P.Rr > kMaxGaussRadius || P.Rc > kMaxGaussRadius || P.Rr < 0 || P.Rc < 0) {
+            set_error("anti-aliasing kernel radius %d exceeds %d", std::max(P.Rr, P.Rc), kMaxGaussRadius);
+            return TDK_ERR_INVALID_ARGUMENT;
+        }
+        for (int i = 0; i < 4; i++) dv[l].dst[i] = i < n_arrays ? P.dst[i] : nullptr;
+        dv[l].stride = P.stride; dv[l].Ho = P.H; dv[l].Wo = P.W;
+        dv[l].mx = P.mx; dv[l].my = P.my;
+        double *wr = host.data() + ((size_t)l * 2 + 0) * kSlot, *wc = host.data() + ((size_t)l * 2 + 1) * kSlot;
+        if (P.wr && P.Rr > 0) memcpy(wr, P.wr, sizeof(double) * (2 * P.Rr + 1)); else wr[0] = 1.0;
+        if (P.wc && P.Rc > 0) memcpy(wc, P.wc, sizeof(double) * (2 * P.Rc + 1)); else wc[0] = 1.0;
+        dv[l].aa.wr = weights + ((size_t)l * 2 + 0) * kSlot;
+        dv[l].aa.wc = weights + ((size_t)l * 2 + 1) * kSlot;
+        dv[l].aa.Rr = (P.wr && P.Rr > 0) ? P.Rr : 0;
+        dv[l].aa.Rc = (P.wc && P.Rc > 0) ? P.Rc : 0;
+    }
+    if (upload_weights) {
+        TDK_HIP(hipMemcpyAsync(weights, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        TDK_HIP(hipStreamSynchronize(stream));   // `host` goes out of scope
+    }
+    ClipSlot *slots = static_cast<ClipSlot *>(clip_slots);
+    const int64_t images = (int64_t)n_arrays * batch;
+    if (slots) {
+        const int n = (int)(images * n_out);
+        k_clip_reset<<<(n + 255) / 256, 256, 0, stream>>>(slots, n);
+        TDK_LAUNCH_CHECK();
+    }
+    auto shrinks = [&](int l) {
+        return taps_inside(dv[l].mx, W, dv[l].Wo) && taps_inside(dv[l].my, H, dv[l].Ho);
+    };
+    // --- the identity-scale level: no filter, same shape
+    for (int l = 0; l < n_out; l++) {
+        if (dv[l].Ho != H || dv[l].Wo != W || dv[l].aa.Rr || dv[l].aa.Rc) continue;
+        Level0Args a;
+        for (int i = 0; i < 4; i++) { a.src[i] = i < n_arrays ? srcs[i] : nullptr; a.dst[i] = dv[l].dst[i]; }
+        a.src_stride = src_stride; a.dst_stride = dv[l].stride; a.H = H; a.W = W;
+        a.n_arrays = n_arrays; a.batch = batch; a.lvl = l; a.n_out = n_out;
+        a.mx = dv[l].mx; a.my = dv[l].my; a.slots = slots;
+        const int64_t per_image = (int64_t)((W + 63) / 64) * ((H + 4 * kL0Rows - 1) / (4 * kL0Rows));
+        const int64_t blocks = (images < 8 ? images : 8 * ((images + 7) / 8)) * per_image;
+        if (blocks >= (1ll << 31)) { set_error("level 0: grid too large"); return TDK_ERR_INVALID_ARGUMENT; }
+        k_level0_rows<<<(unsigned)blocks, 256, 0, stream>>>(a);
+        TDK_LAUNCH_CHECK();
+        done[l] = true;
+    }
+    // --- the first level with radius 1 (and the one with radius 3 if there is one) of a batch large enough to
+    // fill the chip with full-height strips: one streaming pass over the source
+    {
+        int lA = -1, lB = -1;
+        for (int l = 0; l < n_out && lA < 0; l++)
+            if (!done[l] && dv[l].aa.Rr == 1 && dv[l].aa.Rc == 1 && shrinks(l)) lA = l;
+        for (int l = 0; l < n_out && lA >= 0 && lB < 0; l++)
+            if (!done[l] && dv[l].aa.Rr == 3 && dv[l].aa.Rc == 3 && shrinks(l)) lB = l;
+        const int n_strips = (W + 247) / 248, strip_w = (W + n_strips - 1) / n_strips;
+        if (stream_mode && lA >= 0 && (images * n_strips >= 256 || stream_mode == 2)) {
+            const int nl = lB >= 0 ? 2 : 1;
+            StreamArgs sa;
+            for (int i = 0; i < 4; i++) sa.src[i] = i < n_arrays ? srcs[i] : nullptr;
+            sa.src_stride = src_stride; sa.H = H; sa.W = W; sa.n_arrays = n_arrays; sa.batch = batch; sa.n_out = n_out;
+            sa.n_strips = n_strips; sa.strip_w = strip_w;
+            sa.pitch = std::min(256, (strip_w + 2 * 3 + 1 + 7) & ~7);
+            sa.slots = slots;
+            // row segments: enough blocks for several full rounds of the 1024 resident ones (a segment pays
+            // 2 RM warm-up rows)
+            int n_segs = 1;
+            while (images * n_strips * n_segs < 8192 && H / (n_segs * 2) >= 48) n_segs *= 2;
+            sa.seg_rows = (H + n_segs - 1) / n_segs;
+            sa.n_segs = (H + sa.seg_rows - 1) / sa.seg_rows;
+            size_t lds = 0;
+            for (int k = 0; k < 2; k++) {
+                const int l = k == 0 ? lA : (nl == 2 ? lB : lA);
+                for (int i = 0; i < 4; i++) sa.lv[k].dst[i] = dv[l].dst[i];
+                sa.lv[k].dst_stride = dv[l].stride; sa.lv[k].Ho = dv[l].Ho; sa.lv[k].Wo = dv[l].Wo;
+                sa.lv[k].mx = dv[l].mx; sa.lv[k].my = dv[l].my;
+                sa.lv[k].wr = dv[l].aa.wr; sa.lv[k].wc = dv[l].aa.wc; sa.lv[k].lvl = l;
+                if (k < nl) lds += sizeof(double) * kStreamRing * sa.pitch;
+            }
+            // outputs per strip must fit the kStreamMaxGroups 64-column groups
+            bool fits = true;
+            for (int k = 0; k < nl; k++) {
+                const AxisMap &m = sa.lv[k].mx;
+                const double step = (axis_pos(m, sa.lv[k].Wo - 1) - axis_pos(m, 0)) / std::max(1, sa.lv[k].Wo - 1);
+                if (!(step > 0.0) || (double)strip_w / step + 2.0 > 64.0 * kStreamMaxGroups) fits = false;
+                const AxisMap &my = sa.lv[k].my;
+                const double stepy = (axis_pos(my, sa.lv[k].Ho - 1) - axis_pos(my, 0)) / std::max(1, sa.lv[k].Ho - 1);
+                if (!(stepy > 0.0) || (double)kStreamK / stepy + 2.0 > 64.0) fits = false;
+            }
+            const int64_t blocks = 8 * ((images + 7) / 8) * n_strips * sa.n_segs;
+            if (fits && blocks < (1ll << 31) && lds <= 160 * 1024) {
+                static bool attr_set = false;
+                if (!attr_set) {   // > 64 KiB of dynamic LDS has to be asked for
+                    TDK_HIP(hipFuncSetAttribute((const void *)k_pyramid_stream<1, 3>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    TDK_HIP(hipFuncSetAttribute((const void *)k_pyramid_stream<1, 0>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    attr_set = true;
+                }
+                if (nl == 2) k_pyramid_stream<1, 3><<<(unsigned)blocks, 256, lds, stream>>>(sa);
+                else k_pyramid_stream<1, 0><<<(unsigned)blocks, 256, lds, stream>>>(sa);
+                TDK_LAUNCH_CHECK();
+                done[lA] = true;
+                if (nl == 2) done[lB] = true;
+            }
+        }
+    }
+    // --- levels that shrink both axes and whose tiles fit in LDS take the tiled kernel, all of them in one
+    // launch; whatever is left (an enlarged axis, very deep levels, level 0 with a filter) the general one
+    AaMultiArgs m;
+    m.n = 0;
+    size_t lds_max = 0;
+    int tiles_total = 0;
+    for (int l = 0; l < n_out; l++) {
+        if (done[l] || m.n == kAaMaxFused || !shrinks(l)) continue;
+        AaTileArgs t;
+        const int Rk = dv[l].aa.Rr == dv[l].aa.Rc ? dv[l].aa.Rr : 0;
+        // output rows per block: 20 for the 3-tap level, 12 from R = 3 on (measured on the VGA bench batch)
+        t.tile_rows = Rk == 1 ? 20 : 12;
+        t.mx = dv[l].mx; t.my = dv[l].my;
+        // LDS tile bounds from the level's own map
+        int max_v = 0, max_c = 0;
+        for (int oy0 = 0; oy0 < dv[l].Ho; oy0 += t.tile_rows) {
+            const int oy1 = std::min(oy0 + t.tile_rows, dv[l].Ho);
+            const int yv0 = (int)floor(axis_pos(t.my, oy0)), yv1 = std::min((int)floor(axis_pos(t.my, oy1 - 1)) + 1, H - 1);
+            max_v = std::max(max_v, yv1 - yv0 + 1);
+        }
+        for (int ox0 = 0; ox0 < dv[l].Wo; ox0 += kAaCols) {
+            const int ox1 = std::min(ox0 + kAaCols, dv[l].Wo);
+            const int xv0 = (int)floor(axis_pos(t.mx, ox0)), xv1 = std::min((int)floor(axis_pos(t.mx, ox1 - 1)) + 1, W - 1);
+            max_c = std::max(max_c, xv1 - xv0 + 1 + 2 * dv[l].aa.Rc);
+        }
+        t.max_v_rows = max_v;
+        t.max_cols = max_c;
+        const size_t lds = sizeof(double) * ((size_t)t.max_v_rows * t.max_cols + 2 * dv[l].aa.Rr +
+                                             2 * dv[l].aa.Rc + 2) + (size_t)t.tile_rows * 12 + 8;
+        if (lds > 64 * 1024) continue;
+        for (int i = 0; i < 4; i++) { t.src[i] = i < n_arrays ? srcs[i] : nullptr; t.dst[i] = dv[l].dst[i]; }
+        t.src_stride = src_stride; t.dst_stride = dv[l].stride;
+        t.H = H; t.W = W; t.Ho = dv[l].Ho; t.Wo = dv[l].Wo;
+        t.aa = dv[l].aa;
+        t.lvl = l;
+        tiles_total += ((dv[l].Ho + t.tile_rows - 1) / t.tile_rows) * ((dv[l].Wo + kAaCols - 1) / kAaCols);
+        m.lv[m.n] = t;
+        m.tile_end[m.n] = tiles_total;
+        m.n++;
+        done[l] = true;
+        if (lds > lds_max) lds_max = lds;
+    }
+    if (m.n > 0) {
+        m.n_arrays = n_arrays;
+        m.batch = batch;
+        m.n_out = n_out;
+        m.slots = slots;
+        const int64_t blocks = (images < 8 ? images : 8 * ((images + 7) / 8)) * tiles_total;
+        if (blocks >= (1ll << 31)) {
+            set_error("anti-aliased pyramid: %lld blocks exceed the grid limit", (long long)blocks);
+            return TDK_ERR_INVALID_ARGUMENT;
+        }
+        k_rescale_aa_multi<<<(unsigned)blocks, 256, lds_max, stream>>>(m);
+        TDK_LAUNCH_CHECK();
+    }
+    {
+        GenericArgs g;
+        g.n = 0;
+        int total = 0;
+        for (int l = 0; l < n_out; l++) {
+            if (done[l]) continue;
+            g.lv[g.n] = dv[l];
+            g.lvl[g.n] = l;
+            total += (dv[l].Ho + 3) / 4;   // four output rows per block
+            g.blk_end[g.n] = total;
+            g.n++;
+        }
+        if (g.n > 0) {
+            for (int i = 0; i < 4; i++) g.src[i] = i < n_arrays ? srcs[i] : nullptr;
+            g.src_stride = src_stride; g.H = H; g.W = W; g.slots = slots; g.n_arrays = n_arrays; g.n_out = n_out;
+            dim3 grid(total, n_arrays, batch);
+            k_rescale_generic<<<grid, 256, 0, stream>>>(g);
+            TDK_LAUNCH_CHECK();
+        }
+    }
+    if (slots) {
+        ClipArgs c;
+        for (int i = 0; i < 4; i++) c.src[i] = i < n_arrays ? srcs[i] : nullptr;
+        c.src_stride = src_stride; c.H = H; c.W = W; c.n_arrays = n_arrays; c.batch = batch; c.n_out = n_out;
+        for (int l = 0; l < n_out; l++) c.lv[l] = dv[l];
+        c.slots = slots;
+        if (images > 65535) { set_error("clip: more than 65535 images per launch"); return TDK_ERR_INVALID_ARGUMENT; }
+        int rc_max = 0;
+        int64_t n_max = 0;
+        for (int l = 0; l < n_out; l++) {
+            rc_max = std::max(rc_max, dv[l].aa.Rc);
+            n_max = std::max(n_max, (int64_t)dv[l].Ho * dv[l].Wo);
+        }
+        const size_t lds = sizeof(double) * (size_t)kClipTileRows * (kClipTileCols + 2 * rc_max);
+        const int tiles = ((W + kClipTileCols - 1) / kClipTileCols) * ((H + kClipTileRows - 1) / kClipTileRows);
+        dim3 gb((unsigned)std::min(tiles, 64), (unsigned)n_out, (unsigned)images);
+        k_clip_bounds<<<gb, 256, lds, stream>>>(c);
+        TDK_LAUNCH_CHECK();
+        dim3 ga((unsigned)std::min<int64_t>((n_max + 255) / 256, 64), (unsigned)n_out, (unsigned)images);
+        k_clip_apply<<<ga, 256, 0, stream>>>(c);
+        TDK_LAUNCH_CHECK();
+    }
+    return TDK_OK;
+}
+
+}  // namespace tdk
+
+namespace {
+
+// one image, one level, host pointers in and out
+tdk_status rescale_host(const double *image, int H, int W, double *out, int Ho, int Wo, tdk::PyramidLevelDesc &lv,
+                        bool clip) {
+    void *d_img, *d_out, *d_w, *d_clip = nullptr;
+    TDK_TRY(tdk::scratch(0, (size_t)H * W * 8, &d_img));
+    TDK_HIP(hipMemcpyAsync(d_img, image, (size_t)H * W * 8, hipMemcpyHostToDevice, tdk::stream()));
+    TDK_TRY(tdk::scratch(1, (size_t)Ho * Wo * 8, &d_out));
+    TDK_TRY(tdk::scratch(2, tdk::pyramid_weight_doubles(1) * 8, &d_w));
+    if (clip) TDK_TRY(tdk::scratch(3, tdk::pyramid_clip_bytes(1, 1), &d_clip));
+    const double *srcs[1] = {(const double *)d_img};
+    lv.dst[0] = (double *)d_out; lv.dst[1] = lv.dst[2] = lv.dst[3] = nullptr;
+    lv.stride = 0; lv.H = Ho; lv.W = Wo;
+    TDK_TRY(tdk::launch_pyramid(srcs, 1, H, W, 0, 1, &lv, 1, (double *)d_w, true, d_clip, 1, tdk::stream()));
+    TDK_HIP(hipMemcpyAsync(out, d_out, (size_t)Ho * Wo * 8, hipMemcpyDeviceToHost, tdk::stream()));
+    TDK_HIP(hipStreamSynchronize(tdk::stream()));
+    return TDK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+tdk_status tdk_rescale(const double *image, int H, int W, double *out, int Ho, int Wo) {
+    TDK_REQUIRE(H > 0 && W > 0 && Ho > 0 && Wo > 0 && image && out, "bad argument");
+    tdk::PyramidLevelDesc lv;
+    lv.H = Ho; lv.W = Wo;
+    std::vector<double> storage(2 * (2 * kMaxGaussRadius + 1));
+    tdk::ideal_level_plan(&lv, H, W, false, storage.data());
+    return rescale_host(image, H, W, out, Ho, Wo, lv, false);
+}
+
+tdk_status tdk_rescale_anti_aliased(const double *image, int H, int W, double *out, int Ho, int Wo) {
+    TDK_REQUIRE(H > 0 && W > 0 && Ho > 0 && Wo > 0 && image && out, "bad argument");
+    tdk::PyramidLevelDesc lv;
+    lv.H = Ho; lv.W = Wo;
+    std::vector<double> storage(2 * (2 * kMaxGaussRadius + 1));
+    tdk::ideal_level_plan(&lv, H, W, true, storage.data());
+    return rescale_host(image, H, W, out, Ho, Wo, lv, false);
+}
+
+tdk_status tdk_rescale_skimage(const double *image, int H, int W, double *out, int Ho, int Wo, const double *map,
+                               const double *w_rows, int radius_rows, const double *w_cols, int radius_cols,
+                               int clip) {
+    TDK_REQUIRE(H > 0 && W > 0 && Ho > 0 && Wo > 0 && image && out && map, "bad argument");
+    TDK_REQUIRE(radius_rows >= 0 && radius_cols >= 0 && radius_rows <= kMaxGaussRadius && radius_cols <= kMaxGaussRadius,
+                "kernel radius out of range");
+    TDK_REQUIRE(map[0] > 0.0 && map[2] > 0.0, "the map's scales must be positive");
+    tdk::PyramidLevelDesc lv;
+    lv.mx = tdk::affine_axis(map[0], map[1]);
+    lv.my = tdk::affine_axis(map[2], map[3]);
+    lv.wr = radius_rows > 0 ? w_rows : nullptr; lv.Rr = radius_rows;
+    lv.wc = radius_cols > 0 ? w_cols : nullptr; lv.Rc = radius_cols;
+    return rescale_host(image, H, W, out, Ho, Wo, lv, clip != 0);
+}
+
+}  // extern "C"

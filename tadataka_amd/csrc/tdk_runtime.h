@@ -26,41 +26,36 @@ tdk_status scratch(int slot, size_t bytes, void **ptr);
 // Pinned host staging buffer (grow-only) for small D2H results.
 tdk_status pinned(int slot, size_t bytes, void **ptr);
 
-// granular.hip: bilinear rescale of `batch` images laid out with the given strides
-tdk_status launch_rescale(const double *src, int H, int W, double *dst, int Ho, int Wo, int batch,
-                          int64_t src_stride, int64_t dst_stride, hipStream_t stream);
-
-// granular.hip: every pyramid level of `n_arrays` arrays in one launch.
-// mode 0: one thread per output pixel, blocks ordered so that all levels of one
-// (pair, array) are dispatched together (level 0 is re-read from the Infinity
-// Cache, not HBM); mode 1: level-0 tiles staged in LDS, one pass.
+// pyramid.hip: skimage.transform.rescale on the device.  A level's sample positions and Gaussian kernels either
+// come from the host (a "plan": the affine map skimage's resize() estimates and scipy.ndimage's kernels, both
+// products of the caller's NumPy -- tdk_dvo_set_level_plan, tdk_rescale_skimage) or are the ideal ones.
+struct AxisMap {
+    double a, b;   // position of output index o: a * o + b (one product, one sum) ...
+    double s;      // ... or, ideal: (o + 0.5) * s - 0.5 with s = n_in / n_out
+    int ideal;
+};
+AxisMap ideal_axis(int n_in, int n_out);
+AxisMap affine_axis(double a, double b);
 struct PyramidLevelDesc {
     double *dst[4];
     int64_t stride;
     int H, W;
+    AxisMap mx, my;          // columns, rows
+    const double *wr, *wc;   // HOST: scipy's kernels, 2 R + 1 entries (centre at [R]); null = axis not filtered
+    int Rr, Rc;
 };
-tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride,
-                          int n_out, const PyramidLevelDesc *levels, int batch, int mode, hipStream_t stream);
-// the same levels with skimage's anti-aliasing prefilter (Gaussian, sigma = (factor - 1) / 2 per axis)
-tdk_status launch_pyramid_aa(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride, int n_out,
-                             const PyramidLevelDesc *levels, int batch, double *weights, bool upload_weights,
-                             hipStream_t stream, unsigned skip_mask = 0u);   // bit l: level l is built elsewhere
-size_t pyramid_aa_weight_doubles(int n_out);
+// ideal maps and (anti_aliasing) libm kernels for a level of an H x W source; `storage` holds the kernels:
+// 2 * (2 * pyramid_max_radius() + 1) doubles that must outlive the launch
+void ideal_level_plan(PyramidLevelDesc *lv, int H, int W, bool anti_aliasing, double *storage);
+int pyramid_max_radius();
+size_t pyramid_weight_doubles(int n_out);
+size_t pyramid_clip_bytes(int64_t n_images, int n_out);
+// every level of `levels` for `n_arrays` arrays of `batch` images in a few launches (see pyramid.hip)
+tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride, int n_out,
+                          const PyramidLevelDesc *levels, int batch, double *weights, bool upload_weights,
+                          void *clip_slots, int stream_mode, hipStream_t stream);
 
-// pyramid_sep.hip: the same levels as one separable resampling filter per axis (FMA chains over tap
-// lists built on the host; last-bit differences from the ndimage operation order).  A plan holds the
-// tap lists of one pyramid geometry on the device; levels it cannot take (enlarged axes, tiles beyond
-// LDS) are left to launch_pyramid_aa -- pyramid_sep_mask() has a bit per level it builds.
-struct PyramidSepPlan;
-tdk_status pyramid_sep_create(int H, int W, int n_out, const int *Ho, const int *Wo, hipStream_t stream,
-                              PyramidSepPlan **out, unsigned *handled_mask);
-tdk_status pyramid_sep_destroy(PyramidSepPlan *p);
-bool pyramid_sep_matches(const PyramidSepPlan *p, int H, int W, int n_out, const PyramidLevelDesc *levels);
-unsigned pyramid_sep_mask(const PyramidSepPlan *p);
-tdk_status launch_pyramid_sep(PyramidSepPlan *p, const double *const *srcs, int n_arrays, int64_t src_stride,
-                              const PyramidLevelDesc *levels, int batch, hipStream_t stream);
-
-// dvo.hip: level-0 arrays of a DVO batch, for producers that fill it on the device (tdk_sd_export_dvo)
+// dvo.hip: the full-resolution input arrays of a DVO batch, for producers that fill it on the device (tdk_sd_export_dvo)
 struct DvoLevel0 {
     double *I0, *D0, *I1, *W0;   // [n_pairs][stride]; W0 is null without a weight map
     double *poses;               // [n_pairs][12] last accepted poses of the device loop

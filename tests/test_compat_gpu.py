@@ -171,19 +171,20 @@ def test_pose_change_estimator_pyramid_vs_reference(golden):
     pair = synthetic.make_pair(120, 160, seed=4)
     cm = _camera_model(pair["cam"])
     import tadataka.vo.dvo as dvo
-    assert dvo.ANTI_ALIASING is True      # the reference's pyramid is skimage's rescale: anti-aliased by default
+    assert dvo.PYRAMID == "ideal"         # tests/conftest.py: the fixtures of rounds 1-4 are the ideal reading
     # both fixtures come from the reference's own PoseChangeEstimator, with skimage's rescale
-    # stubbed by the plain bilinear ("pyr") / the anti-aliased ("pyr_aa") restatement
+    # stubbed by the plain bilinear ("pyr") / the anti-aliased ("pyr_aa") restatement at the IDEAL sample
+    # positions (tests/test_gpu_round5.py holds the same run against the real scikit-image)
     try:
         for tag, aa in (("pyr_aa", True), ("pyr", False)):
-            dvo.ANTI_ALIASING = aa
+            dvo.PYRAMID = "ideal" if aa else "bilinear"
             for wname in (None, "huber"):
                 est = PoseChangeEstimator(cm, cm, n_coarse_to_fine=3, max_iter=20)
                 pose = est(pair["I0"], pair["D0"], pair["I1"], wname)
                 assert np.allclose(pose.rotation.as_rotvec(), p[f"{tag}_{wname}_rotvec"], atol=POSE_ATOL)
                 assert np.allclose(pose.t, p[f"{tag}_{wname}_t"], atol=POSE_ATOL)
     finally:
-        dvo.ANTI_ALIASING = True
+        dvo.PYRAMID = "ideal"
 
 
 # --- tests/vo/test_dvo.py (synthetic pair in place of the missing New-Tsukuba depth) -------

@@ -179,49 +179,25 @@ def test_dvo_pyramid_vs_golden(ops, orc, golden):
     batch.close()
 
 
-_PYRAMID_SCRIPT = """
-import hashlib, sys
-import numpy as np
-from tadataka_amd import ops, synthetic
-H, W, B = 61, 83, 3
-batch = ops.DvoBatch(B, H, W, n_levels=4, ratio=1.5, with_weight_map=True)
-for i in range(B):
-    pr = synthetic.make_pair(H, W, seed=20 + i)
-    batch.upload(i, pr["I0"], pr["D0"], pr["I1"], np.full((H, W), 0.5 + 0.1 * i))
-batch.set_anti_aliasing(False)      # the three plain-bilinear builders
-batch.build_pyramid()
-h = hashlib.sha256()
-for i in range(B):
-    for level in (1, 2, 3):
-        for name in ("I0", "D0", "I1", "W0"):
-            h.update(np.ascontiguousarray(batch.download(i, level, name)).tobytes())
-print(h.hexdigest())
-"""
-
-
-def test_dvo_pyramid_modes_bit_identical(ops, orc):
-    """The three pyramid builders (one launch / LDS tiles / one launch per
-    level) produce the same bytes, and those are the oracle's, on odd shapes,
-    several pairs, four levels and a weight map."""
-    import hashlib
-    import os
-    import subprocess
-    import sys
+def test_dvo_bilinear_pyramid_bit_identical(ops, orc):
+    """The plain-bilinear pyramid (anti_aliasing=False at the ideal sample positions) of a batch equals the oracle's
+    on odd shapes, several pairs, four levels and a weight map."""
     from tadataka_amd import synthetic
     H, W, B = 61, 83, 3
-    h = hashlib.sha256()
+    batch = ops.DvoBatch(B, H, W, n_levels=4, ratio=1.5, with_weight_map=True)
+    pairs = []
     for i in range(B):
         pr = synthetic.make_pair(H, W, seed=20 + i)
         pr["W0"] = np.full((H, W), 0.5 + 0.1 * i)
+        batch.upload(i, pr["I0"], pr["D0"], pr["I1"], pr["W0"])
+        pairs.append(pr)
+    batch.set_anti_aliasing(False)
+    batch.build_pyramid()
+    for i, pr in enumerate(pairs):
         for level in (1, 2, 3):
             for name in ("I0", "D0", "I1", "W0"):
-                h.update(np.ascontiguousarray(orc.rescale(pr[name], 1 / 1.5 ** level)).tobytes())
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for mode in ("", "lds", "levels"):
-        env = dict(os.environ, PYTHONPATH=root, TDK_PYRAMID=mode)
-        out = subprocess.run([sys.executable, "-c", _PYRAMID_SCRIPT], env=env, cwd=root, check=True,
-                             capture_output=True, text=True, timeout=300)
-        assert out.stdout.strip().splitlines()[-1] == h.hexdigest(), mode
+                assert np.array_equal(batch.download(i, level, name), orc.rescale(pr[name], 1 / 1.5 ** level)), (i, level, name)
+    batch.close()
 
 
 def test_anti_aliased_rescale_and_pyramid_bit_exact(ops, orc):
@@ -238,7 +214,7 @@ def test_anti_aliased_rescale_and_pyramid_bit_exact(ops, orc):
         assert np.array_equal(ops.rescale(img, scale, anti_aliasing=True), orc.rescale(img, scale, anti_aliasing=True))
     H, W, B = 61, 83, 3
     batch = ops.DvoBatch(B, H, W, n_levels=4, ratio=1.5, with_weight_map=True)
-    batch.set_anti_aliasing(True, exact=True)      # scipy.ndimage's operation order: bit for bit
+    batch.set_anti_aliasing(True)      # scipy.ndimage's operation order: bit for bit
     pairs = []
     for i in range(B):
         pr = synthetic.make_pair(H, W, seed=30 + i)
@@ -251,14 +227,6 @@ def test_anti_aliased_rescale_and_pyramid_bit_exact(ops, orc):
             for name in ("I0", "D0", "I1", "W0"):
                 assert np.array_equal(batch.download(i, level, name),
                                       orc.rescale(pr[name], 1 / 1.5 ** level, anti_aliasing=True)), (i, level, name)
-    # the default: the same linear map as folded tap lists (FMA chains), last-bit differences only
-    batch.set_anti_aliasing(True)
-    batch.build_pyramid()
-    for i, pr in enumerate(pairs):
-        for level in (1, 2, 3):
-            for name in ("I0", "D0", "I1", "W0"):
-                want = orc.rescale(pr[name], 1 / 1.5 ** level, anti_aliasing=True)
-                assert np.max(np.abs(batch.download(i, level, name) - want)) <= 1e-13 * max(1.0, np.max(np.abs(want)))
     batch.set_anti_aliasing(False)
     batch.build_pyramid()
     assert np.array_equal(batch.download(1, 2, "I1"), orc.rescale(pairs[1]["I1"], 1 / 1.5 ** 2))
