@@ -149,8 +149,12 @@ __device__ __forceinline__ bool clip_needed(const ClipSlot &s) {
     return dec(s.out_max) > dec(s.tap_max) || dec(s.out_min) < dec(s.tap_min);
 }
 
+// behind the n slots: an int counter and the list of flagged slots (k_clip_gate)
+__device__ __forceinline__ int *clip_list(ClipSlot *slots, int n) { return reinterpret_cast<int *>(slots + n); }
+
 __global__ void k_clip_reset(ClipSlot *slots, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) clip_list(slots, n)[0] = 0;
     if (i >= n) return;
     ClipSlot s;
     s.out_max = 0ull; s.tap_max = 0ull; s.hi = 0ull;
@@ -615,8 +619,26 @@ struct StreamArgs {
     int pitch;                                    // ring row pitch: strip_w + 2 RM + 1 columns, rounded up (<= 256 threads)
     int n_segs, seg_rows;                         // row segments: a block emits the outputs whose upper tap lies in its segment
     StreamLevel lv[2];
+    // the identity-scale level (rescale(., 1.0)), written from the same pass: bit `arr` of l0_mask set = this array has one
+    double *l0_dst[4];
+    int64_t l0_stride;
+    AxisMap l0_mx, l0_my;
+    int l0_lvl;
+    unsigned l0_mask;
     ClipSlot *slots;
 };
+
+// lane i <- lane i - 1 / lane i + 1 of the wave (DPP wave_shr:1 / wave_shl:1); the lane without a source keeps x
+__device__ __forceinline__ double from_left_lane(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), 0x138, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), 0x138, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_right_lane(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), 0x130, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), 0x130, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 
 template <int R>
 __device__ __forceinline__ double stream_vtap(const double *w, int c, const double (&wk)[R + 1]) {
@@ -655,19 +677,21 @@ __device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *_
             if (g * 64 + lane >= ncols) continue;
             const double *p0 = ring + slot0 * SW + xoff[g];
             const double *p1 = ring + slot1 * SW + xoff[g];
-            double u[2][2 * R + 2];                               // V rows y0, y0 + 1, columns x0 - R .. x0 + 1 + R
-#pragma unroll
-            for (int q = 0; q < 2 * R + 2; q++) { u[0][q] = p0[q - R]; u[1][q] = p1[q - R]; }
             double f[2][2];
 #pragma unroll
             for (int ry = 0; ry < 2; ry++) {
+                const double *pr = ry ? p1 : p0;
+                double u[2 * R + 2];                              // one V row, columns x0 - R .. x0 + 1 + R
+#pragma unroll
+                for (int q = 0; q < 2 * R + 2; q++) u[q] = pr[q - R];
 #pragma unroll
                 for (int rx = 0; rx < 2; rx++) {
-                    double tmp = u[ry][R + rx] * wck[R];
+                    double tmp = u[R + rx] * wck[R];
 #pragma unroll
-                    for (int j = -R; j < 0; j++) tmp += (u[ry][R + rx + j] + u[ry][R + rx - j]) * wck[R + j];
+                    for (int j = -R; j < 0; j++) tmp += (u[R + rx + j] + u[R + rx - j]) * wck[R + j];
                     f[ry][rx] = tmp;
                 }
+                if (R >= 3) __builtin_amdgcn_sched_barrier(0);    // the two rows one after the other: 16 VGPRs less at R = 3
             }
             const double wx = wxs[g];
             const double top = (1.0 - wx) * f[0][0] + wx * f[0][1];
@@ -681,7 +705,7 @@ __device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *_
 }
 
 template <int RA, int RB>
-__global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pyramid_stream(StreamArgs a) {
     constexpr int RM = RA > RB ? RA : RB;
     constexpr int NL = RB > 0 ? 2 : 1;
     constexpr int K = kStreamK;
@@ -689,6 +713,7 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
     double *ringA = reinterpret_cast<double *>(aa_smem);                    // [Ring][SW]
     const int SW = a.pitch;
     double *ringB = ringA + (NL > 1 ? kStreamRing * SW : 0);
+    double *edge = ringB + kStreamRing * SW;   // [K + 2][4 waves][2]: the first / last lane's column, for the neighbour wave
 
     // 1-D grid, XCD-major like k_rescale_aa_multi: XCD k takes images k, k + 8, ...; the strips of an
     // image are neighbours in dispatch order (their halo columns meet in one L2)
@@ -753,6 +778,17 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
     trB.init();
     ClipSlot *slotA = a.slots ? a.slots + ((int64_t)pair * a.n_arrays + arr) * a.n_out + a.lv[0].lvl : nullptr;
     ClipSlot *slotB = a.slots && NL > 1 ? a.slots + ((int64_t)pair * a.n_arrays + arr) * a.n_out + a.lv[1].lvl : nullptr;
+    // level 0: thread = output column.  Its taps are its own column and ONE neighbour column (the map is within a
+    // pixel of the identity -- checked on the host), rows y - 1 .. y + 1 of the register window.
+    const bool do_l0 = ((a.l0_mask >> arr) & 1u) != 0;            // block-uniform
+    double *dst0 = nullptr;
+    ClipSlot *slot0 = nullptr;
+    ClipTrack tr0;
+    tr0.init();
+    if (do_l0) {
+        dst0 = a.l0_dst[arr] + (int64_t)pair * a.l0_stride;
+        slot0 = a.slots ? a.slots + ((int64_t)pair * a.n_arrays + arr) * a.n_out + a.l0_lvl : nullptr;
+    }
 
     // the column's window: w[i] = source row (y - RM + i) for the chunk that starts at V row y
     double w[K + 2 * RM], nxt[K];
@@ -790,6 +826,10 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
                 if constexpr (NL > 1) ringB[slot * SW + threadIdx.x] = vb;
             }
         }
+        if (do_l0 && (lane == 0 || lane == 63)) {                 // rows y - 1 .. y + K of the wave's border columns
+#pragma unroll
+            for (int i = 0; i < K + 2; i++) edge[(i * 4 + wave) * 2 + (lane == 63)] = w[RM - 1 + i];
+        }
         __syncthreads();
         // outputs whose lower row tap y0 + 1 is now in the ring: y0 + 1 <= y + K - 1
         const int ynew = y + K - 1 >= y_last ? (1 << 30) : y + K - 1;   // the last chunk emits whatever is left
@@ -798,12 +838,55 @@ __global__ __launch_bounds__(256) void k_pyramid_stream(StreamArgs a) {
         if constexpr (NL > 1)
             nextB = stream_emit<RB>(a.lv[1], ringB, SW, dstB, nextB, endB, ynew, ya, ngB, ncolsB, oxB0, xoffB, wxB,
                                     wckB, wave, lane, unit, trB, slotB);
+        if (do_l0) {
+            const int oy_end0 = min(yb, H);                       // this block's level-0 rows: those of its segment
+            // the column terms, recomputed per chunk (six operations) rather than held in registers across it
+            const int l0_x = xa - RM + (int)threadIdx.x;          // halo threads hold the reflected columns
+            const bool l0_own = l0_x >= xa && l0_x < xb;
+            const double l0_c = axis_pos(a.l0_mx, l0_x);
+            const double l0_fc = floor(l0_c);
+            const double l0_dc = l0_c - l0_fc;
+            const bool l0_left = (int)l0_fc < l0_x;               // taps (x - 1, x)
+            const bool l0_right = (int)ceil(l0_c) > l0_x;         // taps (x, x + 1); neither: the position is the pixel itself
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const int oy = y + j;
+                if (oy >= oy_end0) break;                         // uniform
+                const double r = axis_pos(a.l0_my, oy);
+                const double fr = floor(r);
+                const double dr = r - fr;
+                const bool up = (int)fr < oy, down = (int)ceil(r) > oy;   // uniform: row taps (y - 1, y) / (y, y + 1) / y
+                const double a0 = up ? w[j + RM - 1] : w[j + RM];
+                const double a1 = down ? w[j + RM + 1] : w[j + RM];
+                // (both shifts unconditionally: DPP reads its source lanes under the current EXEC mask)
+                const double l0v = from_left_lane(a0), r0v = from_right_lane(a0);
+                const double l1v = from_left_lane(a1), r1v = from_right_lane(a1);
+                double n0 = l0_left ? l0v : r0v;
+                double n1 = l0_left ? l1v : r1v;
+                if ((lane == 0 && l0_left && wave > 0) || (lane == 63 && l0_right && wave < 3)) {
+                    const int nb = lane == 0 ? (wave - 1) * 2 + 1 : (wave + 1) * 2;   // the neighbour wave's border lane
+                    n0 = edge[((j + (up ? 0 : 1)) * 4) * 2 + nb];
+                    n1 = edge[((j + (down ? 2 : 1)) * 4) * 2 + nb];
+                }
+                const double f00 = l0_left ? n0 : a0, f01 = l0_right ? n0 : a0;
+                const double f10 = l0_left ? n1 : a1, f11 = l0_right ? n1 : a1;
+                const double top = (1.0 - l0_dc) * f00 + l0_dc * f01;
+                const double bot = (1.0 - l0_dc) * f10 + l0_dc * f11;
+                const double v = (1.0 - dr) * top + dr * bot;
+                if (l0_own) {
+                    dst0[(int64_t)oy * W + l0_x] = v;
+                    if (slot0) tr0.add(slot0, v, f00, f01, f10, f11);
+                }
+                __builtin_amdgcn_sched_barrier(0);                // one row at a time
+            }
+        }
         if (kStreamRing < 2 * K + 1) __syncthreads();             // the next chunk's V rows overwrite rows read above
 #pragma unroll
         for (int i = 0; i < 2 * RM; i++) w[i] = w[K + i];
 #pragma unroll
         for (int i = 0; i < K; i++) w[2 * RM + i] = nxt[i];
     }
+    if (slot0) tr0.flush(slot0);
     if (slotA) trA.flush(slotA);
     if constexpr (NL > 1)
         if (slotB) trB.flush(slotB);
@@ -822,26 +905,42 @@ struct ClipArgs {
 
 constexpr int kClipTileRows = 16, kClipTileCols = 64;
 
-// grid: (tiles of the SOURCE image, n_out, images).  A tile's filtered values: vertical pass into LDS
-// (columns + 2 Rc of halo), horizontal pass from LDS -- scipy's order, as everywhere in this file.
+// one thread per slot: the flagged ones go on a list (almost always empty)
+__global__ void k_clip_gate(ClipSlot *slots, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !clip_needed(slots[i])) return;
+    int *list = clip_list(slots, n);
+    list[1 + atomicAdd(&list[0], 1)] = i;
+}
+
+// A fixed grid walks (flagged slot) x (tile of the SOURCE image); nothing flagged: every block returns after one load.
+// A tile's filtered values: vertical pass into LDS (columns + 2 Rc of halo), horizontal pass from LDS -- scipy's
+// order, as everywhere in this file.
 __global__ __launch_bounds__(256) void k_clip_bounds(ClipArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
-    const int image = blockIdx.z, l = blockIdx.y;
-    ClipSlot *slot = a.slots + (int64_t)image * a.n_out + l;
-    if (!clip_needed(*slot)) return;
-    const int pair = image / a.n_arrays, arr = image - pair * a.n_arrays;
-    const DevLevel &L = a.lv[l];
-    const int H = a.H, W = a.W, Rr = L.aa.Rr, Rc = L.aa.Rc;
-    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    const int n_slots = a.n_arrays * a.batch * a.n_out;
+    const int *list = clip_list(a.slots, n_slots);
+    const int n_flagged = list[0];
+    if (n_flagged == 0) return;
+    const int H = a.H, W = a.W;
     const int tiles_x = (W + kClipTileCols - 1) / kClipTileCols, tiles_y = (H + kClipTileRows - 1) / kClipTileRows;
-    const int SC = kClipTileCols + 2 * Rc;
+    const int per_slot = tiles_x * tiles_y;
     double *V = reinterpret_cast<double *>(aa_smem);
-    double vmax = -INFINITY, vmin = INFINITY;
-    bool nan = false;
-    for (int t = blockIdx.x; t < tiles_x * tiles_y; t += gridDim.x) {
+    for (int64_t item = blockIdx.x; item < (int64_t)n_flagged * per_slot; item += gridDim.x) {
+        const int k = (int)(item / per_slot), t = (int)(item - (int64_t)k * per_slot);
+        const int si = list[1 + k];
+        const int image = si / a.n_out, l = si - image * a.n_out;
+        ClipSlot *slot = a.slots + si;
+        const int pair = image / a.n_arrays, arr = image - pair * a.n_arrays;
+        const DevLevel &L = a.lv[l];
+        const int Rr = L.aa.Rr, Rc = L.aa.Rc;
+        const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+        const int SC = kClipTileCols + 2 * Rc;
         const int ty = t / tiles_x, tx = t - ty * tiles_x;
         const int y0 = ty * kClipTileRows, x0 = tx * kClipTileCols;
         const int nr = min(kClipTileRows, H - y0), nc = min(kClipTileCols, W - x0);
+        double vmax = -INFINITY, vmin = INFINITY;
+        bool nan = false;
         __syncthreads();
         for (int i = threadIdx.x; i < nr * (nc + 2 * Rc); i += 256) {
             const int r = i / (nc + 2 * Rc), c = i - r * (nc + 2 * Rc);
@@ -861,35 +960,47 @@ __global__ __launch_bounds__(256) void k_clip_bounds(ClipArgs a) {
             vmin = fmin(vmin, tmp);
             nan |= tmp != tmp;
         }
-    }
-    vmax = wave_max(vmax);
-    vmin = wave_min(vmin);
-    const bool any_nan = __ballot(nan) != 0ull;
-    if ((threadIdx.x & 63) == 0) {
-        if (vmax != -INFINITY || vmin != INFINITY) {
-            atomicMax(&slot->hi, enc(vmax));
-            atomicMin(&slot->lo, enc(vmin));
+        vmax = wave_max(vmax);
+        vmin = wave_min(vmin);
+        const bool any_nan = __ballot(nan) != 0ull;
+        if ((threadIdx.x & 63) == 0) {
+            if (vmax != -INFINITY || vmin != INFINITY) {
+                atomicMax(&slot->hi, enc(vmax));
+                atomicMin(&slot->lo, enc(vmin));
+            }
+            if (any_nan) atomicOr(&slot->nan_img, 1u);
         }
-        if (any_nan) atomicOr(&slot->nan_img, 1u);
     }
 }
 
-// grid: (blocks over the level's outputs, n_out, images)
+constexpr int kClipApplyChunk = 4096;
+
 __global__ __launch_bounds__(256) void k_clip_apply(ClipArgs a) {
-    const int image = blockIdx.z, l = blockIdx.y;
-    const ClipSlot slot = a.slots[(int64_t)image * a.n_out + l];
-    if (!clip_needed(slot)) return;
-    const int pair = image / a.n_arrays, arr = image - pair * a.n_arrays;
-    const DevLevel &L = a.lv[l];
-    double *d = L.dst[arr] + (int64_t)pair * L.stride;
-    const int64_t n = (int64_t)L.Ho * L.Wo;
-    // ndarray.min() / .max() of an image with a NaN are NaN, and numpy.clip with a NaN bound returns NaN
-    const double lo = slot.nan_img ? NAN : dec(slot.lo), hi = slot.nan_img ? NAN : dec(slot.hi);
-    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const double x = d[i];
-        const double m = (x != x || lo != lo) ? NAN : (x > lo ? x : lo);
-        const double v = (m != m || hi != hi) ? NAN : (m < hi ? m : hi);
-        if (__double_as_longlong(v) != __double_as_longlong(x)) d[i] = v;
+    const int n_slots = a.n_arrays * a.batch * a.n_out;
+    const int *list = clip_list(a.slots, n_slots);
+    const int n_flagged = list[0];
+    if (n_flagged == 0) return;
+    int64_t n_max = 0;
+    for (int l = 0; l < a.n_out; l++) n_max = max(n_max, (int64_t)a.lv[l].Ho * a.lv[l].Wo);
+    const int per_slot = (int)((n_max + kClipApplyChunk - 1) / kClipApplyChunk);
+    for (int64_t item = blockIdx.x; item < (int64_t)n_flagged * per_slot; item += gridDim.x) {
+        const int k = (int)(item / per_slot), chunk = (int)(item - (int64_t)k * per_slot);
+        const int si = list[1 + k];
+        const int image = si / a.n_out, l = si - image * a.n_out;
+        const ClipSlot slot = a.slots[si];
+        const int pair = image / a.n_arrays, arr = image - pair * a.n_arrays;
+        const DevLevel &L = a.lv[l];
+        double *d = L.dst[arr] + (int64_t)pair * L.stride;
+        const int64_t n = (int64_t)L.Ho * L.Wo;
+        // ndarray.min() / .max() of an image with a NaN are NaN, and numpy.clip with a NaN bound returns NaN
+        const double lo = slot.nan_img ? NAN : dec(slot.lo), hi = slot.nan_img ? NAN : dec(slot.hi);
+        const int64_t i0 = (int64_t)chunk * kClipApplyChunk, i1 = min(i0 + kClipApplyChunk, n);
+        for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+            const double x = d[i];
+            const double m = (x != x || lo != lo) ? NAN : (x > lo ? x : lo);
+            const double v = (m != m || hi != hi) ? NAN : (m < hi ? m : hi);
+            if (__double_as_longlong(v) != __double_as_longlong(x)) d[i] = v;
+        }
     }
 }
 
@@ -952,7 +1063,10 @@ void ideal_level_plan(PyramidLevelDesc *lv, int H, int W, bool anti_aliasing, do
 }
 
 size_t pyramid_weight_doubles(int n_out) { return (size_t)n_out * 2 * (2 * kMaxGaussRadius + 1); }
-size_t pyramid_clip_bytes(int64_t n_images, int n_out) { return sizeof(ClipSlot) * (size_t)n_images * (size_t)n_out; }
+size_t pyramid_clip_bytes(int64_t n_images, int n_out) {
+    const size_t n = (size_t)n_images * (size_t)n_out;
+    return sizeof(ClipSlot) * n + sizeof(int) * (n + 1);      // slots, counter, list of flagged slots
+}
 int pyramid_max_radius() { return kMaxGaussRadius; }
 
 // Every level in `levels` (n_out of them; a level-0 entry has H x W = the source's) of `n_arrays` arrays of
@@ -1003,21 +1117,6 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
     auto shrinks = [&](int l) {
         return taps_inside(dv[l].mx, W, dv[l].Wo) && taps_inside(dv[l].my, H, dv[l].Ho);
     };
-    // --- the identity-scale level: no filter, same shape
-    for (int l = 0; l < n_out; l++) {
-        if (dv[l].Ho != H || dv[l].Wo != W || dv[l].aa.Rr || dv[l].aa.Rc) continue;
-        Level0Args a;
-        for (int i = 0; i < 4; i++) { a.src[i] = i < n_arrays ? srcs[i] : nullptr; a.dst[i] = dv[l].dst[i]; }
-        a.src_stride = src_stride; a.dst_stride = dv[l].stride; a.H = H; a.W = W;
-        a.n_arrays = n_arrays; a.batch = batch; a.lvl = l; a.n_out = n_out;
-        a.mx = dv[l].mx; a.my = dv[l].my; a.slots = slots;
-        const int64_t per_image = (int64_t)((W + 63) / 64) * ((H + 4 * kL0Rows - 1) / (4 * kL0Rows));
-        const int64_t blocks = (images < 8 ? images : 8 * ((images + 7) / 8)) * per_image;
-        if (blocks >= (1ll << 31)) { set_error("level 0: grid too large"); return TDK_ERR_INVALID_ARGUMENT; }
-        k_level0_rows<<<(unsigned)blocks, 256, 0, stream>>>(a);
-        TDK_LAUNCH_CHECK();
-        done[l] = true;
-    }
     // --- the first level with radius 1 (and the one with radius 3 if there is one) of a batch large enough to
     // fill the chip with full-height strips: one streaming pass over the source
     {
@@ -1035,6 +1134,24 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
             sa.n_strips = n_strips; sa.strip_w = strip_w;
             sa.pitch = std::min(256, (strip_w + 2 * 3 + 1 + 7) & ~7);
             sa.slots = slots;
+            // the identity-scale level rides along if its map stays within a pixel of the identity (every output's
+            // taps are its own column and one neighbour, rows y - 1 .. y + 1)
+            sa.l0_mask = 0u; sa.l0_lvl = 0; sa.l0_stride = 0;
+            sa.l0_mx = sa.l0_my = ideal_axis(1, 1);
+            for (int i = 0; i < 4; i++) sa.l0_dst[i] = nullptr;
+            int l0 = -1;
+            for (int l = 0; l < n_out && l0 < 0; l++) {
+                if (done[l] || dv[l].Ho != H || dv[l].Wo != W || dv[l].aa.Rr || dv[l].aa.Rc) continue;
+                auto near_identity = [](const AxisMap &m, int n) {
+                    return fabs(axis_pos(m, 0)) < 0.5 && fabs(axis_pos(m, n - 1) - (double)(n - 1)) < 0.5;
+                };
+                if (near_identity(dv[l].mx, W) && near_identity(dv[l].my, H)) l0 = l;
+            }
+            if (l0 >= 0) {
+                for (int i = 0; i < 4; i++) sa.l0_dst[i] = dv[l0].dst[i];
+                sa.l0_stride = dv[l0].stride; sa.l0_mx = dv[l0].mx; sa.l0_my = dv[l0].my; sa.l0_lvl = l0;
+                sa.l0_mask = (1u << n_arrays) - 1u;
+            }
             // row segments: enough blocks for several full rounds of the 1024 resident ones (a segment pays
             // 2 RM warm-up rows)
             int n_segs = 1;
@@ -1050,6 +1167,8 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
                 sa.lv[k].wr = dv[l].aa.wr; sa.lv[k].wc = dv[l].aa.wc; sa.lv[k].lvl = l;
                 if (k < nl) lds += sizeof(double) * kStreamRing * sa.pitch;
             }
+            if (nl == 1) lds += sizeof(double) * kStreamRing * sa.pitch;      // (ringB's place: the border columns sit behind it)
+            lds += sizeof(double) * (kStreamK + 2) * 8;
             // outputs per strip must fit the kStreamMaxGroups 64-column groups
             bool fits = true;
             for (int k = 0; k < nl; k++) {
@@ -1075,8 +1194,24 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
                 TDK_LAUNCH_CHECK();
                 done[lA] = true;
                 if (nl == 2) done[lB] = true;
+                if (l0 >= 0) done[l0] = true;
             }
         }
+    }
+    // --- the identity-scale level (no filter, same shape) where the streaming kernel did not take it
+    for (int l = 0; l < n_out; l++) {
+        if (done[l] || dv[l].Ho != H || dv[l].Wo != W || dv[l].aa.Rr || dv[l].aa.Rc) continue;
+        Level0Args a;
+        for (int i = 0; i < 4; i++) { a.src[i] = i < n_arrays ? srcs[i] : nullptr; a.dst[i] = dv[l].dst[i]; }
+        a.src_stride = src_stride; a.dst_stride = dv[l].stride; a.H = H; a.W = W;
+        a.n_arrays = n_arrays; a.batch = batch; a.lvl = l; a.n_out = n_out;
+        a.mx = dv[l].mx; a.my = dv[l].my; a.slots = slots;
+        const int64_t per_image = (int64_t)((W + 63) / 64) * ((H + 4 * kL0Rows - 1) / (4 * kL0Rows));
+        const int64_t blocks = (images < 8 ? images : 8 * ((images + 7) / 8)) * per_image;
+        if (blocks >= (1ll << 31)) { set_error("level 0: grid too large"); return TDK_ERR_INVALID_ARGUMENT; }
+        k_level0_rows<<<(unsigned)blocks, 256, 0, stream>>>(a);
+        TDK_LAUNCH_CHECK();
+        done[l] = true;
     }
     // --- levels that shrink both axes and whose tiles fit in LDS take the tiled kernel, all of them in one
     // launch; whatever is left (an enlarged axis, very deep levels, level 0 with a filter) the general one
@@ -1159,20 +1294,15 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
         c.src_stride = src_stride; c.H = H; c.W = W; c.n_arrays = n_arrays; c.batch = batch; c.n_out = n_out;
         for (int l = 0; l < n_out; l++) c.lv[l] = dv[l];
         c.slots = slots;
-        if (images > 65535) { set_error("clip: more than 65535 images per launch"); return TDK_ERR_INVALID_ARGUMENT; }
         int rc_max = 0;
-        int64_t n_max = 0;
-        for (int l = 0; l < n_out; l++) {
-            rc_max = std::max(rc_max, dv[l].aa.Rc);
-            n_max = std::max(n_max, (int64_t)dv[l].Ho * dv[l].Wo);
-        }
+        for (int l = 0; l < n_out; l++) rc_max = std::max(rc_max, dv[l].aa.Rc);
         const size_t lds = sizeof(double) * (size_t)kClipTileRows * (kClipTileCols + 2 * rc_max);
-        const int tiles = ((W + kClipTileCols - 1) / kClipTileCols) * ((H + kClipTileRows - 1) / kClipTileRows);
-        dim3 gb((unsigned)std::min(tiles, 64), (unsigned)n_out, (unsigned)images);
-        k_clip_bounds<<<gb, 256, lds, stream>>>(c);
+        const int n = (int)(images * n_out);
+        k_clip_gate<<<(n + 255) / 256, 256, 0, stream>>>(slots, n);
         TDK_LAUNCH_CHECK();
-        dim3 ga((unsigned)std::min<int64_t>((n_max + 255) / 256, 64), (unsigned)n_out, (unsigned)images);
-        k_clip_apply<<<ga, 256, 0, stream>>>(c);
+        k_clip_bounds<<<1024, 256, lds, stream>>>(c);
+        TDK_LAUNCH_CHECK();
+        k_clip_apply<<<1024, 256, 0, stream>>>(c);
         TDK_LAUNCH_CHECK();
     }
     return TDK_OK;
