@@ -52,6 +52,11 @@ tdk_status tdk_device_count(int *count);
 tdk_status tdk_set_device(int device);
 tdk_status tdk_get_device(int *device);
 tdk_status tdk_sync(void);
+/* Debugging aid.  With TDK_DEBUG_CANARY=1 in the environment (read once, at the first allocation) every device
+ * allocation of the library sits between two 4 KiB red zones of 0xFF bytes; this call (and tdk_sync, and every
+ * destroy) verifies them and returns TDK_ERR_HIP, the damaged allocation named in tdk_last_error(), if a kernel or
+ * a copy wrote outside an allocation.  n_allocations (optional): live allocations, -1 when the mode is off. */
+tdk_status tdk_debug_check_canaries(int *n_allocations);
 tdk_status tdk_device_name(char *buf, int buflen);
 /* Page-locked host memory for the asynchronous uploads (tdk_dvo_upload_async). */
 tdk_status tdk_pinned_alloc(size_t bytes, void **out);

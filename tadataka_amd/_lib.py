@@ -79,6 +79,7 @@ PROTOTYPES = {
     "tdk_image_gradient": [_d, _i, _i, _d, _d],
     "tdk_rescale": [_d, _i, _i, _d, _i, _i],
     "tdk_rescale_anti_aliased": [_d, _i, _i, _d, _i, _i],
+    "tdk_debug_check_canaries": [c_int_p],
     "tdk_rescale_skimage": [_d, _i, _i, _d, _i, _i, _d, _d, _i, _d, _i, _i],
     "tdk_dvo_set_anti_aliasing": [_vp, _i],
     "tdk_dvo_set_level_plan": [_vp, _i, _d, _d, _i, _d, _i],

@@ -65,6 +65,17 @@ struct DvoLevel0 {
 };
 tdk_status dvo_level0(tdk_dvo *h, DvoLevel0 *out);
 
+// Device allocations of the whole library go through these (the hipMalloc / hipFree macros below), so that
+// TDK_DEBUG_CANARY=1 can put every one of them between two 4 KiB red zones of 0xFF bytes (a NaN pattern as doubles):
+// the kernels rely on documented padding (stream loads overrun a block's range by a few hundred pixels)
+// and an allocation-size regression would otherwise be a silent out-of-bounds access.  The zones are verified by
+// tdk_debug_check_canaries(), by tdk_sync() and when an allocation is freed; a violation is reported with the name of
+// the allocation (the pointer expression and source line of its hipMalloc) and makes those calls return TDK_ERR_HIP.
+hipError_t dev_malloc(void **ptr, size_t bytes, const char *what, const char *file, int line);
+hipError_t dev_free(void *ptr);
+bool canaries_enabled();
+tdk_status check_canaries();
+
 // Other translation units keep process-wide device state of their own (the map pool and the staging ring of
 // semi_dense.hip); a hook registered here runs when tdk_set_device leaves a device, BEFORE its streams go away.
 void on_device_release(void (*hook)());
@@ -94,6 +105,11 @@ void on_device_release(void (*hook)());
             return TDK_ERR_INVALID_ARGUMENT;                     \
         }                                                        \
     } while (0)
+
+#ifndef TDK_RUNTIME_IMPL
+#define hipMalloc(ptr, bytes) tdk::dev_malloc((void **)(ptr), (bytes), #ptr, __FILE__, __LINE__)
+#define hipFree(ptr) tdk::dev_free((void *)(ptr))
+#endif
 
 // Launch check: catches bad configurations right after the <<<>>>.
 #define TDK_LAUNCH_CHECK() TDK_HIP(hipGetLastError())

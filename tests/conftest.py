@@ -52,6 +52,31 @@ def _ideal_pyramid_for_the_round_1_to_4_fixtures(request):
         dvo.PYRAMID = saved
 
 
+_CANARY = {"tests": 0, "max_live": 0}
+
+
+@pytest.fixture(autouse=True)
+def _canary_check_after_every_gpu_test(request):
+    """TDK_DEBUG_CANARY=1 pytest -m gpu: after every GPU test the red zones around every live device allocation
+    are verified (tdk_debug_check_canaries); a damaged one fails the test that left it behind."""
+    yield
+    if os.environ.get("TDK_DEBUG_CANARY") != "1" or "gpu" not in request.keywords or not _has_gpu():
+        return
+    import ctypes
+    from tadataka_amd import _lib
+    n = ctypes.c_int()
+    st = _lib.load().tdk_debug_check_canaries(ctypes.byref(n))
+    assert st == 0, _lib.load().tdk_last_error().decode()
+    _CANARY["tests"] += 1
+    _CANARY["max_live"] = max(_CANARY["max_live"], n.value)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if os.environ.get("TDK_DEBUG_CANARY") == "1" and _CANARY["tests"]:
+        print(f"\ncanaries: verified after {_CANARY['tests']} GPU tests, up to {_CANARY['max_live']} live device "
+              f"allocations between red zones at a time, exit status {int(exitstatus)}")
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):
