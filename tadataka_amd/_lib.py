@@ -171,16 +171,17 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("TDK_LIBRARY") or LIB_PATH      # TDK_LIBRARY: another build of the same ABI (make asan)
+    if not os.path.exists(path):
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (or `make -C tadataka_amd/csrc`).  There is no CPU fallback.")
     # HIP maps all streams of a process onto a few hardware queues (4 by default) and a stream that waits for an
     # event of another stream holds up every stream behind it in its queue.  Each DvoBatch owns a stream, uploads
     # and the stateless operators have theirs: give them queues of their own unless the caller decided otherwise.
     # (Read by the HIP runtime when it starts: no effect if something else initialised HIP in this process first.)
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.tdk_version.restype = C.c_char_p
     lib.tdk_last_error.restype = C.c_char_p
     for name, argtypes in PROTOTYPES.items():
