@@ -52,6 +52,15 @@ tdk_status tdk_device_count(int *count);
 tdk_status tdk_set_device(int device);
 tdk_status tdk_get_device(int *device);
 tdk_status tdk_sync(void);
+/* Library-wide options (the stateless entries and every handle read them at each call).
+ *   TDK_OPT_PYRAMID_STREAM   which kernel builds the first two shrinking pyramid levels: 1 (default) the streaming
+ *                            kernel for batches that fill the chip (>= 256 full-height strips), LDS tiles otherwise;
+ *                            0 always the tiles; 2 always the streaming kernel.  Bit-identical either way.
+ *   TDK_OPT_SD_WARP_GATHER   increment_age / propagate: 1 (default) the gather kernels, with the slot path as the
+ *                            device-side fallback of tracks whose displacement box exceeds the gather's window;
+ *                            0 the slot path for every track.  Bit-identical either way. */
+enum { TDK_OPT_PYRAMID_STREAM = 0, TDK_OPT_SD_WARP_GATHER = 1 };
+tdk_status tdk_set_option(int option, int value);
 /* Debugging aid.  With TDK_DEBUG_CANARY=1 in the environment (read once, at the first allocation) every device
  * allocation of the library sits between two 4 KiB red zones of 0xFF bytes; this call (and tdk_sync, and every
  * destroy) verifies them and returns TDK_ERR_HIP, the damaged allocation named in tdk_last_error(), if a kernel or
@@ -222,6 +231,14 @@ tdk_status tdk_dvo_get_student_redos(tdk_dvo *h, int64_t *pairs);
  * over the residuals (one per fixed-point step, reciprocal arithmetic); 2 the nine passes with IEEE divisions
  * (the CPU restatement's operations).  Defaults from TDK_STUDENT=sequential / TDK_STUDENT_EXACT=1 at creation. */
 tdk_status tdk_dvo_set_student_passes(tdk_dvo *h, int mode);
+/* Per-batch options.  Defaults are what the library would choose; the alternatives give the same results (the
+ * tests compare them in-process) and exist to A/B a path or to force a rare one.
+ *   TDK_DVO_OPT_CHAIN   1 (default): a batch of up to 2^22 pixels queues its whole coarse-to-fine chain at once and
+ *                       waits once (speculative level chain); 0: the host drives level by level, round by round
+ *   TDK_DVO_OPT_TUKEY   0 (default): the two medians of Tukey's scale from sampled brackets + one pass; 1: by radix
+ *                       select; 2: brackets, but every pair takes the exact fallback of a failed bracket */
+enum { TDK_DVO_OPT_CHAIN = 0, TDK_DVO_OPT_TUKEY = 1 };
+tdk_status tdk_dvo_set_option(tdk_dvo *h, int option, int value);
 /* The robust scale the last Student-t / Tukey evaluation of each pair used: the variance after ten steps
  * (weights.py:16) or c * MAD (weights.py:34).  scale: n_pairs doubles (host). */
 tdk_status tdk_dvo_get_robust_scale(tdk_dvo *h, double *scale);
@@ -485,6 +502,19 @@ typedef struct tdk_ba tdk_ba;
 tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *viewpoint_indices,
                          const int64_t *point_indices, const double *x_true, int64_t n,
                          tdk_ba **out);
+/* The same with options (bits): which of the library's kernels serve the handle is normally decided by its shape;
+ * these bits force the alternatives (which exist for other shapes) onto any shape -- the tests run them on small
+ * windows against the dense solve.
+ *   TDK_BA_OPT_SCHUR_PAIRS    Schur complement by the pair-wise kernel (dense observation table) instead of the FP64
+ *                             MFMA kernel that windows of <= 8 poses take; W_ij is then stored, not rebuilt
+ *   TDK_BA_OPT_SCHUR_GENERAL  ... by the general kernel (per-point observation lists, atomics): what graphs too large
+ *                             for the dense table take
+ *   TDK_BA_OPT_SOLVE_HOST     the reduced camera system is solved on the host (what windows beyond 20 poses do)
+ *   TDK_BA_OPT_SOLVE_PIVOTED  device solve: skip the attempt without pivoting */
+enum { TDK_BA_OPT_SCHUR_PAIRS = 1, TDK_BA_OPT_SCHUR_GENERAL = 2, TDK_BA_OPT_SOLVE_HOST = 4, TDK_BA_OPT_SOLVE_PIVOTED = 8 };
+tdk_status tdk_ba_create_ex(int64_t n_poses, int64_t n_points, const int64_t *viewpoint_indices,
+                            const int64_t *point_indices, const double *x_true, int64_t n_observations,
+                            unsigned int options, tdk_ba **out);
 tdk_status tdk_ba_destroy(tdk_ba *h);
 tdk_status tdk_ba_error(tdk_ba *h, const double *poses, const double *points, double *sum_sq);
 /* The block sums of tdk_ba_block_reduce on the handle's graph, without atomics:

@@ -8,9 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# TDK_LIB_TAG=<tag> loads lib/libtadataka_hip_<tag>.so: an experimental build for A/B measurements (tools/ab_build.sh)
-_TAG = os.environ.get("TDK_LIB_TAG", "")
-LIB_PATH = os.path.join(_HERE, "lib", "libtadataka_hip%s.so" % ("_" + _TAG if _TAG else ""))
+LIB_PATH = os.path.join(_HERE, "lib", "libtadataka_hip.so")
 
 c_double_p = C.POINTER(C.c_double)
 c_int64_p = C.POINTER(C.c_int64)
@@ -80,6 +78,8 @@ PROTOTYPES = {
     "tdk_rescale": [_d, _i, _i, _d, _i, _i],
     "tdk_rescale_anti_aliased": [_d, _i, _i, _d, _i, _i],
     "tdk_debug_check_canaries": [c_int_p],
+    "tdk_set_option": [_i, _i],
+    "tdk_dvo_set_option": [_vp, _i, _i],
     "tdk_rescale_skimage": [_d, _i, _i, _d, _i, _i, _d, _d, _i, _d, _i, _i],
     "tdk_dvo_set_anti_aliasing": [_vp, _i],
     "tdk_dvo_set_level_plan": [_vp, _i, _d, _d, _i, _d, _i],
@@ -144,6 +144,7 @@ PROTOTYPES = {
     "tdk_ba_exp_so3": [_d, _i64, _d],
     "tdk_ba_block_reduce": [_d, _i64, _d, _i64, _d, c_int64_p, c_int64_p, _i64, _d, _d, _d, _d, _d],
     "tdk_ba_create": [_i64, _i64, c_int64_p, c_int64_p, _d, _i64, C.POINTER(_vp)],
+    "tdk_ba_create_ex": [_i64, _i64, c_int64_p, c_int64_p, _d, _i64, C.c_uint, C.POINTER(_vp)],
     "tdk_ba_destroy": [_vp],
     "tdk_ba_error": [_vp, _d, _d, _d],
     "tdk_ba_step": [_vp, _d, _d, C.c_double, _d, _d, _d],

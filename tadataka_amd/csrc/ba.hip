@@ -830,7 +830,6 @@ void ba_make_plan(const int64_t *vp, const int64_t *pt, int64_t n, int64_t n_pos
     int64_t len = (n / 1024 + kBlock - 1) / kBlock * kBlock;
     if (len < kBlock) len = kBlock;
     if (len > 8 * kBlock) len = 8 * kBlock;
-    if (const char *v = getenv("TDK_BA_SEGLEN")) len = atoll(v) > 0 ? atoll(v) : len;   // tuning knob
     plan->segs.clear();
     plan->seg_ptr.assign((size_t)n_poses + 1, 0);
     for (int64_t j = 0; j < n_poses; j++) {
@@ -958,6 +957,7 @@ struct BaSums { double *U, *ea, *V, *eb, *W; };
 
 struct tdk_ba {
     int64_t n_poses, n_points, n;
+    unsigned options;     // TDK_BA_OPT_* of tdk_ba_create_ex
     int sorted;
     int n_segs;
     int *d_obs_sorted, *d_pt32, *d_seg_ptr, *d_ticket;   // pose-sorted observation list (NULL: identity), segments
@@ -1026,13 +1026,9 @@ void ba_collect_profile(tdk_ba *h) {
 }
 
 // W_ij rebuilt from the parameters by the Schur / back-substitution kernels instead of stored by the reduce:
-// whenever the MFMA Schur kernel applies (windows of up to 8 poses with a dense observation table), unless
-// TDK_BA_W=stored or TDK_BA_SCHUR=pairs ask for the stored form (the other Schur kernels read W from memory)
-bool ba_recompute_w(const tdk_ba *h) {
-    static const bool stored = [] { const char *v = getenv("TDK_BA_W"); return v && !strcmp(v, "stored"); }();
-    static const bool no_mfma = [] { const char *v = getenv("TDK_BA_SCHUR"); return v && !strcmp(v, "pairs"); }();
-    return !stored && !no_mfma && h->d_obs_at != nullptr && h->d_mpart != nullptr;
-}
+// whenever the MFMA Schur kernel applies (windows of up to 8 poses with a dense observation table; d_mpart is
+// only allocated then).  The other Schur kernels read W from memory.
+bool ba_recompute_w(const tdk_ba *h) { return h->d_obs_at != nullptr && h->d_mpart != nullptr; }
 
 // what a reduce computes at parameters that are already on the device
 enum { REDUCE_ERROR = 0, REDUCE_SUMS = 1, REDUCE_STEP = 2 };
@@ -1433,8 +1429,7 @@ __global__ void k_ba_add(const double *__restrict__ a, const double *__restrict_
 tdk_status ba_update_launch(tdk_ba *h, double mu) {
     const int dim = (int)(6 * h->n_poses);
     const int gp = grid_for(h->n_points);
-    static const bool no_mfma = [] { const char *v = getenv("TDK_BA_SCHUR"); return v && !strcmp(v, "pairs"); }();
-    const bool mfma = h->d_obs_at != nullptr && h->d_mpart != nullptr && !no_mfma;
+    const bool mfma = h->d_obs_at != nullptr && h->d_mpart != nullptr;
     const bool recomp = ba_recompute_w(h);
     k_ba_invert_V<<<gp, kBlock, 0, tdk::stream()>>>(h->cur.V, mu, h->n_points, h->d_Vinv, h->d_poses, (int)h->n_poses,
                                                     recomp ? h->d_rod : nullptr);
@@ -1489,8 +1484,7 @@ tdk_status ba_update_launch(tdk_ba *h, double mu) {
     }
     if (h->dev_solve) {
         BaTimer t(h, BA_K_SOLVE);
-        // TDK_BA_SOLVE=pivoted: skip the attempt without pivoting (tests)
-        static const int pivoted_only = [] { const char *v = getenv("TDK_BA_SOLVE"); return v && !strcmp(v, "pivoted"); }();
+        const int pivoted_only = (h->options & TDK_BA_OPT_SOLVE_PIVOTED) ? 1 : 0;   // skip the attempt without pivoting
         rcs_solve_kernel(dim)<<<1, kBlock, rcs_solve_lds(dim), tdk::stream()>>>(
             h->d_S, h->d_e, h->cur.U, h->cur.ea, mu, dim, pivoted_only, h->d_poses, h->d_da, h->d_cposes,
             h->d_err + h->n_poses);
@@ -1543,12 +1537,12 @@ tdk_status ba_update_launch(tdk_ba *h, double mu) {
 
 // second set of block sums for the damping trials of tdk_ba_solve
 tdk_status ba_ensure_alt(tdk_ba *h) {
-    if (h->alt.W) return TDK_OK;
+    if (h->alt.U) return TDK_OK;
     TDK_HIP(hipMalloc(&h->alt.U, (size_t)h->n_poses * 21 * 8));
     TDK_HIP(hipMalloc(&h->alt.ea, (size_t)h->n_poses * 6 * 8));
     TDK_HIP(hipMalloc(&h->alt.V, (size_t)h->n_points * 48));
     TDK_HIP(hipMalloc(&h->alt.eb, (size_t)h->n_points * 24));
-    TDK_HIP(hipMalloc(&h->alt.W, (size_t)h->n * 18 * 8));
+    if (!ba_recompute_w(h)) TDK_HIP(hipMalloc(&h->alt.W, (size_t)h->n * 18 * 8));
     return TDK_OK;
 }
 
@@ -1561,13 +1555,20 @@ extern "C" {
 
 tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *vp, const int64_t *pt,
                          const double *x_true, int64_t n, tdk_ba **out) {
+    return tdk_ba_create_ex(n_poses, n_points, vp, pt, x_true, n, 0u, out);
+}
+
+tdk_status tdk_ba_create_ex(int64_t n_poses, int64_t n_points, const int64_t *vp, const int64_t *pt,
+                            const double *x_true, int64_t n, unsigned int options, tdk_ba **out) {
     TDK_REQUIRE(out && vp && pt && x_true, "null pointer");
+    TDK_REQUIRE(options < 16u, "unknown option bits");
     TDK_REQUIRE(n >= 1 && n_poses >= 1 && n_points >= 1 && n_poses <= 2048, "bad sizes");
     TDK_REQUIRE(n < (1ll << 31) && n_points < (1ll << 31), "more than 2^31 observations or points");
     int sorted = 0;
     TDK_TRY(check_indices(vp, pt, n, n_poses, n_points, &sorted));
     TDK_TRY(tdk::ensure_device());
     tdk_ba *h = new tdk_ba();   // value-initialised: every pointer is null until allocated
+    h->options = options;
     const tdk_status st = ba_allocate(h, n_poses, n_points, vp, pt, x_true, n, sorted);
     if (st != TDK_OK) {
         tdk_ba_destroy(h);      // nothing leaks when an allocation in the middle fails
@@ -1624,13 +1625,12 @@ static tdk_status ba_allocate(tdk_ba *h, int64_t n_poses, int64_t n_points, cons
     h->dev_solve = false;
     if (dim <= kDevSolveMaxDim) {
         const size_t lds = rcs_solve_lds(dim);
-        static const bool host_solve = [] { const char *v = getenv("TDK_BA_SOLVE"); return v && !strcmp(v, "host"); }();
+        const bool host_solve = (h->options & TDK_BA_OPT_SOLVE_HOST) != 0;
         h->dev_solve = !host_solve &&
                        (lds <= 64 * 1024 ||
                         hipFuncSetAttribute(reinterpret_cast<const void *>(rcs_solve_kernel(dim)),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess);
     }
-    TDK_HIP(hipMalloc(&h->cur.W, (size_t)n * 18 * 8));
     TDK_HIP(hipMalloc(&h->d_Vinv, (size_t)n_points * 48));
     TDK_HIP(hipMalloc(&h->d_S, (size_t)dim * dim * 8));
     TDK_HIP(hipMalloc(&h->d_e, (size_t)dim * 8));
@@ -1645,8 +1645,7 @@ static tdk_status ba_allocate(tdk_ba *h, int64_t n_poses, int64_t n_points, cons
     TDK_HIP(hipMalloc(&h->d_rod, (size_t)n_poses * 8 * 8));
     h->pchunk = 2048;
     h->npchunks = (n_points + h->pchunk - 1) / h->pchunk;
-    const char *force = getenv("TDK_BA_SCHUR");   // "atomics": always take the general kernel (tests)
-    if (!(force && !strcmp(force, "atomics")) && n_poses * n_points <= (1ll << 26) && n < (1ll << 31) &&
+    if (!(h->options & TDK_BA_OPT_SCHUR_GENERAL) && n_poses * n_points <= (1ll << 26) && n < (1ll << 31) &&
         n_poses <= 256) {
         std::vector<int> table((size_t)(n_poses * n_points), -1);
         bool unique = true;
@@ -1659,14 +1658,16 @@ static tdk_status ba_allocate(tdk_ba *h, int64_t n_poses, int64_t n_points, cons
             const int64_t pairs = n_poses * (n_poses + 1) / 2;
             TDK_HIP(hipMalloc(&h->d_obs_at, table.size() * sizeof(int)));
             TDK_HIP(hipMalloc(&h->d_spart, (size_t)(pairs * h->npchunks) * kSchurAccPad * 8));
-            if (n_poses <= 8) {   // 6 P <= 48 rows = three 16-row blocks of the FP64 MFMA tile
+            if (n_poses <= 8 && !(h->options & TDK_BA_OPT_SCHUR_PAIRS)) {   // 6 P <= 48 rows = three 16-row blocks of the FP64 MFMA tile
+                static_assert(8 <= kBlock, "k_ba_invert_V fills rod8 from the first n_poses threads of block 0");
                 h->mfma_blocks = 768;   // 3 resident blocks per CU (50 KB of LDS each), ~2 chunks of 32 points per block at 50 000 points
-                if (const char *v = getenv("TDK_BA_MFMA_BLOCKS")) h->mfma_blocks = std::max(1, std::min(768, atoi(v)));
                 TDK_HIP(hipMalloc(&h->d_mpart, (size_t)h->mfma_blocks * (6 * 256 + 64) * 8));
             }
             TDK_HIP(hipMemcpy(h->d_obs_at, table.data(), table.size() * sizeof(int), hipMemcpyHostToDevice));
         }
     }
+    // W_ij per observation (18 doubles each: 58 MB for the 8 x 50 000 window) only where a kernel reads it
+    if (!ba_recompute_w(h)) TDK_HIP(hipMalloc(&h->cur.W, (size_t)n * 18 * 8));
     TDK_HIP(hipMemcpyAsync(h->d_xt, x_true, (size_t)n * 16, hipMemcpyHostToDevice, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(h->d_vp, vp, (size_t)n * 8, hipMemcpyHostToDevice, tdk::stream()));
     TDK_HIP(hipMemcpyAsync(h->d_pt, pt, (size_t)n * 8, hipMemcpyHostToDevice, tdk::stream()));

@@ -2301,6 +2301,7 @@ struct tdk_dvo {
     bool weights_dirty;         // the device copy of the kernels is stale (a plan changed)
     int n_cu, device;           // compute units and index of the batch's device
     int student_mode;           // Student-t variance: 0 two Taylor passes, 1 nine sequential passes, 2 ... with IEEE divisions
+    int opt_chain, opt_tukey;   // tdk_dvo_set_option
     double *d_aa_weights;       // the pyramid's 1-D kernels, per level and axis (allocated on first use)
     int *h_flag;   // "pairs still running", written by k_dvo_reduce (mapped pinned host memory)
     int *d_chain_state, *d_gate;   // the speculative level chain: [n_levels][n_pairs] state arrays, the current level
@@ -2328,9 +2329,9 @@ void plan_blocks(const tdk_dvo *h, const tdk_dvo::Level &L, int *nblk, int64_t *
     // flat (+-0.5 %) from 12 to 40 pixels per thread on the bench workload
     // -- unless the batch is so small that this would leave CUs without a block
     // (a single pair): then down to 4 pixels per thread, aiming at >= 512 blocks
-    static const int64_t target_blocks = [] { const char *v = getenv("TDK_DVO_TARGET_BLOCKS"); return v && atoll(v) > 0 ? atoll(v) : 512ll; }();
+    constexpr int64_t target_blocks = 512;
     int64_t px_per_thread = L.N * h->n_pairs / (target_blocks * (int64_t)kBlock);
-    static const int64_t min_px = [] { const char *v = getenv("TDK_DVO_MIN_PX"); return v ? atoll(v) : 4ll; }();
+    constexpr int64_t min_px = 4;
     px_per_thread = px_per_thread < min_px ? min_px : (px_per_thread > 16 ? 16 : px_per_thread);
     int64_t per_block = (int64_t)kBlock * px_per_thread;
     int64_t nb = (L.N + per_block - 1) / per_block;
@@ -2471,13 +2472,10 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
     dim3 grid(nb, n);
     TDK_HIP(hipMemsetAsync(h->d_count, 0, sizeof(int) * n, h->stream));
     const bool exact = h->student_mode == 2;
-    // TDK_TUKEY=radix: the two medians by radix select (2 x 3 passes over the residual map) instead of the
-    // sampled brackets + one pass; TDK_TUKEY=fallback: brackets, but every pair takes the exact slow path of
+    // tdk_dvo_set_option(TDK_DVO_OPT_TUKEY): 1 = the two medians by radix select (2 x 3 passes over the residual
+    // map) instead of the sampled brackets + one pass; 2 = brackets, but every pair takes the exact slow path of
     // k_tukey_finish (tests).  All three give the same doubles.
-    static const int tukey_mode = [] {
-        const char *v = getenv("TDK_TUKEY");
-        return v && !strcmp(v, "radix") ? 1 : (v && !strcmp(v, "fallback") ? 2 : 0);
-    }();
+    const int tukey_mode = h->opt_tukey;
     const bool taylor = weight_mode == TDK_W_STUDENT_T && h->student_mode == 0;
     const bool brackets = weight_mode == TDK_W_TUKEY && tukey_mode != 1;
     TukeyArgs tka{h->d_tk, h->d_tk_med, h->tk_cap};
@@ -2486,10 +2484,9 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
                                                            h->d_tk_sample);
         TDK_LAUNCH_CHECK();
     }
-    // Student-t, Taylor scheme: pass A rides in the mask pass (TDK_STUDENT_FUSED=0: on its own, after it), so the
-    // sample's fixed-point sequence comes first, from residuals computed on the spot
-    static const bool fused_env = [] { const char *v = getenv("TDK_STUDENT_FUSED"); return !(v && v[0] == '0'); }();
-    const bool fused_a = taylor && fused_env;
+    // Student-t, Taylor scheme: pass A rides in the mask pass, so the sample's fixed-point sequence comes first,
+    // from residuals computed on the spot
+    const bool fused_a = taylor;
     double *partial_v1 = fused_a ? h->d_spartial + (size_t)kStatBlocks * kStudentSums * n : h->d_spartial;
     if (fused_a) {
         k_student_predict<true><<<n, kBlock, 0, h->stream>>>(nullptr, L.stride, (int)L.N, d_state, h->d_st_pts, ptrs_of(L),
@@ -2514,8 +2511,7 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
         k_tukey_plan<<<gp, 256, 0, h->stream>>>(h->d_tk, h->d_count, d_state, 0, h->d_rm, L.stride, (int)L.N, h->d_tk_med,
                                                 h->tk_cap, nullptr, force, src, h->d_tk_fallback, n);
         TDK_LAUNCH_CHECK();
-        // TDK_TUKEY_BAND=radix: the band's order statistics by the eight radix sweeps of round 3's first version
-        static const int use_bins = [] { const char *v = getenv("TDK_TUKEY_BAND"); return v && !strcmp(v, "radix") ? 0 : 1; }();
+        const int use_bins = 1;
         k_band_median<<<n, kTukeyThreads, 0, h->stream>>>(src, h->d_count, d_state, 1.0, median, use_bins);
         TDK_LAUNCH_CHECK();
         k_tukey_dev_bracket<<<n, kTukeyThreads, 0, h->stream>>>(d_state, h->d_tk, h->d_tk_sample, median);
@@ -2727,7 +2723,7 @@ struct LevelRun {
 
 static LevelRun begin_level(tdk_dvo *h, int level, int max_iter) {
     const bool small = (int64_t)h->n_pairs * h->lv[level].N <= (1ll << 22) && !h->profiling;
-    static const int small_burst = [] { const char *v = getenv("TDK_DVO_BURST"); return v && atoi(v) > 0 ? atoi(v) : 2; }();
+    constexpr int small_burst = 2;
     // a pair goes through at most 2 max_iter + 1 evaluations: the first, then per tested candidate a
     // probe and -- if it was accepted and is not the last -- the full evaluation at the accepted pose
     return LevelRun{level, 0, 2 * max_iter + 1, small ? small_burst : 1, false};   // a level starts with full evaluations
@@ -2779,8 +2775,7 @@ tdk_status run_level(tdk_dvo *h, int level, int weight_mode, int max_iter, int64
 // k_chain_init / chain_next_level).  Weight modes without robust statistics only (their extra kernels per
 // full evaluation are decided on the host).
 static bool chain_applies(const tdk_dvo *h, int weight_mode) {
-    static const int enabled = [] { const char *v = getenv("TDK_DVO_CHAIN"); return v ? atoi(v) : 1; }();
-    return enabled && !h->profiling && (int64_t)h->n_pairs * h->lv[0].N <= (1ll << 22) &&
+    return h->opt_chain && !h->profiling && (int64_t)h->n_pairs * h->lv[0].N <= (1ll << 22) &&
            weight_mode != TDK_W_STUDENT_T && weight_mode != TDK_W_TUKEY;
 }
 
@@ -2897,10 +2892,9 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
         h->n_cu = cus > 0 ? cus : 256;
         h->device = dev;
     }
-    {   // defaults of tdk_dvo_set_student_passes from the environment
-        const char *ex = getenv("TDK_STUDENT_EXACT"), *sq = getenv("TDK_STUDENT");
-        h->student_mode = (ex && atoi(ex) != 0) ? 2 : ((sq && !strcmp(sq, "sequential")) ? 1 : 0);
-    }
+    h->student_mode = 0;
+    h->opt_chain = 1;
+    h->opt_tukey = 0;
     h->max_blocks = 1024;
     h->d_rm = nullptr; h->d_wscale = nullptr; h->d_stat = nullptr; h->d_spartial = nullptr; h->d_st_pts = nullptr; h->d_st_redo = nullptr;
     h->d_count = nullptr; h->d_select = nullptr; h->d_hist = nullptr;
@@ -3159,8 +3153,7 @@ static tdk_status build_pyramid_of(tdk_dvo *h, unsigned arrays) {
     }
     if (h->clip && h->d_clip == nullptr)
         TDK_HIP(hipMalloc(&h->d_clip, tdk::pyramid_clip_bytes((int64_t)h->n_pairs * 4, h->n_levels)));
-    const char *env = getenv("TDK_PYRAMID_STREAM");           // 0: never, 1 (default): large batches, 2: always
-    const int use_stream = env ? atoi(env) : 1;
+    const int use_stream = tdk::option(TDK_OPT_PYRAMID_STREAM);   // 0: never, 1 (default): large batches, 2: always
     // two groups of arrays: those with a level 0 of their own (sources: the uploads, levels 0 .. n - 1) and the rest
     // (sources: level 0 = the upload, levels 1 .. n - 1); the device kernels are stored per level: slot l of the
     // weight buffer is level l in both groups
@@ -3394,6 +3387,23 @@ tdk_status tdk_dvo_set_anti_aliasing(tdk_dvo *h, int enabled) {
     h->anti_aliasing = enabled != 0;
     h->weights_dirty = true;
     return TDK_OK;
+}
+
+tdk_status tdk_dvo_set_option(tdk_dvo *h, int option, int value) {
+    TDK_REQUIRE(h != nullptr, "handle is NULL");
+    switch (option) {
+        case TDK_DVO_OPT_CHAIN:
+            TDK_REQUIRE(value == 0 || value == 1, "TDK_DVO_OPT_CHAIN: 0 or 1");
+            h->opt_chain = value;
+            return TDK_OK;
+        case TDK_DVO_OPT_TUKEY:
+            TDK_REQUIRE(value >= 0 && value <= 2, "TDK_DVO_OPT_TUKEY: 0, 1 or 2");
+            h->opt_tukey = value;
+            return TDK_OK;
+        default:
+            tdk::set_error("invalid argument: unknown option %d", option);
+            return TDK_ERR_INVALID_ARGUMENT;
+    }
 }
 
 tdk_status tdk_dvo_set_level_plan(tdk_dvo *h, int level, const double *map, const double *w_rows, int radius_rows,

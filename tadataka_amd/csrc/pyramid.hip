@@ -1324,7 +1324,8 @@ tdk_status rescale_host(const double *image, int H, int W, double *out, int Ho, 
     const double *srcs[1] = {(const double *)d_img};
     lv.dst[0] = (double *)d_out; lv.dst[1] = lv.dst[2] = lv.dst[3] = nullptr;
     lv.stride = 0; lv.H = Ho; lv.W = Wo;
-    TDK_TRY(tdk::launch_pyramid(srcs, 1, H, W, 0, 1, &lv, 1, (double *)d_w, true, d_clip, 1, tdk::stream()));
+    TDK_TRY(tdk::launch_pyramid(srcs, 1, H, W, 0, 1, &lv, 1, (double *)d_w, true, d_clip,
+                                tdk::option(TDK_OPT_PYRAMID_STREAM), tdk::stream()));
     TDK_HIP(hipMemcpyAsync(out, d_out, (size_t)Ho * Wo * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
     return TDK_OK;

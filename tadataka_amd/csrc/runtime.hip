@@ -31,6 +31,9 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+static int g_options[2] = {1, 1};   // TDK_OPT_PYRAMID_STREAM, TDK_OPT_SD_WARP_GATHER
+int option(int which) { return g_options[which]; }
+
 hipStream_t stream() { return g_stream; }
 hipStream_t upload_stream() { return g_upload_stream; }
 
@@ -236,6 +239,13 @@ tdk_status tdk_sync(void) {
     TDK_TRY(tdk::ensure_device());
     TDK_HIP(hipDeviceSynchronize());   // the library stream and every batch's own stream
     return tdk::check_canaries();      // (TDK_DEBUG_CANARY=1 only)
+}
+
+tdk_status tdk_set_option(int option, int value) {
+    TDK_REQUIRE(option == TDK_OPT_PYRAMID_STREAM || option == TDK_OPT_SD_WARP_GATHER, "unknown option");
+    TDK_REQUIRE(value >= 0 && value <= (option == TDK_OPT_PYRAMID_STREAM ? 2 : 1), "value out of range");
+    tdk::g_options[option] = value;
+    return TDK_OK;
 }
 
 tdk_status tdk_debug_check_canaries(int *n_allocations) {

@@ -313,16 +313,13 @@ constexpr int kGatherMaxRx = 64, kGatherMaxRy = 12;       // largest displacemen
 constexpr int kGatherMaxCand = 320;                       // (rx + 1)(ry + 1): candidates scanned per target
 
 // rng[kRngStride track ..]: max(-dx), max(-dy), max(dx), max(dy) over the in-range sources (memset to 0x80808080 before)
-constexpr int kFusedTH = 8;                                 // target rows per tile of the fused gather
-constexpr int kFusedMaxWin = 1024;                          // window sources it keeps in LDS
 __device__ __forceinline__ bool gather_applies(const int *__restrict__ rng, int track, int &dxmin, int &dymin,
-                                               int &rx, int &ry, int max_win = 0) {
+                                               int &rx, int &ry) {
     const int nx = rng[kRngStride * track], ny = rng[kRngStride * track + 1], mx = rng[kRngStride * track + 2],
               my = rng[kRngStride * track + 3];
     if (mx < -0x40000000) { dxmin = 0; dymin = 0; rx = -1; ry = -1; return true; }   // no source in range at all
     dxmin = -nx; dymin = -ny;
     rx = mx + nx; ry = my + ny;
-    if (max_win > 0 && (kGatherTW + rx) * (kFusedTH + ry) > max_win) return false;
     return rx <= kGatherMaxRx && ry <= kGatherMaxRy && (rx + 1) * (ry + 1) <= kGatherMaxCand;
 }
 
@@ -576,182 +573,12 @@ __global__ __launch_bounds__(kBlock) void k_sd_gather2(int H, int W, const Track
     }
 }
 
-// The gather FUSED with the warp (round 4, second step).  k_sd_targets + k_sd_gather2 move 89 bytes per pixel:
-// the target index and the warped hypothesis of every source are written (20 B) and read back (21 B) only to
-// carry them from one kernel to the next.  Here a block warps the sources of its window ITSELF (depth0 and
-// var0, 16 B x the window overlap of about 1.3, mostly L2 hits) and keeps target and hypothesis in LDS:
-//   k_sd_targets<.., STORE = false>   the box only (8 B/px read, nothing written)
-//   k_sd_gather_fused                 per 64 x 8 tile: window sources -> warp -> vote (LDS) -> fold from LDS;
-//                                     one global gather left, the age of the last writer
-// 8 + 21 + 8 + 24 = 61 bytes per pixel.  The window must fit kFusedMaxWin sources (rx <= 20 with ry <= 4, say);
-// a track beyond that goes the slot path.  Same warp arithmetic (perspective_warp, propagate_variance), same
-// sources in the same order -> same bits as every other path.
-template <bool AGE, bool PROP>
-__global__ __launch_bounds__(kBlock) void k_sd_gather_fused(int H, int W, const TrackWarp *__restrict__ tw,
-                                                            const double *__restrict__ depth0,
-                                                            const double *__restrict__ var0,
-                                                            const int *__restrict__ rng,
-                                                            const uint64_t *__restrict__ age0, int64_t stride,
-                                                            double default_depth, double default_variance, double bias,
-                                                            uint64_t *__restrict__ age1, double *__restrict__ depth1,
-                                                            double *__restrict__ var1, int nb, int n_tracks,
-                                                            unsigned int *__restrict__ fallbacks) {
-    constexpr int kRows = kFusedTH / kGatherTH;              // targets per thread
-    constexpr int kBatch = kFusedMaxWin / kBlock;            // window sources per thread
-    __shared__ int cnt[kBlock * kRows];
-    __shared__ __attribute__((aligned(16))) int slot[kBlock * kRows * kSlots];   // window indices
-    __shared__ short wtl[kFusedMaxWin];                      // window source -> target of this tile, or -1
-    __shared__ __attribute__((aligned(16))) double hyp_raw[2 * (PROP ? kFusedMaxWin : 1)];
-    double2 *hyp = reinterpret_cast<double2 *>(hyp_raw);      // window source -> (depth1, variance1a)
-    int track, blk;
-    if (!xcd_major_track(nb, n_tracks, track, blk)) return;
-    int dxmin, dymin, rx, ry;
-    if (!gather_applies(rng, track, dxmin, dymin, rx, ry, kFusedMaxWin)) {
-        if (blk == 0 && threadIdx.x == 0 && fallbacks) atomicAdd(fallbacks, 1u);
-        return;
-    }
-    const int dxmax = dxmin + rx, dymax = dymin + ry;
-    const TrackWarp &t = tw[track];
-    const Cam c0{t.cam0[0], t.cam0[1], t.cam0[2], t.cam0[3]}, c1{t.cam1[0], t.cam1[1], t.cam1[2], t.cam1[3]};
-    const int64_t base = (int64_t)track * stride;
-    const double *__restrict__ d0 = depth0 + base;
-    const double *__restrict__ v0 = var0 + base;
-    const int tiles_x = (W + kGatherTW - 1) / kGatherTW, tiles_y = (H + kFusedTH - 1) / kFusedTH;
-    const int lx = threadIdx.x & 63;
-    const int ly = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int ww = kGatherTW + max(rx, 0), wh = kFusedTH + max(ry, 0);
-    const int n_win = rx >= 0 ? ww * wh : 0;                        // <= kFusedMaxWin
-    const unsigned m_ww = ((1u << 24) + ww - 1) / ww;               // idx / ww = idx m_ww >> 24 (idx < 4096, ww <= 128)
-#pragma unroll
-    for (int e = 0; e < kRows; e++) cnt[threadIdx.x + e * kBlock] = 0;
-    for (int tile = blk; tile < tiles_x * tiles_y; tile += nb) {
-        const int tyi = tile / tiles_x, txi = tile - tyi * tiles_x;
-        const int tx0 = txi * kGatherTW, ty0 = tyi * kFusedTH;
-        const int wx0 = tx0 - dxmax, wy0 = ty0 - dymax;      // window origin in source coordinates
-        __syncthreads();                                      // the previous tile's folds are through, counts zero
-        {
-            int sxs[kBatch], sys[kBatch];
-            double dd[kBatch], vv[kBatch];
-#pragma unroll
-            for (int j = 0; j < kBatch; j++) {
-                const int idx = j * kBlock + (int)threadIdx.x;
-                const int r = (int)(((unsigned)idx * m_ww) >> 24), c = idx - r * ww;
-                const int sy = wy0 + r, sx = wx0 + c;
-                const bool ok = idx < n_win && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
-                sxs[j] = ok ? sx : -1; sys[j] = sy;
-                dd[j] = 0.0; vv[j] = 0.0;
-                if (j * kBlock < n_win) {                     // (uniform: a whole round or none)
-                    const int i = ok ? sy * W + sx : 0;
-                    dd[j] = d0[i];
-                    if (PROP) vv[j] = v0[i];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < kBatch; j++) {
-                if (j * kBlock >= n_win) continue;
-                const int idx = j * kBlock + (int)threadIdx.x;
-                int tl = -1;
-                if (sxs[j] >= 0) {
-                    double ux, uy, d1;
-                    tdk::perspective_warp(t.T10, c0, c1, (double)sxs[j], (double)sys[j], dd[j], ux, uy, d1);
-                    if (tdk::in_range(ux, uy, H, W)) {
-                        const unsigned qx = (unsigned)((int)ux - tx0), qy = (unsigned)((int)uy - ty0);   // `as usize`
-                        if (qx < (unsigned)kGatherTW && qy < (unsigned)kFusedTH) {
-                            tl = (int)qy * kGatherTW + (int)qx;
-                            const int k = atomicAdd(&cnt[tl], 1);
-                            if (k < kSlots) slot[tl * kSlots + k] = idx;
-                            if (PROP) hyp[idx] = make_double2(d1, propagate_variance(dd[j], d1, vv[j], bias));
-                        }
-                    }
-                }
-                if (idx < n_win) wtl[idx] = (short)tl;
-            }
-        }
-        __syncthreads();
-        const int x = tx0 + lx;
-        int kk[kRows], me[kRows], s[kRows][kSlots], lastw[kRows];
-        uint64_t a0[kRows];
-#pragma unroll
-        for (int e = 0; e < kRows; e++) {
-            const int tl = (ly + e * kGatherTH) * kGatherTW + lx, y = ty0 + ly + e * kGatherTH;
-            me[e] = (x < W && y < H) ? y * W + x : -1;
-            const int k = kk[e] = cnt[tl];
-            cnt[tl] = 0;                                      // for the next tile (this thread is the only reader)
-            const int4 q = *reinterpret_cast<const int4 *>(slot + tl * kSlots);
-            s[e][0] = q.x; s[e][1] = k > 1 ? q.y : 0x7fffffff; s[e][2] = k > 2 ? q.z : 0x7fffffff;
-            s[e][3] = k > 3 ? q.w : 0x7fffffff;
-            if (k > 1 && k <= kSlots) {   // votes arrive in any order; window order IS raster order
-                sort2(s[e][0], s[e][1]); sort2(s[e][2], s[e][3]); sort2(s[e][0], s[e][2]); sort2(s[e][1], s[e][3]);
-                sort2(s[e][1], s[e][2]);
-            }
-            int li = -1;                                      // window index of the last writer
-            if (me[e] >= 0 && k > 0) {
-                if (k <= kSlots) li = k > 3 ? s[e][3] : k > 2 ? s[e][2] : k > 1 ? s[e][1] : s[e][0];
-                else {
-                    // more than four sources on this target: its candidates s = t - d, d in the box, in raster
-                    // order; the last one that lands here
-                    for (int cj = 0; cj <= ry; cj++)
-                        for (int ci = 0; ci <= rx; ci++) {
-                            const int wi = (ly + e * kGatherTH + cj) * ww + lx + ci;
-                            if (wtl[wi] == tl) li = wi;
-                        }
-                }
-            }
-            lastw[e] = -1;
-            if (li >= 0) {
-                const int r = (int)(((unsigned)li * m_ww) >> 24), c = li - r * ww;
-                lastw[e] = (wy0 + r) * W + wx0 + c;
-            }
-            if (AGE) a0[e] = age0[base + max(lastw[e], 0)];
-        }
-#pragma unroll
-        for (int e = 0; e < kRows; e++) {
-            if (me[e] < 0) continue;
-            const int k = kk[e];
-            double d = default_depth, v = default_variance;
-            if (PROP && k > 0) {
-                bool have = false;
-                auto fold = [&](const double2 w) {
-                    if (!have) { d = w.x; v = w.y; have = true; }
-                    else {
-                        double nd, nv;
-                        handle_collision(w.x, d, w.y, v, nd, nv);
-                        d = nd; v = nv;
-                    }
-                };
-                if (k <= kSlots) {
-                    fold(hyp[s[e][0]]);
-                    if (k > 1) fold(hyp[s[e][1]]);
-                    if (k > 2) fold(hyp[s[e][2]]);
-                    if (k > 3) fold(hyp[s[e][3]]);
-                } else {
-                    const int tl = (ly + e * kGatherTH) * kGatherTW + lx;
-                    for (int cj = 0; cj <= ry; cj++)
-                        for (int ci = 0; ci <= rx; ci++) {
-                            const int wi = (ly + e * kGatherTH + cj) * ww + lx + ci;
-                            if (wtl[wi] == tl) fold(hyp[wi]);
-                        }
-                }
-            }
-            if (AGE) {
-                uint64_t a = 0;
-                if (lastw[e] >= 0) {
-                    a = a0[e] + 1;
-                    a = a > t.age_cap ? t.age_cap : a;
-                }
-                age1[base + me[e]] = a;
-            }
-            if (PROP) { depth1[base + me[e]] = d; var1[base + me[e]] = v; }
-        }
-    }
-}
-
 // the slot path only where the gather did not apply (see above): the three launches of launch_warp_step
 // that follow k_sd_gather2 test this first
 __device__ __forceinline__ bool slot_path_wanted(const int *__restrict__ rng, int track) {
     if (rng == nullptr) return true;
     int a, b, c, d;
-    return !gather_applies(rng, track, a, b, c, d, rng[kRngStride * track + 4]);
+    return !gather_applies(rng, track, a, b, c, d);
 }
 
 // Does ANY track of the step need the slot path?  Asked once per block of the three slot-path launches, which
@@ -1393,8 +1220,7 @@ tdk_status launch_warp_step(int n_tracks, int H, int W, const TrackWarp *d_tw, c
     const WarpLists lists = carve_lists(list_buf, stride, n_tracks);
     const int nb = grid_for(N);
     const unsigned grid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)nb;
-    const char *gv = getenv("TDK_SD_GATHER");   // (read per call: the tests switch it)
-    const int use_gather = gv ? atoi(gv) : 1;
+    const int use_gather = tdk::option(TDK_OPT_SD_WARP_GATHER);   // 0: the slot path for every track (tests)
     // the target indices alias `next`, which the slot path only writes AFTER k_sd_gather2 has run (and only for
     // the tracks that fell back); the boxes have their own 4 n_tracks ints behind the lists
     int *rng = nullptr;
@@ -1413,24 +1239,6 @@ tdk_status launch_warp_step(int n_tracks, int H, int W, const TrackWarp *d_tw, c
         const int n_tiles2 = ((W + 2 * kGatherTW - 1) / (2 * kGatherTW)) * ((H + kGatherTH - 1) / kGatherTH);
         const int tnb = px2 ? std::max(1, (n_tiles2 + 3) / 4) : gnb;
         const unsigned tgrid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)tnb;
-        if (use_gather == 2) {
-            // fused (opt-in): the box, then warp + vote + fold per tile (k_sd_gather_fused)
-            if (px2)
-                k_sd_targets<false, 2, false><<<tgrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, bias, stride, nullptr,
-                                                                             nullptr, rng, tnb, n_tracks, kFusedMaxWin);
-            else
-                k_sd_targets<false, 1, false><<<tgrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, bias, stride, nullptr,
-                                                                             nullptr, rng, tnb, n_tracks, kFusedMaxWin);
-            TDK_LAUNCH_CHECK();
-            const int n_tiles8 = ((W + kGatherTW - 1) / kGatherTW) * ((H + kFusedTH - 1) / kFusedTH);
-            int fnb = std::max(1, (n_tiles8 + 1) / 2);
-            if (const char *v = getenv("TDK_SD_GATHER_NB")) fnb = std::max(1, atoi(v));
-            const unsigned fgrid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)fnb;
-            k_sd_gather_fused<AGE, PROP><<<fgrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, rng, age0, stride,
-                                                                        default_depth, default_variance, bias, age1,
-                                                                        depth1, var1, fnb, n_tracks, d_fallbacks);
-            TDK_LAUNCH_CHECK();
-        } else {
         if (px2)
             k_sd_targets<PROP, 2, true><<<tgrid, kBlock, 0, stream>>>(H, W, d_tw, depth0, var0, bias, stride, lists.next,
                                                                        warped, rng, tnb, n_tracks, 0);
@@ -1441,14 +1249,12 @@ tdk_status launch_warp_step(int n_tracks, int H, int W, const TrackWarp *d_tw, c
         {
             const int n_tiles8 = ((W + kGatherTW - 1) / kGatherTW) * ((H + 2 * kGatherTH - 1) / (2 * kGatherTH));
             int g2nb = std::max(1, (n_tiles8 + 1) / 2);
-            if (const char *v = getenv("TDK_SD_GATHER_NB")) g2nb = std::max(1, atoi(v));
             const unsigned g2grid = 8u * (unsigned)((n_tracks + 7) / 8) * (unsigned)g2nb;
             k_sd_gather2<AGE, PROP, 2><<<g2grid, kBlock, 0, stream>>>(H, W, d_tw, lists.next, warped, rng, age0, stride,
                                                                        default_depth, default_variance, bias, age1,
                                                                        depth1, var1, g2nb, n_tracks, d_fallbacks);
         }
         TDK_LAUNCH_CHECK();
-        }
     }
     // with the gather queued the slot path is the exception: a capped grid whose blocks ask first whether any
     // track needs them (any_slot_track); without it, the full grid

@@ -18,6 +18,7 @@ hipStream_t stream();
 // destination must not be in use on stream() (a fresh allocation, or the caller has ordered it).
 hipStream_t upload_stream();
 tdk_status ensure_device();
+int option(int which);   // tdk_set_option
 
 // Grow-only device buffers, indexed by slot; contents are undefined between calls.
 constexpr int kScratchSlots = 16;

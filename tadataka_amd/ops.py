@@ -156,6 +156,16 @@ def resize(image, output_shape, anti_aliasing=False, mode="ideal", plan=None, cl
     return out
 
 
+LIBRARY_OPTIONS = {"pyramid_stream": 0, "sd_warp_gather": 1}
+
+
+def set_option(name, value):
+    """tdk_set_option (library-wide): "pyramid_stream" 1 (default) streaming kernel for batches that fill the chip /
+    0 LDS tiles always / 2 streaming kernel always; "sd_warp_gather" 1 (default) gather kernels with the slot path as
+    device-side fallback / 0 slot path for every track.  Bit-identical either way."""
+    call("tdk_set_option", LIBRARY_OPTIONS[name], int(value))
+
+
 # ---- DVO batch ----------------------------------------------------------------
 def pose12(R, t):
     return np.concatenate([_f64(R, (9,)), _f64(t, (3,))])
@@ -342,6 +352,14 @@ class DvoBatch(object):
         v = C.c_int64()
         call("tdk_dvo_get_tukey_fallbacks", self._h, C.byref(v))
         return int(v.value)
+
+    OPTIONS = {"chain": 0, "tukey": 1}
+
+    def set_option(self, name, value):
+        """tdk_dvo_set_option: "chain" 1 (default) the whole coarse-to-fine chain of a small batch is queued at once /
+        0 the host drives it level by level; "tukey" 0 (default) sampled brackets / 1 radix select / 2 brackets with the
+        exact fallback forced.  Same results either way."""
+        call("tdk_dvo_set_option", self._h, self.OPTIONS[name], int(value))
 
     def set_student_passes(self, mode):
         """0: Taylor passes (default); 1: nine sequential passes; 2: nine passes with IEEE divisions."""
@@ -1017,15 +1035,18 @@ def ba_block_reduce(poses, points, x_true, viewpoint_indices, point_indices):
 class BundleAdjustment(object):
     """Device-resident observation graph for sparse bundle adjustment (tdk_ba)."""
 
-    def __init__(self, n_poses, n_points, viewpoint_indices, point_indices, x_true):
+    # tdk_ba_create_ex options: kernels that serve other shapes, forced onto this one (tests)
+    SCHUR_PAIRS, SCHUR_GENERAL, SOLVE_HOST, SOLVE_PIVOTED = 1, 2, 4, 8
+
+    def __init__(self, n_poses, n_points, viewpoint_indices, point_indices, x_true, options=0):
         vp = np.ascontiguousarray(viewpoint_indices, dtype=np.int64)
         pt = np.ascontiguousarray(point_indices, dtype=np.int64)
         self.n = vp.shape[0]
         xt = _f64(x_true, (self.n, 2))
         self.n_poses, self.n_points = int(n_poses), int(n_points)
         self._h = C.c_void_p()
-        call("tdk_ba_create", self.n_poses, self.n_points, vp.ctypes.data_as(c_int64_p),
-             pt.ctypes.data_as(c_int64_p), _p(xt), self.n, C.byref(self._h))
+        call("tdk_ba_create_ex", self.n_poses, self.n_points, vp.ctypes.data_as(c_int64_p),
+             pt.ctypes.data_as(c_int64_p), _p(xt), self.n, int(options), C.byref(self._h))
 
     def close(self):
         if self._h:

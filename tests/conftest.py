@@ -60,10 +60,14 @@ def _canary_check_after_every_gpu_test(request):
     """TDK_DEBUG_CANARY=1 pytest -m gpu: after every GPU test the red zones around every live device allocation
     are verified (tdk_debug_check_canaries); a damaged one fails the test that left it behind."""
     yield
-    if os.environ.get("TDK_DEBUG_CANARY") != "1" or "gpu" not in request.keywords or not _has_gpu():
+    if "gpu" not in request.keywords or not _has_gpu():
         return
     import ctypes
     from tadataka_amd import _lib
+    for option in (0, 1):                       # library-wide options a test may have switched: back to the defaults
+        _lib.load().tdk_set_option(option, 1)
+    if os.environ.get("TDK_DEBUG_CANARY") != "1":
+        return
     n = ctypes.c_int()
     st = _lib.load().tdk_debug_check_canaries(ctypes.byref(n))
     assert st == 0, _lib.load().tdk_last_error().decode()

@@ -477,56 +477,36 @@ def test_bundle_adjustment_full_size_step():
     g.close()
 
 
-_BA_FALLBACK_SCRIPT = """
-import sys
-import numpy as np
-from tadataka_amd import ops, synthetic
-out = sys.argv[1]
-res = {}
-for name, (P, Q, seed) in {"lds": (6, 400, 3), "global": (20, 300, 7), "wide": (24, 200, 9)}.items():
-    rng = np.random.default_rng(seed)
-    c = synthetic.make_ba_case(n_poses=P, n_points=Q, seed=seed)
-    keep = rng.uniform(0, 1, len(c["vp_idx"])) < 0.7
-    vp, pt = c["vp_idx"][keep], c["pt_idx"][keep]
-    x_true = ops.ba_projection(c["poses"], c["points"], vp, pt, jacobians=False)
-    g = ops.BundleAdjustment(P, Q, vp, pt, x_true)
-    dposes, dpoints, err = g.step(c["poses_noisy"], c["points_noisy"], 0.05)
-    res[name + "_dposes"], res[name + "_dpoints"], res[name + "_err"] = dposes, dpoints, err
-    g.close()
-np.savez(out, **res)
-"""
-
-
 @pytest.mark.gpu
-def test_bundle_adjustment_schur_kernels_agree(tmp_path):
-    """The pair-wise Schur kernel (dense observation table, no atomics) and the
-    general per-point kernel (atomics; LDS-private S for few poses, global S for
-    many) give the same LM step on ragged visibility; so do the reduced camera
-    system solved on the device (one workgroup in LDS, up to 20 poses: elimination
-    without pivoting while the pivots stay safely positive, else -- or always with
-    TDK_BA_SOLVE=pivoted -- partial pivoting) and on the host (TDK_BA_SOLVE=host;
-    always for wider windows such as "wide")."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def test_bundle_adjustment_schur_kernels_agree():
+    """The pair-wise Schur kernel (dense observation table, no atomics) and the general per-point kernel (atomics;
+    LDS-private S for few poses, global S for many) give the same LM step on ragged visibility; so do the reduced
+    camera system solved on the device (one workgroup in LDS, up to 20 poses: elimination without pivoting while
+    the pivots stay safely positive, else -- or always with SOLVE_PIVOTED -- partial pivoting) and on the host
+    (SOLVE_HOST; always for wider windows such as "wide").  The alternatives are selected with tdk_ba_create_ex's
+    option bits, in this process."""
+    from tadataka_amd import ops, synthetic
+    BA = ops.BundleAdjustment
     results = {}
-    for mode in ("pairs", "atomics", "hostsolve", "pivoted"):
-        out = str(tmp_path / f"{mode}.npz")
-        env = dict(os.environ, PYTHONPATH=root)
-        if mode == "atomics":
-            env["TDK_BA_SCHUR"] = "atomics"
-        if mode == "hostsolve":
-            env["TDK_BA_SOLVE"] = "host"
-        if mode == "pivoted":
-            env["TDK_BA_SOLVE"] = "pivoted"
-        subprocess.run([sys.executable, "-c", _BA_FALLBACK_SCRIPT, out], env=env, cwd=root, check=True,
-                       capture_output=True, text=True, timeout=300)
-        results[mode] = np.load(out)
+    for mode, options in (("default", 0), ("pairs", BA.SCHUR_PAIRS), ("general", BA.SCHUR_GENERAL),
+                          ("hostsolve", BA.SOLVE_HOST), ("pivoted", BA.SOLVE_PIVOTED),
+                          ("general+host", BA.SCHUR_GENERAL | BA.SOLVE_HOST)):
+        res = {}
+        for name, (P, Q, seed) in {"lds": (6, 400, 3), "global": (20, 300, 7), "wide": (24, 200, 9)}.items():
+            rng = np.random.default_rng(seed)
+            c = synthetic.make_ba_case(n_poses=P, n_points=Q, seed=seed)
+            keep = rng.uniform(0, 1, len(c["vp_idx"])) < 0.7
+            vp, pt = c["vp_idx"][keep], c["pt_idx"][keep]
+            x_true = ops.ba_projection(c["poses"], c["points"], vp, pt, jacobians=False)
+            g = BA(P, Q, vp, pt, x_true, options=options)
+            dposes, dpoints, err = g.step(c["poses_noisy"], c["points_noisy"], 0.05)
+            res[name + "_dposes"], res[name + "_dpoints"], res[name + "_err"] = dposes, dpoints, err
+            g.close()
+        results[mode] = res
     a = results["pairs"]
-    for other in ("atomics", "hostsolve", "pivoted"):
+    for other in results:
         b = results[other]
-        for key in a.files:
+        for key in a:
             assert np.allclose(a[key], b[key], rtol=1e-8, atol=1e-11), (other, key)
 
 

@@ -526,35 +526,21 @@ def test_update_depth_unusual_intensity_ranges(ops, orc):
 
 
 def test_ba_schur_mfma_matches_pair_kernel_and_is_reproducible(ops):
-    """The FP64-MFMA Schur complement (windows of <= 8 poses) against the pair-wise kernel
-    (TDK_BA_SCHUR=pairs, run in a child process) on ragged visibility, and bit-reproducible."""
-    import subprocess
+    """The FP64-MFMA Schur complement (windows of <= 8 poses; W_ij rebuilt from the parameters) against the
+    pair-wise kernel (tdk_ba_create_ex: SCHUR_PAIRS; W_ij stored by the reduce) on ragged visibility, and
+    bit-reproducible."""
     from tadataka_amd import synthetic
-    code = r'''
-import sys, numpy as np
-sys.path.insert(0, %r)
-from tadataka_amd import ops, synthetic
-c = synthetic.make_ba_case(n_poses=5, n_points=777, seed=8)
-rng = np.random.default_rng(3)
-keep = rng.uniform(size=len(c["vp_idx"])) < 0.8
-vp, pt = c["vp_idx"][keep], c["pt_idx"][keep]
-xt = ops.ba_projection(c["poses"], c["points"], vp, pt, jacobians=False)
-ba = ops.BundleAdjustment(5, 777, vp, pt, xt)
-dp, dq, err = ba.step(c["poses_noisy"], c["points_noisy"], 1e-2)
-np.save(sys.argv[1], np.concatenate([dp.ravel(), dq.ravel(), [err]]))
-'''
-    import os, sys, tempfile
-    from conftest import REPO
+    c = synthetic.make_ba_case(n_poses=5, n_points=777, seed=8)
+    rng = np.random.default_rng(3)
+    keep = rng.uniform(size=len(c["vp_idx"])) < 0.8
+    vp, pt = c["vp_idx"][keep], c["pt_idx"][keep]
+    xt = ops.ba_projection(c["poses"], c["points"], vp, pt, jacobians=False)
     outs = []
-    for env_extra in ({}, {}, {"TDK_BA_SCHUR": "pairs"}):
-        with tempfile.NamedTemporaryFile(suffix=".npy", delete=False) as f:
-            path = f.name
-        env = dict(os.environ, **env_extra)
-        p = subprocess.run([sys.executable, "-c", code % REPO, path], env=env, stdout=subprocess.PIPE,
-                           stderr=subprocess.STDOUT, text=True, timeout=300)
-        assert p.returncode == 0, p.stdout[-2000:]
-        outs.append(np.load(path))
-        os.unlink(path)
+    for options in (0, 0, ops.BundleAdjustment.SCHUR_PAIRS):
+        ba = ops.BundleAdjustment(5, 777, vp, pt, xt, options=options)
+        dp, dq, err = ba.step(c["poses_noisy"], c["points_noisy"], 1e-2)
+        outs.append(np.concatenate([dp.ravel(), dq.ravel(), [err]]))
+        ba.close()
     assert np.array_equal(outs[0], outs[1])                                   # run to run
     scale = np.max(np.abs(outs[2]))
     assert np.max(np.abs(outs[0] - outs[2])) < 1e-9 * scale                   # against the pair kernel

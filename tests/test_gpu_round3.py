@@ -250,7 +250,7 @@ def test_anti_aliased_pyramid_vga_7_levels(ops):
 
 
 # ---------------------------------------------------------------------------
-# TDK_STUDENT_EXACT=1: the IEEE-division variant of the Student-t variance fixed point
+# tdk_dvo_set_student_passes(2): the IEEE-division variant of the Student-t variance fixed point
 # ---------------------------------------------------------------------------
 _STUDENT_EXACT_SCRIPT = """
 import os, sys
@@ -262,6 +262,7 @@ from scipy.spatial.transform import Rotation
 d = np.load("tests/golden/dvo_small.npz")
 cam = d["cam"]; H, W = d["I0"].shape
 batch = ops.DvoBatch(1, H, W)
+batch.set_student_passes(int(sys.argv[1]))
 batch.upload(0, d["I0"], d["D0"], d["I1"])
 iu = np.triu_indices(6)
 worst = 0.0
@@ -279,16 +280,15 @@ print("RESULT", worst, perr)
 """
 
 
-@pytest.mark.parametrize("exact", ["0", "1"])
-def test_student_t_exact_switch(exact):
-    """Both arithmetic variants of the Student-t fixed point against the reference's own
-    per-iteration normal equations (dvo_small.npz): reciprocal arithmetic (default) and
-    TDK_STUDENT_EXACT=1 (IEEE divisions, the CPU restatement's operations).  The switch is
-    read once per process, hence the subprocess."""
+@pytest.mark.parametrize("passes", ["0", "1", "2"])
+def test_student_t_exact_switch(passes):
+    """The arithmetic variants of the Student-t fixed point against the reference's own per-iteration normal
+    equations (dvo_small.npz): tdk_dvo_set_student_passes 0 (two Taylor passes, default), 1 (nine sequential
+    passes, reciprocal arithmetic), 2 (IEEE divisions, the CPU restatement's operations)."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, TDK_STUDENT_EXACT=exact)
-    out = subprocess.run([sys.executable, "-c", _STUDENT_EXACT_SCRIPT], env=env, cwd=root, check=True,
+    env = dict(os.environ)
+    out = subprocess.run([sys.executable, "-c", _STUDENT_EXACT_SCRIPT, passes], env=env, cwd=root, check=True,
                          capture_output=True, text=True, timeout=300)
     line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1].split()
     worst, perr = float(line[1]), float(line[2])
@@ -918,6 +918,7 @@ fall = 0
 ident = np.concatenate([np.eye(3).ravel(), np.zeros(3)])
 for (H, W, B, quant) in ((480, 640, 3, None), (53, 71, 2, None), (120, 160, 4, 64), (96, 128, 2, 4)):
     batch = ops.DvoBatch(B, H, W)
+    batch.set_option("tukey", int(sys.argv[1]))
     for i in range(B):
         pr = synthetic.make_pair(H, W, seed=300 + i, rot_scale=0.01, trans_scale=0.03)
         I0, I1 = pr["I0"], pr["I1"]
@@ -946,9 +947,9 @@ def test_tukey_brackets_radix_and_fallback_agree_bit_for_bit():
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for mode in ("", "radix", "fallback"):
-        env = dict(os.environ, TDK_TUKEY=mode)
-        out = subprocess.run([sys.executable, "-c", _TUKEY_SCRIPT], env=env, cwd=root, check=True,
+    for mode, value in (("", "0"), ("radix", "1"), ("fallback", "2")):      # tdk_dvo_set_option(TDK_DVO_OPT_TUKEY)
+        env = dict(os.environ)
+        out = subprocess.run([sys.executable, "-c", _TUKEY_SCRIPT, value], env=env, cwd=root, check=True,
                              capture_output=True, text=True, timeout=600)
         line = [l for l in out.stdout.splitlines() if l.startswith("RESULT")][-1].split()
         res[mode] = (line[1], int(line[2]))

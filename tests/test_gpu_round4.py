@@ -265,8 +265,8 @@ def test_device_map_escape_tracking(ops, orc, monkeypatch):
 @pytest.mark.parametrize("shape,levels", [((480, 640), 3), ((480, 640), 2), ((120, 160), 3), ((97, 131), 3),
                                           ((720, 1280), 3), ((250, 249), 3), ((251, 497), 5)])
 def test_streaming_pyramid_is_bit_identical(ops, orc, monkeypatch, shape, levels):
-    """TDK_PYRAMID_STREAM=2 forces the streaming kernel for the first one / two levels of any batch
-    (by default it takes batches of >= 256 strips); =0 keeps the tiled kernel.  Every level of every
+    """tdk_set_option(TDK_OPT_PYRAMID_STREAM, 2) forces the streaming kernel for the first one / two levels of any
+    batch (by default it takes batches of >= 256 strips); 0 keeps the tiled kernel.  Every level of every
     array must come out bit for bit the same, and equal to the oracle's anti-aliased rescale: one
     strip (W < 249), three strips (VGA), strips that do not divide the width, odd heights, a frame
     whose last chunk is partial, deeper pyramids whose later levels stay on the tiles."""
@@ -281,7 +281,7 @@ def test_streaming_pyramid_is_bit_identical(ops, orc, monkeypatch, shape, levels
         pairs.append(pr)
     got = {}
     for mode in ("0", "2"):
-        monkeypatch.setenv("TDK_PYRAMID_STREAM", mode)
+        ops.set_option("pyramid_stream", int(mode))
         batch = ops.DvoBatch(B, H, W, n_levels=levels, ratio=1.5, with_weight_map=True)
         batch.set_anti_aliasing(True)
         for i, pr in enumerate(pairs):
@@ -397,7 +397,7 @@ def _warp_case(H, W, seed, kind):
 @pytest.mark.parametrize("kind", ["stereo", "motion", "zoom"])
 @pytest.mark.parametrize("shape", [(480, 640), (97, 131), (60, 64)])
 def test_forward_warp_gather_equals_slot_path_and_oracle(ops, orc, monkeypatch, kind, shape):
-    """increment_age and propagate: the gather path (default), the slot path (TDK_SD_GATHER=0) and the
+    """increment_age and propagate: the gather path (default), the slot path (TDK_OPT_SD_WARP_GATHER = 0) and the
     oracle give the same bits -- for a stereo baseline, a small general motion and a zoom-out whose
     displacement box exceeds the gather's window (there the default path IS the slot path: it falls back
     on the device); frame sizes that are not multiples of the 64 x 4 tiles included."""
@@ -406,9 +406,9 @@ def test_forward_warp_gather_equals_slot_path_and_oracle(ops, orc, monkeypatch, 
     cam = c["cam"]
     want_age = orc.increment_age(age0, cam, cam, T10, c["prior_depth"])
     want_d, want_v = orc.propagate(T10, cam, cam, c["prior_depth"], var0, 1.0, 10.0, 0.01)
-    # 1 = k_sd_targets + k_sd_gather2 (default), 2 = box pass + k_sd_gather_fused (opt-in), 0 = slots
-    for mode in ("1", "2", "0"):
-        monkeypatch.setenv("TDK_SD_GATHER", mode)
+    # 1 = k_sd_targets + k_sd_gather2 (default), 0 = slots
+    for mode in ("1", "0"):
+        ops.set_option("sd_warp_gather", int(mode))
         got_age = ops.increment_age(age0, cam, cam, T10, c["prior_depth"])
         got_d, got_v = ops.propagate(T10, cam, cam, c["prior_depth"], var0, 1.0, 10.0, 0.01)
         assert np.array_equal(got_age, want_age), (mode, kind)
@@ -445,8 +445,8 @@ def test_forward_warp_more_than_four_sources_inside_the_window(ops, orc, monkeyp
     sd.set_params(ops.make_params(0.5, 10.0, 0.01, 0.01, 0.004, 0.01), 1.0, 10.0, 0.01)
     sd.push_frame(0, cam, c["ref_image"], c["T_wr"])
     sd.push_frame(0, cam, c["key_image"], c["T_wk"])
-    for mode in ("1", "2", "0"):
-        monkeypatch.setenv("TDK_SD_GATHER", mode)
+    for mode in ("1", "0"):
+        ops.set_option("sd_warp_gather", int(mode))
         got_age = ops.increment_age(age0, cam, cam, T10, d0)
         got_d, got_v = ops.propagate(T10, cam, cam, d0, var0, 1.0, 10.0, 0.01)
         assert np.array_equal(got_age, want_age), mode
@@ -464,7 +464,7 @@ def test_forward_warp_more_than_four_sources_inside_the_window(ops, orc, monkeyp
 def test_session_counts_warp_fallbacks(ops, orc, monkeypatch):
     """The session's fused increment_age + propagate: tracks with a small displacement box take the gather,
     a track with a zoom-out takes the slot path in the same launch; both bit-exact, the counter says which."""
-    monkeypatch.delenv("TDK_SD_GATHER", raising=False)
+    ops.set_option("sd_warp_gather", 1)
     H, W, n = 96, 128, 3
     pargs = (0.5, 10.0, 0.01, 0.01, 0.004, 0.01)
     sd = ops.SemiDenseSession(n, H, W, max_refframes=2)

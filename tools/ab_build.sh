@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: bash tools/ab_build.sh <tag> "<extra hipcc flags, e.g. -DTDK_EXP_SETPRIO=1>"
 # Builds an experimental copy of the library as tadataka_amd/lib/libtadataka_hip_<tag>.so (A/B runs:
-# TDK_LIB_TAG=<tag> python tools/kbench.py).  Only dvo.hip is recompiled with the extra flags.
+# TDK_LIBRARY=$PWD/tadataka_amd/lib/libtadataka_hip_<tag>.so python tools/kbench.py).  Only dvo.hip is recompiled with the extra flags.
 set -e
 TAG=$1; FLAGS=$2
 cd "$(dirname "$0")/../tadataka_amd/csrc"

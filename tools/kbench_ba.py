@@ -23,7 +23,7 @@ def main():
         h.sum_squared_error(b["poses_noisy"], b["points_noisy"])
         h.step(b["poses_noisy"], b["points_noisy"], 1e-3)
     prof = h.get_profile()
-    print("seglen", os.environ.get("TDK_BA_SEGLEN", "auto"),
+    print(
           {k: round(v[1] / max(v[0], 1) * 1e3, 1) for k, v in prof.items()}, "us per launch")
     h.close()
 

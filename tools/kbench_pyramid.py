@@ -1,6 +1,6 @@
 """Times tdk_dvo_build_pyramid on the bench batch (256 VGA pairs x 3 arrays, 3 levels), alone on the
 device, for the pyramid readings the library offers:
-    ideal / tiles     ideal constants, TDK_PYRAMID_STREAM=0
+    ideal / tiles     ideal constants, tdk_set_option(TDK_OPT_PYRAMID_STREAM, 0)
     ideal / stream    ideal constants, the streaming kernel (the headline of rounds 1-4)
     skimage D0        skimage to the bit, level 0 of its own for the depth map only
     skimage all       skimage to the bit, level 0 (rescale(., 1.0)) for every array -- what the reference builds
@@ -26,7 +26,7 @@ CASES = (("ideal / tiles", "0", None), ("ideal / stream", "1", None), ("skimage 
          ("skimage all", "1", ("all", True)), ("skimage noclip", "1", ("all", False)))
 for rep in range(2):
     for name, stream, sk in CASES:
-        os.environ["TDK_PYRAMID_STREAM"] = stream
+        ops.set_option("pyramid_stream", int(stream))
         batch = ops.DvoBatch(B, H, W, n_levels=L, ratio=1.5)
         if sk is None:
             batch.set_anti_aliasing(True)

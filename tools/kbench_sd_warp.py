@@ -1,5 +1,5 @@
 """Kernel time of the semi-dense forward warp (increment_age + propagate) of bench.py's semi_dense_vga
-workload: 64 VGA tracks, SURVEY 8(d) cfg3 maps; gather path (default) against the slot path (TDK_SD_GATHER=0)."""
+workload: 64 VGA tracks, SURVEY 8(d) cfg3 maps; gather path (default) against the slot path (tdk_set_option(TDK_OPT_SD_WARP_GATHER, 0))."""
 import os
 import sys
 
@@ -11,7 +11,7 @@ from tadataka_amd import _lib, ops, synthetic  # noqa: E402
 _lib.require_gpu()
 B, H, W = 64, 480, 640
 for mode in ("0", "1", "0", "1"):
-    os.environ["TDK_SD_GATHER"] = mode
+    ops.set_option("sd_warp_gather", int(mode))
     sd = ops.SemiDenseSession(B, H, W, max_refframes=2)
     sd.set_age_policy(False)
     sd.set_params(ops.make_params(0.5, 10.0, 0.01, 0.01, 0.002, 0.02), 1.0, 10.0, 0.01)
@@ -29,5 +29,5 @@ for mode in ("0", "1", "0", "1"):
     for _ in range(20):
         sd.propagate(T10s, commit=False)
         ms += sd.timing()["warp_ms"]
-    print(f"TDK_SD_GATHER={mode}: warp step {ms / 20:.3f} ms for {B} tracks ({56.0 * B * H * W / (ms / 20 * 1e-3) / 1e12:.2f} TB/s of 56 B/px), fallbacks {sd.warp_fallbacks()}")
+    print(f"sd_warp_gather={mode}: warp step {ms / 20:.3f} ms for {B} tracks ({56.0 * B * H * W / (ms / 20 * 1e-3) / 1e12:.2f} TB/s of 56 B/px), fallbacks {sd.warp_fallbacks()}")
     sd.close()
