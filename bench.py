@@ -609,8 +609,9 @@ def workload_dvo_stream(args):
 def workload_semi_dense_dropin(args):
     """The mapping calls of examples/semi_dense_vo.py:182-199 exactly as the example writes them --
     Frame(...), increment_age, propagate, update_depth from rust_bindings.semi_dense, one 640x480 frame
-    per iteration, the refframes list growing -- timed per frame on the host.  Lazy maps (the default:
-    maps stay on the device) and eager ndarrays (TDK_SD_EAGER=1 behaviour: six maps downloaded per frame)."""
+    per iteration, the refframes list growing -- timed per frame on the host.  Eager ndarrays (the default: six
+    maps downloaded per frame, as the reference returns them) and device maps (tadataka_amd.enable_device_maps():
+    the maps stay on the device)."""
     import tadataka_amd  # noqa: F401
     import rust_bindings.semi_dense as rsd
     from rust_bindings.camera import CameraParameters
@@ -677,7 +678,7 @@ def workload_semi_dense_dropin(args):
                 _lib.call("tdk_sync")
                 out[label]["ms_per_frame_pipelined"] = (time.perf_counter() - t_start) / (2 * (n_frames - 1)) * 1e3
         finally:
-            rsd.LAZY_MAPS = True
+            rsd.LAZY_MAPS = False
     assert out["lazy_device_maps"]["success_pixels_last_frame"] == out["eager_ndarrays"]["success_pixels_last_frame"]
     return out
 

@@ -47,3 +47,16 @@ def install(thirdparty=None):
 
 
 install()
+
+
+def enable_device_maps(enabled=True):
+    """rust_bindings.semi_dense.increment_age / propagate / update_depth (and Frame.image) return plain ndarrays, as
+    the reference's do -- one download per returned map.  enable_device_maps() makes them return
+    tadataka_amd.ops.DeviceMap instead: array-likes that stay in HBM and are downloaded when somebody looks at them,
+    so that the loop of examples/semi_dense_vo.py:182-199, which hands every map straight into the next call, moves
+    nothing over PCIe.  A DeviceMap is not an ndarray subclass (isinstance(m, np.ndarray) is False): opt in where
+    that is acceptable.  Returns the previous setting."""
+    import rust_bindings.semi_dense as sd
+    previous = sd.LAZY_MAPS
+    sd.LAZY_MAPS = bool(enabled)
+    return previous

@@ -1,17 +1,15 @@
 """rust_bindings.semi_dense (src/py/semi_dense.rs:35-246): Frame, Params,
 increment_age, propagate, update_depth, estimate_debug_ on the MI355X.
 
-The maps stay on the device.  examples/semi_dense_vo.py:182-199 hands every map one
-of these functions returns straight into the next call (and into PoseChangeEstimator
-as depth map and 1 / variance), so the functions return `tadataka_amd.ops.DeviceMap`s:
-array-likes that live in HBM and are downloaded the first time somebody looks at them
-(np.asarray, indexing, arithmetic, plotting ...).  Passed back in, they are used where
-they are; plain ndarrays are accepted as before (and uploaded).  Frame.image is such a
-map too, backed by the image the frame keeps on the device.  Set
-rust_bindings.semi_dense.LAZY_MAPS = False (or TDK_SD_EAGER=1) to get plain ndarrays
-back from every call (one download per returned map)."""
-import os
-
+By default every call returns plain ndarrays, exactly as the reference's extension module
+does (one download per returned map).  examples/semi_dense_vo.py:182-199 hands every map
+one of these functions returns straight into the next call (and into PoseChangeEstimator
+as depth map and 1 / variance); after `tadataka_amd.enable_device_maps()` the functions
+return `tadataka_amd.ops.DeviceMap`s instead: array-likes that live in HBM and are
+downloaded the first time somebody looks at them (np.asarray, indexing, arithmetic,
+plotting ...).  Passed back in, they are used where they are; plain ndarrays are accepted
+either way (and uploaded).  Frame.image is such a map too then, backed by the image the
+frame keeps on the device."""
 import numpy as np
 
 from rust_bindings._check import f64, typed
@@ -20,7 +18,7 @@ from tadataka_amd import ops
 from tadataka_amd._lib import TDK_ERR_NO_DEVICE, TdkError
 
 
-LAZY_MAPS = os.environ.get("TDK_SD_EAGER", "0") in ("", "0")
+LAZY_MAPS = False          # tadataka_amd.enable_device_maps()
 
 
 def _out(*maps):

@@ -36,7 +36,9 @@ class Pose(object):
     @property
     def rotation(self):
         if self._rotation is None:
-            self._rotation = Rotation.from_matrix(self._R)
+            # from here on the Rotation is the single source of truth, as in the reference (from_matrix
+            # re-orthonormalises: R and rotation.as_matrix() may differ in the last bits)
+            self._rotation, self._R = Rotation.from_matrix(self._R), None
         return self._rotation
 
     @rotation.setter
@@ -77,7 +79,8 @@ class Pose(object):
         return Pose(*convert_coordinate(self.rotation, self.t))
 
     def __mul__(self, other):
-        return Pose(self.rotation * other.rotation,
+        rotation = self.rotation                    # (first: R below is then this Rotation's matrix)
+        return Pose(rotation * other.rotation,
                     np.dot(self.R, other.t) + self.t)
 
     def __eq__(self, other):

@@ -4,7 +4,6 @@ Everything here runs on the MI355X through libtadataka_hip.so; there is no CPU
 implementation behind these functions.
 """
 import ctypes as C
-import sys
 
 import numpy as np
 
@@ -575,10 +574,11 @@ def update_depth_frames(key, refs, age, prior_depth, prior_variance, params):
 # fresh arrays): reading them leaves the device copy valid.  Everything else -- views (T, flat, real,
 # reshape, ravel, squeeze, view, ...), mutating methods (fill, sort, put, itemset, partition, ...), ctypes /
 # __array_interface__ -- counts as a writable reference that escaped.
+# (astype(copy=False), conj / conjugate of a real array return the array ITSELF; clip, round, choose, dot, cumsum,
+# cumprod, take accept an `out` positionally: none of them is in the list)
 _MAP_PURE_ATTRS = frozenset((
-    "all", "any", "argmax", "argmin", "argsort", "astype", "choose", "clip", "compress", "conj", "conjugate",
-    "copy", "cumprod", "cumsum", "dot", "dump", "dumps", "flatten", "item", "itemsize", "max", "mean", "min",
-    "nonzero", "prod", "ptp", "repeat", "round", "searchsorted", "std", "strides", "sum", "take", "tobytes",
+    "all", "any", "argmax", "argmin", "argsort", "compress", "copy", "dump", "dumps", "flatten", "item", "itemsize",
+    "max", "mean", "min", "nonzero", "prod", "ptp", "repeat", "searchsorted", "std", "strides", "sum", "tobytes",
     "tofile", "tolist", "tostring", "trace", "var"))
 
 
@@ -593,11 +593,15 @@ _MAP_PURE_FUNCS = frozenset((
     "stack", "std", "sum", "unique", "var", "where", "zeros_like", "ones_like", "empty_like", "full_like"))
 
 
-def _host_args(x, pure):
-    """DeviceMaps -> their host arrays inside the positional / keyword arguments of a NumPy function."""
+def _host_args(x, pure, top=False):
+    """DeviceMaps -> their host arrays inside the positional / keyword arguments of a NumPy function.  Of the
+    positional arguments of a `pure` function only the FIRST is read-only for certain: several of them accept an
+    `out` array positionally (np.clip(a, lo, hi, out), np.round(a, decimals, out), np.sum(a, axis, dtype, out))."""
     if isinstance(x, DeviceMap):
         return x._materialise() if pure else x._expose()
     if isinstance(x, (list, tuple)):
+        if top:
+            return type(x)(_host_args(y, pure and k == 0) for k, y in enumerate(x))
         return type(x)(_host_args(y, pure) for y in x)
     if isinstance(x, dict):
         return {k: _host_args(v, pure and k != "out") for k, v in x.items()}
@@ -618,10 +622,10 @@ class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
     Host and device copy cannot diverge: writes through the map (m[mask] = v, ufunc out=, m.fill)
     and every *writable reference to the host copy that leaves the object* -- np.asarray(m), a slice
     m[a:b], m.T, iteration, a bound method -- mark the map `escaped`; an escaped map's host copy is
-    sent to the device again before each device use, for as long as such a reference is alive
-    (sys.getrefcount of the host array: views keep their base alive), so
+    sent to the device again before EVERY later device use (whether the reference is still alive is not
+    something a Python object can know portably: no reference counting is consulted), so
     `np.asarray(depth_map)[mask] = 0` followed by update_depth behaves as it does with the ndarrays
-    the reference returns.  A map that borrows a frame's image (Frame.image) becomes a map of its own
+    the reference returns.  Read-only looks (np.array_equal, m.max(), arithmetic, m.copy()) never escape a map.  A map that borrows a frame's image (Frame.image) becomes a map of its own
     at that point; the frame keeps its image, as the reference's getter returns a copy."""
 
     __array_priority__ = 100.0
@@ -687,9 +691,6 @@ class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
             self._h, self._owner, self._ptr = h, None, None
         else:
             call("tdk_map_upload", self._h, self._host.ctypes.data_as(C.c_void_p))
-        # 2 = our attribute + getrefcount's argument: nobody else holds the array or a view of it
-        if sys.getrefcount(self._host) <= 2:
-            self._escaped = False
 
     def safe_invert(self, epsilon=1e-16):
         """1 / (self + epsilon) on the device (tadataka.numeric.safe_invert)."""
@@ -758,7 +759,7 @@ class DeviceMap(np.lib.mixins.NDArrayOperatorsMixin):
         if name in ("ndim", "shape", "size") and len(args) == 1 and not kwargs and isinstance(args[0], DeviceMap):
             return getattr(args[0], name)               # no reason to fetch the data for these
         pure = name in _MAP_PURE_FUNCS
-        return func(*_host_args(args, pure), **_host_args(kwargs, pure))
+        return func(*_host_args(args, pure, top=True), **_host_args(kwargs, pure))
 
     ndim = 2
 

@@ -188,7 +188,7 @@ def _collect(directory, names, timeout, what):
             except OSError:
                 pass
             if time.time() - t0 > timeout:
-                raise TransportUnavailable("%s: %s did not appear in %s within %.0f s" % (what, name, directory, timeout))
+                raise RendezvousTimeout("%s: %s did not appear in %s within %.0f s" % (what, name, directory, timeout))
             time.sleep(0.005)
     return out
 
@@ -222,7 +222,13 @@ def _retire(directory, phases, rank, world):
 
 
 class TransportUnavailable(RuntimeError):
-    """RCCL could not be brought up; every rank of the launch raises this together."""
+    """RCCL could not be brought up; every rank of the launch raises this together (the outcome was agreed through
+    the rendezvous, see _agree), so a unanimous fallback is possible."""
+
+
+class RendezvousTimeout(RuntimeError):
+    """A peer's file did not appear in time.  NOT a collective outcome: a dead or late peer is seen by each surviving
+    rank when ITS OWN time-out fires, so nothing may be decided on it -- it is never turned into a fallback."""
 
 
 class FileComm(object):

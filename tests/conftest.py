@@ -81,6 +81,18 @@ def pytest_sessionfinish(session, exitstatus):
               f"allocations between red zones at a time, exit status {int(exitstatus)}")
 
 
+@pytest.fixture
+def device_maps():
+    """tadataka_amd.enable_device_maps() for one test: rust_bindings.semi_dense returns DeviceMaps (the default is
+    plain ndarrays, as the reference returns)."""
+    import tadataka_amd
+    previous = tadataka_amd.enable_device_maps(True)
+    try:
+        yield
+    finally:
+        tadataka_amd.enable_device_maps(previous)
+
+
 @pytest.fixture(scope="session")
 def golden():
     def load(name):

@@ -463,7 +463,7 @@ def _sliding_camera_frames(H, W, n_frames):
     return synthetic.make_track(H, W, n_frames)
 
 
-def test_semi_dense_vo_example_loop_through_rust_bindings(ops, monkeypatch):
+def test_semi_dense_vo_example_loop_through_rust_bindings(ops, monkeypatch, device_maps):
     """The loop body of examples/semi_dense_vo.py (dvo -> Frame -> increment_age -> propagate ->
     update_depth -> refframes.append -> hand the maps over), written with the example's own calls
     and names, on the drop-in packages.  Bit-exact against the oracle chain fed with the same
@@ -641,7 +641,7 @@ def test_update_depth_maps_age_check_without_a_wait(ops):
     assert int(fast[-1][0].max()) == n_frames - 1
 
 
-def test_device_map_behaves_like_an_array(ops):
+def test_device_map_behaves_like_an_array(ops, device_maps):
     """What a caller may do with a returned map: look at it, compute with it, write into it and hand
     it back (the device copy follows), mix it with ndarrays."""
     from rust_bindings.camera import CameraParameters
@@ -664,14 +664,15 @@ def test_device_map_behaves_like_an_array(ops):
     ref1[0, :] = 7
     a2 = increment_age(a1, cp, cp, T10, c["prior_depth"])
     assert np.array_equal(a2, orc.increment_age(ref1, cam, cam, T10, c["prior_depth"]))
-    # eager mode: plain ndarrays
-    import rust_bindings.semi_dense as sd
-    sd.LAZY_MAPS = False
+    # the default (without tadataka_amd.enable_device_maps()): plain ndarrays, as the reference returns
+    import tadataka_amd
+    tadataka_amd.enable_device_maps(False)
     try:
         a3 = increment_age(c["age"], cp, cp, T10, c["prior_depth"])
         assert type(a3) is np.ndarray and np.array_equal(a3, orc.increment_age(c["age"], cam, cam, T10, c["prior_depth"]))
+        assert isinstance(a3, np.ndarray)
     finally:
-        sd.LAZY_MAPS = True
+        tadataka_amd.enable_device_maps(True)
     with pytest.raises(TypeError):
         increment_age(c["age"].astype(np.int64), cp, cp, T10, c["prior_depth"])
 

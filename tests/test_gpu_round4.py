@@ -168,7 +168,7 @@ def _edit_cases():
 
 
 @pytest.mark.parametrize("edit", _edit_cases(), ids=lambda f: f.__name__)
-def test_device_map_edits_reach_update_depth(ops, orc, edit):
+def test_device_map_edits_reach_update_depth(ops, orc, edit, device_maps):
     """Everything that is legal on the ndarray the reference returns -- np.asarray(m)[mask] = x,
     m[a:b][:] = x, m.fill(x), np.copyto(m, ...), views, iteration -- followed by handing the map back
     into update_depth: the result is the oracle's on the edited map."""
@@ -198,11 +198,11 @@ def test_device_map_edits_reach_update_depth(ops, orc, edit):
     assert np.array_equal(f, of) and np.array_equal(d, od) and np.array_equal(v, ov)
 
 
-def test_device_map_escape_tracking(ops, orc, monkeypatch):
-    """A writable reference that is still alive keeps the map `escaped` (every device use re-sends the
-    host copy, so later writes through the reference are seen); once it is gone the map stops
-    uploading; read-only looks (np.array_equal, m.max(), arithmetic) never cost an upload; copies are
-    maps of their own; the caller's ndarray is not aliased."""
+def test_device_map_escape_tracking(ops, orc, monkeypatch, device_maps):
+    """Once a writable reference to the host copy has left the map it is `escaped` for good: every device use
+    re-sends the host copy, so later writes through the reference are seen (no reference counting is consulted:
+    whether the reference is still alive is not knowable portably); read-only looks (np.array_equal, m.max(),
+    arithmetic) never cost an upload; copies are maps of their own; the caller's ndarray is not aliased."""
     import copy
     from rust_bindings.camera import CameraParameters
     from rust_bindings.semi_dense import increment_age
@@ -236,10 +236,10 @@ def test_device_map_escape_tracking(ops, orc, monkeypatch):
     assert np.array_equal(increment_age(a1, cp, cp, T10, depth), orc.increment_age(twin, cam, cam, T10, c["prior_depth"]))
     assert len(uploads) == 2
     del held
-    increment_age(a1, cp, cp, T10, depth)            # one more (the reference was alive at the last check) ...
-    n = len(uploads)
-    increment_age(a1, cp, cp, T10, depth)            # ... and then none
-    assert len(uploads) == n and n <= 3
+    increment_age(a1, cp, cp, T10, depth)            # the map stays escaped: one upload per device use
+    assert len(uploads) == 3
+    import inspect
+    assert "getrefcount" not in inspect.getsource(ops.DeviceMap)
     # copies own their buffer; destroying one leaves the other intact
     b = copy.copy(a1); d = copy.deepcopy(a1)
     assert b._h.value != a1._h.value and d._h.value != a1._h.value
