@@ -12,12 +12,15 @@
  * fixtures (tests/golden/, made by tests/golden/generate_golden.py in the
  * build container) captured from the reference's unmodified Python DVO
  * orchestration and from its sympy-generated Cython transform_project.
- * NOT pinned by any reference output (no Rust toolchain, missing dataset
- * depth maps): the numeric results of semi-dense estimate/update_depth beyond
- * the Rust unit-test literals, and the skimage pyramid (restated twice: plain
- * bilinear and with skimage's default anti-aliasing prefilter, whose Gaussian
- * half IS pinned, against scipy.ndimage) -- "parity unpinned" for those two,
- * see DESIGN.md.
+ * and, since round 5, fixtures captured from the reference's PoseChangeEstimator run
+ * on the REAL scikit-image 0.18.3 (tests/golden/generate_golden_skimage.py under the
+ * build container's /opt/conda interpreter): orc_rescale_skimage is bit-identical with
+ * skimage.transform.rescale given the interpreter-dependent constants it takes as
+ * inputs, the whole coarse-to-fine loop reproduces the reference to 1e-16.
+ * NOT pinned by any reference output (no Rust toolchain, missing dataset depth maps):
+ * the numeric results of semi-dense estimate/update_depth beyond the Rust unit-test
+ * literals and the reference's own flag assertions -- "parity unpinned" for those,
+ * see DESIGN.md 3; and sparseba's damping convention (the package is absent).
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off so that +,-,*,/ and
  * sqrt are evaluated exactly as written, one IEEE rounding each).
