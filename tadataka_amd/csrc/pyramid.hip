@@ -709,6 +709,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     constexpr int RM = RA > RB ? RA : RB;
     constexpr int NL = RB > 0 ? 2 : 1;
     constexpr int K = kStreamK;
+    static_assert(K == 8, "the level-0 row terms are computed by lane & 7");
     extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
     double *ringA = reinterpret_cast<double *>(aa_smem);                    // [Ring][SW]
     const int SW = a.pitch;
@@ -848,14 +849,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const double l0_dc = l0_c - l0_fc;
             const bool l0_left = (int)l0_fc < l0_x;               // taps (x - 1, x)
             const bool l0_right = (int)ceil(l0_c) > l0_x;         // taps (x, x + 1); neither: the position is the pixel itself
+            // the row terms: lane j computes those of row y + j, the rows read them by lane (-0.04 ms of 1.73)
+            const double my_r = axis_pos(a.l0_my, y + (lane & 7));
+            const double my_fr = floor(my_r);
+            const double my_dr = my_r - my_fr;
+            const unsigned up_bits = (unsigned)__ballot((int)my_fr < y + (lane & 7)) & 0xffu;
+            const unsigned down_bits = (unsigned)__ballot((int)ceil(my_r) > y + (lane & 7)) & 0xffu;
 #pragma unroll
             for (int j = 0; j < K; j++) {
                 const int oy = y + j;
                 if (oy >= oy_end0) break;                         // uniform
-                const double r = axis_pos(a.l0_my, oy);
-                const double fr = floor(r);
-                const double dr = r - fr;
-                const bool up = (int)fr < oy, down = (int)ceil(r) > oy;   // uniform: row taps (y - 1, y) / (y, y + 1) / y
+                const double dr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_dr), j),
+                                                   __builtin_amdgcn_readlane(__double2loint(my_dr), j));
+                const bool up = (up_bits >> j) & 1u, down = (down_bits >> j) & 1u;   // uniform: row taps (y - 1, y) / (y, y + 1) / y
                 const double a0 = up ? w[j + RM - 1] : w[j + RM];
                 const double a1 = down ? w[j + RM + 1] : w[j + RM];
                 // (both shifts unconditionally: DPP reads its source lanes under the current EXEC mask)

@@ -20,7 +20,14 @@ if case == "ideal":
 else:
     batch.set_skimage_pyramid(level0=["D0"] if case == "skimage_d0" else "all", clip=case != "skimage_noclip")
 batch.fill_synthetic(cam, poses, seed0=0)
+import time
+for _ in range(5):
+    batch.build_pyramid()
+_lib.call("tdk_sync")
+t0 = time.perf_counter()
 for _ in range(n):
     batch.build_pyramid()
 _lib.call("tdk_sync")
+if len(sys.argv) > 3:
+    print(f"{(time.perf_counter() - t0) / n * 1e3:.3f} ms per build")
 batch.close()
