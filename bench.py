@@ -34,6 +34,7 @@ sampler sees the run) and ms_per_step is the mean over all timed steps.
 One JSON line on stdout (rank 0).
 """
 import argparse
+import ctypes as C
 import json
 import math
 import os
@@ -898,6 +899,7 @@ def main():
     work_px = [0, 0]          # source pixels of PhotometricError evaluations / of pose updates (device counters)
     pair0_pose = [None]
     gather = sharding.PoseGather(B, comm)
+    gather_host_s = [0.0]     # host time in finish() of the previous step's gather + start() of this one's
     batches[0].build_pyramid()
 
     def step():
@@ -917,8 +919,10 @@ def main():
         # the only exchange: the recovered poses, all-gathered (RCCL over xGMI) from where the
         # device loop left them.  The gather of this step is queued now and collected after the
         # next step's estimation (flush() collects the last one inside the timed region).
+        t_g = time.perf_counter()
         previous = gather.finish() if gather.pending else None
         gather.start(poses, cur)
+        gather_host_s[0] += time.perf_counter() - t_g
         return previous, px, k % n_batches
 
     def fence():
@@ -933,6 +937,7 @@ def main():
     for bt in batches:
         bt.set_profiling(True)
     work_px[0] = work_px[1] = 0
+    gather_host_s[0] = 0.0
 
     def timed_block():
         fence()
@@ -1004,6 +1009,13 @@ def main():
                                      "k_rescale_aa_multi for anti-aliased levels), host-timed over %d builds" % n_builds,
                                      bytes_note="compulsory traffic: 3 arrays x (frame read once + levels written), "
                                                 "+ one frame written per array whose level 0 is a rescale of its own")
+    # which device every rank ran on (a one-hot sum: rank r contributes its HIP device index at position r)
+    dev = C.c_int()
+    _lib.call("tdk_get_device", C.byref(dev))
+    onehot = np.zeros(world)
+    onehot[rank] = float(dev.value)
+    rank_devices = [int(v) for v in sharding.reduce_scalars(onehot, "sum", comm)]
+    gather_us_max = float(sharding.reduce_scalars([gather_host_s[0] / max(total_steps, 1) * 1e6], "max", comm)[0])
     pixels_all, error_px_all, update_px_all = (float(v) for v in sharding.reduce_scalars(
         [float(pixels), float(work_px[0]), float(work_px[1])], "sum", comm))
 
@@ -1086,6 +1098,9 @@ def main():
             "dvo_iterations_per_pair_per_step": pixels / total_steps / B / (H * W),
             "max_translation_error": t_err,
             "rccl_ranks": world if (world > 1 and comm.kind == "rccl") else 0,
+            "rank_devices": rank_devices,     # HIP device index of rank 0, 1, ... (one process per GPU: all different)
+            "device_name": _lib.device_name(),
+            "pose_gather_host_us_per_step": gather_us_max,   # finish(step k - 1) + start(step k), max over ranks
             "exchange": {"rccl": "ncclAllGather of the device-resident poses (tdk_comm, C ABI)",
                          "file": "files in TMPDIR -- %s" % comm_error,
                          "local": "none (one process)"}[comm.kind],
