@@ -546,6 +546,8 @@ __device__ __forceinline__ void eval_body(const LevelPtrs &L, const PairParams *
 
 enum { MODE_FULL0 = 0, MODE_PROBE = 1, MODE_FULLK = 2, MODE_FUSED = 3 };   // what a pair's next evaluation is (reduce_pair)
 
+// (forcing four waves per SIMD -- amdgpu_waves_per_eu(4, 4): 128 VGPRs, 116 bytes of scratch per lane in the
+// pipeline -- makes a full-resolution launch 3.30 ms instead of 0.56: measured in round 5, not kept)
 template <int WMODE>
 __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairParams *__restrict__ params,
                                                         const double *__restrict__ poses,
