@@ -131,6 +131,26 @@ def main():
                    "source": os.path.basename(root.rstrip("/"))},
                   open(os.path.join(root, "pmc_dvo_eval.json"), "w"), indent=1)
 
+    # the pyramid kernel (round 5: the largest single kernel of a step)
+    pf = [(k, v) for k, v in fetch.items() if k[0].startswith("k_pyramid_stream")]
+    pw = [(k, v) for k, v in write.items() if k[0].startswith("k_pyramid_stream")]
+    if pf and pw:
+        f_ = mean([x for _, v in pf for x in v["FETCH_SIZE"]])
+        w_ = mean([x for _, v in pw for x in v["WRITE_SIZE"]])
+        moved = (2.0 * f_ + w_) * 1024.0
+        durs = [x for sub in ("trace_single",) for (n, g), d in trace_by_grid(root, sub).items()
+                if n.startswith("k_pyramid_stream") for x in d]
+        t = mean(durs) * 1e-9 if durs else float("nan")
+        levels_px = 480 * 640 + 320 * 427 + 213 * 284
+        algo = 8.0 * 256 * 3 * (480 * 640 + levels_px)     # frame read once; level 0, 1, 2 written
+        print(f"\n== k_pyramid_stream (256 pairs x 3 arrays, levels 0 / 1 / 2 in one pass), alone ==")
+        print(f"FETCH_SIZE raw {f_:.0f} KiB  WRITE_SIZE raw {w_:.0f} KiB -> {moved/1e9:.3f} GB moved per launch; "
+              f"compulsory {algo/1e9:.3f} GB ({moved/algo:.2f}x); {t*1e6:.0f} us per launch = "
+              f"{algo/t/1e9:.0f} GB/s algorithmic = {algo/t/8e12:.3f} of the 8 TB/s HBM peak")
+        out["pyramid_stream"] = {"hbm_bytes_per_launch": moved, "algorithmic_bytes": algo, "avg_us_alone": t * 1e6,
+                                 "frac_of_hbm_peak": algo / t / 8e12}
+
+
     for sub in ("pmc_sq", "pmc_sq2"):
         d = pmc_by_grid(root, sub)
         ev = sorted([(k, v) for k, v in d.items() if k[0].startswith("k_dvo_eval")], key=lambda kv: -kv[0][1])   # full evaluations
