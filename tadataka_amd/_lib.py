@@ -6,6 +6,7 @@ calls the test oracle.
 """
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtadataka_hip.so")
@@ -202,8 +203,15 @@ def check(status):
     raise TdkError(status, msg)
 
 
+# The C library is not thread-safe (one stream and grow-only scratch pools for the stateless entries, handles that
+# must not be used from two threads at once) and ctypes releases the GIL around every foreign call: this lock
+# serialises the calls of all Python threads of the process, status word and tdk_last_error() included.
+_call_lock = threading.RLock()
+
+
 def call(name, *args):
-    check(getattr(load(), name)(*args))
+    with _call_lock:
+        check(getattr(load(), name)(*args))
 
 
 def device_count():
