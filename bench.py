@@ -448,7 +448,9 @@ def workload_dvo_720p(args):
     err1 = np.linalg.norm(P[:, 9:] - truth[:, 9:], axis=1)
     kernel_ms = prof["total_ms"] / max(prof["launches"], 1)
     return {"config": "BASELINE configs[3], one GPU's shard: 64 pairs of 1280x720, 1 level, max_iter 2, "
-                      f"weights={args.weights}, inputs generated on the device",
+                      f"weights={args.weights}, inputs generated on the device and resident: re-estimation at one level "
+                      "(_PoseChangeEstimator), no rescale in the loop -- `--config cfg4` times the same shard with the "
+                      "reference's rescale(., 1.0) of every new frame in the step",
             "value": px / dt / 1e6, "unit": "Mpx/s per DVO iter", "ms_per_step": dt / steps * 1e3,
             "frame_pairs_per_s": B * steps / dt,
             "median_translation_error_ratio": float(np.median(err1 / err0)),
