@@ -546,8 +546,12 @@ __device__ __forceinline__ void eval_body(const LevelPtrs &L, const PairParams *
 
 enum { MODE_FULL0 = 0, MODE_PROBE = 1, MODE_FULLK = 2, MODE_FUSED = 3 };   // what a pair's next evaluation is (reduce_pair)
 
-// (forcing four waves per SIMD -- amdgpu_waves_per_eu(4, 4): 128 VGPRs, 116 bytes of scratch per lane in the
-// pipeline -- makes a full-resolution launch 3.30 ms instead of 0.56: measured in round 5, not kept)
+// Occupancy is not what limits this kernel (round 5, both measured on the bench batch and not kept):
+//   * forcing four waves per SIMD (amdgpu_waves_per_eu(4, 4): 128 VGPRs, 116 bytes of scratch per lane in the
+//     pipeline) makes a full-resolution launch 3.30 ms instead of 0.553;
+//   * 14 of the 21 H accumulators in LDS instead of registers ([14][256] doubles per block, ds_add_f64 of the
+//     rounded product -- the LDS pipe is otherwise idle): 127 VGPRs without scratch, 38 KB of LDS, four waves per
+//     SIMD -- 0.560 ms against 0.553.  The fourth wave finds no free issue slots: FP64 issue at the power cap.
 template <int WMODE>
 __global__ __launch_bounds__(kBlock) void k_dvo_eval(LevelPtrs L, const PairParams *__restrict__ params,
                                                         const double *__restrict__ poses,
