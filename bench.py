@@ -1011,6 +1011,32 @@ def main():
                                      "k_rescale_aa_multi for anti-aliased levels), host-timed over %d builds" % n_builds,
                                      bytes_note="compulsory traffic: 3 arrays x (frame read once + levels written), "
                                                 "+ one frame written per array whose level 0 is a rescale of its own")
+    # The same step with the other pyramid readings, a few steps each, AFTER the headline (every rank: step() holds
+    # the collective): what the reference's level 0 + clip cost, and the reading rounds 1-4 measured.
+    alt_pyramids = {}
+    pair0_headline = None if pair0_pose[0] is None else pair0_pose[0].copy()
+    if skimage_mode and not args.no_solo_pass:
+        for label in ("skimage-depth-level0", "ideal"):
+            for bt in batches:
+                bt.set_profiling(False)
+                if label == "ideal":
+                    bt.set_ideal_pyramid()
+                else:
+                    bt.set_skimage_pyramid(fixture_plans, level0=["D0"])
+            for _ in range(max(2, args.warmup)):
+                step()
+            if gather.pending:
+                gather.finish()
+            n_alt = max(4, min(args.steps, 20))
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(n_alt):
+                step()
+            if gather.pending:
+                gather.finish()
+            fence()
+            dt_alt = float(sharding.reduce_scalars([time.perf_counter() - t0], "max", comm)[0])
+            alt_pyramids[label] = {"ms_per_step": dt_alt / n_alt * 1e3, "steps": n_alt}
     # which device every rank ran on (a one-hot sum: rank r contributes its HIP device index at position r)
     dev = C.c_int()
     _lib.call("tdk_get_device", C.byref(dev))
@@ -1113,12 +1139,18 @@ def main():
             out["roofline_fp64"] = rf
         if pyramid_alone:
             out["pyramid_roofline"] = pyramid_alone
+        if alt_pyramids:
+            alt_pyramids["note"] = ("the same step, same batches, after the timed region: 'skimage-depth-level0' = level 0 of "
+                                    "its own for the depth map only (poses identical to 1e-16, DESIGN.md 3); 'ideal' = ideal "
+                                    "sample positions, level 0 = the frame, no clip (what rounds 1-4 measured: "
+                                    "BENCH_r04 2.73 ms)")
+            out["other_pyramid_readings"] = alt_pyramids
 
-        if golden is not None and pair0_pose[0] is not None:
+        if golden is not None and pair0_headline is not None:
             from scipy.spatial.transform import Rotation
             tag = ("v3_" if skimage_mode else ("pyr_aa_" if anti_aliasing else "pyr_")) + str(weights)
             if f"{tag}_t" in golden:
-                p0 = pair0_pose[0]                      # pair 0 of batch 0, from the last step that ran it
+                p0 = pair0_headline                     # pair 0 of batch 0, from the last headline step that ran it
                 err = max(float(np.max(np.abs(p0[:9].reshape(3, 3) -
                                               Rotation.from_rotvec(golden[f"{tag}_rotvec"]).as_matrix()))),
                           float(np.max(np.abs(p0[9:] - golden[f"{tag}_t"]))))
