@@ -55,7 +55,9 @@ tdk_status tdk_sync(void);
 /* Library-wide options (the stateless entries and every handle read them at each call).
  *   TDK_OPT_PYRAMID_STREAM   which kernel builds the first two shrinking pyramid levels: 1 (default) the streaming
  *                            kernel for batches that fill the chip (>= 256 full-height strips), LDS tiles otherwise;
- *                            0 always the tiles; 2 always the streaming kernel.  Bit-identical either way.
+ *                            0 always the tiles; 2 always the streaming kernel; 3 as 1, but level 0 by the streaming
+ *                            kernel of its own that one-level pyramids use (k_level0_stream) instead of fused into the
+ *                            pass over the source (same time on the bench batch).  Bit-identical either way.
  *   TDK_OPT_SD_WARP_GATHER   increment_age / propagate: 1 (default) the gather kernels, with the slot path as the
  *                            device-side fallback of tracks whose displacement box exceeds the gather's window;
  *                            0 the slot path for every track.  Bit-identical either way. */

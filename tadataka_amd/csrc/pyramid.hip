@@ -640,6 +640,90 @@ __device__ __forceinline__ double from_right_lane(double x) {
     return __hiloint2double(hi, lo);
 }
 
+// ---------------------------------------------------------------------------
+// The identity-scale level as a streaming kernel of its own (batches whose other levels do not go through
+// k_pyramid_stream: one-level pyramids such as BASELINE configs[3]).  A wave owns 62 columns (lanes 1 .. 62; lanes
+// 0 and 63 carry the neighbour columns, reflected at the image border) and walks down a segment of 64 rows with the
+// rows y - 1, y, y + 1 of its columns in registers: every pixel is loaded once (8 rows ahead), the neighbour column
+// comes by DPP, no LDS, no barrier.  Same operations as k_level0_rows / k_rescale_generic: bit-identical.
+// ---------------------------------------------------------------------------
+constexpr int kL0Cols = 62, kL0Seg = 64, kL0Ahead = 8;
+
+__global__ __launch_bounds__(256) void k_level0_stream(Level0Args a) {
+    const int H = a.H, W = a.W;
+    const int strips = (W + kL0Cols - 1) / kL0Cols, sblocks = (strips + 3) >> 2, segs = (H + kL0Seg - 1) / kL0Seg;
+    const int per_image = sblocks * segs;
+    const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+    const int images = a.n_arrays * a.batch;
+    const int image = (q / per_image) * 8 + xcd, part = q - (q / per_image) * per_image;
+    if (image >= images) return;
+    const int pair = image / a.n_arrays, arr = image - pair * a.n_arrays;
+    const int seg = part / sblocks, sb = part - seg * sblocks;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int strip = sb * 4 + wave;
+    if (strip >= strips) return;                                  // wave-uniform
+    const int x = strip * kL0Cols - 1 + lane;                     // this lane's column (before reflection)
+    const bool own = lane >= 1 && lane <= kL0Cols && x < W;
+    const unsigned xcol = (unsigned)skimage_reflect(min(x, W + 1), W);
+    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    double *d = a.dst[arr] + (int64_t)pair * a.dst_stride;
+    ClipSlot *slot = a.slots ? a.slots + ((int64_t)pair * a.n_arrays + arr) * a.n_out + a.lvl : nullptr;
+    ClipTrack tr;
+    tr.init();
+    // column terms
+    const double c = axis_pos(a.mx, x);
+    const double fc = floor(c);
+    const double dc = c - fc;
+    const bool left = (int)fc < x, right = (int)ceil(c) > x;      // taps (x - 1, x) / (x, x + 1) / x itself
+    // row terms of the segment: lane j computes those of row y0 + j
+    const int y0 = seg * kL0Seg, y1 = min(y0 + kL0Seg, H);
+    const double my_r = axis_pos(a.my, y0 + lane);
+    const double my_fr = floor(my_r);
+    const double my_dr = my_r - my_fr;
+    const unsigned long long up_bits = __ballot((int)my_fr < y0 + lane);
+    const unsigned long long down_bits = __ballot((int)ceil(my_r) > y0 + lane);
+    // window: w[i] = row y - 1 + i for the group of kL0Ahead rows that starts at y
+    double w[kL0Ahead + 2], nxt[kL0Ahead];
+#pragma unroll
+    for (int i = 0; i < kL0Ahead + 2; i++) w[i] = s[(int64_t)skimage_reflect(y0 - 1 + i, H) * W + xcol];
+    for (int y = y0; y < y1; y += kL0Ahead) {
+        if (y + kL0Ahead < y1) {                                  // the next group's rows y + 9 .. y + 16
+#pragma unroll
+            for (int i = 0; i < kL0Ahead; i++)
+                nxt[i] = s[(int64_t)skimage_reflect(y + kL0Ahead + 1 + i, H) * W + xcol];
+        }
+#pragma unroll
+        for (int j = 0; j < kL0Ahead; j++) {
+            const int oy = y + j;
+            if (oy >= y1) break;                                  // uniform
+            const int k = oy - y0;
+            const double dr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_dr), k),
+                                               __builtin_amdgcn_readlane(__double2loint(my_dr), k));
+            const bool up = (up_bits >> k) & 1ull, down = (down_bits >> k) & 1ull;   // uniform
+            const double a0 = up ? w[j] : w[j + 1];
+            const double a1 = down ? w[j + 2] : w[j + 1];
+            const double l0v = from_left_lane(a0), r0v = from_right_lane(a0);
+            const double l1v = from_left_lane(a1), r1v = from_right_lane(a1);
+            const double n0 = left ? l0v : r0v, n1 = left ? l1v : r1v;
+            const double f00 = left ? n0 : a0, f01 = right ? n0 : a0;
+            const double f10 = left ? n1 : a1, f11 = right ? n1 : a1;
+            const double top = (1.0 - dc) * f00 + dc * f01;
+            const double bot = (1.0 - dc) * f10 + dc * f11;
+            const double v = (1.0 - dr) * top + dr * bot;
+            if (own) {
+                d[(int64_t)oy * W + x] = v;
+                if (slot) tr.add(slot, v, f00, f01, f10, f11);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++) w[i] = w[kL0Ahead + i];
+#pragma unroll
+        for (int i = 0; i < kL0Ahead; i++) w[2 + i] = nxt[i];
+    }
+    if (slot) tr.flush(slot);
+}
+
 template <int R>
 __device__ __forceinline__ double stream_vtap(const double *w, int c, const double (&wk)[R + 1]) {
     double tmp = w[c] * wk[R];
@@ -1153,6 +1237,7 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
                 };
                 if (near_identity(dv[l].mx, W) && near_identity(dv[l].my, H)) l0 = l;
             }
+            if (stream_mode == 3) l0 = -1;                        // (experiment: level 0 by k_level0_stream)
             if (l0 >= 0) {
                 for (int i = 0; i < 4; i++) sa.l0_dst[i] = dv[l0].dst[i];
                 sa.l0_stride = dv[l0].stride; sa.l0_mx = dv[l0].mx; sa.l0_my = dv[l0].my; sa.l0_lvl = l0;
@@ -1212,10 +1297,20 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
         a.src_stride = src_stride; a.dst_stride = dv[l].stride; a.H = H; a.W = W;
         a.n_arrays = n_arrays; a.batch = batch; a.lvl = l; a.n_out = n_out;
         a.mx = dv[l].mx; a.my = dv[l].my; a.slots = slots;
-        const int64_t per_image = (int64_t)((W + 63) / 64) * ((H + 4 * kL0Rows - 1) / (4 * kL0Rows));
-        const int64_t blocks = (images < 8 ? images : 8 * ((images + 7) / 8)) * per_image;
-        if (blocks >= (1ll << 31)) { set_error("level 0: grid too large"); return TDK_ERR_INVALID_ARGUMENT; }
-        k_level0_rows<<<(unsigned)blocks, 256, 0, stream>>>(a);
+        auto near_identity = [](const AxisMap &m, int n) {
+            return fabs(axis_pos(m, 0)) < 0.5 && fabs(axis_pos(m, n - 1) - (double)(n - 1)) < 0.5;
+        };
+        const int64_t per_image_s = (int64_t)(((W + kL0Cols - 1) / kL0Cols + 3) / 4) * ((H + kL0Seg - 1) / kL0Seg);
+        if (images * per_image_s >= 1024 && W >= 3 && H >= 3 && near_identity(a.mx, W) && near_identity(a.my, H)) {
+            const int64_t blocks = 8 * ((images + 7) / 8) * per_image_s;
+            if (blocks >= (1ll << 31)) { set_error("level 0: grid too large"); return TDK_ERR_INVALID_ARGUMENT; }
+            k_level0_stream<<<(unsigned)blocks, 256, 0, stream>>>(a);
+        } else {
+            const int64_t per_image = (int64_t)((W + 63) / 64) * ((H + 4 * kL0Rows - 1) / (4 * kL0Rows));
+            const int64_t blocks = (images < 8 ? images : 8 * ((images + 7) / 8)) * per_image;
+            if (blocks >= (1ll << 31)) { set_error("level 0: grid too large"); return TDK_ERR_INVALID_ARGUMENT; }
+            k_level0_rows<<<(unsigned)blocks, 256, 0, stream>>>(a);
+        }
         TDK_LAUNCH_CHECK();
         done[l] = true;
     }

@@ -243,7 +243,7 @@ tdk_status tdk_sync(void) {
 
 tdk_status tdk_set_option(int option, int value) {
     TDK_REQUIRE(option == TDK_OPT_PYRAMID_STREAM || option == TDK_OPT_SD_WARP_GATHER, "unknown option");
-    TDK_REQUIRE(value >= 0 && value <= (option == TDK_OPT_PYRAMID_STREAM ? 2 : 1), "value out of range");
+    TDK_REQUIRE(value >= 0 && value <= (option == TDK_OPT_PYRAMID_STREAM ? 3 : 1), "value out of range");
     tdk::g_options[option] = value;
     return TDK_OK;
 }

@@ -23,7 +23,8 @@ _lib.require_gpu()
 cam = synthetic.camera_for(W, H)
 poses = np.tile(ops.pose12(np.eye(3), np.zeros(3)), (B, 1))
 CASES = (("ideal / tiles", "0", None), ("ideal / stream", "1", None), ("skimage D0", "1", (["D0"], True)),
-         ("skimage all", "1", ("all", True)), ("skimage noclip", "1", ("all", False)))
+         ("skimage all", "1", ("all", True)), ("skimage noclip", "1", ("all", False)),
+         ("skimage all, L0 own kernel", "3", ("all", True)), ("skimage noclip, L0 own", "3", ("all", False)))
 for rep in range(2):
     for name, stream, sk in CASES:
         ops.set_option("pyramid_stream", int(stream))
@@ -45,6 +46,6 @@ for rep in range(2):
         px = B * 3 * H * W
         out = sum(B * 3 * int(round(H / 1.5 ** l)) * int(round(W / 1.5 ** l)) for l in range(1, L))
         out += B * bin(batch.level0_mask & 7).count("1") * H * W
-        print(f"{name:16s}: {dt * 1e3:.3f} ms per build, {(px + out) * 8 / dt / 1e12:.2f} TB/s of compulsory traffic "
+        print(f"{name:28s}: {dt * 1e3:.3f} ms per build, {(px + out) * 8 / dt / 1e12:.2f} TB/s of compulsory traffic "
               f"({(px + out) * 8 / 1e9:.2f} GB)", flush=True)
         batch.close()
