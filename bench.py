@@ -1142,8 +1142,8 @@ def main():
         if alt_pyramids:
             alt_pyramids["note"] = ("the same step, same batches, after the timed region: 'skimage-depth-level0' = level 0 of "
                                     "its own for the depth map only (poses identical to 1e-16, DESIGN.md 3); 'ideal' = ideal "
-                                    "sample positions, level 0 = the frame, no clip (what rounds 1-4 measured: "
-                                    "BENCH_r04 2.73 ms)")
+                                    "sample positions, level 0 = the frame, no clip (what rounds 1-4 measured" +
+                                    (": BENCH_r04 2.73 ms)" if is_cfg2 else ")"))
             out["other_pyramid_readings"] = alt_pyramids
 
         if golden is not None and pair0_headline is not None:
