@@ -76,3 +76,32 @@ def test_argument_validation_needs_no_gpu(lib):
     assert h.tdk_calc_depth0(T, x0, x1, C.byref(d)) == 0
     from oracle import oracle as orc
     assert d.value == orc.calc_depth0(np.array(T).reshape(4, 4), [0.1, 0.2], [0.3, 0.2])
+
+
+def test_round5_entries_validate_their_arguments_without_a_gpu(lib):
+    """tdk_rescale_skimage / tdk_set_option / tdk_ba_create_ex reject bad arguments before they touch a device."""
+    import ctypes as C
+    h = lib.load()
+    img = np.zeros((4, 5))
+    out = np.zeros((2, 3))
+    m = np.array([2.0, 0.5, 2.0, 0.5])
+    w = np.ones(2 * 65 + 1)
+    dp = C.POINTER(C.c_double)
+    p = lambda a: a.ctypes.data_as(dp)      # noqa: E731
+    # kernel radius beyond the 64 the kernels hold
+    assert h.tdk_rescale_skimage(p(img), 4, 5, p(out), 2, 3, p(m), p(w), 65, None, 0, 1) == lib.TDK_ERR_INVALID_ARGUMENT
+    # a map whose scale is not positive
+    bad = np.array([0.0, 0.5, 2.0, 0.5])
+    assert h.tdk_rescale_skimage(p(img), 4, 5, p(out), 2, 3, p(bad), None, 0, None, 0, 1) == lib.TDK_ERR_INVALID_ARGUMENT
+    assert h.tdk_rescale_skimage(None, 4, 5, p(out), 2, 3, p(m), None, 0, None, 0, 1) == lib.TDK_ERR_INVALID_ARGUMENT
+    assert h.tdk_set_option(7, 1) == lib.TDK_ERR_INVALID_ARGUMENT
+    assert h.tdk_set_option(0, 9) == lib.TDK_ERR_INVALID_ARGUMENT
+    assert h.tdk_set_option(0, 1) == 0 and h.tdk_set_option(1, 1) == 0
+    vp = np.zeros(3, dtype=np.int64); pt = np.arange(3, dtype=np.int64); xt = np.zeros((3, 2))
+    hd = C.c_void_p()
+    i64p = C.POINTER(C.c_int64)
+    assert h.tdk_ba_create_ex(1, 3, vp.ctypes.data_as(i64p), pt.ctypes.data_as(i64p), p(xt), 3, 16, C.byref(hd)) \
+        == lib.TDK_ERR_INVALID_ARGUMENT
+    assert b"option" in h.tdk_last_error()
+    n = C.c_int(5)
+    assert h.tdk_debug_check_canaries(C.byref(n)) == 0 and n.value in (-1, 0)   # off (or on with nothing allocated)
