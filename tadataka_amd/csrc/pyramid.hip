@@ -789,7 +789,7 @@ __device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *_
 }
 
 template <int RA, int RB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_pyramid_stream(StreamArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k_pyramid_stream(StreamArgs a) {
     constexpr int RM = RA > RB ? RA : RB;
     constexpr int NL = RB > 0 ? 2 : 1;
     constexpr int K = kStreamK;
