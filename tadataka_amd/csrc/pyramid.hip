@@ -600,7 +600,8 @@ __device__ __forceinline__ int first_owned(int s0, const AxisMap &m, int n_out) 
 // ---------------------------------------------------------------------------
 constexpr int kStreamK = 8;                       // source rows per chunk
 constexpr int kStreamRing = kStreamK + 2;         // V rows per level ring (>= K + 2; < 2 K + 1: a second barrier per chunk)
-constexpr int kStreamMaxGroups = 3;               // 64-column groups of outputs per strip and level (checked on the host)
+constexpr int kStreamGroupsA = 3;                 // 64-column groups of outputs per strip: radius 1 (factor >= 1.25; checked on
+constexpr int kStreamGroupsB = 2;                 // the host), radius 3 (factor >= 2.25: at most 110 outputs per 248 columns)
 
 struct StreamLevel {
     double *dst[4];
@@ -733,12 +734,12 @@ __device__ __forceinline__ double stream_vtap(const double *w, int c, const doub
 }
 
 // the horizontal pass + blend of one level for the output rows [oy_lo, oy_hi) of this chunk
-template <int R>
+template <int R, int G>
 __device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *__restrict__ ring, int SW, double *dst,
                                            int oy_lo, int oy_end, int ynew, int ya, int n_groups,
                                            int ncols, int ox_first,
-                                           const int (&xoff)[kStreamMaxGroups],
-                                           const double (&wxs)[kStreamMaxGroups], const double (&wck)[R + 1],
+                                           const int (&xoff)[G],
+                                           const double (&wxs)[G], const double (&wck)[R + 1],
                                            int wave, int lane, int &unit, ClipTrack &tr, ClipSlot *slot) {
     // the row terms of the next rows: lane i computes those of row oy_lo + i, the rows read them by lane;
     // the rows to emit now are those whose lower tap y0 + 1 is in the ring (a prefix: y0 is monotone)
@@ -754,7 +755,7 @@ __device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *_
         const int slot0 = (y0 - ya) % kStreamRing, slot1 = (y0 + 1 - ya) % kStreamRing;
         double *dst_row = dst + (int64_t)(oy_lo + i) * L.Wo + ox_first;   // uniform base, the lane is the offset
 #pragma unroll
-        for (int g = 0; g < kStreamMaxGroups; g++) {
+        for (int g = 0; g < G; g++) {
             if (g >= n_groups) break;
             const bool mine = ((unit++) & 3) == wave;             // units dealt round-robin to the waves
             if (!mine) continue;
@@ -822,10 +823,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     // group the lane's left tap as a ring column and its blend weight
     double wkA[RA + 1], wckA[RA + 1];
     double wkB[RB + 1], wckB[RB + 1];
-    int oxA0, ncolsA, ngA, xoffA[kStreamMaxGroups];
-    double wxA[kStreamMaxGroups];
-    int oxB0 = 0, ncolsB = 0, ngB = 0, xoffB[kStreamMaxGroups];
-    double wxB[kStreamMaxGroups];
+    int oxA0, ncolsA, ngA, xoffA[kStreamGroupsA];
+    double wxA[kStreamGroupsA];
+    int oxB0 = 0, ncolsB = 0, ngB = 0, xoffB[kStreamGroupsB];
+    double wxB[kStreamGroupsB];
     {
         const StreamLevel &L = a.lv[0];
 #pragma unroll
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         ncolsA = (xb >= W ? L.Wo : first_owned(xb, L.mx, L.Wo)) - oxA0;
         ngA = (ncolsA + 63) >> 6;
 #pragma unroll
-        for (int g = 0; g < kStreamMaxGroups; g++) {
+        for (int g = 0; g < kStreamGroupsA; g++) {
             const double cx = axis_pos(L.mx, oxA0 + g * 64 + lane);
             const double fx0 = floor(cx);
             wxA[g] = cx - fx0;
@@ -849,7 +850,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         ncolsB = (xb >= W ? L.Wo : first_owned(xb, L.mx, L.Wo)) - oxB0;
         ngB = (ncolsB + 63) >> 6;
 #pragma unroll
-        for (int g = 0; g < kStreamMaxGroups; g++) {
+        for (int g = 0; g < kStreamGroupsB; g++) {
             const double cx = axis_pos(L.mx, oxB0 + g * 64 + lane);
             const double fx0 = floor(cx);
             wxB[g] = cx - fx0;
@@ -918,10 +919,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         __syncthreads();
         // outputs whose lower row tap y0 + 1 is now in the ring: y0 + 1 <= y + K - 1
         const int ynew = y + K - 1 >= y_last ? (1 << 30) : y + K - 1;   // the last chunk emits whatever is left
-        nextA = stream_emit<RA>(a.lv[0], ringA, SW, dstA, nextA, endA, ynew, ya, ngA, ncolsA, oxA0, xoffA, wxA, wckA,
+        nextA = stream_emit<RA, kStreamGroupsA>(a.lv[0], ringA, SW, dstA, nextA, endA, ynew, ya, ngA, ncolsA, oxA0, xoffA, wxA, wckA,
                                 wave, lane, unit, trA, slotA);
         if constexpr (NL > 1)
-            nextB = stream_emit<RB>(a.lv[1], ringB, SW, dstB, nextB, endB, ynew, ya, ngB, ncolsB, oxB0, xoffB, wxB,
+            nextB = stream_emit<RB, kStreamGroupsB>(a.lv[1], ringB, SW, dstB, nextB, endB, ynew, ya, ngB, ncolsB, oxB0, xoffB, wxB,
                                     wckB, wave, lane, unit, trB, slotB);
         if (do_l0) {
             const int oy_end0 = min(yb, H);                       // this block's level-0 rows: those of its segment
@@ -1260,12 +1261,12 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
             }
             if (nl == 1) lds += sizeof(double) * kStreamRing * sa.pitch;      // (ringB's place: the border columns sit behind it)
             lds += sizeof(double) * (kStreamK + 2) * 8;
-            // outputs per strip must fit the kStreamMaxGroups 64-column groups
+            // outputs per strip must fit the 64-column groups the kernel holds terms for
             bool fits = true;
             for (int k = 0; k < nl; k++) {
                 const AxisMap &m = sa.lv[k].mx;
                 const double step = (axis_pos(m, sa.lv[k].Wo - 1) - axis_pos(m, 0)) / std::max(1, sa.lv[k].Wo - 1);
-                if (!(step > 0.0) || (double)strip_w / step + 2.0 > 64.0 * kStreamMaxGroups) fits = false;
+                if (!(step > 0.0) || (double)strip_w / step + 2.0 > 64.0 * (k == 0 ? kStreamGroupsA : kStreamGroupsB)) fits = false;
                 const AxisMap &my = sa.lv[k].my;
                 const double stepy = (axis_pos(my, sa.lv[k].Ho - 1) - axis_pos(my, 0)) / std::max(1, sa.lv[k].Ho - 1);
                 if (!(stepy > 0.0) || (double)kStreamK / stepy + 2.0 > 64.0) fits = false;
