@@ -2303,6 +2303,7 @@ struct tdk_dvo {
                                 // lv[0] IS the upload)
     unsigned level0_mask;       // bit k: array k (I0, D0, I1, W0) gets rescale(., 1.0) as its level 0
     bool clip;                  // clip=True: outputs clipped to the extremes of the filtered image
+    bool clip_clean;            // the last build left the clip slots reset (few slots: k_clip_small)
     void *d_clip;               // ClipSlot[n_pairs * 4 * n_levels]
     bool weights_dirty;         // the device copy of the kernels is stale (a plan changed)
     int n_cu, device;           // compute units and index of the batch's device
@@ -2889,6 +2890,7 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
     for (int k = 0; k < 4; k++) h->raw[k] = nullptr;
     h->level0_mask = 0u;
     h->clip = false;
+    h->clip_clean = false;
     h->d_clip = nullptr;
     h->weights_dirty = true;
     {
@@ -3163,6 +3165,15 @@ static tdk_status build_pyramid_of(tdk_dvo *h, unsigned arrays) {
     // two groups of arrays: those with a level 0 of their own (sources: the uploads, levels 0 .. n - 1) and the rest
     // (sources: level 0 = the upload, levels 1 .. n - 1); the device kernels are stored per level: slot l of the
     // weight buffer is level l in both groups
+    // (the slots are shared by the two groups: "left clean" is only tracked when a build is one launch group)
+    int n_groups_used = 0;
+    for (int group = 0; group < 2; group++) {
+        int n = 0;
+        for (int k = 0; k < 4; k++)
+            if (((arrays >> k) & 1u) && (((h->level0_mask >> k) & 1u) != 0) == (group == 0)) n++;
+        if (n > 0 && h->n_levels - (group == 0 ? 0 : 1) > 0) n_groups_used++;
+    }
+    if (n_groups_used != 1) h->clip_clean = false;
     for (int group = 0; group < 2; group++) {
         int sel[4], n_sel = 0;
         for (int k = 0; k < 4; k++) {
@@ -3180,7 +3191,8 @@ static tdk_status build_pyramid_of(tdk_dvo *h, unsigned arrays) {
         for (int l = first; l < h->n_levels; l++) describe(l, sel, n_sel, &lv[l - first]);
         double *weights = h->d_aa_weights + tdk::pyramid_weight_doubles(first);
         TDK_TRY(tdk::launch_pyramid(srcs, n_sel, S.H, S.W, S.stride, n_out, lv, h->n_pairs, weights, h->weights_dirty,
-                                    h->clip ? h->d_clip : nullptr, use_stream, h->stream));
+                                    h->clip ? h->d_clip : nullptr, use_stream, h->stream,
+                                    n_groups_used == 1 ? &h->clip_clean : nullptr));
     }
     h->weights_dirty = false;
     return TDK_OK;

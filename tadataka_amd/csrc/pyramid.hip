@@ -152,15 +152,19 @@ __device__ __forceinline__ bool clip_needed(const ClipSlot &s) {
 // behind the n slots: an int counter and the list of flagged slots (k_clip_gate)
 __device__ __forceinline__ int *clip_list(ClipSlot *slots, int n) { return reinterpret_cast<int *>(slots + n); }
 
-__global__ void k_clip_reset(ClipSlot *slots, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) clip_list(slots, n)[0] = 0;
-    if (i >= n) return;
+__device__ __forceinline__ void clip_slot_clear(ClipSlot *slot) {
     ClipSlot s;
     s.out_max = 0ull; s.tap_max = 0ull; s.hi = 0ull;
     s.out_min = ~0ull; s.tap_min = ~0ull; s.lo = ~0ull;
     s.nan_out = 0u; s.nan_img = 0u;
-    slots[i] = s;
+    *slot = s;
+}
+
+__global__ void k_clip_reset(ClipSlot *slots, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) clip_list(slots, n)[0] = 0;
+    if (i >= n) return;
+    clip_slot_clear(slots + i);
 }
 
 struct AaLevel {
@@ -1095,6 +1099,75 @@ __global__ __launch_bounds__(256) void k_clip_apply(ClipArgs a) {
     }
 }
 
+// Few slots (a single pair: 3 images x 3 levels): gate, bounds and clip in ONE launch, a block per slot -- a flagged
+// slot's block walks the whole source image by itself (rare, and then a few hundred microseconds); the three
+// launches above cost a single-pair call 10 us more than this one.
+__global__ __launch_bounds__(256) void k_clip_small(ClipArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char aa_smem[];
+    __shared__ double red_max[4], red_min[4];
+    __shared__ int red_nan[4];
+    const int si = blockIdx.x;
+    ClipSlot *slot = a.slots + si;
+    if (!clip_needed(*slot)) {                                     // block-uniform
+        if (threadIdx.x == 0) clip_slot_clear(slot);               // left clean for the next build (no reset launch)
+        return;
+    }
+    const int image = si / a.n_out, l = si - image * a.n_out;
+    const int pair = image / a.n_arrays, arr = image - pair * a.n_arrays;
+    const DevLevel &L = a.lv[l];
+    const int H = a.H, W = a.W, Rr = L.aa.Rr, Rc = L.aa.Rc;
+    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    const int tiles_x = (W + kClipTileCols - 1) / kClipTileCols, tiles_y = (H + kClipTileRows - 1) / kClipTileRows;
+    const int SC = kClipTileCols + 2 * Rc;
+    double *V = reinterpret_cast<double *>(aa_smem);
+    double vmax = -INFINITY, vmin = INFINITY;
+    bool nan = false;
+    for (int t = 0; t < tiles_x * tiles_y; t++) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int y0 = ty * kClipTileRows, x0 = tx * kClipTileCols;
+        const int nr = min(kClipTileRows, H - y0), nc = min(kClipTileCols, W - x0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * (nc + 2 * Rc); i += 256) {
+            const int r = i / (nc + 2 * Rc), c = i - r * (nc + 2 * Rc);
+            V[r * SC + c] = column_tap(s, H, W, y0 + r, mirror_idx(x0 - Rc + c, W), L.aa.wr, Rr);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nr * nc; i += 256) {
+            const int r = i / nc, c = i - r * nc;
+            const double *row = V + r * SC + c + Rc;
+            double tmp;
+            if (Rc == 0) tmp = row[0];
+            else {
+                tmp = row[0] * L.aa.wc[Rc];
+                for (int j = -Rc; j < 0; j++) tmp += (row[j] + row[-j]) * L.aa.wc[Rc + j];
+            }
+            vmax = fmax(vmax, tmp);
+            vmin = fmin(vmin, tmp);
+            nan |= tmp != tmp;
+        }
+    }
+    vmax = wave_max(vmax);
+    vmin = wave_min(vmin);
+    const bool any_nan = __ballot(nan) != 0ull;
+    if ((threadIdx.x & 63) == 0) {
+        red_max[threadIdx.x >> 6] = vmax; red_min[threadIdx.x >> 6] = vmin; red_nan[threadIdx.x >> 6] = any_nan;
+    }
+    __syncthreads();
+    const bool img_nan = red_nan[0] | red_nan[1] | red_nan[2] | red_nan[3];
+    // ndarray.min() / .max() of an image with a NaN are NaN, and numpy.clip with a NaN bound returns NaN
+    const double hi = img_nan ? NAN : fmax(fmax(red_max[0], red_max[1]), fmax(red_max[2], red_max[3]));
+    const double lo = img_nan ? NAN : fmin(fmin(red_min[0], red_min[1]), fmin(red_min[2], red_min[3]));
+    double *d = L.dst[arr] + (int64_t)pair * L.stride;
+    const int64_t n = (int64_t)L.Ho * L.Wo;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const double x = d[i];
+        const double m = (x != x || lo != lo) ? NAN : (x > lo ? x : lo);
+        const double v = (m != m || hi != hi) ? NAN : (m < hi ? m : hi);
+        if (__double_as_longlong(v) != __double_as_longlong(x)) d[i] = v;
+    }
+    if (threadIdx.x == 0) clip_slot_clear(slot);
+}
+
 // scipy.ndimage._filters._gaussian_kernel1d (order 0) with libm's exp and a sequential sum: the kernels of a
 // level without a plan (the ideal reading; a plan brings the caller's NumPy kernels)
 void gaussian_weights(double sigma, int radius, double *w) {
@@ -1167,7 +1240,7 @@ int pyramid_max_radius() { return kMaxGaussRadius; }
 // clip=False.  stream_mode: 0 never the streaming kernel, 1 for batches that fill the chip, 2 always.
 tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride, int n_out,
                           const PyramidLevelDesc *levels, int batch, double *weights, bool upload_weights,
-                          void *clip_slots, int stream_mode, hipStream_t stream) {
+                          void *clip_slots, int stream_mode, hipStream_t stream, bool *slots_clean) {
     if (n_out <= 0) return TDK_OK;
     if (n_out > kMaxOut || n_arrays > 4) {
         set_error("pyramid too deep");
@@ -1200,11 +1273,13 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
     }
     ClipSlot *slots = static_cast<ClipSlot *>(clip_slots);
     const int64_t images = (int64_t)n_arrays * batch;
-    if (slots) {
+    // (a build with few slots leaves them clean -- k_clip_small -- so the next one of the same owner needs no reset)
+    if (slots && !(slots_clean && *slots_clean)) {
         const int n = (int)(images * n_out);
         k_clip_reset<<<(n + 255) / 256, 256, 0, stream>>>(slots, n);
         TDK_LAUNCH_CHECK();
     }
+    if (slots_clean) *slots_clean = false;
     auto shrinks = [&](int l) {
         return taps_inside(dv[l].mx, W, dv[l].Wo) && taps_inside(dv[l].my, H, dv[l].Ho);
     };
@@ -1400,12 +1475,18 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
         for (int l = 0; l < n_out; l++) rc_max = std::max(rc_max, dv[l].aa.Rc);
         const size_t lds = sizeof(double) * (size_t)kClipTileRows * (kClipTileCols + 2 * rc_max);
         const int n = (int)(images * n_out);
-        k_clip_gate<<<(n + 255) / 256, 256, 0, stream>>>(slots, n);
-        TDK_LAUNCH_CHECK();
-        k_clip_bounds<<<1024, 256, lds, stream>>>(c);
-        TDK_LAUNCH_CHECK();
-        k_clip_apply<<<1024, 256, 0, stream>>>(c);
-        TDK_LAUNCH_CHECK();
+        if (n <= 64) {
+            k_clip_small<<<n, 256, lds, stream>>>(c);
+            TDK_LAUNCH_CHECK();
+            if (slots_clean) *slots_clean = true;
+        } else {
+            k_clip_gate<<<(n + 255) / 256, 256, 0, stream>>>(slots, n);
+            TDK_LAUNCH_CHECK();
+            k_clip_bounds<<<1024, 256, lds, stream>>>(c);
+            TDK_LAUNCH_CHECK();
+            k_clip_apply<<<1024, 256, 0, stream>>>(c);
+            TDK_LAUNCH_CHECK();
+        }
     }
     return TDK_OK;
 }
@@ -1427,7 +1508,7 @@ tdk_status rescale_host(const double *image, int H, int W, double *out, int Ho, 
     lv.dst[0] = (double *)d_out; lv.dst[1] = lv.dst[2] = lv.dst[3] = nullptr;
     lv.stride = 0; lv.H = Ho; lv.W = Wo;
     TDK_TRY(tdk::launch_pyramid(srcs, 1, H, W, 0, 1, &lv, 1, (double *)d_w, true, d_clip,
-                                tdk::option(TDK_OPT_PYRAMID_STREAM), tdk::stream()));
+                                tdk::option(TDK_OPT_PYRAMID_STREAM), tdk::stream(), nullptr));
     TDK_HIP(hipMemcpyAsync(out, d_out, (size_t)Ho * Wo * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
     return TDK_OK;
