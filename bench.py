@@ -556,13 +556,18 @@ def workload_dvo_stream(args):
     ident = np.tile(ops.pose12(np.eye(3), np.zeros(3)), (B, 1))
     out = {"config": f"BASELINE configs[1] as a stream: {B} pairs per batch, per step the I1 "
                      "frames of the next batch are uploaded from pinned host memory on a copy stream under the "
-                     "current batch's estimation (three batches in flight: upload / pyramid / estimation); 3-level anti-aliased "
-                     "pyramid + estimation as in the headline"}
+                     "current batch's estimation (three batches in flight: upload / pyramid / estimation); pyramid "
+                     f"(--pyramid {args.pyramid}) + estimation as in the headline"}
     n_b = 3     # frames arrive for batch k + 2, the pyramid of batch k + 1 is built, batch k is estimated
     batches = []
     for k in range(n_b):
         bt = ops.DvoBatch(B, H, W, n_levels=3, ratio=1.5)
+        if args.pyramid.startswith("skimage"):
+            bt.set_skimage_pyramid(level0="all" if args.pyramid == "skimage" else ["D0"])
+        else:
+            bt.set_anti_aliasing(args.pyramid != "bilinear")
         bt.fill_synthetic(cam, true_poses(B, k * B), seed0=k * B, noise=0.02)
+        bt.build_pyramid()                                        # (level 0 is a level of the pyramid in skimage mode)
         batches.append(bt)
     # "u8": only what changed is rebuilt (the levels of I1: tdk_dvo_build_pyramid_arrays); "u8_full_pyramid": every
     # array's levels per step as in rounds 2-3 (a consumer that also replaces I0 / D0 per step)
