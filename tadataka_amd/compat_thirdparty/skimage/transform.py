@@ -2,8 +2,10 @@ import numpy as np
 
 from tadataka_amd import ops
 
-# what scikit-image 0.16.2's rescale / resize default to, and all this stand-in implements
-_DEFAULTS = {"order": 1, "mode": "reflect", "cval": 0, "clip": True, "preserve_range": False,
+# what scikit-image's rescale / resize default to, and all this stand-in implements.  The result is what
+# scikit-image 0.18.3 returns ON THIS INTERPRETER, to the bit (tadataka_amd/rescale_plan.py makes skimage's own NumPy
+# calls for the estimated affine map and the Gaussian kernels; tests/golden/skimage_rescale.npz pins the kernels).
+_DEFAULTS = {"order": 1, "mode": "reflect", "cval": 0, "preserve_range": False,
              "multichannel": False, "anti_aliasing_sigma": None}
 
 
@@ -29,7 +31,7 @@ def _as_float(image):
     return np.asarray(a, dtype=np.float64)
 
 
-def rescale(image, scale, anti_aliasing=True, **kwargs):
+def rescale(image, scale, anti_aliasing=True, clip=True, **kwargs):
     """Bilinear (order=1) rescale of a 2-D image; anti_aliasing as in 0.15+ (Gaussian
     prefilter with sigma = (1/scale - 1) / 2 when shrinking).  Any other option raises."""
     _check_kwargs(kwargs)
@@ -38,14 +40,13 @@ def rescale(image, scale, anti_aliasing=True, **kwargs):
         raise NotImplementedError("only 2-D images are rescaled on the hot path")
     if np.ndim(scale) != 0:
         raise NotImplementedError("only a scalar scale is implemented")
-    return ops.rescale(image, scale, anti_aliasing=bool(anti_aliasing) and scale < 1.0)
+    return ops.rescale(image, scale, anti_aliasing=bool(anti_aliasing), mode="skimage", clip=bool(clip))
 
 
-def resize(image, output_shape, anti_aliasing=True, **kwargs):
+def resize(image, output_shape, anti_aliasing=True, clip=True, **kwargs):
     _check_kwargs(kwargs)
     image = _as_float(image)
     if image.ndim != 2:
         raise NotImplementedError("only 2-D images are resized on the hot path")
-    return ops.resize(image, tuple(int(v) for v in output_shape[:2]),
-                      anti_aliasing=bool(anti_aliasing) and
-                      (output_shape[0] < image.shape[0] or output_shape[1] < image.shape[1]))
+    return ops.resize(image, tuple(int(v) for v in output_shape[:2]), anti_aliasing=bool(anti_aliasing),
+                      mode="skimage", clip=bool(clip))
