@@ -12,6 +12,7 @@ echo "== 1. TDK_DEBUG_CANARY=1 python -m pytest tests -q -m gpu"
 TDK_DEBUG_CANARY=1 python -m pytest tests -q -m gpu 2>&1 | tail -4
 echo
 echo "== 2. AddressSanitizer on the host side of libtadataka_hip (make asan), GPU suite + CPU suite"
+make -s -C tadataka_amd/csrc asan -j8 > /dev/null 2>&1 || echo "make asan FAILED"
 # libstdc++ beside it: the sanitizer resolves __cxa_throw when it starts, and python itself does not link libstdc++
 RT="$(make -s -C tadataka_amd/csrc asan-runtime) $(readlink -f $(gcc -print-file-name=libstdc++.so))"
 LD_PRELOAD="$RT" ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0:log_path=gpurun_out/asan \
