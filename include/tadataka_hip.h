@@ -19,11 +19,12 @@
  *   - pointers are HOST pointers unless the name ends in `_dev`.
  *   - calls are serialised on one HIP stream per process; they block until the
  *     result is in the output buffers unless stated otherwise.
- *   - NOT thread-safe: the stateless entry points share grow-only device / pinned
- *     scratch pools and that stream, and a handle (tdk_dvo, tdk_sd, tdk_ba, tdk_comm)
- *     must not be used from two threads at once.  The reference's extension modules
- *     hold the GIL for the whole call (single-threaded by construction); a binding
- *     that releases the GIL (ctypes does) must serialise calls into this library.
+ *   - thread-safe by serialisation (since round 5): the library keeps process-wide state (one stream and
+ *     grow-only device / pinned scratch pools for the stateless entry points) and a handle (tdk_dvo, tdk_sd,
+ *     tdk_ba, tdk_comm) cannot serve two callers at once, so EVERY entry takes one process-wide recursive
+ *     mutex for its duration.  Concurrent callers are correct, not concurrent: the reference's extension
+ *     modules hold the GIL for the whole call (single-threaded by construction); a binding that releases the
+ *     GIL (ctypes does) needs nothing more.  tdk_last_error() is per thread.
  */
 #ifndef TADATAKA_HIP_H
 #define TADATAKA_HIP_H

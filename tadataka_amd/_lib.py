@@ -203,9 +203,9 @@ def check(status):
     raise TdkError(status, msg)
 
 
-# The C library is not thread-safe (one stream and grow-only scratch pools for the stateless entries, handles that
-# must not be used from two threads at once) and ctypes releases the GIL around every foreign call: this lock
-# serialises the calls of all Python threads of the process, status word and tdk_last_error() included.
+# ctypes releases the GIL around every foreign call.  The C library serialises its entries itself (one process-wide
+# recursive mutex, include/tadataka_hip.h); this lock additionally keeps a call and the reading of its status /
+# tdk_last_error() together for all Python threads of the process.
 _call_lock = threading.RLock()
 
 

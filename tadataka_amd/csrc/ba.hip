@@ -863,6 +863,7 @@ extern "C" {
 tdk_status tdk_ba_projection(const double *poses, int64_t n_poses, const double *points, int64_t n_points,
                              const int64_t *vp, const int64_t *pt, int64_t n, double *x_pred, double *A,
                              double *B) {
+    TDK_API_GUARD;
     TDK_REQUIRE(n >= 0 && n_poses >= 0 && n_points >= 0, "negative size");
     if (n == 0) return tdk::ensure_device();
     TDK_REQUIRE(poses && points && vp && pt, "null pointer");
@@ -887,6 +888,7 @@ tdk_status tdk_ba_projection(const double *poses, int64_t n_poses, const double 
 }
 
 tdk_status tdk_ba_exp_so3(const double *rotvecs, int64_t n, double *R) {
+    TDK_API_GUARD;
     TDK_REQUIRE(n >= 0 && (n == 0 || (rotvecs && R)), "bad argument");
     if (n == 0) return tdk::ensure_device();
     void *d_in, *d_out;
@@ -902,6 +904,7 @@ tdk_status tdk_ba_exp_so3(const double *rotvecs, int64_t n, double *R) {
 tdk_status tdk_ba_block_reduce(const double *poses, int64_t n_poses, const double *points, int64_t n_points,
                                const double *x_true, const int64_t *vp, const int64_t *pt, int64_t n, double *U,
                                double *ea, double *V, double *eb, double *err) {
+    TDK_API_GUARD;
     TDK_REQUIRE(n >= 0 && n_poses >= 1 && n_points >= 1 && n_poses <= 65535, "bad sizes");
     TDK_REQUIRE(n < (1ll << 31) && n_points < (1ll << 31), "more than 2^31 observations or points");
     TDK_REQUIRE(poses && points && U && ea && V && eb && err && (n == 0 || (x_true && vp && pt)), "null pointer");
@@ -1555,11 +1558,13 @@ extern "C" {
 
 tdk_status tdk_ba_create(int64_t n_poses, int64_t n_points, const int64_t *vp, const int64_t *pt,
                          const double *x_true, int64_t n, tdk_ba **out) {
+    TDK_API_GUARD;
     return tdk_ba_create_ex(n_poses, n_points, vp, pt, x_true, n, 0u, out);
 }
 
 tdk_status tdk_ba_create_ex(int64_t n_poses, int64_t n_points, const int64_t *vp, const int64_t *pt,
                             const double *x_true, int64_t n, unsigned int options, tdk_ba **out) {
+    TDK_API_GUARD;
     TDK_REQUIRE(out && vp && pt && x_true, "null pointer");
     TDK_REQUIRE(options < 16u, "unknown option bits");
     TDK_REQUIRE(n >= 1 && n_poses >= 1 && n_points >= 1 && n_poses <= 2048, "bad sizes");
@@ -1678,6 +1683,7 @@ static tdk_status ba_allocate(tdk_ba *h, int64_t n_poses, int64_t n_points, cons
 }
 
 tdk_status tdk_ba_destroy(tdk_ba *h) {
+    TDK_API_GUARD;
     if (!h) return TDK_OK;
     (void)hipStreamSynchronize(tdk::stream());
     void *ptrs[] = {h->d_poses, h->d_points, h->d_xt, h->d_vp, h->d_pt, h->d_row_ptr, h->d_obs, h->cur.U, h->cur.ea,
@@ -1691,12 +1697,14 @@ tdk_status tdk_ba_destroy(tdk_ba *h) {
 }
 
 tdk_status tdk_ba_error(tdk_ba *h, const double *poses, const double *points, double *sum_sq) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && poses && points && sum_sq, "null pointer");
     return ba_reduce(h, poses, points, REDUCE_ERROR, sum_sq);
 }
 
 tdk_status tdk_ba_block_sums(tdk_ba *h, const double *poses, const double *points, double *U, double *ea,
                              double *V, double *eb, double *sum_sq) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && poses && points, "null pointer");
     double err = 0.0;
     TDK_TRY(ba_reduce(h, poses, points, REDUCE_SUMS, &err));
@@ -1720,6 +1728,7 @@ tdk_status tdk_ba_block_sums(tdk_ba *h, const double *poses, const double *point
 }
 
 tdk_status tdk_ba_set_profiling(tdk_ba *h, int enabled) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     h->profiling = enabled != 0;
     h->ev_used = 0;
@@ -1728,6 +1737,7 @@ tdk_status tdk_ba_set_profiling(tdk_ba *h, int enabled) {
 }
 
 tdk_status tdk_ba_get_profile(tdk_ba *h, int64_t *launches, double *total_ms) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && launches && total_ms, "null pointer");
     for (int k = 0; k < BA_K_COUNT; k++) { launches[k] = h->prof_launches[k]; total_ms[k] = h->prof_ms[k]; }
     return TDK_OK;
@@ -1735,6 +1745,7 @@ tdk_status tdk_ba_get_profile(tdk_ba *h, int64_t *launches, double *total_ms) {
 
 tdk_status tdk_ba_step(tdk_ba *h, const double *poses, const double *points, double mu, double *dposes,
                        double *dpoints, double *sum_sq) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && poses && points && dposes && dpoints && sum_sq, "null pointer");
     TDK_REQUIRE(mu >= 0.0, "mu must be non-negative");
     TDK_TRY(ba_upload(h, poses, points));
@@ -1762,6 +1773,7 @@ tdk_status tdk_ba_step(tdk_ba *h, const double *poses, const double *points, dou
 tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, double initial_mu, double nu,
                         double absolute_error_threshold, double relative_error_threshold,
                         double *error_history, int *n_iter) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && poses && points, "null pointer");
     TDK_REQUIRE(max_iter >= 0 && initial_mu > 0.0 && nu > 1.0, "bad Levenberg-Marquardt parameters");
     const size_t np6 = (size_t)h->n_poses * 6, nq3 = (size_t)h->n_points * 3;

@@ -112,6 +112,7 @@ tdk_status comm_reserve(tdk_comm *c, size_t doubles) {
 extern "C" {
 
 tdk_status tdk_comm_unique_id(uint8_t *id128) {
+    TDK_API_GUARD;
     TDK_REQUIRE(id128 != nullptr, "id is NULL");
     TDK_TRY(load_rccl());
     ncclUniqueId id;
@@ -124,6 +125,7 @@ tdk_status tdk_comm_unique_id(uint8_t *id128) {
 tdk_status tdk_comm_available(void) { return load_rccl(); }
 
 tdk_status tdk_comm_destroy(tdk_comm *c) {
+    TDK_API_GUARD;
     if (!c) return TDK_OK;
     if (c->pending && c->done) (void)hipEventSynchronize(c->done);   // a gather in flight still writes d_poses_all / h_poses_all
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -139,6 +141,7 @@ tdk_status tdk_comm_destroy(tdk_comm *c) {
 }
 
 tdk_status tdk_comm_create(const uint8_t *id128, int rank, int world, tdk_comm **out) {
+    TDK_API_GUARD;
     TDK_REQUIRE(id128 && out, "null pointer");
     TDK_REQUIRE(world >= 1 && rank >= 0 && rank < world, "rank out of range");
     TDK_TRY(tdk::ensure_device());
@@ -166,6 +169,7 @@ tdk_status tdk_comm_create(const uint8_t *id128, int rank, int world, tdk_comm *
 }
 
 tdk_status tdk_comm_rank(tdk_comm *c, int *rank, int *world) {
+    TDK_API_GUARD;
     TDK_REQUIRE(c != nullptr, "comm is NULL");
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
@@ -173,6 +177,7 @@ tdk_status tdk_comm_rank(tdk_comm *c, int *rank, int *world) {
 }
 
 tdk_status tdk_comm_all_gather(tdk_comm *c, const double *send, int64_t count, double *recv) {
+    TDK_API_GUARD;
     TDK_REQUIRE(c && send && recv && count >= 0, "bad argument");
     if (count == 0) return TDK_OK;
     const size_t n = (size_t)count, total = n * (size_t)c->world;
@@ -189,6 +194,7 @@ tdk_status tdk_comm_all_gather(tdk_comm *c, const double *send, int64_t count, d
 }
 
 tdk_status tdk_comm_all_reduce(tdk_comm *c, double *values, int64_t count, int op) {
+    TDK_API_GUARD;
     TDK_REQUIRE(c && values && count >= 0 && (op == 0 || op == 1), "bad argument");
     if (count == 0) return TDK_OK;
     const size_t n = (size_t)count;
@@ -205,11 +211,13 @@ tdk_status tdk_comm_all_reduce(tdk_comm *c, double *values, int64_t count, int o
 }
 
 tdk_status tdk_comm_barrier(tdk_comm *c) {
+    TDK_API_GUARD;
     double one = 1.0;
     return tdk_comm_all_reduce(c, &one, 1, 0);
 }
 
 tdk_status tdk_dvo_gather_poses_start(tdk_dvo *h, tdk_comm *c) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && c, "null pointer");
     TDK_REQUIRE(!c->pending, "finish the previous gather first");
     tdk::DvoLevel0 L;
@@ -238,6 +246,7 @@ tdk_status tdk_dvo_gather_poses_start(tdk_dvo *h, tdk_comm *c) {
 }
 
 tdk_status tdk_dvo_gather_poses_finish(tdk_comm *c, double *poses_all) {
+    TDK_API_GUARD;
     TDK_REQUIRE(c && poses_all, "null pointer");
     TDK_REQUIRE(c->pending, "no gather in flight");
     TDK_HIP(hipEventSynchronize(c->done));

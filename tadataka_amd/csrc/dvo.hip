@@ -2861,6 +2861,7 @@ extern "C" {
 
 tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, double ratio,
                           int with_weight_map, tdk_dvo **out) {
+    TDK_API_GUARD;
     TDK_REQUIRE(out != nullptr, "out is NULL");
     TDK_REQUIRE(n_pairs >= 1 && n_pairs <= 65535, "n_pairs must be in [1, 65535]");
     TDK_REQUIRE(height >= 2 && width >= 2, "frames must be at least 2x2");
@@ -2958,6 +2959,7 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
 }
 
 tdk_status tdk_dvo_destroy(tdk_dvo *h) {
+    TDK_API_GUARD;
     if (!h) return TDK_OK;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (int l = 0; l < h->n_levels; l++) {   // hipFree(nullptr) is a no-op: a partially built handle is fine
@@ -2993,6 +2995,7 @@ tdk_status tdk_dvo_destroy(tdk_dvo *h) {
 
 tdk_status tdk_dvo_upload(tdk_dvo *h, int pair, const double *I0, const double *D0, const double *I1,
                           const double *weight_map) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && I0 && D0 && I1, "null pointer");
     TDK_REQUIRE(pair >= 0 && pair < h->n_pairs, "pair out of range");
     TDK_REQUIRE(weight_map == nullptr || h->with_w, "batch was created without a weight map");
@@ -3010,6 +3013,7 @@ tdk_status tdk_dvo_upload(tdk_dvo *h, int pair, const double *I0, const double *
 }
 
 tdk_status tdk_dvo_upload_mixed(tdk_dvo *h, int pair, const double *const *host4, const double *const *device4) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && host4 && device4, "null pointer");
     TDK_REQUIRE(pair >= 0 && pair < h->n_pairs, "pair out of range");
     TDK_REQUIRE((host4[3] == nullptr && device4[3] == nullptr) || h->with_w, "batch was created without a weight map");
@@ -3062,6 +3066,7 @@ static tdk_status ensure_copy_stream(tdk_dvo *h) {
 }
 
 tdk_status tdk_dvo_upload_async(tdk_dvo *h, int which, int first_pair, int n_pairs, const double *pinned_host) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && pinned_host, "null pointer");
     TDK_REQUIRE(which >= 0 && which <= 3 && (which != 3 || h->with_w), "no such array");
     TDK_REQUIRE(first_pair >= 0 && n_pairs >= 1 && first_pair + n_pairs <= h->n_pairs, "pair range out of bounds");
@@ -3085,6 +3090,7 @@ tdk_status tdk_dvo_upload_async(tdk_dvo *h, int which, int first_pair, int n_pai
 }
 
 tdk_status tdk_dvo_upload_async_u8(tdk_dvo *h, int which, int first_pair, int n_pairs, const uint8_t *pinned_host) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && pinned_host, "null pointer");
     TDK_REQUIRE(which >= 0 && which <= 2, "8-bit frames: I0, D0 (rarely) or I1");
     TDK_REQUIRE(first_pair >= 0 && n_pairs >= 1 && first_pair + n_pairs <= h->n_pairs, "pair range out of bounds");
@@ -3113,6 +3119,7 @@ tdk_status tdk_dvo_upload_async_u8(tdk_dvo *h, int which, int first_pair, int n_
 
 tdk_status tdk_dvo_fill_synthetic(tdk_dvo *h, const double *camera, const double *poses12, uint64_t seed0,
                                   double noise) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && camera && poses12, "null pointer");
     TDK_TRY(after_uploads(h));
     TDK_HIP(hipMemcpyAsync(h->d_poses_in, poses12, sizeof(double) * 12 * h->n_pairs, hipMemcpyHostToDevice,
@@ -3199,11 +3206,13 @@ static tdk_status build_pyramid_of(tdk_dvo *h, unsigned arrays) {
 }
 
 tdk_status tdk_dvo_build_pyramid(tdk_dvo *h) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     return build_pyramid_of(h, 15u);
 }
 
 tdk_status tdk_dvo_build_pyramid_arrays(tdk_dvo *h, unsigned int arrays) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     TDK_REQUIRE(arrays != 0u && arrays <= 15u, "arrays: bit 0 I0, bit 1 D0, bit 2 I1, bit 3 W0");
     TDK_REQUIRE(h->with_w || !(arrays & 8u), "no weight map in this batch");
@@ -3211,6 +3220,7 @@ tdk_status tdk_dvo_build_pyramid_arrays(tdk_dvo *h, unsigned int arrays) {
 }
 
 tdk_status tdk_dvo_level_shape(tdk_dvo *h, int level, int *height, int *width) {
+    TDK_API_GUARD;
     TDK_TRY(check_level(h, level));
     if (height) *height = h->lv[level].H;
     if (width) *width = h->lv[level].W;
@@ -3218,6 +3228,7 @@ tdk_status tdk_dvo_level_shape(tdk_dvo *h, int level, int *height, int *width) {
 }
 
 tdk_status tdk_dvo_download(tdk_dvo *h, int pair, int level, int which, double *out) {
+    TDK_API_GUARD;
     TDK_TRY(check_level(h, level));
     TDK_REQUIRE(out && pair >= 0 && pair < h->n_pairs && which >= 0 && which <= 3, "bad argument");
     const tdk_dvo::Level &L = h->lv[level];
@@ -3233,6 +3244,7 @@ tdk_status tdk_dvo_download(tdk_dvo *h, int pair, int level, int which, double *
 tdk_status tdk_dvo_evaluate(tdk_dvo *h, int level, const double *camera0, const double *camera1,
                             const double *poses12, int weight_mode, double *Hout, double *bout,
                             int64_t *n_update, double *sum_sq, int64_t *n_error) {
+    TDK_API_GUARD;
     TDK_TRY(check_level(h, level));
     TDK_REQUIRE(camera0 && camera1 && poses12, "null pointer");
     TDK_TRY(check_weight_mode(h, weight_mode));
@@ -3261,6 +3273,7 @@ tdk_status tdk_dvo_evaluate(tdk_dvo *h, int level, const double *camera0, const 
 
 tdk_status tdk_dvo_photometric_error(tdk_dvo *h, int level, const double *camera0, const double *camera1,
                                      const double *poses12, double *sum_sq, int64_t *n_error) {
+    TDK_API_GUARD;
     TDK_TRY(check_level(h, level));
     TDK_REQUIRE(camera0 && camera1 && poses12, "null pointer");
     TDK_TRY(upload_params(h, camera0, camera1));
@@ -3304,6 +3317,7 @@ static tdk_status publish_and_wait(tdk_dvo *h, double *poses12) {
 
 tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0, const double *camera1,
                                   double *poses12, int weight_mode, int max_iter, int *n_evals) {
+    TDK_API_GUARD;
     TDK_TRY(check_level(h, level));
     TDK_REQUIRE(camera0 && camera1 && poses12 && max_iter >= 0, "bad argument");
     TDK_TRY(check_weight_mode(h, weight_mode));
@@ -3328,6 +3342,7 @@ tdk_status tdk_dvo_estimate_level(tdk_dvo *h, int level, const double *camera0, 
 
 tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *camera1, double *poses12,
                             int weight_mode, int max_iter, int64_t *pixel_evals) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && camera0 && camera1 && poses12 && max_iter >= 0, "bad argument");
     TDK_TRY(check_weight_mode(h, weight_mode));
     TDK_TRY(upload_params(h, camera0, camera1));
@@ -3350,6 +3365,7 @@ tdk_status tdk_dvo_estimate(tdk_dvo *h, const double *camera0, const double *cam
 }
 
 tdk_status tdk_dvo_get_tukey_fallbacks(tdk_dvo *h, int64_t *pairs) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && pairs, "null pointer");
     *pairs = 0;
     if (!h->d_tk_fallback) return TDK_OK;
@@ -3361,6 +3377,7 @@ tdk_status tdk_dvo_get_tukey_fallbacks(tdk_dvo *h, int64_t *pairs) {
 }
 
 tdk_status tdk_dvo_set_student_passes(tdk_dvo *h, int mode) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     TDK_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (Taylor passes), 1 (sequential) or 2 (sequential, IEEE divisions)");
     h->student_mode = mode;
@@ -3368,6 +3385,7 @@ tdk_status tdk_dvo_set_student_passes(tdk_dvo *h, int mode) {
 }
 
 tdk_status tdk_dvo_get_robust_scale(tdk_dvo *h, double *scale) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && scale, "null pointer");
     TDK_REQUIRE(h->d_wscale != nullptr, "no robust evaluation has run on this batch");
     TDK_HIP(hipMemcpyAsync(scale, h->d_wscale, sizeof(double) * h->n_pairs, hipMemcpyDeviceToHost, h->stream));
@@ -3376,6 +3394,7 @@ tdk_status tdk_dvo_get_robust_scale(tdk_dvo *h, double *scale) {
 }
 
 tdk_status tdk_dvo_get_student_redos(tdk_dvo *h, int64_t *pairs) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && pairs, "null pointer");
     *pairs = 0;
     if (!h->d_st_redo) return TDK_OK;
@@ -3387,6 +3406,7 @@ tdk_status tdk_dvo_get_student_redos(tdk_dvo *h, int64_t *pairs) {
 }
 
 tdk_status tdk_dvo_get_counts(tdk_dvo *h, int64_t *error_pixels, int64_t *update_pixels) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     if (error_pixels) *error_pixels = h->count_error_px;
     if (update_pixels) *update_pixels = h->count_update_px;
@@ -3394,12 +3414,14 @@ tdk_status tdk_dvo_get_counts(tdk_dvo *h, int64_t *error_pixels, int64_t *update
 }
 
 tdk_status tdk_dvo_get_warnings(tdk_dvo *h, int *too_large) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && too_large, "null pointer");
     memcpy(too_large, h->host_warn.data(), sizeof(int) * (size_t)h->n_pairs);
     return TDK_OK;
 }
 
 tdk_status tdk_dvo_set_anti_aliasing(tdk_dvo *h, int enabled) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     TDK_REQUIRE(enabled == 0 || enabled == 1, "enabled must be 0 or 1");
     h->anti_aliasing = enabled != 0;
@@ -3408,6 +3430,7 @@ tdk_status tdk_dvo_set_anti_aliasing(tdk_dvo *h, int enabled) {
 }
 
 tdk_status tdk_dvo_set_option(tdk_dvo *h, int option, int value) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     switch (option) {
         case TDK_DVO_OPT_CHAIN:
@@ -3426,6 +3449,7 @@ tdk_status tdk_dvo_set_option(tdk_dvo *h, int option, int value) {
 
 tdk_status tdk_dvo_set_level_plan(tdk_dvo *h, int level, const double *map, const double *w_rows, int radius_rows,
                                   const double *w_cols, int radius_cols) {
+    TDK_API_GUARD;
     TDK_TRY(check_level(h, level));
     tdk_dvo::Plan &P = h->plan[level];
     h->weights_dirty = true;
@@ -3446,6 +3470,7 @@ tdk_status tdk_dvo_set_level_plan(tdk_dvo *h, int level, const double *map, cons
 }
 
 tdk_status tdk_dvo_set_rescale_options(tdk_dvo *h, unsigned int level0_arrays, int clip) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     TDK_REQUIRE(level0_arrays <= 15u, "level0_arrays: bit 0 I0, bit 1 D0, bit 2 I1, bit 3 W0");
     if (!h->with_w) level0_arrays &= 7u;
@@ -3472,12 +3497,14 @@ tdk_status tdk_dvo_set_rescale_options(tdk_dvo *h, unsigned int level0_arrays, i
 }
 
 tdk_status tdk_dvo_get_stream(tdk_dvo *h, void **stream_out) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr && stream_out != nullptr, "null pointer");
     *stream_out = (void *)h->stream;
     return TDK_OK;
 }
 
 tdk_status tdk_dvo_set_profiling(tdk_dvo *h, int enabled) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     h->profiling = enabled == 2 ? 2 : (enabled != 0 ? 1 : 0);
     h->ev_used = 0;
@@ -3487,6 +3514,7 @@ tdk_status tdk_dvo_set_profiling(tdk_dvo *h, int enabled) {
 }
 
 tdk_status tdk_dvo_get_profile(tdk_dvo *h, int64_t *launches, double *total_ms, int64_t *pixels) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     if (launches) *launches = h->prof_launches[0][0];
     if (total_ms) *total_ms = h->prof_ms[0][0];
@@ -3495,6 +3523,7 @@ tdk_status tdk_dvo_get_profile(tdk_dvo *h, int64_t *launches, double *total_ms, 
 }
 
 tdk_status tdk_dvo_get_profile_kind(tdk_dvo *h, int kind, int64_t *launches, double *total_ms, int64_t *pixels) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr && kind >= 0 && kind <= 2, "bad argument");
     if (launches) *launches = h->prof_launches[0][kind];
     if (total_ms) *total_ms = h->prof_ms[0][kind];
@@ -3504,6 +3533,7 @@ tdk_status tdk_dvo_get_profile_kind(tdk_dvo *h, int kind, int64_t *launches, dou
 
 tdk_status tdk_dvo_get_profile_level(tdk_dvo *h, int level, int kind, int64_t *launches, double *total_ms,
                                      int64_t *pixels) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr && kind >= 0 && kind <= 2, "bad argument");
     TDK_TRY(check_level(h, level));
     if (launches) *launches = h->prof_launches[level][kind];

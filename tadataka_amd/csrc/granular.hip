@@ -166,14 +166,17 @@ __global__ __launch_bounds__(kBlock) void k_rgb2gray(const T *__restrict__ rgb, 
 extern "C" {
 
 tdk_status tdk_normalize(const double *kp, int64_t n, const double *camera, double *out) {
+    TDK_API_GUARD;
     return normalize_impl(kp, n, camera, out, 0);
 }
 
 tdk_status tdk_unnormalize(const double *kp, int64_t n, const double *camera, double *out) {
+    TDK_API_GUARD;
     return normalize_impl(kp, n, camera, out, 1);
 }
 
 tdk_status tdk_project_vecs(const double *points, int64_t n, double *out) {
+    TDK_API_GUARD;
     TDK_REQUIRE(n >= 0 && (n == 0 || (points && out)), "null pointer");
     if (n == 0) return tdk::ensure_device();
     void *d_in, *d_out;
@@ -185,6 +188,7 @@ tdk_status tdk_project_vecs(const double *points, int64_t n, double *out) {
 }
 
 tdk_status tdk_inv_project_vecs(const double *xs, const double *depths, int64_t n, double *out) {
+    TDK_API_GUARD;
     TDK_REQUIRE(n >= 0 && (n == 0 || (xs && depths && out)), "null pointer");
     if (n == 0) return tdk::ensure_device();
     void *d_xs, *d_d, *d_out;
@@ -198,6 +202,7 @@ tdk_status tdk_inv_project_vecs(const double *xs, const double *depths, int64_t 
 }
 
 tdk_status tdk_transform(const double *T, const double *points, int64_t n, double *out) {
+    TDK_API_GUARD;
     TDK_REQUIRE(n >= 0 && T && (n == 0 || (points && out)), "null pointer");
     if (n == 0) return tdk::ensure_device();
     Mat4 M;
@@ -212,6 +217,7 @@ tdk_status tdk_transform(const double *T, const double *points, int64_t n, doubl
 
 tdk_status tdk_warp_vecs(const double *T10, const double *xs, const double *depths, int64_t n,
                          double *out_xs, double *out_depths) {
+    TDK_API_GUARD;
     TDK_REQUIRE(n >= 0 && T10 && (n == 0 || (xs && depths && out_xs && out_depths)), "null pointer");
     if (n == 0) return tdk::ensure_device();
     Mat4 M;
@@ -230,6 +236,7 @@ tdk_status tdk_warp_vecs(const double *T10, const double *xs, const double *dept
 
 tdk_status tdk_interpolation(const double *image, int H, int W, const double *coordinates, int64_t m,
                              double *out) {
+    TDK_API_GUARD;
     TDK_REQUIRE(H > 0 && W > 0 && m >= 0 && image && (m == 0 || (coordinates && out)), "bad argument");
     if (m == 0) return tdk::ensure_device();
     void *d_img, *d_c, *d_out, *d_bad;
@@ -253,12 +260,14 @@ tdk_status tdk_interpolation(const double *image, int H, int W, const double *co
 }
 
 tdk_status tdk_calc_depth0(const double *T10, const double *x0, const double *x1, double *depth) {
+    TDK_API_GUARD;
     TDK_REQUIRE(T10 && x0 && x1 && depth, "null pointer");
     *depth = tdk::calc_depth0(T10, x0[0], x0[1], x1[0], x1[1]);
     return TDK_OK;
 }
 
 tdk_status tdk_image_gradient(const double *image, int H, int W, double *gx, double *gy) {
+    TDK_API_GUARD;
     TDK_REQUIRE(H > 0 && W > 0 && image && gx && gy, "bad argument");
     size_t bytes = (size_t)H * W * 8;
     void *d_img, *d_gx, *d_gy;
@@ -273,6 +282,7 @@ tdk_status tdk_image_gradient(const double *image, int H, int W, double *gx, dou
 }
 
 tdk_status tdk_rgb2gray(const double *rgb, int H, int W, int channels, double *gray) {
+    TDK_API_GUARD;
     TDK_REQUIRE(H > 0 && W > 0 && channels >= 3 && channels <= 4 && rgb && gray, "bad argument");
     const int64_t n = (int64_t)H * W;
     void *d_rgb, *d_out;
@@ -284,6 +294,7 @@ tdk_status tdk_rgb2gray(const double *rgb, int H, int W, int channels, double *g
 }
 
 tdk_status tdk_rgb2gray_u8(const uint8_t *rgb, int H, int W, int channels, double *gray) {
+    TDK_API_GUARD;
     TDK_REQUIRE(H > 0 && W > 0 && channels >= 3 && channels <= 4 && rgb && gray, "bad argument");
     const int64_t n = (int64_t)H * W;
     void *d_rgb, *d_out;

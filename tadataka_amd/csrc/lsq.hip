@@ -300,6 +300,7 @@ extern "C" {
 
 tdk_status tdk_weighted_normal_equations(const double *A, const double *b, const double *w, int64_t n, int p,
                                          double *AtWA, double *AtWb) {
+    TDK_API_GUARD;
     TDK_REQUIRE(p >= 1 && p <= kMaxP, "p must be in [1, 8]");
     TDK_REQUIRE(n >= 0 && AtWA && AtWb && (n == 0 || (A && b)), "bad argument");
     const int nt = p * (p + 1) / 2, nacc = nt + p;
@@ -338,6 +339,7 @@ tdk_status tdk_weighted_normal_equations(const double *A, const double *b, const
 tdk_status tdk_dvo_pose_update(const double *camera1, const double *residuals, const double *GX1,
                                const double *GY1, int H, int W, const double *P1, int64_t n, int weight_mode,
                                const double *weights, double *H21, double *b6, int64_t *n_valid) {
+    TDK_API_GUARD;
     TDK_REQUIRE(camera1 && residuals && GX1 && GY1 && P1 && H21 && b6 && n_valid, "null pointer");
     TDK_REQUIRE(H >= 1 && W >= 1 && n >= 0, "bad size");
     TDK_REQUIRE(weight_mode == TDK_W_NONE || weight_mode == TDK_W_HUBER || weight_mode == TDK_W_MAP,
@@ -380,6 +382,7 @@ tdk_status tdk_dvo_pose_update(const double *camera1, const double *residuals, c
 }
 
 tdk_status tdk_robust_weights(const double *residuals, int64_t m, int mode, double *weights) {
+    TDK_API_GUARD;
     // the reference defaults: k = 1.345 | nu = 5, n_iter = 10 | beta = 4.6851, c = 1.4826
     const double p0 = mode == TDK_W_HUBER ? kHuberK : (mode == TDK_W_STUDENT_T ? 5.0 : 4.6851);
     const double p1 = mode == TDK_W_STUDENT_T ? 10.0 : 1.4826;
@@ -388,6 +391,7 @@ tdk_status tdk_robust_weights(const double *residuals, int64_t m, int mode, doub
 
 tdk_status tdk_robust_weights_ex(const double *residuals, int64_t m, int mode, double p0, double p1,
                                  double *weights) {
+    TDK_API_GUARD;
     TDK_REQUIRE(m >= 0 && (m == 0 || (residuals && weights)), "bad argument");
     TDK_REQUIRE(mode == TDK_W_HUBER || mode == TDK_W_STUDENT_T || mode == TDK_W_TUKEY,
                 "mode must be huber, student-t or tukey");

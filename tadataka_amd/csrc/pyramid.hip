@@ -1519,6 +1519,7 @@ tdk_status rescale_host(const double *image, int H, int W, double *out, int Ho, 
 extern "C" {
 
 tdk_status tdk_rescale(const double *image, int H, int W, double *out, int Ho, int Wo) {
+    TDK_API_GUARD;
     TDK_REQUIRE(H > 0 && W > 0 && Ho > 0 && Wo > 0 && image && out, "bad argument");
     tdk::PyramidLevelDesc lv;
     lv.H = Ho; lv.W = Wo;
@@ -1528,6 +1529,7 @@ tdk_status tdk_rescale(const double *image, int H, int W, double *out, int Ho, i
 }
 
 tdk_status tdk_rescale_anti_aliased(const double *image, int H, int W, double *out, int Ho, int Wo) {
+    TDK_API_GUARD;
     TDK_REQUIRE(H > 0 && W > 0 && Ho > 0 && Wo > 0 && image && out, "bad argument");
     tdk::PyramidLevelDesc lv;
     lv.H = Ho; lv.W = Wo;
@@ -1539,6 +1541,7 @@ tdk_status tdk_rescale_anti_aliased(const double *image, int H, int W, double *o
 tdk_status tdk_rescale_skimage(const double *image, int H, int W, double *out, int Ho, int Wo, const double *map,
                                const double *w_rows, int radius_rows, const double *w_cols, int radius_cols,
                                int clip) {
+    TDK_API_GUARD;
     TDK_REQUIRE(H > 0 && W > 0 && Ho > 0 && Wo > 0 && image && out && map, "bad argument");
     TDK_REQUIRE(radius_rows >= 0 && radius_cols >= 0 && radius_rows <= kMaxGaussRadius && radius_cols <= kMaxGaussRadius,
                 "kernel radius out of range");

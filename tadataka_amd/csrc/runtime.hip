@@ -31,6 +31,11 @@ void set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+std::recursive_mutex &api_mutex() {
+    static std::recursive_mutex m;
+    return m;
+}
+
 static int g_options[2] = {1, 1};   // TDK_OPT_PYRAMID_STREAM, TDK_OPT_SD_WARP_GATHER
 int option(int which) { return g_options[which]; }
 
@@ -214,6 +219,7 @@ tdk_status tdk_device_count(int *count) {
 }
 
 tdk_status tdk_set_device(int device) {
+    TDK_API_GUARD;
     // Pools and the stream belong to the current device: drop them first.
     if (tdk::g_ready) {
         TDK_HIP(hipStreamSynchronize(tdk::g_stream));
@@ -230,18 +236,21 @@ tdk_status tdk_set_device(int device) {
 }
 
 tdk_status tdk_get_device(int *device) {
+    TDK_API_GUARD;
     TDK_REQUIRE(device != nullptr, "device is NULL");
     TDK_HIP(hipGetDevice(device));
     return TDK_OK;
 }
 
 tdk_status tdk_sync(void) {
+    TDK_API_GUARD;
     TDK_TRY(tdk::ensure_device());
     TDK_HIP(hipDeviceSynchronize());   // the library stream and every batch's own stream
     return tdk::check_canaries();      // (TDK_DEBUG_CANARY=1 only)
 }
 
 tdk_status tdk_set_option(int option, int value) {
+    TDK_API_GUARD;
     TDK_REQUIRE(option == TDK_OPT_PYRAMID_STREAM || option == TDK_OPT_SD_WARP_GATHER, "unknown option");
     TDK_REQUIRE(value >= 0 && value <= (option == TDK_OPT_PYRAMID_STREAM ? 3 : 1), "value out of range");
     tdk::g_options[option] = value;
@@ -249,6 +258,7 @@ tdk_status tdk_set_option(int option, int value) {
 }
 
 tdk_status tdk_debug_check_canaries(int *n_allocations) {
+    TDK_API_GUARD;
     if (n_allocations) {
         std::lock_guard<std::mutex> lock(tdk::g_alloc_mu);
         *n_allocations = tdk::canaries_enabled() ? (int)tdk::g_allocs.size() : -1;
@@ -257,6 +267,7 @@ tdk_status tdk_debug_check_canaries(int *n_allocations) {
 }
 
 tdk_status tdk_pinned_alloc(size_t bytes, void **out) {
+    TDK_API_GUARD;
     TDK_REQUIRE(out != nullptr && bytes > 0, "bad argument");
     TDK_TRY(tdk::ensure_device());
     TDK_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
@@ -264,11 +275,13 @@ tdk_status tdk_pinned_alloc(size_t bytes, void **out) {
 }
 
 tdk_status tdk_pinned_free(void *ptr) {
+    TDK_API_GUARD;
     if (ptr) TDK_HIP(hipHostFree(ptr));
     return TDK_OK;
 }
 
 tdk_status tdk_device_name(char *buf, int buflen) {
+    TDK_API_GUARD;
     TDK_REQUIRE(buf != nullptr && buflen > 0, "bad buffer");
     TDK_TRY(tdk::ensure_device());
     int dev = 0;

@@ -1293,6 +1293,7 @@ tdk_status launch_update_depth(int n_tracks, int H, int W, const TrackKey *d_key
 extern "C" {
 
 tdk_status tdk_sobel(const double *image, int H, int W, double *gx, double *gy) {
+    TDK_API_GUARD;
     TDK_REQUIRE(image && gx && gy, "null pointer");
     TDK_TRY(check_image_dims(H, W));
     size_t bytes = (size_t)H * W * 8;
@@ -1311,6 +1312,7 @@ tdk_status tdk_sobel(const double *image, int H, int W, double *gx, double *gy) 
 
 tdk_status tdk_increment_age(const uint64_t *age0, int H, int W, const double *camera0, const double *camera1,
                              const double *T10, const double *depth0, uint64_t *age1) {
+    TDK_API_GUARD;
     TDK_REQUIRE(age0 && camera0 && camera1 && T10 && depth0 && age1, "null pointer");
     TDK_TRY(check_image_dims(H, W));
     const int N = H * W;
@@ -1333,6 +1335,7 @@ tdk_status tdk_increment_age(const uint64_t *age0, int H, int W, const double *c
 tdk_status tdk_propagate(const double *T10, const double *camera0, const double *camera1, const double *depth0,
                          const double *variance0, int H, int W, double default_depth, double default_variance,
                          double uncertaintity_bias, double *depth1, double *variance1) {
+    TDK_API_GUARD;
     TDK_REQUIRE(T10 && camera0 && camera1 && depth0 && variance0 && depth1 && variance1, "null pointer");
     TDK_TRY(check_image_dims(H, W));
     const int N = H * W;
@@ -1426,6 +1429,7 @@ tdk_status tdk_update_depth(const double *key_camera, const double *key_image, c
                             const uint64_t *age, const double *prior_depth, const double *prior_variance, int H,
                             int W, const tdk_semi_dense_params *params, double *depth, double *variance,
                             int64_t *flag) {
+    TDK_API_GUARD;
     TDK_REQUIRE(key_camera && key_image && key_T && age && prior_depth && prior_variance && params && depth &&
                     variance && flag && n_ref >= 0,
                 "bad argument");
@@ -1442,6 +1446,7 @@ tdk_status tdk_update_depth(const double *key_camera, const double *key_image, c
 }
 
 tdk_status tdk_frame_create(const double *image, int height, int width, tdk_frame **out) {
+    TDK_API_GUARD;
     TDK_REQUIRE(image && out, "null pointer");
     TDK_TRY(check_image_dims(height, width));
     TDK_TRY(tdk::ensure_device());
@@ -1467,6 +1472,7 @@ tdk_status tdk_frame_create(const double *image, int height, int width, tdk_fram
 }
 
 tdk_status tdk_frame_destroy(tdk_frame *f) {
+    TDK_API_GUARD;
     if (!f) return TDK_OK;
     (void)hipStreamSynchronize(tdk::stream());
     (void)hipFree(f->image);
@@ -1479,6 +1485,7 @@ tdk_status tdk_update_depth_frames(const double *key_camera, const tdk_frame *ke
                                    const double *ref_Ts, const uint64_t *age, const double *prior_depth,
                                    const double *prior_variance, const tdk_semi_dense_params *params,
                                    double *depth, double *variance, int64_t *flag) {
+    TDK_API_GUARD;
     TDK_REQUIRE(key_camera && key_frame && key_T && age && prior_depth && prior_variance && params && depth &&
                     variance && flag && n_ref >= 0,
                 "bad argument");
@@ -1629,6 +1636,7 @@ uint64_t max_u64(const void *host, size_t n) {
 extern "C" {
 
 tdk_status tdk_map_create(int height, int width, const void *host, tdk_map **out) {
+    TDK_API_GUARD;
     TDK_REQUIRE(out != nullptr, "null pointer");
     TDK_TRY(check_image_dims(height, width));
     TDK_TRY(tdk::ensure_device());
@@ -1655,6 +1663,7 @@ tdk_status tdk_map_create(int height, int width, const void *host, tdk_map **out
 }
 
 tdk_status tdk_map_destroy(tdk_map *m) {
+    TDK_API_GUARD;
     if (!m) return TDK_OK;
     map_release((size_t)m->H * m->W * 8, m->data);
     delete m;
@@ -1662,6 +1671,7 @@ tdk_status tdk_map_destroy(tdk_map *m) {
 }
 
 tdk_status tdk_map_upload(tdk_map *m, const void *host) {
+    TDK_API_GUARD;
     TDK_REQUIRE(m && host, "null pointer");
     TDK_HIP(hipMemcpyAsync(m->data, host, (size_t)m->H * m->W * 8, hipMemcpyHostToDevice, tdk::stream()));
     m->bound = max_u64(host, (size_t)m->H * m->W);
@@ -1670,6 +1680,7 @@ tdk_status tdk_map_upload(tdk_map *m, const void *host) {
 }
 
 tdk_status tdk_map_download(const tdk_map *m, void *host) {
+    TDK_API_GUARD;
     TDK_REQUIRE(m && host, "null pointer");
     TDK_HIP(hipMemcpyAsync(host, m->data, (size_t)m->H * m->W * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));   // also waits for the kernels that produce the map
@@ -1677,18 +1688,21 @@ tdk_status tdk_map_download(const tdk_map *m, void *host) {
 }
 
 tdk_status tdk_map_shape(const tdk_map *m, int *height, int *width) {
+    TDK_API_GUARD;
     TDK_REQUIRE(m && height && width, "null pointer");
     *height = m->H; *width = m->W;
     return TDK_OK;
 }
 
 tdk_status tdk_map_device_ptr(const tdk_map *m, void **ptr) {
+    TDK_API_GUARD;
     TDK_REQUIRE(m && ptr, "null pointer");
     *ptr = m->data;
     return TDK_OK;
 }
 
 tdk_status tdk_frame_download(const tdk_frame *f, double *image) {
+    TDK_API_GUARD;
     TDK_REQUIRE(f && image, "null pointer");
     TDK_HIP(hipMemcpyAsync(image, f->image, (size_t)f->H * f->W * 8, hipMemcpyDeviceToHost, tdk::stream()));
     TDK_HIP(hipStreamSynchronize(tdk::stream()));
@@ -1696,12 +1710,14 @@ tdk_status tdk_frame_download(const tdk_frame *f, double *image) {
 }
 
 tdk_status tdk_frame_device_ptr(const tdk_frame *f, void **ptr) {
+    TDK_API_GUARD;
     TDK_REQUIRE(f && ptr, "null pointer");
     *ptr = f->image;
     return TDK_OK;
 }
 
 tdk_status tdk_map_safe_invert(const tdk_map *v, double epsilon, tdk_map *out) {
+    TDK_API_GUARD;
     TDK_REQUIRE(v && out && same_shape(v, out), "maps must share one shape");
     const int64_t n = (int64_t)v->H * v->W;
     int g = grid_for(n);
@@ -1714,6 +1730,7 @@ tdk_status tdk_map_safe_invert(const tdk_map *v, double epsilon, tdk_map *out) {
 
 tdk_status tdk_increment_age_maps(const tdk_map *age0, const double *camera0, const double *camera1,
                                   const double *T10, const tdk_map *depth0, tdk_map *age1) {
+    TDK_API_GUARD;
     TDK_REQUIRE(age0 && camera0 && camera1 && T10 && depth0 && age1, "null pointer");
     TDK_REQUIRE(same_shape(age0, depth0) && same_shape(age0, age1), "maps must share one shape");
     TDK_REQUIRE(age1->data != age0->data, "age1 must not alias age0");
@@ -1734,6 +1751,7 @@ tdk_status tdk_propagate_maps(const double *T10, const double *camera0, const do
                               const tdk_map *depth0, const tdk_map *variance0, double default_depth,
                               double default_variance, double uncertaintity_bias, tdk_map *depth1,
                               tdk_map *variance1) {
+    TDK_API_GUARD;
     TDK_REQUIRE(T10 && camera0 && camera1 && depth0 && variance0 && depth1 && variance1, "null pointer");
     TDK_REQUIRE(same_shape(depth0, variance0) && same_shape(depth0, depth1) && same_shape(depth0, variance1),
                 "maps must share one shape");
@@ -1759,6 +1777,7 @@ tdk_status tdk_update_depth_maps(const double *key_camera, const tdk_frame *key_
                                  const tdk_map *age, const tdk_map *prior_depth, const tdk_map *prior_variance,
                                  const tdk_semi_dense_params *params, tdk_map *depth, tdk_map *variance,
                                  tdk_map *flag) {
+    TDK_API_GUARD;
     TDK_REQUIRE(key_camera && key_frame && key_T && age && prior_depth && prior_variance && params && depth &&
                     variance && flag && n_ref >= 0,
                 "bad argument");
@@ -1815,6 +1834,7 @@ tdk_status tdk_estimate_one(const int64_t *u_key, double prior_depth, double pri
                             const double *key_camera, const double *key_image, const double *key_T,
                             const double *ref_camera, const double *ref_image, const double *ref_T, int H, int W,
                             const tdk_semi_dense_params *params, double *depth, double *variance, int64_t *flag) {
+    TDK_API_GUARD;
     TDK_REQUIRE(u_key && key_camera && key_image && key_T && ref_camera && ref_image && ref_T && params &&
                     depth && variance && flag,
                 "null pointer");
@@ -1855,6 +1875,7 @@ tdk_status tdk_estimate_one(const int64_t *u_key, double prior_depth, double pri
 
 tdk_status tdk_regularize(const double *depth, const double *variance, const int64_t *flag, int H, int W,
                           double *regularized) {
+    TDK_API_GUARD;
     TDK_REQUIRE(depth && variance && flag && regularized, "null pointer");
     TDK_TRY(check_image_dims(H, W));
     size_t b8 = (size_t)H * W * 8;
@@ -1873,6 +1894,7 @@ tdk_status tdk_regularize(const double *depth, const double *variance, const int
 
 tdk_status tdk_fusion_arrays(const double *mu1, const double *mu2, const double *var1, const double *var2,
                              int64_t n, double *mu, double *var) {
+    TDK_API_GUARD;
     TDK_REQUIRE(n >= 0 && (n == 0 || (mu1 && mu2 && var1 && var2 && mu && var)), "null pointer");
     if (n == 0) return TDK_OK;
     size_t b8 = (size_t)n * 8;
@@ -1950,6 +1972,7 @@ tdk_status sd_check_track(const tdk_sd *h, int track) {
 extern "C" {
 
 tdk_status tdk_sd_destroy(tdk_sd *h) {
+    TDK_API_GUARD;
     if (!h) return TDK_OK;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->images);
@@ -1967,6 +1990,7 @@ tdk_status tdk_sd_destroy(tdk_sd *h) {
 }
 
 tdk_status tdk_sd_create(int n_tracks, int height, int width, int max_refframes, tdk_sd **out) {
+    TDK_API_GUARD;
     TDK_REQUIRE(out != nullptr, "out is NULL");
     TDK_REQUIRE(n_tracks >= 1 && n_tracks <= 65535, "n_tracks must be in [1, 65535]");
     TDK_REQUIRE(max_refframes >= 1 && max_refframes <= 1024, "max_refframes must be in [1, 1024]");
@@ -2031,6 +2055,7 @@ tdk_status tdk_sd_create(int n_tracks, int height, int width, int max_refframes,
 
 tdk_status tdk_sd_set_params(tdk_sd *h, const tdk_semi_dense_params *params, double default_depth,
                              double default_variance, double uncertaintity_bias) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && params, "null pointer");
     h->params = *params;
     h->default_depth = default_depth;
@@ -2041,12 +2066,14 @@ tdk_status tdk_sd_set_params(tdk_sd *h, const tdk_semi_dense_params *params, dou
 }
 
 tdk_status tdk_sd_set_age_policy(tdk_sd *h, int saturate) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     h->saturate_age = saturate != 0;
     return TDK_OK;
 }
 
 tdk_status tdk_sd_get_warp_fallbacks(tdk_sd *h, int64_t *tracks) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && tracks, "null pointer");
     unsigned int v = 0;
     TDK_HIP(hipMemcpyAsync(&v, h->d_warp_fallbacks, sizeof(v), hipMemcpyDeviceToHost, h->stream));
@@ -2057,6 +2084,7 @@ tdk_status tdk_sd_get_warp_fallbacks(tdk_sd *h, int64_t *tracks) {
 
 tdk_status tdk_sd_set_maps(tdk_sd *h, int track, const double *depth, const double *variance,
                            const uint64_t *age) {
+    TDK_API_GUARD;
     TDK_TRY(sd_check_track(h, track));
     const size_t off = (size_t)track * h->stride, b8 = (size_t)h->N * 8;
     if (depth) TDK_HIP(hipMemcpyAsync(h->depth[h->cur] + off, depth, b8, hipMemcpyHostToDevice, h->stream));
@@ -2079,6 +2107,7 @@ static tdk_status sd_read(tdk_sd *h, int which, int track, double *depth, double
 
 tdk_status tdk_sd_get_maps(tdk_sd *h, int track, double *depth, double *variance, uint64_t *age,
                            int64_t *flag) {
+    TDK_API_GUARD;
     TDK_TRY(sd_check_track(h, track));
     TDK_REQUIRE(flag == nullptr || (h->have_result && h->result_has_flag), "no update_depth has run yet: there is no flag map");
     return sd_read(h, h->cur, track, depth, variance, age, flag);
@@ -2086,6 +2115,7 @@ tdk_status tdk_sd_get_maps(tdk_sd *h, int track, double *depth, double *variance
 
 tdk_status tdk_sd_get_results(tdk_sd *h, int track, double *depth, double *variance, uint64_t *age,
                               int64_t *flag) {
+    TDK_API_GUARD;
     TDK_TRY(sd_check_track(h, track));
     TDK_REQUIRE(h->have_result, "no step has run yet");
     TDK_REQUIRE(flag == nullptr || h->result_has_flag, "the last call (tdk_sd_propagate) produced no flag map");
@@ -2094,6 +2124,7 @@ tdk_status tdk_sd_get_results(tdk_sd *h, int track, double *depth, double *varia
 
 tdk_status tdk_sd_push_frame(tdk_sd *h, int track, const double *camera, const double *image,
                              const double *transform_wf) {
+    TDK_API_GUARD;
     TDK_TRY(sd_check_track(h, track));
     TDK_REQUIRE(camera && image, "null pointer");
     const int64_t idx = h->n_frames[track];
@@ -2226,6 +2257,7 @@ extern "C" {
 
 tdk_status tdk_sd_step(tdk_sd *h, const double *transforms10, const double *key_transforms_wf, int commit,
                        int64_t *flag_histogram) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && transforms10, "null pointer");
     TDK_REQUIRE(h->params_set, "tdk_sd_set_params has not been called");
     TDK_TRY(sd_upload_warp(h, transforms10));
@@ -2246,6 +2278,7 @@ tdk_status tdk_sd_step(tdk_sd *h, const double *transforms10, const double *key_
 }
 
 tdk_status tdk_sd_propagate(tdk_sd *h, const double *transforms10, int commit) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && transforms10, "null pointer");
     TDK_REQUIRE(h->params_set, "tdk_sd_set_params has not been called");
     TDK_TRY(sd_upload_warp(h, transforms10));
@@ -2263,6 +2296,7 @@ tdk_status tdk_sd_propagate(tdk_sd *h, const double *transforms10, int commit) {
 
 tdk_status tdk_sd_update_depth(tdk_sd *h, const double *key_transforms_wf, int commit,
                                int64_t *flag_histogram) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h != nullptr, "handle is NULL");
     TDK_REQUIRE(h->params_set, "tdk_sd_set_params has not been called");
     TDK_TRY(sd_upload_keys(h, key_transforms_wf));
@@ -2281,6 +2315,7 @@ tdk_status tdk_sd_update_depth(tdk_sd *h, const double *key_transforms_wf, int c
 }
 
 tdk_status tdk_sd_export_dvo(tdk_sd *h, tdk_dvo *batch) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && batch, "null pointer");
     tdk::DvoLevel0 L;
     TDK_TRY(tdk::dvo_level0(batch, &L));
@@ -2307,6 +2342,7 @@ tdk_status tdk_sd_export_dvo(tdk_sd *h, tdk_dvo *batch) {
 }
 
 tdk_status tdk_sd_get_timing(tdk_sd *h, double *ms3) {
+    TDK_API_GUARD;
     TDK_REQUIRE(h && ms3, "null pointer");
     TDK_REQUIRE(h->have_result, "no step has run yet");
     for (int k = 0; k < 3; k++) ms3[k] = h->ms[k];

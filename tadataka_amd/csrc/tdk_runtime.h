@@ -7,6 +7,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "../../include/tadataka_hip.h"
 
 namespace tdk {
@@ -19,6 +21,11 @@ hipStream_t stream();
 hipStream_t upload_stream();
 tdk_status ensure_device();
 int option(int which);   // tdk_set_option
+// One process-wide recursive mutex taken by EVERY entry of the C ABI (TDK_API_GUARD at its top): the library keeps
+// process-wide state (one stream and grow-only scratch pools for the stateless entries, the allocation registry) and
+// a handle must not be used from two threads at once, so concurrent callers are serialised here instead of being
+// asked to do it themselves.  (tdk_last_error() stays per thread.)
+std::recursive_mutex &api_mutex();
 
 // Grow-only device buffers, indexed by slot; contents are undefined between calls.
 constexpr int kScratchSlots = 16;
@@ -111,6 +118,8 @@ void on_device_release(void (*hook)());
 #define hipMalloc(ptr, bytes) tdk::dev_malloc((void **)(ptr), (bytes), #ptr, __FILE__, __LINE__)
 #define hipFree(ptr) tdk::dev_free((void *)(ptr))
 #endif
+
+#define TDK_API_GUARD std::lock_guard<std::recursive_mutex> tdk_api_guard_(tdk::api_mutex())
 
 // Launch check: catches bad configurations right after the <<<>>>.
 #define TDK_LAUNCH_CHECK() TDK_HIP(hipGetLastError())
