@@ -360,12 +360,7 @@ def workload_dvo_single_pair(args, golden):
         # the plans of the interpreter the fixture's reference run used (the default: this interpreter's own)
         def fixture_plans(shape, n_levels, ratio):
             from tadataka_amd import rescale_plan
-            plans = []
-            for lv in range(n_levels):
-                ho, wo = rescale_plan.rescale_shape(shape, 1 / ratio ** lv)
-                key = f"plan_{shape[0]}x{shape[1]}_{ho}x{wo}"
-                plans.append({"map": golden[key + "_map"], "wr": golden[key + "_wr"], "wc": golden[key + "_wc"]})
-            return plans
+            return rescale_plan.recorded_level_plans(golden, shape, n_levels, ratio)
         dvo.PYRAMID_PLANS = fixture_plans
     pose = est(pair["I0"], pair["D0"], pair["I1"], weights)          # creates the device batch
     n_calls = 100
@@ -849,12 +844,7 @@ def main():
     # run on that interpreter's scikit-image), this interpreter's own otherwise
     fixture_plans = None
     if skimage_mode and golden_early is not None:
-        fixture_plans = []
-        for lv in range(args.levels):
-            ho, wo = rescale_plan.rescale_shape((H, W), 1 / 1.5 ** lv)
-            key = f"plan_{H}x{W}_{ho}x{wo}"
-            fixture_plans.append({"map": golden_early[key + "_map"], "wr": golden_early[key + "_wr"],
-                                  "wc": golden_early[key + "_wc"]})
+        fixture_plans = rescale_plan.recorded_level_plans(golden_early, (H, W), args.levels, 1.5)
     if rank != 0:
         golden_early = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

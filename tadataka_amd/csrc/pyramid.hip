@@ -110,6 +110,19 @@ __device__ __forceinline__ double wave_min(double v) {
     return v;
 }
 
+// v_max_f64 / v_min_f64 as they are: fmax / fmin put a canonicalising v_max_f64 x, x in front of every operand that
+// comes from memory (6 of the 16 operations of a tracked output).  A quiet NaN operand is dropped, as with fmax.
+__device__ __forceinline__ double raw_max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double raw_min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Per thread only the running extremes of the taps live in registers.  An output that could leave the GLOBAL tap
 // range must leave the thread's running range first, so only such outputs (rare: a plateau at an extreme, a NaN)
 // are recorded -- straight into the slot, behind a plain load that drops what would not move it.
@@ -120,8 +133,8 @@ struct ClipTrack {
         tmin = INFINITY;
     }
     __device__ __forceinline__ void add(ClipSlot *slot, double out, double f00, double f01, double f10, double f11) {
-        tmax = fmax(tmax, fmax(fmax(f00, f01), fmax(f10, f11)));
-        tmin = fmin(tmin, fmin(fmin(f00, f01), fmin(f10, f11)));
+        tmax = raw_max(tmax, raw_max(raw_max(f00, f01), raw_max(f10, f11)));
+        tmin = raw_min(tmin, raw_min(raw_min(f00, f01), raw_min(f10, f11)));
         if (!(out <= tmax && out >= tmin)) record(slot, out);     // also taken by a NaN
     }
     __device__ __noinline__ static void record(ClipSlot *slot, double out) {
@@ -139,6 +152,48 @@ struct ClipTrack {
         if ((threadIdx.x & 63) == 0 && (c != -INFINITY || d != INFINITY)) {
             atomicMax(&slot->tap_max, enc(c));
             atomicMin(&slot->tap_min, enc(d));
+        }
+    }
+};
+
+// The tracker of a level whose taps are the source pixels themselves (the identity-scale level inside the streaming
+// kernel): a thread sees every pixel of its column once, so the EXACT extremes of taps and outputs cost two
+// operations each per row -- no per-output comparison, no recording path.  A NaN output only sets a flag.
+struct ClipTrackExact {
+    double tmax, tmin, omax, omin;
+    int nan;                                                      // wave-uniform
+    __device__ __forceinline__ void init() {
+        tmax = omax = -INFINITY;
+        tmin = omin = INFINITY;
+        nan = 0;
+    }
+    __device__ __forceinline__ void tap(double x) {
+        tmax = raw_max(tmax, x);
+        tmin = raw_min(tmin, x);
+    }
+    __device__ __forceinline__ void out(double v) {
+        omax = raw_max(omax, v);
+        omin = raw_min(omin, v);
+    }
+    // called by EVERY lane of the wave (a scalar OR of the comparison's mask): lanes that hold no output of their
+    // own carry blends of real pixels, so a NaN among them means a NaN in the image -- which flags the slot anyway
+    __device__ __forceinline__ void nan_check(double v, bool live) {   // live: wave-uniform
+        const unsigned long long m = __ballot(v != v);
+        nan |= (m != 0ull) & live;
+    }
+    // every lane of the wave must call this
+    __device__ __forceinline__ void flush(ClipSlot *slot) {
+        const double c = wave_max(tmax), d = wave_min(tmin), e = wave_max(omax), f = wave_min(omin);
+        if ((threadIdx.x & 63) == 0) {
+            if (c != -INFINITY || d != INFINITY) {
+                atomicMax(&slot->tap_max, enc(c));
+                atomicMin(&slot->tap_min, enc(d));
+            }
+            if (e != -INFINITY || f != INFINITY) {
+                atomicMax(&slot->out_max, enc(e));
+                atomicMin(&slot->out_min, enc(f));
+            }
+            if (nan) atomicOr(&slot->nan_out, 1u);
         }
     }
 };
@@ -633,15 +688,17 @@ struct StreamArgs {
     ClipSlot *slots;
 };
 
-// lane i <- lane i - 1 / lane i + 1 of the wave (DPP wave_shr:1 / wave_shl:1); the lane without a source keeps x
+// lane i <- lane i - 1 / lane i + 1 of the wave (DPP wave_shr:1 / wave_shl:1); the lane without a source gets 0
+// (bound_ctrl with nothing to preserve: one v_mov_b32_dpp per half, no copy of x in front of it) -- the callers
+// never use that lane's value
 __device__ __forceinline__ double from_left_lane(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), 0x138, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), 0x138, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double from_right_lane(double x) {
-    const int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(x), 0x130, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(x), 0x130, 0xf, 0xf, false);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -739,7 +796,7 @@ __device__ __forceinline__ double stream_vtap(const double *w, int c, const doub
 
 // the horizontal pass + blend of one level for the output rows [oy_lo, oy_hi) of this chunk
 template <int R, int G>
-__device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *__restrict__ ring, int SW, double *dst,
+__device__ __forceinline__ int stream_emit(const AxisMap Lmy, const int LWo, const double *__restrict__ ring, int SW, double *dst,
                                            int oy_lo, int oy_end, int ynew, int ya, int n_groups,
                                            int ncols, int ox_first,
                                            const int (&xoff)[G],
@@ -747,7 +804,7 @@ __device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *_
                                            int wave, int lane, int &unit, ClipTrack &tr, ClipSlot *slot) {
     // the row terms of the next rows: lane i computes those of row oy_lo + i, the rows read them by lane;
     // the rows to emit now are those whose lower tap y0 + 1 is in the ring (a prefix: y0 is monotone)
-    const double my_cy = axis_pos(L.my, oy_lo + lane);
+    const double my_cy = axis_pos(Lmy, oy_lo + lane);
     const double my_fy = floor(my_cy);
     const double my_wy = my_cy - my_fy;
     const int my_y0 = (int)my_fy;
@@ -757,7 +814,7 @@ __device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *_
         const double wy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_wy), i),
                                            __builtin_amdgcn_readlane(__double2loint(my_wy), i));
         const int slot0 = (y0 - ya) % kStreamRing, slot1 = (y0 + 1 - ya) % kStreamRing;
-        double *dst_row = dst + (int64_t)(oy_lo + i) * L.Wo + ox_first;   // uniform base, the lane is the offset
+        double *dst_row = dst + (int64_t)(oy_lo + i) * LWo + ox_first;   // uniform base, the lane is the offset
 #pragma unroll
         for (int g = 0; g < G; g++) {
             if (g >= n_groups) break;
@@ -782,7 +839,8 @@ __device__ __forceinline__ int stream_emit(const StreamLevel &L, const double *_
                 }
                 if (R >= 3) __builtin_amdgcn_sched_barrier(0);    // the two rows one after the other: 16 VGPRs less at R = 3
             }
-            const double wx = wxs[g];
+            double wx = wxs[g];
+            asm volatile("" : "+v"(wx));                          // 1 - wx is computed here, not held per group across the chunk
             const double top = (1.0 - wx) * f[0][0] + wx * f[0][1];
             const double bot = (1.0 - wx) * f[1][0] + wx * f[1][1];
             const double v = (1.0 - wy) * top + wy * bot;
@@ -873,7 +931,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     const bool do_l0 = ((a.l0_mask >> arr) & 1u) != 0;            // block-uniform
     double *dst0 = nullptr;
     ClipSlot *slot0 = nullptr;
-    ClipTrack tr0;
+    ClipTrackExact tr0;
     tr0.init();
     if (do_l0) {
         dst0 = a.l0_dst[arr] + (int64_t)pair * a.l0_stride;
@@ -892,7 +950,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     const int endB = NL > 1 ? (last_seg ? a.lv[1].Ho : first_owned(yb, a.lv[1].my, a.lv[1].Ho)) : 0;
     const int y_last = min(yb, H - 1);                            // last V row this block needs
     const int n_chunks = (y_last - ya + K) / K;
+    // Arguments used once per chunk (the levels' row maps, the identity level's maps) are read from the kernel-argument
+    // segment when they are needed -- scalar loads -- instead of living in SGPRs across the loop: the kernel had ~50
+    // SGPRs spilled into VGPR lanes and ~100 v_readlane per chunk to get them back (12 % of its vector instructions).
+    // The pointer is laundered per chunk so that the loads stay inside the loop.
+    typedef const __attribute__((address_space(4))) StreamArgs *KArgs;
+    KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
     for (int c = 0; c < n_chunks; c++) {
+        asm volatile("" : "+s"(ka));
         const int y = ya + c * K;                                 // first V row of this chunk
         if (c + 1 < n_chunks) {                                   // prefetch the next chunk's K rows
             const int r0 = y + K + RM;
@@ -923,55 +988,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         __syncthreads();
         // outputs whose lower row tap y0 + 1 is now in the ring: y0 + 1 <= y + K - 1
         const int ynew = y + K - 1 >= y_last ? (1 << 30) : y + K - 1;   // the last chunk emits whatever is left
-        nextA = stream_emit<RA, kStreamGroupsA>(a.lv[0], ringA, SW, dstA, nextA, endA, ynew, ya, ngA, ncolsA, oxA0, xoffA, wxA, wckA,
-                                wave, lane, unit, trA, slotA);
-        if constexpr (NL > 1)
-            nextB = stream_emit<RB, kStreamGroupsB>(a.lv[1], ringB, SW, dstB, nextB, endB, ynew, ya, ngB, ncolsB, oxB0, xoffB, wxB,
-                                    wckB, wave, lane, unit, trB, slotB);
+        {
+            AxisMap my;
+            my.a = ka->lv[0].my.a; my.b = ka->lv[0].my.b; my.s = ka->lv[0].my.s; my.ideal = ka->lv[0].my.ideal;
+            nextA = stream_emit<RA, kStreamGroupsA>(my, ka->lv[0].Wo, ringA, SW, dstA, nextA, endA, ynew, ya, ngA, ncolsA, oxA0,
+                                                    xoffA, wxA, wckA, wave, lane, unit, trA, slotA);
+        }
+        if constexpr (NL > 1) {
+            AxisMap my;
+            my.a = ka->lv[1].my.a; my.b = ka->lv[1].my.b; my.s = ka->lv[1].my.s; my.ideal = ka->lv[1].my.ideal;
+            nextB = stream_emit<RB, kStreamGroupsB>(my, ka->lv[1].Wo, ringB, SW, dstB, nextB, endB, ynew, ya, ngB, ncolsB, oxB0,
+                                                    xoffB, wxB, wckB, wave, lane, unit, trB, slotB);
+        }
         if (do_l0) {
             const int oy_end0 = min(yb, H);                       // this block's level-0 rows: those of its segment
             // the column terms, recomputed per chunk (six operations) rather than held in registers across it
             const int l0_x = xa - RM + (int)threadIdx.x;          // halo threads hold the reflected columns
             const bool l0_own = l0_x >= xa && l0_x < xb;
-            const double l0_c = axis_pos(a.l0_mx, l0_x);
+            AxisMap l0mx, l0my;
+            l0mx.a = ka->l0_mx.a; l0mx.b = ka->l0_mx.b; l0mx.s = ka->l0_mx.s; l0mx.ideal = ka->l0_mx.ideal;
+            l0my.a = ka->l0_my.a; l0my.b = ka->l0_my.b; l0my.s = ka->l0_my.s; l0my.ideal = ka->l0_my.ideal;
+            const double l0_c = axis_pos(l0mx, l0_x);
             const double l0_fc = floor(l0_c);
             const double l0_dc = l0_c - l0_fc;
             const bool l0_left = (int)l0_fc < l0_x;               // taps (x - 1, x)
             const bool l0_right = (int)ceil(l0_c) > l0_x;         // taps (x, x + 1); neither: the position is the pixel itself
             // the row terms: lane j computes those of row y + j, the rows read them by lane (-0.04 ms of 1.73)
-            const double my_r = axis_pos(a.l0_my, y + (lane & 7));
+            const double my_r = axis_pos(l0my, y + (lane & 7));
             const double my_fr = floor(my_r);
             const double my_dr = my_r - my_fr;
             const unsigned up_bits = (unsigned)__ballot((int)my_fr < y + (lane & 7)) & 0xffu;
             const unsigned down_bits = (unsigned)__ballot((int)ceil(my_r) > y + (lane & 7)) & 0xffu;
+            // The horizontal blend of a SOURCE row, h(i) = (1 - dc) f0 + dc f1 with (f0, f1) = (neighbour, own) /
+            // (own, neighbour) / (own, own), is the same double for both output rows that tap the row, so it is
+            // computed once per source row (K + 2 per chunk) and an output row is one vertical blend of two of them:
+            // 28 instead of 60 vector operations per output row.  The products commute, so one form serves all three
+            // cases: h = wa * own + wn * nb with the weights and nb picked per column.
+            const double l0_wa = l0_left ? l0_dc : 1.0 - l0_dc, l0_wn = l0_left ? 1.0 - l0_dc : l0_dc;
+            const bool l0_edge = (lane == 0 && l0_left && wave > 0) || (lane == 63 && l0_right && wave < 3);
+            const int l0_nb = lane == 0 ? (wave - 1) * 2 + 1 : (wave + 1) * 2;   // the neighbour wave's border lane
+            auto hblend = [&](int i) {                            // i: row y - 1 + i of the window
+                const double own = w[RM - 1 + i];
+                const double lv = from_left_lane(own), rv = from_right_lane(own);
+                double nb = l0_right ? rv : lv;
+                if (l0_edge) nb = edge[(i * 4) * 2 + l0_nb];
+                if (!(l0_left || l0_right)) nb = own;             // the position is the pixel itself
+                return l0_wa * own + l0_wn * nb;
+            };
+            double h_prev = hblend(0), h_cur = hblend(1);
 #pragma unroll
-            for (int j = 0; j < K; j++) {
+            for (int j = 0; j < K; j++) {                         // (straight-line: rows beyond the segment are computed, not stored)
                 const int oy = y + j;
-                if (oy >= oy_end0) break;                         // uniform
+                const double h_next = hblend(j + 2);
                 const double dr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_dr), j),
                                                    __builtin_amdgcn_readlane(__double2loint(my_dr), j));
                 const bool up = (up_bits >> j) & 1u, down = (down_bits >> j) & 1u;   // uniform: row taps (y - 1, y) / (y, y + 1) / y
-                const double a0 = up ? w[j + RM - 1] : w[j + RM];
-                const double a1 = down ? w[j + RM + 1] : w[j + RM];
-                // (both shifts unconditionally: DPP reads its source lanes under the current EXEC mask)
-                const double l0v = from_left_lane(a0), r0v = from_right_lane(a0);
-                const double l1v = from_left_lane(a1), r1v = from_right_lane(a1);
-                double n0 = l0_left ? l0v : r0v;
-                double n1 = l0_left ? l1v : r1v;
-                if ((lane == 0 && l0_left && wave > 0) || (lane == 63 && l0_right && wave < 3)) {
-                    const int nb = lane == 0 ? (wave - 1) * 2 + 1 : (wave + 1) * 2;   // the neighbour wave's border lane
-                    n0 = edge[((j + (up ? 0 : 1)) * 4) * 2 + nb];
-                    n1 = edge[((j + (down ? 2 : 1)) * 4) * 2 + nb];
-                }
-                const double f00 = l0_left ? n0 : a0, f01 = l0_right ? n0 : a0;
-                const double f10 = l0_left ? n1 : a1, f11 = l0_right ? n1 : a1;
-                const double top = (1.0 - l0_dc) * f00 + l0_dc * f01;
-                const double bot = (1.0 - l0_dc) * f10 + l0_dc * f11;
+                const double top = up ? h_prev : h_cur;
+                const double bot = down ? h_next : h_cur;
                 const double v = (1.0 - dr) * top + dr * bot;
-                if (l0_own) {
+                if (l0_own && oy < oy_end0) {
                     dst0[(int64_t)oy * W + l0_x] = v;
-                    if (slot0) tr0.add(slot0, v, f00, f01, f10, f11);
+                    tr0.tap(w[RM + j]); tr0.out(v);               // (tracked whether or not there is a slot: 4 operations)
                 }
+                tr0.nan_check(v, oy < oy_end0);
+                h_prev = h_cur; h_cur = h_next;
                 __builtin_amdgcn_sched_barrier(0);                // one row at a time
             }
         }

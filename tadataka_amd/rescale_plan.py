@@ -29,7 +29,7 @@ from functools import lru_cache
 
 import numpy as np
 
-__all__ = ["resize_map", "gaussian_kernel", "resize_plan", "level_plans", "rescale_shape"]
+__all__ = ["resize_map", "gaussian_kernel", "resize_plan", "level_plans", "rescale_shape", "recorded_level_plans"]
 
 
 def rescale_shape(shape, scale):
@@ -120,3 +120,15 @@ def level_plans(shape, n_levels, ratio=1.5, anti_aliasing=True):
     """Plans of the levels 0 .. n_levels - 1 of PoseChangeEstimator's pyramid (scale 1 / ratio**level)."""
     return [resize_plan(shape, rescale_shape(shape, 1 / pow(ratio, level)), anti_aliasing)
             for level in range(n_levels)]
+
+
+def recorded_level_plans(records, shape, n_levels, ratio=1.5):
+    """The plans another interpreter produced, from records `plan_{H}x{W}_{Ho}x{Wo}_{map,wr,wc}` (a mapping, e.g. an
+    opened tests/golden/skimage_*.npz): with them the device pyramid equals what scikit-image returned THERE, bit for
+    bit -- how bench.py and the tests hold results against the reference run on a real scikit-image."""
+    plans = []
+    for level in range(n_levels):
+        ho, wo = rescale_shape(shape, 1 / pow(ratio, level))
+        key = f"plan_{int(shape[0])}x{int(shape[1])}_{ho}x{wo}"
+        plans.append({"map": records[key + "_map"], "wr": records[key + "_wr"], "wc": records[key + "_wc"]})
+    return plans
