@@ -731,13 +731,15 @@ __global__ __launch_bounds__(256) void k_level0_stream(Level0Args a) {
     const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
     double *d = a.dst[arr] + (int64_t)pair * a.dst_stride;
     ClipSlot *slot = a.slots ? a.slots + ((int64_t)pair * a.n_arrays + arr) * a.n_out + a.lvl : nullptr;
-    ClipTrack tr;
+    ClipTrackExact tr;
     tr.init();
-    // column terms
+    // column terms: h = wa * own + wn * nb (see k_pyramid_stream: the blend of a SOURCE row, shared by the two output
+    // rows that tap it)
     const double c = axis_pos(a.mx, x);
     const double fc = floor(c);
     const double dc = c - fc;
     const bool left = (int)fc < x, right = (int)ceil(c) > x;      // taps (x - 1, x) / (x, x + 1) / x itself
+    const double wa = left ? dc : 1.0 - dc, wn = left ? 1.0 - dc : dc;
     // row terms of the segment: lane j computes those of row y0 + j
     const int y0 = seg * kL0Seg, y1 = min(y0 + kL0Seg, H);
     const double my_r = axis_pos(a.my, y0 + lane);
@@ -749,34 +751,36 @@ __global__ __launch_bounds__(256) void k_level0_stream(Level0Args a) {
     double w[kL0Ahead + 2], nxt[kL0Ahead];
 #pragma unroll
     for (int i = 0; i < kL0Ahead + 2; i++) w[i] = s[(int64_t)skimage_reflect(y0 - 1 + i, H) * W + xcol];
+    auto hblend = [&](double v) {
+        const double lv = from_left_lane(v), rv = from_right_lane(v);
+        double nb = right ? rv : lv;
+        if (!(left || right)) nb = v;
+        return wa * v + wn * nb;
+    };
     for (int y = y0; y < y1; y += kL0Ahead) {
         if (y + kL0Ahead < y1) {                                  // the next group's rows y + 9 .. y + 16
 #pragma unroll
             for (int i = 0; i < kL0Ahead; i++)
                 nxt[i] = s[(int64_t)skimage_reflect(y + kL0Ahead + 1 + i, H) * W + xcol];
         }
+        double h_prev = hblend(w[0]), h_cur = hblend(w[1]);
 #pragma unroll
-        for (int j = 0; j < kL0Ahead; j++) {
+        for (int j = 0; j < kL0Ahead; j++) {                      // (straight-line: rows beyond the segment are computed, not stored)
             const int oy = y + j;
-            if (oy >= y1) break;                                  // uniform
-            const int k = oy - y0;
+            const int k = min(oy - y0, 63);
+            const double h_next = hblend(w[j + 2]);
             const double dr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_dr), k),
                                                __builtin_amdgcn_readlane(__double2loint(my_dr), k));
             const bool up = (up_bits >> k) & 1ull, down = (down_bits >> k) & 1ull;   // uniform
-            const double a0 = up ? w[j] : w[j + 1];
-            const double a1 = down ? w[j + 2] : w[j + 1];
-            const double l0v = from_left_lane(a0), r0v = from_right_lane(a0);
-            const double l1v = from_left_lane(a1), r1v = from_right_lane(a1);
-            const double n0 = left ? l0v : r0v, n1 = left ? l1v : r1v;
-            const double f00 = left ? n0 : a0, f01 = right ? n0 : a0;
-            const double f10 = left ? n1 : a1, f11 = right ? n1 : a1;
-            const double top = (1.0 - dc) * f00 + dc * f01;
-            const double bot = (1.0 - dc) * f10 + dc * f11;
+            const double top = up ? h_prev : h_cur;
+            const double bot = down ? h_next : h_cur;
             const double v = (1.0 - dr) * top + dr * bot;
-            if (own) {
+            if (own && oy < y1) {
                 d[(int64_t)oy * W + x] = v;
-                if (slot) tr.add(slot, v, f00, f01, f10, f11);
+                tr.tap(w[j + 1]); tr.out(v);
             }
+            tr.nan_check(v, oy < y1);
+            h_prev = h_cur; h_cur = h_next;
         }
 #pragma unroll
         for (int i = 0; i < 2; i++) w[i] = w[kL0Ahead + i];
