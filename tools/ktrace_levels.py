@@ -1,3 +1,4 @@
+"""Per-grid (= per pyramid level) averages of the kernels in a rocprofv3 kernel trace: python tools/ktrace_levels.py <kernel_trace.csv>"""
 import csv,collections,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 agg=collections.defaultdict(list)

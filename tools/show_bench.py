@@ -1,3 +1,4 @@
+"""Prints the numbers of a bench.py JSON line that are looked at after every run: python tools/show_bench.py <bench.json>"""
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 print(d["ms_per_step"], d["frame_pairs_per_s"], d["value"], d["roofline"]["frac"], d["timed_seconds"])

@@ -1,3 +1,4 @@
+"""Host-side time of the calls of one step of the stream workload (upload_async / build_pyramid / estimate), for the note on launch overheads."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
