@@ -230,6 +230,10 @@ tdk_status tdk_dvo_get_tukey_fallbacks(tdk_dvo *h, int64_t *pairs);
  * whose prediction was too far off for the remainder bound takes a third pass.  *pairs = how often that
  * happened since the batch was created. */
 tdk_status tdk_dvo_get_student_redos(tdk_dvo *h, int64_t *pairs);
+/* ... and a pair whose third pass still moved an expansion point by more than 1e-4 (a small update mask with gross
+ * outliers: the sample's sequence tens of per cent off) takes the nine remaining steps one after the other, as
+ * weights.py:13-16 does.  *pairs = how often that happened since the batch was created. */
+tdk_status tdk_dvo_get_student_fallbacks(tdk_dvo *h, int64_t *pairs);
 /* How the Student-t variance is iterated: 0 (default) the Taylor passes above; 1 the nine sequential passes
  * over the residuals (one per fixed-point step, reciprocal arithmetic); 2 the nine passes with IEEE divisions
  * (the CPU restatement's operations).  Defaults from TDK_STUDENT=sequential / TDK_STUDENT_EXACT=1 at creation. */

@@ -102,6 +102,7 @@ PROTOTYPES = {
     "tdk_dvo_get_counts": [_vp, c_int64_p, c_int64_p],
     "tdk_dvo_get_tukey_fallbacks": [_vp, c_int64_p],
     "tdk_dvo_get_student_redos": [_vp, c_int64_p],
+    "tdk_dvo_get_student_fallbacks": [_vp, c_int64_p],
     "tdk_dvo_set_student_passes": [_vp, _i],
     "tdk_dvo_get_robust_scale": [_vp, _d],
     "tdk_dvo_set_profiling": [_vp, _i],

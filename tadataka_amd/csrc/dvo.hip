@@ -222,9 +222,16 @@ __global__ void k_norm_tables(const PairParams *__restrict__ params, double scal
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= W + H) return;
     const PairParams pp = params[pair];
-    const double fx0 = pp.cam0[0] * scale, fy0 = pp.cam0[1] * scale;
-    const double ox0 = pp.cam0[2] * scale, oy0 = pp.cam0[3] * scale;
-    tab[(size_t)pair * (W + H) + i] = i < W ? ((double)i - ox0) / fx0 : ((double)(i - W) - oy0) / fy0;
+    // un-fused, as NumPy computes them: with contraction the compiler turns x - offset * scale into one fma (the
+    // product unrounded), the table entries of a level > 0 differ from the reference's in the last bit for cameras
+    // whose scaled offset is not exact, and at the identity prior border pixels change sides of the inclusive mask
+    // (found by tests/test_gpu_fuzz.py: 12 of 1975 pixels of a 32 x 141 level)
+    {
+#pragma clang fp contract(off)
+        const double fx0 = pp.cam0[0] * scale, fy0 = pp.cam0[1] * scale;
+        const double ox0 = pp.cam0[2] * scale, oy0 = pp.cam0[3] * scale;
+        tab[(size_t)pair * (W + H) + i] = i < W ? ((double)i - ox0) / fx0 : ((double)(i - W) - oy0) / fy0;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2189,6 +2196,51 @@ __global__ __launch_bounds__(64) void k_student_chain(const double *__restrict__
         if (pass == 1) atomicAdd(n_redo, 1u);
     }
     p[kStudentPts] = again ? 1.0 : 0.0;
+    // pass C itself moved a point by more than the threshold: the sample's sequence was tens of per cent off (a small
+    // mask with gross outliers -- found by tests/test_gpu_fuzz.py: 137 residuals, seven of them 70 sigma out, variance
+    // 1.2e-4 off after pass C) and the parabolas have not contracted yet -> the pair takes the nine steps one after
+    // the other (k_student_sequential), from v_1 = p[0]
+    if (pass == 2 && moved > kStudentRedo) {
+        p[kStudentPts] = 2.0;
+        atomicAdd(n_redo + 1, 1u);
+    }
+}
+
+// The nine remaining fixed-point steps of a pair that the Taylor passes gave up on, one block per pair, one step after
+// the other over the pair's residual map with the arithmetic of k_robust_student_step<true>.  Every other pair's block
+// returns after one load.  Rare by construction (see k_student_chain); a VGA pair costs it ~1 ms.
+__global__ __launch_bounds__(kBlock) void k_student_sequential(const double *__restrict__ rm, int64_t stride, int N,
+                                                               const int *__restrict__ count,
+                                                               const int *__restrict__ state, double *__restrict__ pts,
+                                                               double *__restrict__ variance) {
+    __shared__ double red[kWaves];
+    const int pair = blockIdx.x;
+    if (state != nullptr && state[pair] != ST_RUNNING) return;
+    double *p = pts + (size_t)pair * kStudentRow;
+    if (p[kStudentPts] != 2.0) return;
+    const double *r = rm + (int64_t)pair * stride;
+    const double n = (double)count[pair];
+    double v = p[0];                                    // v_1 = F(1), exact, from the mask pass
+    for (int it = 1; it < 10; it++) {
+        const double rvar = 1.0 / v;
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < N; i += kBlock) {
+            const double x = r[i];
+            if (x == x) {
+                const double s = x * x;
+                acc += s * ((kStudentNu + 1.0) * fast_rcp(__builtin_fma(s, rvar, kStudentNu)));
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        v = ((red[0] + red[1]) + (red[2] + red[3])) / n;
+    }
+    if (threadIdx.x == 0) {
+        variance[pair] = v;
+        p[kStudentPts] = 0.0;
+    }
 }
 
 // ---- synthetic scene on the device (tadataka_amd/synthetic.py) ------------
@@ -2258,7 +2310,7 @@ struct tdk_dvo {
     double *d_stat;       // [n][4]: lo, hi, median, spare
     double *d_spartial;   // [n][kStatBlocks][kStudentSums] block partials of the statistics passes | [n][kStatBlocks] of the first step (fused pass A)
     double *d_st_pts;     // [n][kStudentRow] Student-t: expansion points of the Taylor passes, redo flag
-    unsigned int *d_st_redo;   // pairs that took a third Taylor pass (diagnostics)
+    unsigned int *d_st_redo;   // [0] pairs that took a third Taylor pass, [1] pairs that fell back to the nine sequential steps (diagnostics)
     int *d_count;         // [n]
     void *d_select;       // SelectState[n]
     unsigned int *d_hist; // [n][kSelectBins]
@@ -2409,8 +2461,8 @@ tdk_status ensure_robust_buffers(tdk_dvo *h) {
     TDK_HIP(hipMalloc(&h->d_stat, sizeof(double) * 4 * n));
     TDK_HIP(hipMalloc(&h->d_spartial, sizeof(double) * kStatBlocks * (kStudentSums + 1) * n));   // + the first step's partials
     TDK_HIP(hipMalloc(&h->d_st_pts, sizeof(double) * kStudentRow * n));
-    TDK_HIP(hipMalloc(&h->d_st_redo, sizeof(unsigned int)));
-    TDK_HIP(hipMemsetAsync(h->d_st_redo, 0, sizeof(unsigned int), h->stream));
+    TDK_HIP(hipMalloc(&h->d_st_redo, 2 * sizeof(unsigned int)));
+    TDK_HIP(hipMemsetAsync(h->d_st_redo, 0, 2 * sizeof(unsigned int), h->stream));
     TDK_HIP(hipMalloc(&h->d_count, sizeof(int) * n));
     TDK_HIP(hipMalloc(&h->d_select, sizeof(SelectState) * n));
     TDK_HIP(hipMalloc(&h->d_cand, sizeof(uint64_t) * kSelectCap * n));
@@ -2566,6 +2618,9 @@ tdk_status prepare_robust(tdk_dvo *h, int level, const double *d_poses, const in
                                                          h->d_wscale, pass, h->d_st_redo);
                 TDK_LAUNCH_CHECK();
             }
+            k_student_sequential<<<n, kBlock, 0, h->stream>>>(h->d_rm, L.stride, (int)L.N, h->d_count, d_state,
+                                                              h->d_st_pts, h->d_wscale);
+            TDK_LAUNCH_CHECK();
             return TDK_OK;
         }
         for (int it = 1; it < 10; it++) {   // n_iter = 10 (weights.py:4)
@@ -3393,6 +3448,18 @@ tdk_status tdk_dvo_get_robust_scale(tdk_dvo *h, double *scale) {
     return TDK_OK;
 }
 
+tdk_status tdk_dvo_get_student_fallbacks(tdk_dvo *h, int64_t *pairs) {
+    TDK_API_GUARD;
+    TDK_REQUIRE(h && pairs, "null pointer");
+    *pairs = 0;
+    if (!h->d_st_redo) return TDK_OK;
+    unsigned int v = 0;
+    TDK_HIP(hipMemcpyAsync(&v, h->d_st_redo + 1, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    TDK_HIP(hipStreamSynchronize(h->stream));
+    *pairs = (int64_t)v;
+    return TDK_OK;
+}
+
 tdk_status tdk_dvo_get_student_redos(tdk_dvo *h, int64_t *pairs) {
     TDK_API_GUARD;
     TDK_REQUIRE(h && pairs, "null pointer");
@@ -3461,7 +3528,10 @@ tdk_status tdk_dvo_set_level_plan(tdk_dvo *h, int level, const double *map, cons
     TDK_REQUIRE(radius_rows >= 0 && radius_cols >= 0 && radius_rows <= tdk::pyramid_max_radius() &&
                 radius_cols <= tdk::pyramid_max_radius(), "kernel radius out of range");
     TDK_REQUIRE((radius_rows == 0 || w_rows) && (radius_cols == 0 || w_cols), "kernel is NULL");
-    TDK_REQUIRE(map[0] > 0.0 && map[2] > 0.0, "the map's scales must be positive");
+    // (a one-pixel output axis: skimage's estimate of the degenerate corner set gives scale 0 and only the offset is used)
+    TDK_REQUIRE((map[0] > 0.0 || (h->lv[level].W == 1 && map[0] == 0.0)) &&
+                    (map[2] > 0.0 || (h->lv[level].H == 1 && map[2] == 0.0)),
+                "the map's scales must be positive");
     for (int k = 0; k < 4; k++) P.map[k] = map[k];
     P.wr.assign(w_rows, w_rows + (radius_rows > 0 ? 2 * radius_rows + 1 : 0));
     P.wc.assign(w_cols, w_cols + (radius_cols > 0 ? 2 * radius_cols + 1 : 0));

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void k_interpolation(const double *__restri
             out[i] = 0.0;
             continue;
         }
-        out[i] = tdk::bilinear(img, H, W, p.x, p.y);
+        out[i] = tdk::bilinear_exact(img, H, W, p.x, p.y);
     }
 }
 

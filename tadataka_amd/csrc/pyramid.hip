@@ -1183,6 +1183,21 @@ __global__ __launch_bounds__(256) void k_clip_apply(ClipArgs a) {
     }
 }
 
+// A level whose taps skip elements of the filtered image (a shrinking map with no prefilter, or with a kernel
+// narrower than the gaps between its taps -- never skimage's own sigma rule, but the plan is the caller's): a NaN
+// that no tap sees still makes numpy.clip's bounds NaN, i.e. every output.  One pass over the source flags the
+// slots of those levels (found by tests/test_gpu_fuzz.py: rescale(anti_aliasing=False) of an image with one NaN).
+__global__ __launch_bounds__(256) void k_clip_nan_scan(ClipArgs a, unsigned level_mask) {
+    const int arr = blockIdx.y, pair = blockIdx.z;
+    const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
+    const int64_t n = (int64_t)a.H * a.W;
+    bool nan = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) nan |= s[i] != s[i];
+    if (__ballot(nan) == 0ull || (threadIdx.x & 63) != 0) return;
+    for (int l = 0; l < a.n_out; l++)
+        if ((level_mask >> l) & 1u) atomicOr(&a.slots[((int64_t)pair * a.n_arrays + arr) * a.n_out + l].nan_out, 1u);
+}
+
 // Few slots (a single pair: 3 images x 3 levels): gate, bounds and clip in ONE launch, a block per slot -- a flagged
 // slot's block walks the whole source image by itself (rare, and then a few hundred microseconds); the three
 // launches above cost a single-pair call 10 us more than this one.
@@ -1269,7 +1284,18 @@ bool taps_inside(const AxisMap &m, int n_in, int n_out) {
     if (n_out >= n_in) return false;
     const double p0 = axis_pos(m, 0), p1 = axis_pos(m, n_out - 1);
     if (!(p0 >= 0.0) || !(p1 > p0)) return false;
-    return (int)floor(p1) + 1 <= n_in - 1;
+    if ((int)floor(p1) + 1 > n_in - 1) return false;
+    // skimage's second tap is ceil(p): at a sample position that is an integer it is the FIRST tap again, and the
+    // pixel next to it is never read.  The tiles and the streaming kernel read it with weight 0 -- the same double for
+    // finite images, NaN for an Inf / NaN neighbour (found by tests/test_gpu_fuzz.py on an 11 x 71 image whose
+    // estimated row map 11/7 o + 2/7 hits 5.0).  A level with such a position goes to the general kernel, which taps
+    // floor / ceil.  (Affine maps only: the ideal reading's taps are floor and floor + 1 by definition.)
+    if (!m.ideal)
+        for (int o = 0; o < n_out; o++) {
+            const double p = axis_pos(m, o);
+            if (p == floor(p)) return false;
+        }
+    return true;
 }
 
 }  // namespace
@@ -1559,6 +1585,24 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
         for (int l = 0; l < n_out; l++) rc_max = std::max(rc_max, dv[l].aa.Rc);
         const size_t lds = sizeof(double) * (size_t)kClipTileRows * (kClipTileCols + 2 * rc_max);
         const int n = (int)(images * n_out);
+        unsigned sparse = 0u;                       // levels whose taps can miss a NaN of the filtered image
+        for (int l = 0; l < n_out; l++) {
+            auto skips = [](const AxisMap &m, int n_in, int n_o, int R) {
+                const double p0 = axis_pos(m, 0), p1 = axis_pos(m, n_o - 1);
+                const double step = n_o > 1 ? (p1 - p0) / (double)(n_o - 1) : 0.0;
+                if (!(step == step) || !(p0 == p0)) return true;
+                const int gap = step > 1.0 ? (int)ceil(step) - 1 : 0;
+                const int lo = std::max(0, (int)floor(std::min(p0, p1))), hi = std::min(n_in - 1, (int)ceil(std::max(p0, p1)));
+                return gap >= 2 * R + 1 || lo > R || (n_in - 1 - hi) > R;
+            };
+            if (skips(dv[l].mx, W, dv[l].Wo, dv[l].aa.Rc) || skips(dv[l].my, H, dv[l].Ho, dv[l].aa.Rr)) sparse |= 1u << l;
+        }
+        if (sparse) {
+            const int64_t per = ((int64_t)H * W + 256 * 16 - 1) / (256 * 16);
+            dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>(per, 1), 256), n_arrays, batch);
+            k_clip_nan_scan<<<grid, 256, 0, stream>>>(c, sparse);
+            TDK_LAUNCH_CHECK();
+        }
         if (n <= 64) {
             k_clip_small<<<n, 256, lds, stream>>>(c);
             TDK_LAUNCH_CHECK();
@@ -1629,7 +1673,9 @@ tdk_status tdk_rescale_skimage(const double *image, int H, int W, double *out, i
     TDK_REQUIRE(H > 0 && W > 0 && Ho > 0 && Wo > 0 && image && out && map, "bad argument");
     TDK_REQUIRE(radius_rows >= 0 && radius_cols >= 0 && radius_rows <= kMaxGaussRadius && radius_cols <= kMaxGaussRadius,
                 "kernel radius out of range");
-    TDK_REQUIRE(map[0] > 0.0 && map[2] > 0.0, "the map's scales must be positive");
+    // (a one-pixel output axis: skimage's estimate of the degenerate corner set gives scale 0 and only the offset is used)
+    TDK_REQUIRE((map[0] > 0.0 || (Wo == 1 && map[0] == 0.0)) && (map[2] > 0.0 || (Ho == 1 && map[2] == 0.0)),
+                "the map's scales must be positive");
     tdk::PyramidLevelDesc lv;
     lv.mx = tdk::affine_axis(map[0], map[1]);
     lv.my = tdk::affine_axis(map[2], map[3]);

@@ -84,6 +84,26 @@ TDK_HD double bilinear(const double *img, int H, int W, double cx, double cy) {
            r1[lxi] * (ux - cx) * (cy - ly) + r1[uxi] * (cx - lx) * (cy - ly);
 }
 
+// The same function with the reference's three short cuts taken literally (a term the reference does not form is
+// replaced by -0.0, the neutral element of the addition, instead of texel * 0): identical to the above for finite
+// images, and for an image with Inf / NaN texels it returns what the reference returns when a coordinate is an
+// integer -- the texel itself, not NaN from 0 * Inf of a neighbour the reference never reads.  The parity-granular
+// operator uses this one; the search loop of update_depth keeps the shorter form (frames are finite).
+TDK_HD double bilinear_exact(const double *img, int H, int W, double cx, double cy) {
+    double lx = floor(cx), ly = floor(cy);
+    int lxi = (int)lx, lyi = (int)ly;
+    int uxi = min(lxi + 1, W - 1), uyi = min(lyi + 1, H - 1);
+    double ux = lx + 1.0, uy = ly + 1.0;
+    const double *r0 = img + (int64_t)lyi * W;
+    const double *r1 = img + (int64_t)uyi * W;
+    const bool ix = lx == cx, iy = ly == cy;
+    const double t00 = r0[lxi] * (ux - cx) * (uy - cy);
+    const double t01 = ix ? -0.0 : r0[uxi] * (cx - lx) * (uy - cy);
+    const double t10 = iy ? -0.0 : r1[lxi] * (ux - cx) * (cy - ly);
+    const double t11 = (ix || iy) ? -0.0 : r1[uxi] * (cx - lx) * (cy - ly);
+    return t00 + t01 + t10 + t11;
+}
+
 // src/numeric.rs:3-5
 TDK_HD double safe_inv(double v) { return 1. / (v + kEpsM); }
 

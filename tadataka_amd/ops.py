@@ -376,6 +376,12 @@ class DvoBatch(object):
         call("tdk_dvo_get_student_redos", self._h, C.byref(v))
         return int(v.value)
 
+    def student_fallbacks(self):
+        """Pairs whose third Taylor pass had not converged either and that took the nine sequential steps."""
+        v = C.c_int64()
+        call("tdk_dvo_get_student_fallbacks", self._h, C.byref(v))
+        return int(v.value)
+
     def set_profiling(self, enabled, all_levels=False):
         """HIP events around the evaluation launches of the finest level (all_levels: of every level)."""
         call("tdk_dvo_set_profiling", self._h, 2 if (enabled and all_levels) else int(bool(enabled)))

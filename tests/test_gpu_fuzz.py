@@ -1,0 +1,536 @@
+"""Randomised parity soak: every kernel family of the HIP path against the CPU oracle on random
+shapes (down to 2 x 2), random poses (small, large, behind the camera), degenerate depths (0, negative,
+NaN, huge), ragged graphs -- the inputs nobody wrote a fixture for.
+
+TDK_FUZZ_N cases per family (default 12, seconds); the soak of profiles/r05_fuzz.txt ran it with
+TDK_FUZZ_N=1500.  TDK_FUZZ_SEED moves the whole sequence.  Bars as everywhere: bit-exact for the
+parity-granular operators, the pyramid and the semi-dense maps; 1e-9 per entry on the normal equations;
+1e-6 on poses."""
+import os
+
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from conftest import b6_err, h21_err
+
+pytestmark = pytest.mark.gpu
+
+N_CASES = int(os.environ.get("TDK_FUZZ_N", "12"))
+SEED = int(os.environ.get("TDK_FUZZ_SEED", "0"))
+RTOL_SUMS = 1e-9
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tadataka_amd import _lib, ops as o
+    _lib.require_gpu()
+    return o
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _pose12(R, t):
+    return np.concatenate([np.asarray(R).ravel(), np.asarray(t).ravel()])
+
+
+def _T(R, t):
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return T
+
+
+def _random_pose(rng):
+    kind = rng.integers(0, 6)
+    if kind == 0:
+        return np.eye(3), np.zeros(3)
+    scale_r = [0.01, 0.01, 0.1, 0.5, 3.0][kind - 1]
+    scale_t = [0.02, 0.2, 0.1, 1.0, 3.0][kind - 1]
+    R = Rotation.from_rotvec(rng.uniform(-scale_r, scale_r, 3)).as_matrix()
+    return R, rng.uniform(-scale_t, scale_t, 3)
+
+
+def _random_scene(rng, H, W):
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    a, b, c = rng.uniform(2, 9, 3)
+    I1 = 0.5 + 0.25 * np.sin(xx / a) * np.cos(yy / b) + 0.2 * np.sin((xx + yy) / c) + 0.02 * rng.uniform(-1, 1, (H, W))
+    I0 = 0.5 + 0.25 * np.sin((xx + 0.3) / a) * np.cos(yy / b) + 0.2 * np.sin((xx + yy) / c) + 0.05 * rng.uniform(-1, 1, (H, W))
+    D0 = 2.0 + 0.3 * np.sin(xx / 11) + 0.2 * np.cos(yy / 7) + rng.uniform(-0.05, 0.05, (H, W))
+    dirt = rng.integers(0, 5)
+    if dirt == 1:      # what a depth sensor reports
+        D0[rng.random((H, W)) < 0.1] = 0.0
+    elif dirt == 2:
+        D0[rng.random((H, W)) < 0.05] = np.nan
+        D0[rng.random((H, W)) < 0.05] = -1.0
+    elif dirt == 3:
+        D0[rng.random((H, W)) < 0.03] = 1e300
+        D0[rng.random((H, W)) < 0.03] = 1e-300
+    if rng.random() < 0.15:    # outliers beyond Huber's k
+        I0[rng.random((H, W)) < 0.05] += rng.choice([-3.0, 3.0])
+    f = rng.uniform(0.5, 2.0) * max(H, W)
+    cam = np.array([f, f * rng.uniform(0.9, 1.1), W / 2 + rng.uniform(-1, 1), H / 2 + rng.uniform(-1, 1)])
+    return I0, D0, I1, cam
+
+
+def _same(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+# ---------------------------------------------------------------------------
+# fused DVO evaluation and the error-only probe
+# ---------------------------------------------------------------------------
+def test_fuzz_dvo_evaluate(ops, orc):
+    rng = np.random.default_rng(1000 + SEED)
+    worst = 0.0
+    for case in range(N_CASES):
+        H, W = (int(v) for v in rng.integers(2, 97, 2))
+        if rng.random() < 0.2:
+            H, W = int(rng.integers(2, 5)), int(rng.integers(2, 40))
+        I0, D0, I1, cam = _random_scene(rng, H, W)
+        wmap = rng.uniform(0.0, 2.0, (H, W))
+        R, t = _random_pose(rng)
+        GX, GY = orc.image_gradient(I1)
+        batch = ops.DvoBatch(1, H, W, with_weight_map=True)
+        batch.upload(0, I0, D0, I1, wmap)
+        P = _pose12(R, t)[None]
+        info = f"case {case}: {H}x{W} pose {Rotation.from_matrix(R).as_rotvec()} {t}"
+        s_ref, n_ref = orc.photometric_error_sums(I0, D0, I1, cam, cam, _T(R, t))
+        ss, ne = batch.photometric_error(0, cam, cam, P)
+        assert ne[0] == n_ref, info
+        if n_ref and np.isfinite(s_ref):
+            assert abs(ss[0] - s_ref) <= RTOL_SUMS * abs(s_ref), info
+        for wname in (None, "huber", "map", "student-t", "tukey"):
+            weights = wmap if wname == "map" else wname
+            mode = ops.W_MAP if wname == "map" else ops.WEIGHT_MODES[wname]
+            ev = batch.evaluate(0, cam, cam, P, mode)
+            assert ev["n_error"][0] == n_ref, (info, wname)
+            if n_ref and np.isfinite(s_ref):
+                assert abs(ev["sum_sq"][0] - s_ref) <= RTOL_SUMS * abs(s_ref), (info, wname)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                Href, bref, M = orc.dvo_normal_equations(I0, D0, I1, GX, GY, cam, cam, R, t, weights)
+            assert ev["n_update"][0] == M, (info, wname)
+            if M < 12 and wname in ("student-t", "tukey"):
+                continue        # the statistics of a handful of residuals (a zero MAD, ...) are not the point here
+            if M == 0 or not (np.all(np.isfinite(Href)) and np.all(np.isfinite(bref))):
+                continue
+            if np.min(Href[[0, 6, 11, 15, 18, 20]]) <= 0.0:
+                continue
+            e1 = h21_err(ev["H"][0], Href)
+            e2 = b6_err(ev["b"][0], bref, Href)
+            worst = max(worst, e1, e2)
+            assert e1 < RTOL_SUMS and e2 < RTOL_SUMS, (info, wname, e1, e2)
+        batch.close()
+    print(f"dvo evaluate: {N_CASES} cases, worst per-entry error {worst:.2e}")
+
+
+def test_fuzz_dvo_estimate_small_scenes(ops, orc):
+    """The device Gauss-Newton loop against the oracle's reference-structured loop (lstsq on J, the same accept rule)
+    on random small pairs with a known pose, one and two pyramid levels, ideal-constants pyramid on both sides."""
+    from tadataka_amd import synthetic
+    rng = np.random.default_rng(2000 + SEED)
+    n = max(2, N_CASES // 3)
+    mism = 0
+    for case in range(n):
+        H, W = int(rng.integers(24, 80)), int(rng.integers(32, 100))
+        pair = synthetic.make_pair(H, W, seed=int(rng.integers(0, 1 << 30)))
+        levels = int(rng.integers(1, 3))
+        wname = [None, "huber", "student-t", "tukey"][int(rng.integers(0, 4))]
+        cam = pair["cam"]
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            Rr, tr = orc.dvo_estimate(pair["I0"], pair["D0"], pair["I1"], cam, cam, wname, n_coarse_to_fine=levels,
+                                      max_iter=20, anti_aliasing=True)[:2]
+        batch = ops.DvoBatch(1, H, W, n_levels=levels)
+        batch.upload(0, pair["I0"], pair["D0"], pair["I1"])
+        batch.build_pyramid()
+        P, _ = batch.estimate(cam, cam, _pose12(np.eye(3), np.zeros(3))[None], ops.WEIGHT_MODES[wname], 20)
+        batch.close()
+        Rr = Rr.as_matrix() if hasattr(Rr, "as_matrix") else np.asarray(Rr)
+        d = max(np.max(np.abs(P[0, :9].reshape(3, 3) - Rr)), np.max(np.abs(P[0, 9:] - tr)))
+        if d >= 1e-6:
+            mism += 1
+        assert d < 1e-6, (case, H, W, levels, wname, d)
+    print(f"dvo estimate: {n} scenes, {mism} beyond 1e-6")
+
+
+# ---------------------------------------------------------------------------
+# skimage.transform.rescale on the device
+# ---------------------------------------------------------------------------
+def test_fuzz_rescale_skimage_bit_exact(ops, orc):
+    from tadataka_amd import rescale_plan
+    rng = np.random.default_rng(3000 + SEED)
+    for case in range(N_CASES):
+        H, W = (int(v) for v in rng.integers(1, 75, 2))
+        scale = float(rng.choice([1 / 1.5, 1 / 2.25, 0.5, 1.0, rng.uniform(0.08, 1.0), rng.uniform(1.0, 2.5)]))
+        aa = bool(rng.integers(0, 2))
+        clip = bool(rng.integers(0, 2))
+        img = rng.uniform(0, 1, (H, W))
+        kind = rng.integers(0, 6)
+        if kind == 1:
+            img[:] = rng.uniform(0.5, 3.0)                       # a plateau: clip=True decides the last bit
+        elif kind == 2:
+            img = np.round(img * 4) / 4                          # plateaus at the extremes
+        elif kind == 3 and H * W > 1:
+            img[rng.integers(0, H), rng.integers(0, W)] = np.nan
+        elif kind == 4:
+            img *= 1e5
+        if min(np.round(H * scale), np.round(W * scale)) < 1:
+            continue                                             # scikit-image raises for an empty output
+        out_shape = ops.rescale_shape(img.shape, scale)
+        plan = rescale_plan.resize_plan(img.shape, out_shape, aa)
+        got = ops.rescale(img, scale, anti_aliasing=aa, mode="skimage", plan=plan, clip=clip)
+        want = orc.rescale_skimage(img, scale, plan=plan, anti_aliasing=aa, clip=clip)
+        assert got.shape == want.shape, (case, H, W, scale)
+        assert _same(got, want), (case, H, W, scale, aa, clip, int(kind), np.nanmax(np.abs(got - want)))
+
+
+def test_fuzz_batch_pyramid_bit_exact(ops, orc):
+    """The batch pyramid (streaming kernel / tiles / general kernel, level 0 through rescale(., 1.0), clip) on
+    random shapes, level counts and batch sizes: every level of every array against the oracle's rescale."""
+    from tadataka_amd import rescale_plan
+    rng = np.random.default_rng(3500 + SEED)
+    n = max(2, N_CASES // 3)
+    for case in range(n):
+        H, W = int(rng.integers(8, 130)), int(rng.integers(8, 300))
+        levels = int(rng.integers(1, 5))
+        ratio = float(rng.choice([1.5, 2.0, 1.3]))
+        while min(H, W) / ratio ** (levels - 1) < 3:
+            levels -= 1
+        B = int(rng.choice([1, 2, 9, 40]))
+        batch = ops.DvoBatch(B, H, W, n_levels=levels, ratio=ratio)
+        plans = rescale_plan.level_plans((H, W), levels, ratio, True)
+        batch.set_skimage_pyramid(plans)
+        frames = []
+        for p in range(B):
+            I0, D0, I1, _ = _random_scene(rng, H, W)
+            if rng.random() < 0.3:
+                D0[:] = 2.0
+            batch.upload(p, I0, D0, I1)
+            frames.append((I0, D0, I1))
+        ops.set_option("pyramid_stream", int(rng.choice([0, 1, 2])))
+        batch.build_pyramid()
+        ops.set_option("pyramid_stream", 1)
+        for p in sorted(set([0, B - 1, int(rng.integers(0, B))])):
+            for l in range(levels):
+                for k, name in enumerate(("I0", "D0", "I1")):
+                    got = batch.download(p, l, name)
+                    want = orc.rescale_skimage(frames[p][k], 1.0 / ratio ** l, plan=plans[l], anti_aliasing=True, clip=True)
+                    assert _same(got, want), (case, H, W, levels, ratio, B, p, l, name)
+        batch.close()
+
+
+# ---------------------------------------------------------------------------
+# granular operators: bit-exact, special values included
+# ---------------------------------------------------------------------------
+def test_fuzz_granular_bit_exact(ops, orc):
+    rng = np.random.default_rng(4000 + SEED)
+    specials = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, 1e-310, 1e308, -1e308, 1.0, -1.0])
+    for case in range(N_CASES):
+        n = int(rng.integers(1, 3000))
+        cam = np.array([rng.uniform(100, 900), rng.uniform(100, 900), rng.uniform(0, 640), rng.uniform(0, 480)])
+        kp = rng.uniform(-1e3, 1e3, (n, 2))
+        P = rng.uniform(-5, 5, (n, 3))
+        xs = rng.uniform(-2, 2, (n, 2))
+        d = rng.uniform(-1, 6, n)
+        for a in (kp, P, xs, d):
+            m = rng.random(a.shape) < 0.05
+            a[m] = rng.choice(specials, int(m.sum()))
+        R, t = _random_pose(rng)
+        T = _T(R, t)
+        assert _same(ops.normalize(kp, cam), orc.normalize(kp, cam)), case
+        assert _same(ops.unnormalize(kp, cam), orc.unnormalize(kp, cam)), case
+        assert _same(ops.project_vecs(P), orc.project_vecs(P)), case
+        assert _same(ops.inv_project_vecs(xs, d), orc.inv_project_vecs(xs, d)), case
+        assert _same(ops.transform(T, P), orc.transform(T, P)), case
+        a, b = ops.warp_vecs(T, xs, d)
+        c, e = orc.warp_vecs(T, xs, d)
+        assert _same(a, c) and _same(b, e), case
+        H, W = (int(v) for v in rng.integers(2, 60, 2))
+        img = rng.uniform(-1, 1, (H, W))
+        m = rng.random(img.shape) < 0.05
+        img[m] = rng.choice(specials, int(m.sum()))
+        c2 = np.column_stack([rng.uniform(0, W - 1, 500), rng.uniform(0, H - 1, 500)])
+        c2[:50] = np.floor(c2[:50])
+        c2[50] = [W - 1, H - 1]
+        g_, o_ = ops.interpolation(img, c2), orc.interpolation(img, c2)
+        assert _same(g_, o_) and np.array_equal(np.signbit(g_), np.signbit(o_)), case   # the sign of a zero included
+        gx, gy = ops.image_gradient(img)
+        ogx, ogy = orc.image_gradient(img)
+        assert _same(gx, ogx) and _same(gy, ogy), case
+        sx, sy = ops.sobel(img)
+        osx, osy = orc.sobel(img)
+        assert _same(sx, osx) and _same(sy, osy), case
+
+
+# ---------------------------------------------------------------------------
+# semi-dense maps: bit-exact
+# ---------------------------------------------------------------------------
+def test_fuzz_semi_dense_warp_bit_exact(ops, orc):
+    rng = np.random.default_rng(5000 + SEED)
+    for case in range(N_CASES):
+        H, W = (int(v) for v in rng.integers(2, 120, 2))
+        f = rng.uniform(0.4, 1.5) * max(H, W)
+        cam0 = np.array([f, f, W / 2, H / 2])
+        cam1 = cam0 * rng.choice([1.0, 1.0, 0.5, 1.3]) if rng.random() < 0.5 else cam0
+        kind = rng.integers(0, 5)
+        if kind == 0:
+            R, t = np.eye(3), np.array([rng.uniform(-0.3, 0.3), 0, 0])          # stereo
+        elif kind == 1:
+            R, t = np.eye(3), np.array([0, 0, rng.uniform(0.5, 2.0)])           # zoom out: many sources per target
+        elif kind == 2:
+            R, t = np.eye(3), np.array([0, 0, -rng.uniform(0.2, 1.0)])          # zoom in
+        else:
+            R, t = _random_pose(rng)
+        T10 = _T(R, t)
+        depth0 = rng.uniform(0.8, 4.0, (H, W))
+        if rng.random() < 0.3:
+            depth0 = np.full((H, W), 2.0) + rng.uniform(-0.01, 0.01, (H, W))
+        if rng.random() < 0.2:
+            depth0[rng.random((H, W)) < 0.1] = rng.choice([0.0, -1.0, np.nan])
+        var0 = rng.uniform(0.01, 1.0, (H, W))
+        age0 = rng.integers(0, 5, (H, W)).astype(np.uint64)
+        for gather in (1, 0):
+            ops.set_option("sd_warp_gather", gather)
+            a = ops.increment_age(age0, cam0, cam1, T10, depth0)
+            d1, v1 = ops.propagate(T10, cam0, cam1, depth0, var0, 1.5, 10.0, 0.01)
+            ops.set_option("sd_warp_gather", 1)
+            assert np.array_equal(a, orc.increment_age(age0, cam0, cam1, T10, depth0)), (case, H, W, int(kind), gather)
+            od, ov = orc.propagate(T10, cam0, cam1, depth0, var0, 1.5, 10.0, 0.01)
+            assert _same(d1, od) and _same(v1, ov), (case, H, W, int(kind), gather)
+
+
+def test_fuzz_update_depth_bit_exact(ops, orc):
+    rng = np.random.default_rng(6000 + SEED)
+    n = max(2, N_CASES // 2)
+    for case in range(n):
+        H, W = int(rng.integers(8, 90)), int(rng.integers(8, 120))
+        f = rng.uniform(0.6, 1.4) * max(H, W)
+        cam = np.array([f, f, W / 2, H / 2])
+        n_ref = int(rng.integers(1, 5))
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+
+        def image():
+            a, b = rng.uniform(1.5, 6, 2)
+            return 0.5 + 0.3 * np.sin(xx / a) * np.cos(yy / b) + 0.1 * rng.uniform(-1, 1, (H, W))
+
+        T_wk = _T(*_random_pose(rng)) if rng.random() < 0.5 else np.eye(4)
+        key = (cam, image(), T_wk)
+        refs = []
+        for r in range(n_ref):
+            dT = _T(Rotation.from_rotvec(rng.uniform(-0.02, 0.02, 3)).as_matrix(), rng.uniform(-0.15, 0.15, 3))
+            if rng.random() < 0.15:
+                dT = np.eye(4)                                    # identical poses: the epipole is at infinity / zero baseline
+            refs.append((cam, image(), T_wk @ dT))
+        age = rng.integers(0, n_ref + 1, (H, W)).astype(np.uint64)
+        prior_depth = rng.uniform(0.6, 6.0, (H, W))
+        prior_var = rng.uniform(1e-3, 0.5, (H, W))
+        if rng.random() < 0.3:
+            prior_depth[rng.random((H, W)) < 0.05] = rng.choice([0.0, -1.0])
+            prior_var[rng.random((H, W)) < 0.05] = rng.choice([0.0, -0.1])
+        pa = (rng.uniform(0.2, 1.0), rng.uniform(4, 12), rng.uniform(0.001, 0.1), rng.uniform(0.001, 0.1),
+              rng.uniform(0.3, 2.0) / f, rng.uniform(0.0, 0.1))
+        g = ops.update_depth(key, refs, age, prior_depth, prior_var, ops.make_params(*pa))
+        o = orc.update_depth(key, refs, age, prior_depth, prior_var, orc.make_params(*pa))
+        assert np.array_equal(g[2], o[2]), (case, H, W, n_ref, np.argwhere(g[2] != o[2])[:5])
+        assert _same(g[0], o[0]) and _same(g[1], o[1]), (case, H, W, n_ref)
+
+
+# ---------------------------------------------------------------------------
+# bundle adjustment: block sums on ragged graphs
+# ---------------------------------------------------------------------------
+def test_fuzz_ba_block_sums(ops, orc):
+    rng = np.random.default_rng(7000 + SEED)
+    worst = 0.0
+    for case in range(N_CASES):
+        nP = int(rng.integers(1, 24))
+        nQ = int(rng.integers(1, 3000))
+        poses = np.column_stack([rng.uniform(-0.3, 0.3, (nP, 3)), rng.uniform(-1, 1, (nP, 3))])
+        if rng.random() < 0.3:
+            poses[rng.integers(0, nP), :3] = 0.0                  # |omega| = 0: the epsilon branch of Rodrigues
+        points = np.column_stack([rng.uniform(-5, 5, (nQ, 2)), rng.uniform(4, 12, nQ)])
+        vis = rng.random((nP, nQ)) < rng.choice([1.0, 0.6, 0.1])
+        if rng.random() < 0.5 and nP > 1:
+            vis[rng.integers(0, nP)] = False                      # a pose nobody observes from
+        # (an observation whose point lies almost in the camera's plane is conditioned like 1 / z': both sides are
+        #  right to rounding and 1e-9 apart -- keep the depths the reference's scenes have)
+        for j in range(nP):
+            zc = (orc.exp_so3(poses[j, :3]) @ points.T)[2] + poses[j, 5]
+            vis[j, zc < 1.0] = False
+        vp, pt = np.nonzero(vis)
+        if rng.random() < 0.3:                                    # point-major order instead of pose-major
+            o = np.lexsort((vp, pt))
+            vp, pt = vp[o], pt[o]
+        if len(vp) == 0:
+            continue
+        x_true = orc.ba_projection(poses, points, vp, pt, jacobians=False) + rng.normal(0, 1e-3, (len(vp), 2))
+        g = ops.ba_block_reduce(poses, points, x_true, vp, pt)
+        o = orc.ba_block_reduce(poses, points, x_true, vp, pt)
+        for name, a, b in zip("U ea V eb".split(), g[:4], o[:4]):
+            scale = max(np.max(np.abs(b)), 1e-300)
+            e = np.max(np.abs(a - b)) / scale
+            worst = max(worst, e)
+            assert e < RTOL_SUMS, (case, nP, nQ, name, e)
+        assert abs(g[4] - o[4]) <= RTOL_SUMS * abs(o[4]), case
+        ba = ops.BundleAdjustment(nP, nQ, vp, pt, x_true)
+        s = ba.block_sums(poses, points)
+        ba.close()
+        for name, a, b in zip("U ea V eb".split(), s[:4], o[:4]):
+            scale = max(np.max(np.abs(b)), 1e-300)
+            assert np.max(np.abs(np.asarray(a).reshape(b.shape) - b)) / scale < RTOL_SUMS, (case, nP, nQ, name, "handle")
+    print(f"ba block sums: worst relative error {worst:.2e}")
+
+
+# ---------------------------------------------------------------------------
+# batches: several pairs with their own cameras and poses, evaluated at a random pyramid level
+# ---------------------------------------------------------------------------
+def test_fuzz_dvo_batches_at_pyramid_levels(ops, orc):
+    rng = np.random.default_rng(8000 + SEED)
+    n = max(2, N_CASES // 6)
+    worst = 0.0
+    for case in range(n):
+        H, W = int(rng.integers(30, 200)), int(rng.integers(30, 330))
+        B = int(rng.choice([2, 3, 8, 9, 17]))
+        levels = int(rng.integers(1, 4))
+        while min(H, W) / 1.5 ** (levels - 1) < 8:
+            levels -= 1
+        batch = ops.DvoBatch(B, H, W, n_levels=levels, with_weight_map=True)
+        cams, poses, Ts = [], [], []
+        for p in range(B):
+            I0, D0, I1, cam = _random_scene(rng, H, W)
+            batch.upload(p, I0, D0, I1, rng.uniform(0.1, 2.0, (H, W)))
+            R, t = _random_pose(rng)
+            cams.append(cam); poses.append(_pose12(R, t)); Ts.append((R, t))
+        batch.build_pyramid()
+        cams = np.array(cams); poses = np.array(poses)
+        level = int(rng.integers(0, levels))
+        scale = 1.0 / 1.5 ** level
+        wname = [None, "huber", "map", "student-t", "tukey"][int(rng.integers(0, 5))]
+        mode = ops.W_MAP if wname == "map" else ops.WEIGHT_MODES[wname]
+        ev = batch.evaluate(level, cams, cams, poses, mode)
+        ss, ne = batch.photometric_error(level, cams, cams, poses)
+        for p in range(B):
+            I0, D0, I1, W0 = (batch.download(p, level, k) for k in ("I0", "D0", "I1", "W0"))
+            cam = cams[p] * scale
+            R, t = Ts[p]
+            s_ref, n_ref = orc.photometric_error_sums(I0, D0, I1, cam, cam, _T(R, t))
+            assert ne[p] == n_ref and ev["n_error"][p] == n_ref, (case, p)
+            if n_ref and np.isfinite(s_ref):
+                assert abs(ss[p] - s_ref) <= RTOL_SUMS * abs(s_ref), (case, p)
+                assert abs(ev["sum_sq"][p] - s_ref) <= RTOL_SUMS * abs(s_ref), (case, p)
+            GX, GY = orc.image_gradient(I1)
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                Href, bref, M = orc.dvo_normal_equations(I0, D0, I1, GX, GY, cam, cam, R, t, W0 if wname == "map" else wname)
+            assert ev["n_update"][p] == M, (case, p, wname)
+            if M < 12 or not (np.all(np.isfinite(Href)) and np.all(np.isfinite(bref))):
+                continue
+            if np.min(Href[[0, 6, 11, 15, 18, 20]]) <= 0.0:
+                continue
+            e1, e2 = h21_err(ev["H"][p], Href), b6_err(ev["b"][p], bref, Href)
+            worst = max(worst, e1, e2)
+            assert e1 < RTOL_SUMS and e2 < RTOL_SUMS, (case, p, H, W, B, level, wname, e1, e2)
+        batch.close()
+    print(f"dvo batches: {n} batches, worst per-entry error {worst:.2e}")
+
+
+# ---------------------------------------------------------------------------
+# the semi-dense session: chained steps of several tracks against the oracle chain
+# ---------------------------------------------------------------------------
+def test_fuzz_sd_session_chain(ops, orc):
+    rng = np.random.default_rng(9000 + SEED)
+    n_cases = max(1, N_CASES // 8)
+    defaults = (1.5, 10.0, 0.01)
+    for case in range(n_cases):
+        H, W = int(rng.integers(12, 110)), int(rng.integers(12, 150))
+        n_tracks = int(rng.choice([1, 2, 5]))
+        n_steps = int(rng.integers(1, 4))
+        f = rng.uniform(0.6, 1.3) * max(H, W)
+        cam = np.array([f, f, W / 2, H / 2])
+        pa = (0.3, 12.0, rng.uniform(0.005, 0.05), rng.uniform(0.005, 0.05), rng.uniform(0.5, 1.5) / f, rng.uniform(0.0, 0.05))
+        pg, po = ops.make_params(*pa), orc.make_params(*pa)
+        sd = ops.SemiDenseSession(n_tracks, H, W, max_refframes=n_steps)
+        sd.set_age_policy(False)
+        sd.set_params(pg, *defaults)
+        ops.set_option("sd_warp_gather", int(rng.integers(0, 2)))
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+        state = []
+        for t in range(n_tracks):
+            a, b = rng.uniform(1.5, 6, 2)
+            frames, T = [], np.eye(4)
+            for s in range(n_steps + 1):
+                img = 0.5 + 0.3 * np.sin((xx + 0.7 * s) / a) * np.cos(yy / b) + 0.05 * rng.uniform(-1, 1, (H, W))
+                frames.append((cam, img, T.copy()))
+                T = T @ _T(Rotation.from_rotvec(rng.uniform(-0.01, 0.01, 3)).as_matrix(), rng.uniform(-0.08, 0.08, 3))
+            depth = rng.uniform(0.8, 5.0, (H, W))
+            var = rng.uniform(0.01, 0.3, (H, W))
+            age = (rng.random((H, W)) < rng.uniform(0.1, 0.9)).astype(np.uint64) * 0      # init_age: zeros
+            sd.push_frame(t, *frames[0])
+            sd.set_maps(t, depth, var, age)
+            state.append(dict(frames=frames, depth=depth, var=var, age=age))
+        for step in range(1, n_steps + 1):
+            T10s, Twfs = [], []
+            for t in range(n_tracks):
+                fr = state[t]["frames"]
+                sd.push_frame(t, fr[step][0], fr[step][1])
+                T10s.append(np.linalg.inv(fr[step][2]) @ fr[step - 1][2])
+                Twfs.append(fr[step][2])
+            sd.step(np.array(T10s), np.array(Twfs), commit=True)
+            for t in range(n_tracks):
+                st = state[t]
+                fr = st["frames"]
+                d, v, a, f_ = orc.semi_dense_step(fr[step], fr[step - 1][0], fr[:step], T10s[t], st["age"], st["depth"],
+                                                  st["var"], po, *defaults)
+                gd, gv, ga, gf = sd.get_maps(t, with_flag=True)
+                assert np.array_equal(ga, a) and np.array_equal(gf, f_), (case, H, W, t, step)
+                assert _same(gd, d) and _same(gv, v), (case, H, W, t, step)
+                st.update(depth=d, var=v, age=a)
+        ops.set_option("sd_warp_gather", 1)
+        sd.close()
+
+
+# ---------------------------------------------------------------------------
+# bundle adjustment: one damped step against the dense normal equations
+# ---------------------------------------------------------------------------
+def test_fuzz_ba_damped_step(ops, orc):
+    rng = np.random.default_rng(10000 + SEED)
+    n = max(2, N_CASES // 4)
+    for case in range(n):
+        P = int(rng.integers(2, 22))
+        Q = int(rng.integers(8, 90))
+        poses = np.column_stack([rng.uniform(-0.2, 0.2, (P, 3)), rng.uniform(-1, 1, (P, 3))])
+        points = np.column_stack([rng.uniform(-4, 4, (Q, 2)), rng.uniform(4, 12, Q)])
+        vis = rng.random((P, Q)) < rng.choice([1.0, 0.8, 0.5])
+        vis[:, vis.sum(0) == 0] = True                      # every point is seen
+        vis[vis.sum(1) == 0, :] = True                      # every pose sees something (mu > 0 anyway)
+        for j in range(P):
+            zc = (orc.exp_so3(poses[j, :3]) @ points.T)[2] + poses[j, 5]
+            vis[j, zc < 1.0] = False
+        vp, pt = np.nonzero(vis)
+        xt = orc.ba_projection(poses, points, vp, pt, jacobians=False)
+        pn = poses + rng.normal(0, 1e-3, poses.shape)
+        qn = points + rng.normal(0, 1e-3, points.shape)
+        mu = float(rng.choice([1e-3, 0.05, 1.0, 30.0]))
+        options = int(rng.choice([0, 0, ops.BundleAdjustment.SCHUR_PAIRS, ops.BundleAdjustment.SCHUR_GENERAL,
+                                  ops.BundleAdjustment.SOLVE_HOST, ops.BundleAdjustment.SOLVE_PIVOTED]))
+        ba = ops.BundleAdjustment(P, Q, vp, pt, xt, options=options)
+        dposes, dpoints, err = ba.step(pn, qn, mu)
+        ba.close()
+        x_pred, A, B = orc.ba_projection(pn, qn, vp, pt)
+        J = np.zeros((2 * len(vp), 6 * P + 3 * Q))
+        for k, (j, i) in enumerate(zip(vp, pt)):
+            J[2 * k:2 * k + 2, 6 * j:6 * j + 6] = A[k]
+            J[2 * k:2 * k + 2, 6 * P + 3 * i:6 * P + 3 * i + 3] = B[k]
+        r = (xt - x_pred).reshape(-1)
+        delta = np.linalg.solve(J.T @ J + mu * np.eye(J.shape[1]), J.T @ r)
+        assert err == pytest.approx(float(r @ r), rel=1e-10), (case, P, Q)
+        assert np.allclose(dposes.reshape(-1), delta[:6 * P], rtol=1e-6, atol=1e-10), (case, P, Q, mu, options)
+        assert np.allclose(dpoints.reshape(-1), delta[6 * P:], rtol=1e-6, atol=1e-10), (case, P, Q, mu, options)
