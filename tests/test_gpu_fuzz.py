@@ -536,3 +536,104 @@ def test_fuzz_ba_damped_step(ops, orc):
         assert err == pytest.approx(float(r @ r), rel=1e-10), (case, P, Q)
         assert np.allclose(dposes.reshape(-1), delta[:6 * P], rtol=1e-6, atol=1e-10), (case, P, Q, mu, options)
         assert np.allclose(dpoints.reshape(-1), delta[6 * P:], rtol=1e-6, atol=1e-10), (case, P, Q, mu, options)
+
+
+# ---------------------------------------------------------------------------
+# array-level operators: robust weights (tadataka/robust/weights.py restated in NumPy), weighted normal equations,
+# the N4 post-steps, rgb2gray, estimate_debug_
+# ---------------------------------------------------------------------------
+def _weights_numpy(r, mode):
+    if mode == "huber":
+        w = np.ones(r.shape); a = np.abs(r); m = a > 1.345
+        w[m] = 1.345 / a[m]
+        return w
+    if mode == "student-t":
+        s = r * r
+        v = 1.0
+        for _ in range(10):
+            v = np.mean(s * (6.0 / (5.0 + s / v)))
+        return np.sqrt(6.0 / (5.0 + s / v))
+    sigma = 1.4826 * np.median(np.abs(r - np.median(r)))
+    x = r / sigma
+    w = np.zeros(r.shape)
+    m = np.abs(x) <= 4.6851
+    w[m] = (1 - (x[m] / 4.6851) ** 2) ** 2
+    return w
+
+
+def test_fuzz_array_level_operators(ops, orc):
+    rng = np.random.default_rng(11000 + SEED)
+    for case in range(N_CASES):
+        n = int(rng.choice([1, 2, 3, 7, 64, 255, 256, 257, 1000, 4097, 20011]))
+        kind = rng.integers(0, 5)
+        r = rng.normal(0, rng.uniform(0.01, 2.0), n)
+        if kind == 1:
+            r = np.round(r * 8) / 8                               # ties: medians of repeated values
+        elif kind == 2 and n > 4:
+            r[rng.random(n) < 0.1] *= 50.0                        # heavy tail
+        elif kind == 3:
+            r = np.abs(r) + 0.5                                   # one-sided
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for mode in ("huber", "student-t", "tukey"):
+                want = _weights_numpy(r, mode)
+                got = ops.robust_weights(r, ops.WEIGHT_MODES[mode])
+                if mode == "huber":
+                    assert np.array_equal(got, want), (case, n, mode)
+                elif np.all(np.isfinite(want)):
+                    assert np.allclose(got, want, rtol=1e-11, atol=1e-14), (case, n, mode, int(kind), np.max(np.abs(got - want)))
+        p = int(rng.integers(1, 9))
+        A = rng.normal(0, 1, (n, p)) * rng.uniform(0.1, 10, p)
+        b = rng.normal(0, 1, n)
+        w = rng.uniform(0, 2, n) if rng.random() < 0.7 else None
+        M, g = ops.weighted_normal_equations(A, b, w)
+        Aw = A if w is None else A * w[:, None]
+        Mr, gr = Aw.T @ A, Aw.T @ b
+        sc = np.sqrt(np.outer(np.diag(Mr), np.diag(Mr))) + 1e-300
+        assert np.max(np.abs(M - Mr) / sc) < RTOL_SUMS, (case, n, p)
+        assert np.max(np.abs(g - gr)) <= RTOL_SUMS * max(np.max(np.sqrt(np.diag(Mr)) * np.sqrt(np.sum((b if w is None else b * np.sqrt(w)) ** 2))), 1e-300), (case, n, p)
+        # N4 post-steps and colour conversion: bit-exact
+        H, W = (int(v) for v in rng.integers(1, 70, 2))
+        depth = rng.uniform(0.5, 5, (H, W)); var = rng.uniform(0.01, 1, (H, W))
+        flag = rng.choice([0, 0, 0, -1, -6, -9], (H, W)).astype(np.int64)
+        assert _same(ops.regularize(depth, var, flag), orc.regularize(depth, var, flag)), (case, H, W, "regularize")
+        m2, v2 = rng.uniform(0.5, 5, (H, W)), rng.uniform(0.01, 1, (H, W))
+        a1, a2 = ops.fusion_arrays(depth, m2, var, v2)
+        o1, o2 = orc.fusion_arrays(depth, m2, var, v2)
+        assert _same(a1, o1) and _same(a2, o2), (case, H, W, "fusion")
+        ch = int(rng.choice([3, 4]))
+        rgb8 = rng.integers(0, 256, (H, W, ch), dtype=np.uint8)
+        assert _same(ops.rgb2gray(rgb8), orc.rgb2gray(rgb8)), (case, H, W, "rgb2gray u8")
+        rgbf = rng.uniform(0, 1, (H, W, ch))
+        assert _same(ops.rgb2gray(rgbf), orc.rgb2gray(rgbf)), (case, H, W, "rgb2gray f64")
+
+
+def test_fuzz_estimate_one_pixel(ops, orc):
+    """rust_bindings.semi_dense.estimate_debug_ (tdk_estimate_one): one pixel's (depth, variance, flag), bit for bit."""
+    rng = np.random.default_rng(12000 + SEED)
+    n = max(4, N_CASES * 4)
+    H, W = 60, 80
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    scene = None
+    for case in range(n):
+        if case % 16 == 0:
+            f = rng.uniform(0.7, 1.3) * W
+            cam = np.array([f, f, W / 2 + rng.uniform(-1, 1), H / 2 + rng.uniform(-1, 1)])
+            a, b = rng.uniform(1.5, 6, 2)
+            key_img = 0.5 + 0.3 * np.sin(xx / a) * np.cos(yy / b) + 0.08 * rng.uniform(-1, 1, (H, W))
+            ref_img = 0.5 + 0.3 * np.sin((xx + 1.3) / a) * np.cos(yy / b) + 0.08 * rng.uniform(-1, 1, (H, W))
+            T_wk = _T(*_random_pose(rng)) if rng.random() < 0.5 else np.eye(4)
+            dT = _T(Rotation.from_rotvec(rng.uniform(-0.03, 0.03, 3)).as_matrix(), rng.uniform(-0.2, 0.2, 3))
+            pa = (rng.uniform(0.2, 1.0), rng.uniform(4, 12), rng.uniform(0.001, 0.1), rng.uniform(0.001, 0.1),
+                  rng.uniform(0.3, 2.0) / f, rng.uniform(0.0, 0.1))
+            scene = ((cam, key_img, T_wk), (cam, ref_img, T_wk @ dT), ops.make_params(*pa), orc.make_params(*pa))
+        key, ref, pg, po = scene
+        u = np.array([rng.integers(-1, W + 1), rng.integers(-1, H + 1)], dtype=np.int64)
+        if not (0 <= u[0] < W and 0 <= u[1] < H):
+            continue                                    # the reference indexes the image with it
+        pd_ = float(rng.choice([rng.uniform(0.3, 8.0), 0.0, -1.0]))
+        pv = float(rng.choice([rng.uniform(1e-4, 1.0), 0.0]))
+        g = ops.estimate_one(u, pd_, pv, key, ref, pg)
+        o = orc.estimate_debug(u, pd_, pv, key, ref, po)
+        assert g[2] == o[2] and _same(np.array(g[:2]), np.array(o[:2])), (case, u, pd_, pv, g, o)
