@@ -637,3 +637,40 @@ def test_fuzz_estimate_one_pixel(ops, orc):
         g = ops.estimate_one(u, pd_, pv, key, ref, pg)
         o = orc.estimate_debug(u, pd_, pv, key, ref, po)
         assert g[2] == o[2] and _same(np.array(g[:2]), np.array(o[:2])), (case, u, pd_, pv, g, o)
+
+
+# ---------------------------------------------------------------------------
+# the drop-in PoseChangeEstimator with its default pyramid (skimage to the bit, level 0 and clip included)
+# ---------------------------------------------------------------------------
+@pytest.mark.skimage_pyramid
+def test_fuzz_dropin_pose_change_estimator(orc):
+    import warnings
+    import tadataka_amd  # noqa: F401
+    import tadataka.vo.dvo as dvo
+    from tadataka.camera import CameraModel, CameraParameters
+    from tadataka_amd import synthetic
+    assert dvo.PYRAMID == "skimage"
+    rng = np.random.default_rng(13000 + SEED)
+    n = max(2, N_CASES // 6)
+    for case in range(n):
+        H, W = int(rng.integers(30, 140)), int(rng.integers(40, 180))
+        levels = int(rng.integers(1, 6))
+        ratio = float(rng.choice([1.5, 1.5, 2.0, 1.3]))
+        while min(H, W) / ratio ** (levels - 1) < 10:
+            levels -= 1
+        pair = synthetic.make_pair(H, W, seed=int(rng.integers(0, 1 << 30)))
+        cam = pair["cam"] * rng.uniform(0.97, 1.03, 4) + np.array([0, 0, rng.uniform(-1, 1), rng.uniform(-1, 1)])
+        opt = [None, "huber", "student-t", "tukey", "map"][int(rng.integers(0, 5))]
+        weights = rng.uniform(0.2, 2.0, (H, W)) if opt == "map" else opt
+        D0 = pair["D0"].copy()
+        if rng.random() < 0.25:
+            D0[rng.random((H, W)) < 0.05] = 0.0                  # missing readings
+        cm = CameraModel(CameraParameters(cam[0:2], cam[2:4]), distortion_model=None)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            est = dvo.PoseChangeEstimator(cm, cm, n_coarse_to_fine=levels, max_iter=20)
+            est.layer_size_ratio = ratio
+            pose = est(pair["I0"], D0, pair["I1"], weights)
+            rot, t = orc.dvo_estimate(pair["I0"], D0, pair["I1"], cam, cam, weights, levels, 20, ratio, pyramid="skimage")
+        d = max(np.max(np.abs(pose.rotation.as_matrix() - rot.as_matrix())), np.max(np.abs(pose.t - t)))
+        assert d < 1e-6, (case, H, W, levels, ratio, opt, d)
