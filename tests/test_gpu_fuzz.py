@@ -674,3 +674,67 @@ def test_fuzz_dropin_pose_change_estimator(orc):
             rot, t = orc.dvo_estimate(pair["I0"], D0, pair["I1"], cam, cam, weights, levels, 20, ratio, pyramid="skimage")
         d = max(np.max(np.abs(pose.rotation.as_matrix() - rot.as_matrix())), np.max(np.abs(pose.t - t)))
         assert d < 1e-6, (case, H, W, levels, ratio, opt, d)
+
+
+# ---------------------------------------------------------------------------
+# the drop-in semi-dense loop through rust_bindings.semi_dense, ndarrays or device-resident maps, with the caller
+# editing maps between the calls
+# ---------------------------------------------------------------------------
+def test_fuzz_dropin_semi_dense_loop(ops, orc):
+    import tadataka_amd
+    from rust_bindings.camera import CameraParameters
+    from rust_bindings.semi_dense import Frame, Params, increment_age, propagate, update_depth
+    rng = np.random.default_rng(14000 + SEED)
+    n_cases = max(2, N_CASES // 4)
+    defaults = (1.2, 8.0, 0.02)
+    for case in range(n_cases):
+        H, W = int(rng.integers(10, 100)), int(rng.integers(10, 130))
+        n_frames = int(rng.integers(2, 5))
+        f = rng.uniform(0.6, 1.3) * max(H, W)
+        cam = np.array([f, f, W / 2 + rng.uniform(-1, 1), H / 2 + rng.uniform(-1, 1)])
+        cp = CameraParameters((cam[0], cam[1]), (cam[2], cam[3]))
+        pa = (0.3, 12.0, rng.uniform(0.005, 0.05), rng.uniform(0.005, 0.05), rng.uniform(0.5, 1.5) / f, rng.uniform(0.0, 0.05))
+        params, po = Params(*pa), orc.make_params(*pa)
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+        a, b = rng.uniform(1.5, 6, 2)
+        previous = tadataka_amd.enable_device_maps(bool(rng.integers(0, 2)))
+        try:
+            T = np.eye(4)
+            img = 0.5 + 0.3 * np.sin(xx / a) * np.cos(yy / b) + 0.05 * rng.uniform(-1, 1, (H, W))
+            frame0 = Frame(cp, img, T)
+            refframes = [frame0]
+            depth0 = rng.uniform(0.8, 5.0, (H, W)); var0 = rng.uniform(0.01, 0.3, (H, W))
+            age0 = np.zeros((H, W), dtype=np.uint64)
+            o_depth, o_var, o_age = depth0.copy(), var0.copy(), age0.copy()
+            o_frames = [(cam, img, T.copy())]
+            for s in range(1, n_frames):
+                T10 = _T(Rotation.from_rotvec(rng.uniform(-0.01, 0.01, 3)).as_matrix(), rng.uniform(-0.08, 0.08, 3))
+                T = T @ np.linalg.inv(T10)
+                img = 0.5 + 0.3 * np.sin((xx + 0.7 * s) / a) * np.cos(yy / b) + 0.05 * rng.uniform(-1, 1, (H, W))
+                frame1 = Frame(cp, img, T)
+                age1 = increment_age(age0, frame0.camera_params, frame1.camera_params, T10, depth0)
+                depth1, var1 = propagate(T10, frame0.camera_params, frame1.camera_params, depth0, var0, *defaults)
+                depth1, var1, flag = update_depth(frame1, refframes, age1, depth1, var1, params)
+                refframes.append(frame1)
+                key = (cam, img, T.copy())
+                d, v, a_, f_ = orc.semi_dense_step(key, cam, o_frames, T10, o_age, o_depth, o_var, po, *defaults)
+                o_frames.append(key)
+                assert np.array_equal(np.asarray(age1), a_) and np.array_equal(np.asarray(flag), f_), (case, H, W, s)
+                assert _same(np.asarray(depth1), d) and _same(np.asarray(var1), v), (case, H, W, s)
+                o_depth, o_var, o_age = d.copy(), v.copy(), a_.copy()
+                # the caller edits a map before handing it on (the example masks by flag): three ways of writing
+                edit = rng.integers(0, 4)
+                m = rng.random((H, W)) < 0.1
+                if edit == 1:
+                    depth1[m] = 1.5
+                    o_depth[m] = 1.5
+                elif edit == 2:
+                    np.asarray(var1)[m] = 0.25
+                    o_var[m] = 0.25
+                elif edit == 3:
+                    age1 = np.array(age1, dtype=np.uint64)
+                    age1[m] = 0
+                    o_age[m] = 0
+                depth0, var0, age0, frame0 = depth1, var1, age1, frame1
+        finally:
+            tadataka_amd.enable_device_maps(previous)
