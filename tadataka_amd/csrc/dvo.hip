@@ -444,6 +444,35 @@ __device__ __forceinline__ void sp_accumulate(Accum &a, int &n_error, int &n_upd
     J[4] = fgx * (1.0 + X * X) + fgy * xy;
     J[5] = fgy * X - fgx * Y;
     double r = s.i0 - s.i1;  // un-warped residual (vo/dvo/__init__.py:90)
+    if (WMODE == TDK_W_HUBER) {
+        // sum w J J^T = sum J J^T + sum (w - 1) J J^T.  Huber's weight is exactly 1 unless |r| > k, which never
+        // happens on [0, 1] images (F4): the first sum costs what weights=None costs, the second runs only in waves
+        // that hold an outlier (the six w * J products were 2.4 % of the kernel).  The rare path is inline asm on
+        // purpose: written as C the compiler merges the two paths' accumulators through copies -- 212 VGPRs, two waves
+        // per SIMD (the round-1 attempt, 19 % slower); tied "+v" operands keep 158.
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+#pragma unroll
+            for (int q = i; q < 6; q++) a.v[k++] += J[i] * J[q];
+            a.v[21 + i] += J[i] * r;
+        }
+        const double ar = fabs(r);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(ar > kHuberK) != 0, 0)) {
+            const double c = ar > kHuberK ? kHuberK / ar - 1.0 : 0.0;
+            k = 0;
+#define TDK_FMAC(ACC, X, Y) asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(ACC) : "v"(X), "v"(Y))
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double cj = c * J[i];
+#pragma unroll
+                for (int q = i; q < 6; q++) { TDK_FMAC(a.v[k], cj, J[q]); k++; }
+                TDK_FMAC(a.v[21 + i], cj, r);
+            }
+#undef TDK_FMAC
+        }
+        return;
+    }
     double wgt = robust_weight<WMODE>(r, s.w0, ws);
     const bool unit_w = (WMODE == TDK_W_NONE);
     int k = 0;
