@@ -277,13 +277,23 @@ __device__ __forceinline__ void sp_coordinate(const Pixel &p, const double *c, d
     v = p.sy * c[1] + c[3];
 }
 
-__device__ __forceinline__ void sp_warp(Pixel &p, bool live, double xn, double yn, double d0, int H, int W,
-                                        const double *P, const double *c) {
-    double px = xn * d0, py = yn * d0;
-    // R p + t with the translation as the first addend of the fma chain (3 instead of 4 operations per row)
-    double qx = __builtin_fma(P[2], d0, __builtin_fma(P[1], py, __builtin_fma(P[0], px, P[9])));
-    double qy = __builtin_fma(P[5], d0, __builtin_fma(P[4], py, __builtin_fma(P[3], px, P[10])));
-    double qz = __builtin_fma(P[8], d0, __builtin_fma(P[7], py, __builtin_fma(P[6], px, P[11])));
+// The warp of one pixel, q = R (d (xn, yn, 1)) + t, as q_k = d (R_k0 xn + (R_k1 yn + R_k2)) + t_k: the bracket depends
+// on the pixel's ROW and the (block-uniform) pose only, so the evaluation blocks tabulate it per row (row_terms) and a
+// pixel costs six fmas instead of the eleven operations of p = d (xn, yn, 1), q = R p + t.  At the identity prior --
+// where the whole border lies on the inclusive mask edge and the last bit of q decides -- the three steps
+// are exact except the one rounding of d * xn, which is the reference's own; elsewhere the two orders differ by
+// roundings (1e-16 relative), as the fma chain did.
+__device__ __forceinline__ void row_terms(const double *P, double yn, double &r0, double &r1, double &r2) {
+    r0 = __builtin_fma(P[1], yn, P[2]);
+    r1 = __builtin_fma(P[4], yn, P[5]);
+    r2 = __builtin_fma(P[7], yn, P[8]);
+}
+
+__device__ __forceinline__ void sp_warp_rows(Pixel &p, bool live, double xn, double ry0, double ry1, double ry2,
+                                             double d0, int H, int W, const double *P, const double *c) {
+    double qx = __builtin_fma(d0, __builtin_fma(P[0], xn, ry0), P[9]);
+    double qy = __builtin_fma(d0, __builtin_fma(P[3], xn, ry1), P[10]);
+    double qz = __builtin_fma(d0, __builtin_fma(P[6], xn, ry2), P[11]);
     {
 #pragma clang fp contract(off)
         double z = qz + tdk::kEps16;
@@ -294,13 +304,22 @@ __device__ __forceinline__ void sp_warp(Pixel &p, bool live, double xn, double y
     // an int, not two bools: loop-carried bools end up as byte arithmetic in VGPRs
     const bool valid = live && u >= 0.0 && u <= (double)(W - 1) && v >= 0.0 && v <= (double)(H - 1);
     p.mask = valid ? (qz > 0.0 ? 2 : 1) : 0;
-    const double lx = floor(u), ly = floor(v);
-    p.wx1 = u - lx;
-    p.wy1 = v - ly;
-    // v_cvt_i32_f64 saturates and maps NaN to 0: masked-out pixels get a clamped, loadable texel
-    p.c0 = clamp0((int)lx, W - 1);
-    p.r0 = clamp0((int)ly, H - 1);
+    // u - floor(u) as one v_fract_f64 and the texel by truncation: the same doubles / integers for every u >= 0, i.e.
+    // for every pixel inside the mask.  v_cvt_i32_f64 saturates and maps NaN to 0: masked-out pixels get a clamped,
+    // loadable texel
+    p.wx1 = __builtin_amdgcn_fract(u);
+    p.wy1 = __builtin_amdgcn_fract(v);
+    p.c0 = clamp0((int)u, W - 1);
+    p.r0 = clamp0((int)v, H - 1);
     p.inside = p.c0 >= 1 && p.c0 <= W - 3 && p.r0 >= 1 && p.r0 <= H - 3;
+}
+
+// ... for callers without a row table (the statistics passes, the samplers): the same operations
+__device__ __forceinline__ void sp_warp(Pixel &p, bool live, double xn, double yn, double d0, int H, int W,
+                                        const double *P, const double *c) {
+    double r0, r1, r2;
+    row_terms(P, yn, r0, r1, r2);
+    sp_warp_rows(p, live, xn, r0, r1, r2, d0, H, W, P, c);
 }
 
 // The 12 texels of one pixel as six 16-byte loads whose addresses are clamped
@@ -435,13 +454,15 @@ __device__ __forceinline__ void sp_accumulate(Accum &a, int &n_error, int &n_upd
     //   [fgx/z, fgy/z, -(fgx X + fgy Y)/z, -fgx XY - fgy (1 + Y^2), fgx (1 + X^2) + fgy XY, fgy X - fgx Y]
     const double X = p.sx, Y = p.sy;
     const double fgx = (0.5 * c[0]) * gx, fgy = (0.5 * c[1]) * gy;   // gx, gy are twice the gradient
-    const double xy = X * Y;
     double J[6];
+    // with s = fgx X + fgy Y the rows -fgx XY - fgy (1 + Y^2) and fgx (1 + X^2) + fgy XY are -(fgy + Y s) and fgx + X s:
+    // 11 instead of 17 operations (round 5: 556.6 -> 552.6 us per full-resolution launch)
+    const double sxy = __builtin_fma(fgy, Y, fgx * X);
     J[0] = fgx * p.rz;
     J[1] = fgy * p.rz;
-    J[2] = -(fgx * X + fgy * Y) * p.rz;
-    J[3] = -(fgx * xy + fgy * (1.0 + Y * Y));
-    J[4] = fgx * (1.0 + X * X) + fgy * xy;
+    J[2] = -sxy * p.rz;
+    J[3] = __builtin_fma(-Y, sxy, -fgy);
+    J[4] = __builtin_fma(X, sxy, fgx);
     J[5] = fgy * X - fgx * Y;
     double r = s.i0 - s.i1;  // un-warped residual (vo/dvo/__init__.py:90)
     if (WMODE == TDK_W_HUBER) {
@@ -497,10 +518,15 @@ __device__ __forceinline__ void eval_body(const LevelPtrs &L, const PairParams *
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double(*red)[kAccPad] = reinterpret_cast<double(*)[kAccPad]>(smem);
     double *xn_tab = reinterpret_cast<double *>(smem + sizeof(double) * kWaves * kAccPad);
-    double *yn_tab = xn_tab + L.W;
+    double *ry_tab = xn_tab + L.W;      // [H][3]: the row terms of the warp at this block's pose
     {
         const double *__restrict__ tab = L.tab + (size_t)pair * (L.W + L.H);
-        for (int i = threadIdx.x; i < L.W + L.H; i += kBlock) xn_tab[i] = tab[i];
+        for (int i = threadIdx.x; i < L.W; i += kBlock) xn_tab[i] = tab[i];
+        for (int i = threadIdx.x; i < L.H; i += kBlock) {
+            double r0, r1, r2;
+            row_terms(b.P, tab[L.W + i], r0, r1, r2);
+            ry_tab[3 * i] = r0; ry_tab[3 * i + 1] = r1; ry_tab[3 * i + 2] = r2;
+        }
     }
     __syncthreads();
 
@@ -540,10 +566,10 @@ __device__ __forceinline__ void eval_body(const LevelPtrs &L, const PairParams *
     int n_error = 0, n_update = 0;   // wave-uniform (SGPRs)
     // prologue: warp pixels 0 and 1, issue the loads of pixel 0
     double d = TDK_DEPTH();
-    sp_warp(pa, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
+    sp_warp_rows(pa, iw < end, xn_tab[x], ry_tab[3 * y], ry_tab[3 * y + 1], ry_tab[3 * y + 2], d, H, W, b.P, b.c);
     TDK_ADVANCE();
     d = TDK_DEPTH();
-    sp_warp(pb, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
+    sp_warp_rows(pb, iw < end, xn_tab[x], ry_tab[3 * y], ry_tab[3 * y + 1], ry_tab[3 * y + 2], d, H, W, b.P, b.c);
     TDK_ADVANCE();
     sp_issue<WMODE, PROBE>(s, pa, TDK_OFF(iw - 2 * kBlock), I0, I1, W0, H, W, b.c);
     // steady state: iw - 2 kBlock is the pixel being accumulated, iw the one being warped.
@@ -556,7 +582,7 @@ __device__ __forceinline__ void eval_body(const LevelPtrs &L, const PairParams *
         TDK_STAGE_FENCE();
         sp_issue<WMODE, PROBE>(s, pb, TDK_OFF(iw - kBlock), I0, I1, W0, H, W, b.c);
         TDK_STAGE_FENCE();
-        sp_warp(pa, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
+        sp_warp_rows(pa, iw < end, xn_tab[x], ry_tab[3 * y], ry_tab[3 * y + 1], ry_tab[3 * y + 2], d, H, W, b.P, b.c);
         TDK_ADVANCE();
         TDK_STAGE_FENCE();
 
@@ -565,7 +591,7 @@ __device__ __forceinline__ void eval_body(const LevelPtrs &L, const PairParams *
         TDK_STAGE_FENCE();
         sp_issue<WMODE, PROBE>(s, pa, TDK_OFF(iw - kBlock), I0, I1, W0, H, W, b.c);
         TDK_STAGE_FENCE();
-        sp_warp(pb, iw < end, xn_tab[x], yn_tab[y], d, H, W, b.P, b.c);
+        sp_warp_rows(pb, iw < end, xn_tab[x], ry_tab[3 * y], ry_tab[3 * y + 1], ry_tab[3 * y + 2], d, H, W, b.P, b.c);
         TDK_ADVANCE();
         TDK_STAGE_FENCE();
     }
@@ -2691,7 +2717,7 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
     // (Capping the evaluation at 2 blocks per CU by padding this request, so that the other batch's pyramid
     // blocks -- 36 KB of LDS, 121 VGPRs -- co-reside on the same SIMDs: full evaluation 0.55 -> 0.65 ms, bench
     // step 2.73 -> 2.92 ms.  The two kernels do not fill each other's issue gaps; measured in round 4, not kept.)
-    const size_t lds = sizeof(double) * (kWaves * kAccPad + (size_t)L.W + (size_t)L.H);
+    const size_t lds = sizeof(double) * (kWaves * kAccPad + (size_t)L.W + 3 * (size_t)L.H);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling && (level == 0 || h->profiling == 2)) {
         while (h->ev_pool.size() < h->ev_used + 2) {
@@ -2950,7 +2976,7 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
     TDK_REQUIRE(n_pairs >= 1 && n_pairs <= 65535, "n_pairs must be in [1, 65535]");
     TDK_REQUIRE(height >= 2 && width >= 2, "frames must be at least 2x2");
     TDK_REQUIRE((int64_t)height * width < (1ll << 28), "frame too large");
-    TDK_REQUIRE((size_t)(height + width + kWaves * kAccPad) * sizeof(double) <= 160 * 1024,
+    TDK_REQUIRE((size_t)(3 * height + width + kWaves * kAccPad) * sizeof(double) <= 160 * 1024,
                 "height + width must stay below 20 000 (per-block coordinate tables live in LDS)");
     TDK_REQUIRE(n_levels >= 1 && n_levels <= kMaxLevels, "n_levels must be in [1, 16]");
     TDK_REQUIRE(ratio > 1.0 || n_levels == 1, "layer_size_ratio must be > 1");
