@@ -162,8 +162,22 @@ __device__ __forceinline__ void gradient2_clamped(const Taps &t, const Warped &p
 // (Student-t: variance; Tukey: sigma_mad).  What solve_linear_equation ends up
 // applying is sqrt(w)^2 of whatever compute_weights returned, i.e. the value
 // below (compute_weights_student_t itself already returns a square root).
+// Student-t and Tukey get the RECIPROCAL of the statistic (one division per block instead of one or two IEEE
+// division sequences of 11 instructions per pixel; the quotients differ from the reference's in the last bit,
+// the weights are held to 1e-9 like every sum they enter).
 template <int WMODE>
 __device__ __forceinline__ double robust_weight(double r, double w0, double ws) {
+    if (WMODE == TDK_W_STUDENT_T) {
+        const double t = __builtin_fma(r * r, ws, kStudentNu);          // nu + r^2 / variance
+        double y = __builtin_amdgcn_rcp(t);
+        y = __builtin_fma(__builtin_fma(-t, y, 1.0), y, y);
+        y = __builtin_fma(__builtin_fma(-t, y, 1.0), y, y);
+        return sqrt((kStudentNu + 1.0) * y);
+    }
+    if (WMODE == TDK_W_TUKEY) {
+        const double x = r * ws, q = x * (1.0 / kTukeyBeta), u = 1.0 - q * q;
+        return fabs(x) <= kTukeyBeta ? u * u : 0.0;
+    }
     if (WMODE == TDK_W_HUBER) {
         // |r| <= 1 < k on [0, 1] images (F4): the division sits behind a branch
         // that is skipped unless some lane of the wave has an outlier
@@ -172,11 +186,6 @@ __device__ __forceinline__ double robust_weight(double r, double w0, double ws) 
         return w;
     }
     if (WMODE == TDK_W_MAP) return w0;
-    if (WMODE == TDK_W_STUDENT_T) return sqrt((kStudentNu + 1.0) / (kStudentNu + (r * r) / ws));
-    if (WMODE == TDK_W_TUKEY) {
-        double x = r / ws, q = x / kTukeyBeta, u = 1.0 - q * q;
-        return fabs(x) <= kTukeyBeta ? u * u : 0.0;
-    }
     return 1.0;
 }
 
@@ -513,7 +522,7 @@ __device__ __forceinline__ void eval_body(const LevelPtrs &L, const PairParams *
                                           double *__restrict__ partials) {
     BlockSetup b;
     load_setup(b, params, poses, pair, scale);
-    const double ws = (WMODE == TDK_W_STUDENT_T || WMODE == TDK_W_TUKEY) ? wscale[pair] : 1.0;
+    const double ws = (WMODE == TDK_W_STUDENT_T || WMODE == TDK_W_TUKEY) ? 1.0 / wscale[pair] : 1.0;   // see robust_weight
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double(*red)[kAccPad] = reinterpret_cast<double(*)[kAccPad]>(smem);
