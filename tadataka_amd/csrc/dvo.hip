@@ -205,6 +205,11 @@ __device__ __forceinline__ void store_partials(const Accum &acc, double (*red)[k
     }
 }
 
+// rows of the row-term table of an evaluation block: its pixel range, the pipeline's overrun, a partial first row
+__host__ __device__ __forceinline__ int eval_rows(int64_t chunk, int W) {
+    return (int)((chunk + 3 * kBlock + W - 1) / W) + 1;
+}
+
 struct BlockSetup {   // block-uniform pose and (level-scaled) cameras
     double P[12], c[4], fx0, fy0, ox0, oy0;
 };
@@ -527,13 +532,19 @@ __device__ __forceinline__ void eval_body(const LevelPtrs &L, const PairParams *
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double(*red)[kAccPad] = reinterpret_cast<double(*)[kAccPad]>(smem);
     double *xn_tab = reinterpret_cast<double *>(smem + sizeof(double) * kWaves * kAccPad);
-    double *ry_tab = xn_tab + L.W;      // [H][3]: the row terms of the warp at this block's pose
+    double *ry_tab = xn_tab + L.W;      // [eval_rows(chunk, W)][3]: the row terms of the warp at this block's pose
+    const int start = (int)(blk * chunk);
+    const int row0 = start / L.W;       // the first image row of this block's pixel range: ry_tab is relative to it
     {
         const double *__restrict__ tab = L.tab + (size_t)pair * (L.W + L.H);
         for (int i = threadIdx.x; i < L.W; i += kBlock) xn_tab[i] = tab[i];
-        for (int i = threadIdx.x; i < L.H; i += kBlock) {
+        // only the rows the block's range (and the pipeline's overrun of < 3 kBlock pixels) can touch; rows beyond
+        // the image belong to masked-out pixels and stay whatever the LDS held
+        const int rows = eval_rows(chunk, L.W);
+        for (int i = threadIdx.x; i < rows; i += kBlock) {
+            if (row0 + i >= L.H) continue;
             double r0, r1, r2;
-            row_terms(b.P, tab[L.W + i], r0, r1, r2);
+            row_terms(b.P, tab[L.W + row0 + i], r0, r1, r2);
             ry_tab[3 * i] = r0; ry_tab[3 * i + 1] = r1; ry_tab[3 * i + 2] = r2;
         }
     }
@@ -551,11 +562,11 @@ __device__ __forceinline__ void eval_body(const LevelPtrs &L, const PairParams *
 #pragma unroll
     for (int i = 0; i < kAcc; i++) acc.v[i] = 0.0;
 
-    const int start = (int)(blk * chunk);
     const int end = (int)min((int64_t)N, (int64_t)start + chunk);
-    // iw: the next pixel to warp, (x, y) its coordinates, advanced by kBlock per step
+    // iw: the next pixel to warp, (x, y) its coordinates (y relative to row0), advanced by kBlock per step
     int iw = start + (int)threadIdx.x;
     int y = iw / W, x = iw - y * W;
+    y -= row0;
     const int step_y = kBlock / W, step_x = kBlock - step_y * W;
 #define TDK_ADVANCE()                      \
     do {                                   \
@@ -2726,7 +2737,7 @@ tdk_status launch_eval(tdk_dvo *h, int level, const double *d_poses, const int *
     // (Capping the evaluation at 2 blocks per CU by padding this request, so that the other batch's pyramid
     // blocks -- 36 KB of LDS, 121 VGPRs -- co-reside on the same SIMDs: full evaluation 0.55 -> 0.65 ms, bench
     // step 2.73 -> 2.92 ms.  The two kernels do not fill each other's issue gaps; measured in round 4, not kept.)
-    const size_t lds = sizeof(double) * (kWaves * kAccPad + (size_t)L.W + 3 * (size_t)L.H);
+    const size_t lds = sizeof(double) * (kWaves * kAccPad + (size_t)L.W + 3 * (size_t)eval_rows(chunk, L.W));
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->profiling && (level == 0 || h->profiling == 2)) {
         while (h->ev_pool.size() < h->ev_used + 2) {
@@ -2985,7 +2996,7 @@ tdk_status tdk_dvo_create(int n_pairs, int height, int width, int n_levels, doub
     TDK_REQUIRE(n_pairs >= 1 && n_pairs <= 65535, "n_pairs must be in [1, 65535]");
     TDK_REQUIRE(height >= 2 && width >= 2, "frames must be at least 2x2");
     TDK_REQUIRE((int64_t)height * width < (1ll << 28), "frame too large");
-    TDK_REQUIRE((size_t)(3 * height + width + kWaves * kAccPad) * sizeof(double) <= 160 * 1024,
+    TDK_REQUIRE((size_t)(height + width + kWaves * kAccPad) * sizeof(double) <= 160 * 1024,
                 "height + width must stay below 20 000 (per-block coordinate tables live in LDS)");
     TDK_REQUIRE(n_levels >= 1 && n_levels <= kMaxLevels, "n_levels must be in [1, 16]");
     TDK_REQUIRE(ratio > 1.0 || n_levels == 1, "layer_size_ratio must be > 1");
