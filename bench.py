@@ -237,13 +237,13 @@ def measure_traffic_in_run(argv):
 def roofline_fp64(prof_kind):
     """SURVEY 8(d)'s secondary ceiling: FP64 vector rate of the evaluation kernel.  FLOPs per pixel
     come from the instruction counters of a rocprofv3 --pmc pass over the same kernel
-    (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64; profiles/r03_fp64_mix.json, made by tools/fp64_mix.sh),
+    (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64; profiles/r05_fp64_mix.json, made by tools/fp64_mix.sh),
     the kernel time from this run's HIP events."""
-    mix = load_profile_json("r03_fp64_mix.json")
+    mix = load_profile_json("r05_fp64_mix.json") or load_profile_json("r03_fp64_mix.json")
     if not mix:
         return None
     out = {"bound": "fp64-vector", "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "source": "profiles/r03_fp64_mix.json (rocprofv3 --pmc, tools/fp64_mix.sh); kernel time: HIP events of this run",
+           "source": "profiles/r05_fp64_mix.json (rocprofv3 --pmc, tools/fp64_mix.sh, the round-5 kernels); kernel time: HIP events of this run",
            "by_mode": {}}
     flops, ms = 0.0, 0.0
     for kind in ("full", "probe"):

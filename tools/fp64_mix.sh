@@ -2,7 +2,7 @@
 # usage (on the GPU box, from the repo root): bash tools/fp64_mix.sh
 # FP64 instruction mix, busy cycles and HBM traffic of k_dvo_eval<huber> at full resolution (256 VGA
 # pairs), full evaluations and error-only probes separately; rocprofv3 --pmc in passes of their own
-# (no tracing next to the counters).  Writes profiles/r03_fp64_mix.json + profiles/r03_fp64_mix.txt.
+# (no tracing next to the counters).  Writes profiles/r05_fp64_mix.json + profiles/r05_fp64_mix.txt.
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/fp64mix; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp; cd /tmp
 for kind in full probe; do
   FLAG=""; [ $kind = probe ] && FLAG="--probe"
@@ -14,4 +14,4 @@ for kind in full probe; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$kind/t -o k -- $CMD > $OUT/$kind.t.log 2>&1
 done
 cd $ROOT
-python tools/fp64_mix_summary.py $OUT | tee profiles/r03_fp64_mix.txt
+python tools/fp64_mix_summary.py $OUT | tee profiles/r05_fp64_mix.txt
