@@ -128,3 +128,33 @@ def run_ba(viewpoint_indices, point_indices, poses, points, keypoints_true):
     rotvecs, ts, points = ba.compute(rotvecs, ts, points, absolute_error_threshold=1e-9,
                                      max_iter=5, relative_error_threshold=0.20)
     return [Pose(Rotation.from_rotvec(r), t) for r, t in zip(rotvecs, ts)], points
+
+
+def can_run_ba(n_viewpoints, n_points, n_visible, n_pose_params, n_point_params):
+    """sparseba.can_run_ba (the package is absent here; its published rule): J^T J cannot be invertible with fewer
+    rows (two per observation) than columns (pose and point parameters)."""
+    return 2 * n_visible >= n_pose_params * n_viewpoints + n_point_params * n_points
+
+
+def test_unique(viewpoint_indices, point_indices):
+    """reference local_ba.py:155-157: no (viewpoint, point) pair observed twice."""
+    A = np.vstack((viewpoint_indices, point_indices))
+    assert(np.unique(A, axis=1).shape[1] == A.shape[1])
+
+
+test_unique.__test__ = False      # a helper of the reference's API, not a test of this repository
+
+
+def try_run_ba(viewpoint_indices, point_indices, poses, points, keypoints_true):
+    """reference local_ba.py:160-179 (called by tadataka/vo/feature_based.py:226): run_ba if the graph can
+    determine its parameters, else a RuntimeWarning and the inputs back."""
+    import warnings
+    assert(len(viewpoint_indices) == len(point_indices))
+    assert(len(set(viewpoint_indices)) == len(poses))
+    assert(len(set(point_indices)) == len(points))
+    test_unique(viewpoint_indices, point_indices)
+    if not can_run_ba(n_viewpoints=len(poses), n_points=len(points), n_visible=len(keypoints_true),
+                      n_pose_params=6, n_point_params=3):
+        warnings.warn("Arguments are not satisfying condition to run BA", RuntimeWarning)
+        return poses, points
+    return run_ba(viewpoint_indices, point_indices, poses, points, keypoints_true)

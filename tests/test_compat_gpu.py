@@ -270,6 +270,23 @@ def test_solve_linear_equation_and_irls_vs_reference(golden):
     # here also agreement with the reference implementation's own result
     beta = irls.fit(g["irls_X"], g["irls_y"])
     assert np.allclose(beta, g["irls_beta"], rtol=1e-8, atol=1e-10)
+    # the rest of the module's surface (irls.py:69-196): the M-estimator object, Residual, the two solvers
+    X, y = g["irls_X"], g["irls_y"]
+    assert np.allclose(irls.fit(X, y, M=irls.HuberT()), beta, rtol=0, atol=0)
+    loose = irls.fit(X, y, M=irls.HuberT(t=1e6))                     # every weight 1: ordinary least squares
+    assert np.allclose(loose, np.linalg.lstsq(X, y, rcond=None)[0], rtol=1e-9, atol=1e-11)
+    assert np.allclose(irls.least_squares(X, y), loose, rtol=1e-9, atol=1e-11)
+    w = np.linspace(0.1, 2.0, len(y))
+    sw = np.sqrt(w)
+    assert np.allclose(irls.weighted_least_squares(X, y, w), np.linalg.lstsq(sw[:, None] * X, sw * y, rcond=None)[0],
+                       rtol=1e-9, atol=1e-11)
+    assert np.allclose(irls.Residual(X, y).compute(beta), y - X @ beta)
+    M, z = irls.HuberT(), np.array([-3.0, -1.345, -0.2, 0.0, 0.7, 1.345, 4.0])
+    assert np.allclose(M.weights(z), [1.345 / 3, 1, 1, 1, 1, 1, 1.345 / 4])
+    assert np.allclose(M.psi(z), [-1.345, -1.345, -0.2, 0.0, 0.7, 1.345, 1.345])
+    assert np.allclose(M(z), [3 * 1.345 - 0.5 * 1.345 ** 2, 0.5 * 1.345 ** 2, 0.02, 0.0, 0.245, 0.5 * 1.345 ** 2,
+                              4 * 1.345 - 0.5 * 1.345 ** 2])
+    assert np.array_equal(M.psi_deriv(z), [False, True, True, True, True, True, False])
 
 
 # --- semi-dense step as examples/semi_dense_vo.py:182-199 runs it ----------------------------
@@ -437,6 +454,29 @@ def test_local_bundle_adjustment_converges_and_matches_dense_lm():
     run(omegas_true, translations_noisy, points_true)
     run(omegas_true, translations_true, points_noisy)
     run(omegas_noisy, translations_noisy, points_noisy)
+
+
+def test_try_run_ba_runs_the_windowed_adjustment():
+    """try_run_ba -> run_ba with Pose objects in and out, as tadataka/vo/feature_based.py:226 calls it: the
+    reprojection error of a perturbed 3-view window goes down."""
+    from scipy.spatial.transform import Rotation
+    from tadataka.local_ba import Projection, calc_error, try_run_ba
+    from tadataka.pose import Pose
+    rng = np.random.default_rng(77)
+    n_points, n_viewpoints = 40, 3
+    vis = np.ones((n_viewpoints, n_points), dtype=bool)
+    viewpoint_indices, point_indices = np.where(vis)
+    omegas = rng.uniform(-0.2, 0.2, (n_viewpoints, 3)); ts = rng.uniform(-0.5, 0.5, (n_viewpoints, 3))
+    points = np.column_stack([rng.uniform(-2, 2, (n_points, 2)), rng.uniform(4, 8, n_points)])
+    projection = Projection(viewpoint_indices, point_indices)
+    keypoints = projection.compute(np.hstack((omegas, ts)), points)
+    poses0 = [Pose(Rotation.from_rotvec(o + 1e-3 * rng.normal(size=3)), t + 1e-2 * rng.normal(size=3)) for o, t in zip(omegas, ts)]
+    points0 = points + 1e-2 * rng.normal(size=points.shape)
+    as_array = lambda ps: np.array([np.concatenate([p.rotation.as_rotvec(), p.t]) for p in ps])
+    e0 = calc_error(keypoints, projection.compute(as_array(poses0), points0))
+    poses1, points1 = try_run_ba(viewpoint_indices, point_indices, poses0, points0, keypoints)
+    assert all(isinstance(p, Pose) for p in poses1) and points1.shape == points.shape
+    assert calc_error(keypoints, projection.compute(as_array(poses1), points1)) < 0.05 * e0
 
 
 def test_bundle_adjustment_full_size_step():

@@ -224,3 +224,24 @@ def test_reference_examples_import_unchanged(example, tmp_path):
     out = subprocess.run([sys.executable, "-c", _EXAMPLE_LOADER, repo, "/root/reference", script], cwd=str(tmp_path),
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "IMPORTS-RESOLVED" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_try_run_ba_guards_of_the_reference():
+    """tadataka.local_ba.try_run_ba (reference local_ba.py:155-179, the call of vo/feature_based.py:226): its three
+    assertions, the uniqueness test and the under-determined graph that comes back unchanged with a RuntimeWarning
+    -- none of which reaches the device."""
+    import warnings
+    import tadataka_amd  # noqa: F401
+    from tadataka.local_ba import can_run_ba, try_run_ba
+    assert can_run_ba(2, 4, 12, 6, 3) and not can_run_ba(2, 4, 11, 6, 3)
+    poses, points = ["pose0", "pose1"], np.zeros((3, 3))
+    vp, pt = np.array([0, 0, 0, 1, 1]), np.array([0, 1, 2, 0, 1])        # 10 rows < 12 + 9 columns
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        out = try_run_ba(vp, pt, poses, points, np.zeros((5, 2)))
+    assert out[0] is poses and out[1] is points
+    assert any(issubclass(w.category, RuntimeWarning) for w in rec)
+    with pytest.raises(AssertionError):
+        try_run_ba(np.array([0, 0, 1, 1]), np.array([0, 0, 1, 2]), poses, points, np.zeros((4, 2)))      # a pair twice
+    with pytest.raises(AssertionError):
+        try_run_ba(np.array([0, 0, 0]), np.array([0, 1, 2]), poses, points, np.zeros((3, 2)))            # a pose unseen
