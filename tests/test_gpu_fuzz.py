@@ -200,13 +200,18 @@ def test_fuzz_batch_pyramid_bit_exact(ops, orc):
     from tadataka_amd import rescale_plan
     rng = np.random.default_rng(3500 + SEED)
     n = max(2, N_CASES // 3)
+    big = os.environ.get("TDK_FUZZ_BIG") == "1"      # frames of several strips / row segments, batches that fill the chip
     for case in range(n):
         H, W = int(rng.integers(8, 130)), int(rng.integers(8, 300))
+        if big:
+            H, W = int(rng.integers(100, 520)), int(rng.integers(200, 900))
         levels = int(rng.integers(1, 5))
         ratio = float(rng.choice([1.5, 2.0, 1.3]))
         while min(H, W) / ratio ** (levels - 1) < 3:
             levels -= 1
         B = int(rng.choice([1, 2, 9, 40]))
+        if big:
+            B = int(rng.choice([3, 30, 90]))
         batch = ops.DvoBatch(B, H, W, n_levels=levels, ratio=ratio)
         plans = rescale_plan.level_plans((H, W), levels, ratio, True)
         batch.set_skimage_pyramid(plans)
