@@ -578,7 +578,7 @@ def fusion_arrays(mu1, mu2, var1, var2):
 def rgb2gray(rgb):
     rgb = np.asarray(rgb)
     if rgb.dtype == np.uint8:
-        rgb = rgb / 255.0
+        rgb = rgb * (1.0 / 255.0)      # img_as_float: np.multiply(image, 1. / imax_in)
     rgb, p = _d(rgb)
     H, W, ch = rgb.shape
     out = np.empty((H, W))

@@ -21,11 +21,15 @@ def _check_kwargs(kwargs):
 def _as_float(image):
     """img_as_float: unsigned integers are scaled to [0, 1], signed ones to [-1, 1], floats pass."""
     a = np.asarray(image)
+    # skimage/util/dtype.py: np.multiply(image, 1. / imax_in) for unsigned input (NOT x / max: the two differ in the
+    # last bit for 24 of the 256 uint8 values); image + 0.5, then *= 2 / (imax_in - imin_in) for signed input
     if a.dtype.kind == "u":
-        return a.astype(np.float64) / float(np.iinfo(a.dtype).max)
+        return a.astype(np.float64) * (1.0 / float(np.iinfo(a.dtype).max))
     if a.dtype.kind == "i":
         info = np.iinfo(a.dtype)
-        return np.maximum(a.astype(np.float64) / float(info.max), -1.0)
+        out = a.astype(np.float64) + 0.5
+        out *= 2 / (float(info.max) - float(info.min))
+        return out
     if a.dtype.kind == "b":
         return a.astype(np.float64)
     return np.asarray(a, dtype=np.float64)

@@ -676,7 +676,9 @@ __global__ __launch_bounds__(kBlock) void k_dvo_probe(LevelPtrs L, const PairPar
     eval_body<TDK_W_NONE, true>(L, params, poses, nullptr, scale, chunk, pair, blk, nblk, partials);
 }
 
-// 8-bit frames -> float64 in [0, 1] (skimage.img_as_float: x / 255), one launch for a range of pairs.
+// 8-bit frames -> float64 in [0, 1] as skimage.img_as_float converts them: x * (1 / 255) -- the product with the rounded
+// reciprocal (skimage/util/dtype.py: np.multiply(image, 1. / imax_in)), which differs from x / 255 in the last bit for 24
+// of the 256 values.  One launch for a range of pairs.
 // Two pixels per thread: a 2-byte load and one 16-byte store per lane, both fully coalesced.
 __global__ __launch_bounds__(kBlock) void k_u8_to_f64(const uint8_t *__restrict__ src, double *__restrict__ dst,
                                                       int64_t N, int64_t stride) {
@@ -693,11 +695,11 @@ __global__ __launch_bounds__(kBlock) void k_u8_to_f64(const uint8_t *__restrict_
                 a = s[i]; b = s[i + 1];
             }
             double2 o;
-            o.x = (double)a / 255.0;
-            o.y = (double)b / 255.0;
+            o.x = (double)a * (1.0 / 255.0);
+            o.y = (double)b * (1.0 / 255.0);
             *reinterpret_cast<double2 *>(d + i) = o;
         } else {
-            d[i] = (double)s[i] / 255.0;
+            d[i] = (double)s[i] * (1.0 / 255.0);
         }
     }
 }

@@ -147,7 +147,7 @@ tdk_status normalize_impl(const double *kp, int64_t n, const double *camera, dou
 }
 
 // skimage.color.rgb2gray as the examples use it (examples/dvo_pose_change.py:22-31):
-// luma of the first three interleaved channels; uint8 input is scaled by 1/255 first
+// luma of the first three interleaved channels; uint8 input is multiplied by 1/255 first (img_as_float)
 // (img_as_float).  -ffp-contract=off keeps the two products and two sums as written.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_rgb2gray(const T *__restrict__ rgb, int64_t n, int channels,
@@ -155,7 +155,10 @@ __global__ __launch_bounds__(kBlock) void k_rgb2gray(const T *__restrict__ rgb, 
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
         const T *p = rgb + i * channels;
         double r, g, b;
-        if (sizeof(T) == 1) { r = (double)p[0] / 255.0; g = (double)p[1] / 255.0; b = (double)p[2] / 255.0; }
+        if (sizeof(T) == 1) {   // img_as_float multiplies by the reciprocal (skimage/util/dtype.py: np.multiply(image, 1. / imax_in)): 24 of the 256 values differ from x / 255 in the last bit
+            const double s = 1.0 / 255.0;
+            r = (double)p[0] * s; g = (double)p[1] * s; b = (double)p[2] * s;
+        }
         else { r = (double)p[0]; g = (double)p[1]; b = (double)p[2]; }
         out[i] = (0.2125 * r + 0.7154 * g) + 0.0721 * b;
     }

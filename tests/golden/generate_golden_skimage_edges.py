@@ -87,6 +87,21 @@ def main():
             img = rng.uniform(0, 1, (40, 40))
             img[17, 22] = np.inf
             add("sparse_inf", img, 0.2, aa, clip)
+    # img_as_float of the integer types (what rgb2gray / rescale do to an 8-bit frame first): a product with the rounded
+    # reciprocal of the type's maximum, not a division -- 24 of the 256 uint8 values differ in the last bit
+    from skimage import img_as_float
+    from skimage.color import rgb2gray
+    for dt in (np.uint8, np.int8, np.uint16, np.int16):
+        info = np.iinfo(dt)
+        x = np.arange(info.min, info.max + 1, dtype=dt)
+        if x.size > 256:
+            x = x[rng.integers(0, x.size, 400)]
+            x[:2] = (info.min, info.max)
+        out[f"as_float_{np.dtype(dt).name}_in"] = x
+        out[f"as_float_{np.dtype(dt).name}_out"] = img_as_float(x)
+    gray8 = rng.integers(0, 256, (12, 16), dtype=np.uint8)
+    out["gray_u8_in"] = gray8
+    out["gray_u8_as_float"] = img_as_float(gray8)
     out["names"] = np.array(names)
     path = os.path.join(HERE, "skimage_rescale_edges.npz")
     np.savez_compressed(path, **out)

@@ -733,7 +733,7 @@ def test_partial_pyramid_rebuild(ops, mode):
 
 def test_async_uploads_from_pinned_memory(ops):
     """tdk_dvo_upload_async / _u8: ranges of pairs from pinned memory on the copy stream, ordered
-    with the batch's own stream; float64 bit for bit, 8-bit frames as x / 255."""
+    with the batch's own stream; float64 bit for bit, 8-bit frames as x * (1 / 255) (img_as_float)."""
     from tadataka_amd import _lib, synthetic
     B, H, W = 5, 37, 53            # odd pixel count: the per-pair stride is padded
     batch = ops.DvoBatch(B, H, W)
@@ -752,7 +752,7 @@ def test_async_uploads_from_pinned_memory(ops):
     _lib.call("tdk_sync")
     for i in range(B):
         want_I1 = new_I1[i - 1] if 1 <= i <= 3 else pairs[i]["I1"]
-        want_I0 = gray[i - 3] / 255.0 if i >= 3 else pairs[i]["I0"]
+        want_I0 = gray[i - 3] * (1.0 / 255.0) if i >= 3 else pairs[i]["I0"]
         assert np.array_equal(batch.download(i, 0, "I1"), want_I1), i
         assert np.array_equal(batch.download(i, 0, "I0"), want_I0), i
         assert np.array_equal(batch.download(i, 0, "D0"), pairs[i]["D0"]), i
@@ -790,7 +790,7 @@ def test_async_upload_is_waited_for_by_whatever_touches_the_arrays_next(ops):
     f64 = rng.uniform(0.0, 1.0, (B, H * W))
     pin = ops.PinnedBuffer((B, H * W))
     pin.array[:] = f64
-    for which, buf, want in (("I1", pin8, gray / 255.0), ("I1", pin, f64)):
+    for which, buf, want in (("I1", pin8, gray * (1.0 / 255.0)), ("I1", pin, f64)):
         # download straight after the upload call
         batch.upload_async(which, 0, B, buf)
         assert np.array_equal(batch.download(B - 1, 0, which).ravel(), want[B - 1])

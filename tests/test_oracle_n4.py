@@ -76,7 +76,7 @@ def test_rgb2gray_definition():
     rgba = np.concatenate([rgb, rng.uniform(0, 1, (7, 9, 1))], axis=2)
     assert np.array_equal(orc.rgb2gray(rgba), orc.rgb2gray(rgb))
     u8 = rng.integers(0, 256, (5, 4, 3)).astype(np.uint8)
-    assert np.max(np.abs(orc.rgb2gray(u8) - (u8 / 255.0) @ np.array([0.2125, 0.7154, 0.0721]))) < 3e-16
+    assert np.max(np.abs(orc.rgb2gray(u8) - (u8 * (1.0 / 255.0)) @ np.array([0.2125, 0.7154, 0.0721]))) < 3e-16
     assert orc.rgb2gray(np.ones((2, 2, 3)))[0, 0] == (0.2125 + 0.7154) + 0.0721
 
 
