@@ -172,7 +172,16 @@ __device__ __forceinline__ double robust_weight(double r, double w0, double ws) 
         double y = __builtin_amdgcn_rcp(t);
         y = __builtin_fma(__builtin_fma(-t, y, 1.0), y, y);
         y = __builtin_fma(__builtin_fma(-t, y, 1.0), y, y);
-        return sqrt((kStudentNu + 1.0) * y);
+        // the square root of q = (nu + 1) / t in (0, 1.2]: v_rsq_f64 + one Goldschmidt step + one correction (8
+        // operations; the compiler's sqrt also rescales denormal arguments and tests for 0 / Inf / NaN: 20)
+        const double q = (kStudentNu + 1.0) * y;
+        const double y0 = __builtin_amdgcn_rsq(q);
+        double g = q * y0, h = 0.5 * y0;
+        const double e = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, e, g);
+        h = __builtin_fma(h, e, h);
+        g = __builtin_fma(__builtin_fma(-g, g, q), h, g);
+        return q > 0.0 ? g : q;      // r = +-Inf: q = 0, the weight is 0 (rsq(0) is Inf); NaN stays NaN
     }
     if (WMODE == TDK_W_TUKEY) {
         const double x = r * ws, q = x * (1.0 / kTukeyBeta), u = 1.0 - q * q;
