@@ -2485,6 +2485,28 @@ void plan_blocks(const tdk_dvo *h, const tdk_dvo::Level &L, int *nblk, int64_t *
     if (nb > cap) nb = cap;
     if (nb > h->max_blocks) nb = h->max_blocks;
     if (nb < 1) nb = 1;
+    // Batches that fill the chip several times over: longer blocks whose count is a whole number of resident rounds.
+    // A block's fixed cost (tables, three pipeline steps to fill and drain, 30 wave reductions) is ~5 pixel-steps: at
+    // 16 pixels per thread a quarter of a coarse level's time, and a last round that is a third full costs as much
+    // again.  Among 16 .. 64 pixels per thread take the count with the best (work / rounded-up rounds) x (1 - fixed
+    // share).  256 VGA pairs: level 2 six blocks of 40 pixels per thread per pair (two full rounds; 0.131 -> 0.123 ms),
+    // level 1 nine of 60 (three rounds; 0.279 -> 0.261 ms), level 0 twenty-one of 57 (seven rounds; 0.545 -> 0.534 ms):
+    // bench step 3.09 -> 3.04 ms.  The probe shares the partition (a pose's error is the same double in both
+    // modes); at eight blocks per CU its rounds no longer come out whole, which costs it ~1 % at level 0.
+    if (px_per_thread >= 16 && h->n_cu > 0) {
+        const double resident = 3.0 * h->n_cu;                   // three blocks per CU at 154 VGPRs
+        const int64_t nb_lo = std::max<int64_t>(1, (L.N + 64 * kBlock - 1) / (64 * kBlock));
+        const int64_t nb_hi = std::min<int64_t>(nb, std::max<int64_t>(1, L.N / (16 * kBlock)));
+        double best = -1.0;
+        int64_t best_nb = nb;
+        for (int64_t cand = nb_lo; cand <= nb_hi; cand++) {
+            const double rounds = (double)cand * h->n_pairs / resident;
+            const double steps = (double)L.N / ((double)cand * kBlock);
+            const double score = rounds / ceil(rounds) * (steps / (steps + 5.0));
+            if (score > best * 1.0001) { best = score; best_nb = cand; }
+        }
+        nb = best_nb;
+    }
     int64_t c = (L.N + nb - 1) / nb;
     c = (c + 2 * kBlock - 1) / (2 * kBlock) * (2 * kBlock);  // even, whole block sweeps
     nb = (L.N + c - 1) / c;
