@@ -1187,12 +1187,13 @@ __global__ __launch_bounds__(256) void k_clip_apply(ClipArgs a) {
 // narrower than the gaps between its taps -- never skimage's own sigma rule, but the plan is the caller's): a NaN
 // that no tap sees still makes numpy.clip's bounds NaN, i.e. every output.  One pass over the source flags the
 // slots of those levels (found by tests/test_gpu_fuzz.py: rescale(anti_aliasing=False) of an image with one NaN).
-__global__ __launch_bounds__(256) void k_clip_nan_scan(ClipArgs a, unsigned level_mask) {
-    const int arr = blockIdx.y, pair = blockIdx.z;
+__global__ __launch_bounds__(256) void k_clip_nan_scan(ClipArgs a, unsigned level_mask, int per_image) {
+    const int image = blockIdx.x / per_image, part = blockIdx.x - image * per_image;   // 1-D grid: no limit on the batch
+    const int pair = image / a.n_arrays, arr = image - pair * a.n_arrays;
     const double *s = a.src[arr] + (int64_t)pair * a.src_stride;
     const int64_t n = (int64_t)a.H * a.W;
     bool nan = false;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) nan |= s[i] != s[i];
+    for (int64_t i = (int64_t)part * 256 + threadIdx.x; i < n; i += (int64_t)per_image * 256) nan |= s[i] != s[i];
     if (__ballot(nan) == 0ull || (threadIdx.x & 63) != 0) return;
     for (int l = 0; l < a.n_out; l++)
         if ((level_mask >> l) & 1u) atomicOr(&a.slots[((int64_t)pair * a.n_arrays + arr) * a.n_out + l].nan_out, 1u);
@@ -1598,9 +1599,9 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
             if (skips(dv[l].mx, W, dv[l].Wo, dv[l].aa.Rc) || skips(dv[l].my, H, dv[l].Ho, dv[l].aa.Rr)) sparse |= 1u << l;
         }
         if (sparse) {
-            const int64_t per = ((int64_t)H * W + 256 * 16 - 1) / (256 * 16);
-            dim3 grid((unsigned)std::min<int64_t>(std::max<int64_t>(per, 1), 256), n_arrays, batch);
-            k_clip_nan_scan<<<grid, 256, 0, stream>>>(c, sparse);
+            const int64_t per = std::min<int64_t>(std::max<int64_t>(((int64_t)H * W + 256 * 16 - 1) / (256 * 16), 1), 256);
+            if (per * images >= (1ll << 31)) { set_error("clip: grid too large"); return TDK_ERR_INVALID_ARGUMENT; }
+            k_clip_nan_scan<<<(unsigned)(per * images), 256, 0, stream>>>(c, sparse, (int)per);
             TDK_LAUNCH_CHECK();
         }
         if (n <= 64) {
