@@ -145,21 +145,27 @@ def test_fuzz_dvo_estimate_small_scenes(ops, orc):
         cam = pair["cam"]
         if rng.random() < 0.7:      # a camera whose scaled parameters are not exact in binary (the pair's own is f = 525 W / 640, o = W / 2)
             cam = cam * rng.uniform(0.97, 1.03, 4) + np.array([0, 0, rng.uniform(-1, 1), rng.uniform(-1, 1)])
+        # a prior other than the identity (what a tracker hands over) and the iteration limits of the reference's tests
+        max_iter = int(rng.choice([20, 20, 5, 2, 1]))
+        R0, t0 = np.eye(3), np.zeros(3)
+        if rng.random() < 0.4:
+            R0 = Rotation.from_rotvec(rng.uniform(-0.004, 0.004, 3)).as_matrix()
+            t0 = rng.uniform(-0.008, 0.008, 3)
         import warnings
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             Rr, tr = orc.dvo_estimate(pair["I0"], pair["D0"], pair["I1"], cam, cam, wname, n_coarse_to_fine=levels,
-                                      max_iter=20, anti_aliasing=True)[:2]
+                                      max_iter=max_iter, anti_aliasing=True, rotation=Rotation.from_matrix(R0), t=t0)[:2]
         batch = ops.DvoBatch(1, H, W, n_levels=levels)
         batch.upload(0, pair["I0"], pair["D0"], pair["I1"])
         batch.build_pyramid()
-        P, _ = batch.estimate(cam, cam, _pose12(np.eye(3), np.zeros(3))[None], ops.WEIGHT_MODES[wname], 20)
+        P, _ = batch.estimate(cam, cam, _pose12(R0, t0)[None], ops.WEIGHT_MODES[wname], max_iter)
         batch.close()
         Rr = Rr.as_matrix() if hasattr(Rr, "as_matrix") else np.asarray(Rr)
         d = max(np.max(np.abs(P[0, :9].reshape(3, 3) - Rr)), np.max(np.abs(P[0, 9:] - tr)))
         if d >= 1e-6:
             mism += 1
-        assert d < 1e-6, (case, H, W, levels, wname, d)
+        assert d < 1e-6, (case, H, W, levels, wname, max_iter, d)
     print(f"dvo estimate: {n} scenes, {mism} beyond 1e-6")
 
 
