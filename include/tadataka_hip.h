@@ -152,7 +152,8 @@ tdk_status tdk_dvo_upload_async(tdk_dvo *h, int which, int first_pair, int n_pai
                                 const double *pinned_host);
 /* The same for 8-bit grey frames as a camera delivers them: [n_pairs][height * width] bytes in
  * pinned memory, converted on the device to the float64 image skimage's img_as_float /
- * rgb2gray-of-grey gives (x / 255).  An eighth of the PCIe bytes of the float64 hand-over. */
+ * rgb2gray-of-grey gives: x * (1 / 255), the product with the rounded reciprocal (skimage/util/dtype.py), which
+ * is not x / 255 for 24 of the 256 values.  An eighth of the PCIe bytes of the float64 hand-over. */
 tdk_status tdk_dvo_upload_async_u8(tdk_dvo *h, int which, int first_pair, int n_pairs,
                                    const uint8_t *pinned_host);
 /* Fills every pair on the device from the analytic synthetic scene of
@@ -399,7 +400,7 @@ tdk_status tdk_fusion_arrays(const double *mu1, const double *mu2, const double 
 /* skimage.color.rgb2gray as the examples call it (examples/dvo_pose_change.py:22-31,
  * examples/semi_dense_vo.py:62-66): 0.2125 R + 0.7154 G + 0.0721 B of the first
  * three of `channels` interleaved channels; rgb is float64 [height][width][channels]
- * (tdk_rgb2gray) or uint8 scaled by 1/255 first, as img_as_float does (tdk_rgb2gray_u8). */
+ * (tdk_rgb2gray) or uint8 multiplied by 1/255 first, as img_as_float does (tdk_rgb2gray_u8). */
 tdk_status tdk_rgb2gray(const double *rgb, int height, int width, int channels, double *gray);
 tdk_status tdk_rgb2gray_u8(const uint8_t *rgb, int height, int width, int channels, double *gray);
 
