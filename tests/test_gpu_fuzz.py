@@ -752,3 +752,74 @@ def test_fuzz_dropin_semi_dense_loop(ops, orc):
                 depth0, var0, age0, frame0 = depth1, var1, age1, frame1
         finally:
             tadataka_amd.enable_device_maps(previous)
+
+
+# ---------------------------------------------------------------------------
+# bundle adjustment: the Levenberg-Marquardt loop on the device against the reference's loop on dense matrices
+# ---------------------------------------------------------------------------
+def test_fuzz_ba_lm_loop(ops, orc):
+    """tdk_ba_solve against LocalBundleAdjustment.compute / lm_update (reference local_ba.py:91-134) carried out on the
+    host with the oracle's Jacobians and dense damped normal equations: the same accepted errors and parameters."""
+    rng = np.random.default_rng(15000 + SEED)
+    n = max(2, N_CASES // 6)
+    total_iters = 0
+    for case in range(n):
+        P, Q = int(rng.integers(2, 9)), int(rng.integers(10, 60))
+        poses = np.column_stack([rng.uniform(-0.2, 0.2, (P, 3)), rng.uniform(-1, 1, (P, 3))])
+        points = np.column_stack([rng.uniform(-4, 4, (Q, 2)), rng.uniform(5, 12, Q)])
+        vis = rng.random((P, Q)) < rng.choice([1.0, 0.8])
+        vis[:, vis.sum(0) < 2] = True
+        vis[vis.sum(1) < 4, :] = True
+        vp, pt = np.nonzero(vis)
+        xt = orc.ba_projection(poses, points, vp, pt, jacobians=False)
+        p0 = poses + rng.normal(0, 2e-3, poses.shape)
+        q0 = points + rng.normal(0, 1e-2, points.shape)
+        max_iter = int(rng.integers(1, 7))
+        mu0, nu = float(rng.choice([1.0, 1e-2])), float(rng.choice([100.0, 10.0]))
+        kw = dict(absolute_error_threshold=1e-14, relative_error_threshold=1e-9)
+
+        def error(pp, qq):
+            x = orc.ba_projection(pp, qq, vp, pt, jacobians=False)
+            return float(np.mean(np.sum((xt - x) ** 2, axis=1)))
+
+        def update(pp, qq, mu):
+            x, A, B = orc.ba_projection(pp, qq, vp, pt)
+            J = np.zeros((2 * len(vp), 6 * P + 3 * Q))
+            for k, (j, i) in enumerate(zip(vp, pt)):
+                J[2 * k:2 * k + 2, 6 * j:6 * j + 6] = A[k]
+                J[2 * k:2 * k + 2, 6 * P + 3 * i:6 * P + 3 * i + 3] = B[k]
+            d = np.linalg.solve(J.T @ J + mu * np.eye(J.shape[1]), J.T @ (xt - x).reshape(-1))
+            return d[:6 * P].reshape(P, 6), d[6 * P:].reshape(Q, 3)
+
+        pp, qq, mu = p0.copy(), q0.copy(), mu0
+        errors = [error(pp, qq)]
+        for _ in range(max_iter):
+            e0 = errors[-1]
+            done = False
+            for trial_mu in (mu / nu, mu):
+                dp, dq = update(pp, qq, trial_mu)
+                e1 = error(pp + dp, qq + dq)
+                if e1 < e0:
+                    pp, qq, mu, done = pp + dp, qq + dq, trial_mu, True
+                    break
+            if not done:
+                e1, trial_mu = np.inf, mu
+                for _guard in range(40):
+                    trial_mu *= nu
+                    dp, dq = update(pp, qq, trial_mu)
+                    e1 = error(pp + dp, qq + dq)
+                    if not e1 > e0:
+                        break
+                pp, qq, mu = pp + dp, qq + dq, trial_mu
+            rel = abs((e0 - e1) / e1)
+            errors.append(e1)
+            if e1 < kw["absolute_error_threshold"] or rel < kw["relative_error_threshold"]:
+                break
+        ba = ops.BundleAdjustment(P, Q, vp, pt, xt)
+        gp, gq, gerr = ba.solve(p0, q0, max_iter=max_iter, initial_mu=mu0, nu=nu, **kw)
+        ba.close()
+        assert len(gerr) == len(errors), (case, P, Q, len(gerr), len(errors), gerr, errors)
+        assert np.allclose(gerr, errors, rtol=1e-6, atol=1e-18), (case, P, Q, gerr, errors)
+        assert np.allclose(gp, pp, rtol=1e-6, atol=1e-9) and np.allclose(gq, qq, rtol=1e-6, atol=1e-9), (case, P, Q)
+        total_iters += len(errors) - 1
+    print(f"ba lm loop: {n} windows, {total_iters} accepted iterations compared")
