@@ -408,9 +408,13 @@ def test_fuzz_dvo_batches_at_pyramid_levels(ops, orc):
     rng = np.random.default_rng(8000 + SEED)
     n = max(2, N_CASES // 6)
     worst = 0.0
+    big = os.environ.get("TDK_FUZZ_BIG") == "1"      # production sizes: the planner's long blocks, many blocks per pair
     for case in range(n):
         H, W = int(rng.integers(30, 200)), int(rng.integers(30, 330))
         B = int(rng.choice([2, 3, 8, 9, 17]))
+        if big:
+            H, W = int(rng.integers(300, 500)), int(rng.integers(400, 700))
+            B = int(rng.choice([9, 40, 70]))
         levels = int(rng.integers(1, 4))
         while min(H, W) / 1.5 ** (levels - 1) < 8:
             levels -= 1
@@ -429,7 +433,7 @@ def test_fuzz_dvo_batches_at_pyramid_levels(ops, orc):
         mode = ops.W_MAP if wname == "map" else ops.WEIGHT_MODES[wname]
         ev = batch.evaluate(level, cams, cams, poses, mode)
         ss, ne = batch.photometric_error(level, cams, cams, poses)
-        for p in range(B):
+        for p in (range(B) if not big else sorted(set(int(v) for v in rng.integers(0, B, 6)))):
             I0, D0, I1, W0 = (batch.download(p, level, k) for k in ("I0", "D0", "I1", "W0"))
             cam = cams[p] * scale
             R, t = Ts[p]
@@ -462,9 +466,12 @@ def test_fuzz_sd_session_chain(ops, orc):
     rng = np.random.default_rng(9000 + SEED)
     n_cases = max(1, N_CASES // 8)
     defaults = (1.5, 10.0, 0.01)
+    big = os.environ.get("TDK_FUZZ_BIG") == "1"
     for case in range(n_cases):
         H, W = int(rng.integers(12, 110)), int(rng.integers(12, 150))
         n_tracks = int(rng.choice([1, 2, 5]))
+        if big:
+            H, W, n_tracks = int(rng.integers(300, 480)), int(rng.integers(400, 640)), int(rng.choice([3, 9]))
         n_steps = int(rng.integers(1, 4))
         f = rng.uniform(0.6, 1.3) * max(H, W)
         cam = np.array([f, f, W / 2, H / 2])
