@@ -27,7 +27,9 @@
 //   k_dvo_eval        1-D XCD-major grid, 256 threads; each thread walks its
 //                     block's contiguous pixel range one pixel per step through a
 //                     three-stage software pipeline (accumulate n | gathers of n+1
-//                     in flight | warp n+2), keeps 28 f64 accumulators and two
+//                     in flight | warp n+2; the warp through per-row terms of the
+//                     block's pose tabulated in LDS, see row_terms), keeps 28 f64
+//                     accumulators and two
 //                     scalar mask counters, transposed wave reduction
 //                     (v_permlane swaps + DPP), LDS across the 4 waves, one
 //                     30-double partial per block.
