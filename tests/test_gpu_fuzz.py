@@ -2,8 +2,9 @@
 shapes (down to 2 x 2), random poses (small, large, behind the camera), degenerate depths (0, negative,
 NaN, huge), ragged graphs -- the inputs nobody wrote a fixture for.
 
-TDK_FUZZ_N cases per family (default 12, seconds); the soak of profiles/r05_fuzz.txt ran it with
-TDK_FUZZ_N=1500.  TDK_FUZZ_SEED moves the whole sequence.  Bars as everywhere: bit-exact for the
+TDK_FUZZ_N cases per family (default 12, seconds); the soaks of profiles/r05_fuzz.txt ran it with
+TDK_FUZZ_N=4000 - 6000 on two dozen seeds (~3.3 min per seed on the GPU box).  TDK_FUZZ_SEED moves the whole
+sequence, TDK_FUZZ_BIG=1 draws production-size frames and batches for the batch families.  Bars as everywhere: bit-exact for the
 parity-granular operators, the pyramid and the semi-dense maps; 1e-9 per entry on the normal equations;
 1e-6 on poses."""
 import os
