@@ -828,6 +828,11 @@ def test_fuzz_ba_lm_loop(ops, orc):
         ba.close()
         assert len(gerr) == len(errors), (case, P, Q, len(gerr), len(errors), gerr, errors)
         assert np.allclose(gerr, errors, rtol=1e-6, atol=1e-18), (case, P, Q, gerr, errors)
-        assert np.allclose(gp, pp, rtol=1e-6, atol=1e-9) and np.allclose(gq, qq, rtol=1e-6, atol=1e-9), (case, P, Q)
+        # the gauge is free and the damping falls to 1e-10 in a converging two-pose window (cond(H) 8e11 there: parameters
+        # 1e-7 apart along the gauge directions): the reprojections are what the two loops must agree on
+        x_dev = orc.ba_projection(gp, gq, vp, pt, jacobians=False)
+        x_host = orc.ba_projection(pp, qq, vp, pt, jacobians=False)
+        assert np.max(np.abs(x_dev - x_host)) < 1e-9, (case, P, Q)
+        assert np.allclose(gp, pp, rtol=1e-4, atol=1e-6) and np.allclose(gq, qq, rtol=1e-4, atol=1e-6), (case, P, Q)
         total_iters += len(errors) - 1
     print(f"ba lm loop: {n} windows, {total_iters} accepted iterations compared")
