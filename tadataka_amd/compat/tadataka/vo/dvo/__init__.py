@@ -177,6 +177,23 @@ def _warn_if_too_large(batch):
         warnings.warn("Camera pose change is too large.", RuntimeWarning)
 
 
+def _reject_integer_frames(**arrays):
+    """Every array the reference hands to PoseChangeEstimator goes through skimage.transform.rescale.  For a float image
+    that is what this port reproduces to the bit; for an INTEGER image skimage first runs the anti-aliasing prefilter in
+    the image's own integer type (scipy.ndimage.gaussian_filter keeps the dtype: the filtered values are quantised) and
+    only then scales to [0, 1] -- rescale(u8, s) != rescale(img_as_float(u8), s) for every s < 1 on scikit-image 0.18.3.
+    That pipeline is not reproduced here, and taking the integers as floats (0 .. 255) would silently be another problem
+    altogether, so integer frames are refused with the conversion the examples apply (examples/dvo_pose_change.py:22-31)."""
+    for name, a in arrays.items():
+        if a is None or isinstance(a, ops.DeviceMap):
+            continue
+        kind = np.asarray(a).dtype.kind
+        if kind in "uib":
+            raise TypeError(f"{name} has dtype {np.asarray(a).dtype}: pass float images (skimage.img_as_float / rgb2gray, as the "
+                            "reference's examples do); the reference's handling of integer frames -- an integer-valued "
+                            "prefilter inside skimage.transform.rescale -- is not reproduced by this port")
+
+
 class PoseChangeEstimator(object):
     """Coarse-to-fine DVO: levels n_coarse_to_fine-1 ... 0 at scale
     1 / layer_size_ratio**level, each level starting from the previous result."""
@@ -195,6 +212,7 @@ class PoseChangeEstimator(object):
         assert(np.ndim(I1) == 2)
         _check_weights_name(weights)
         has_map = _is_map(weights)
+        _reject_integer_frames(I0=I0, D0=D0, I1=I1, weights=weights if has_map else None)
         batch = _batch_for(I0.shape, self.n_coarse_to_fine, self.layer_size_ratio, has_map, PYRAMID)
         batch.upload(0, I0, D0, I1, weights if has_map else None)
         batch.build_pyramid()

@@ -642,3 +642,21 @@ def test_robust_weight_parameters_and_cg():
     assert np.allclose(x_cg, solve_linear_equation(A, b, w), rtol=1e-6, atol=1e-9)
     with pytest.raises(ValueError):
         solve_linear_equation(A, b, method="qr")
+
+
+def test_pose_change_estimator_refuses_integer_frames():
+    """The reference's rescale runs its prefilter in the integer type of an integer image (quantised) before scaling to
+    [0, 1]; that is not reproduced, and 0 .. 255 taken as floats would be a different problem: a TypeError names the
+    conversion the examples apply."""
+    import tadataka.vo.dvo as dvo
+    from tadataka.camera import CameraModel, CameraParameters
+    from tadataka_amd import synthetic
+    pair = synthetic.make_pair(48, 64, seed=3)
+    cm = CameraModel(CameraParameters(pair["cam"][0:2], pair["cam"][2:4]), distortion_model=None)
+    i0 = np.clip(np.rint(pair["I0"] * 255), 0, 255).astype(np.uint8)
+    est = dvo.PoseChangeEstimator(cm, cm, n_coarse_to_fine=2, max_iter=5)
+    with pytest.raises(TypeError, match="float images"):
+        est(i0, pair["D0"], pair["I1"], "huber")
+    with pytest.raises(TypeError, match="D0"):
+        est(pair["I0"], (pair["D0"] * 1000).astype(np.uint16), pair["I1"])
+    est(i0 * (1.0 / 255.0), pair["D0"], pair["I1"], "huber")      # the float version goes through
