@@ -1290,12 +1290,12 @@ bool taps_inside(const AxisMap &m, int n_in, int n_out) {
     // pixel next to it is never read.  The tiles and the streaming kernel read it with weight 0 -- the same double for
     // finite images, NaN for an Inf / NaN neighbour (found by tests/test_gpu_fuzz.py on an 11 x 71 image whose
     // estimated row map 11/7 o + 2/7 hits 5.0).  A level with such a position goes to the general kernel, which taps
-    // floor / ceil.  (Affine maps only: the ideal reading's taps are floor and floor + 1 by definition.)
-    if (!m.ideal)
-        for (int o = 0; o < n_out; o++) {
-            const double p = axis_pos(m, o);
-            if (p == floor(p)) return false;
-        }
+    // floor / ceil.  The ideal reading is the same warp at other positions (oracle: warp_bilinear), and hits integers
+    // whenever in / out reduces to odd / odd (119 -> 79: (o + 0.5) 119 / 79 - 0.5 = 59 at o = 39).
+    for (int o = 0; o < n_out; o++) {
+        const double p = axis_pos(m, o);
+        if (p == floor(p)) return false;
+    }
     return true;
 }
 

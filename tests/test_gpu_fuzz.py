@@ -836,3 +836,71 @@ def test_fuzz_ba_lm_loop(ops, orc):
         assert np.allclose(gp, pp, rtol=1e-4, atol=1e-6) and np.allclose(gq, qq, rtol=1e-4, atol=1e-6), (case, P, Q)
         total_iters += len(errors) - 1
     print(f"ba lm loop: {n} windows, {total_iters} accepted iterations compared")
+
+
+# ---------------------------------------------------------------------------
+# the data paths of a batch: host uploads, pinned float64 / 8-bit uploads on the copy stream, partial pyramid rebuilds
+# ---------------------------------------------------------------------------
+def test_fuzz_batch_data_paths(ops, orc):
+    """Random sequences of upload / upload_async (float64 and 8-bit) / build_pyramid(subset) on one batch against a
+    shadow copy on the host: every level of every array is what the last build of THAT array made of the frame that was
+    current then (levels of an array that was not rebuilt stay as they were), level 0 is always the current frame."""
+    rng = np.random.default_rng(16000 + SEED)
+    n_cases = max(1, N_CASES // 6)
+    names = ("I0", "D0", "I1")
+    for case in range(n_cases):
+        H, W = int(rng.integers(16, 90)), int(rng.integers(16, 120))
+        B = int(rng.choice([1, 3, 9]))
+        L = int(rng.integers(1, 4))
+        while min(H, W) / 1.5 ** (L - 1) < 6:
+            L -= 1
+        batch = ops.DvoBatch(B, H, W, n_levels=L)
+        frames = [[None] * 3 for _ in range(B)]
+        levels = [[[None] * 3 for _ in range(B)] for _ in range(L)]
+        for p in range(B):
+            I0, D0, I1, _ = _random_scene(rng, H, W)
+            batch.upload(p, I0, D0, I1)
+            frames[p] = [I0, D0, I1]
+
+        def rebuild(which):
+            batch.build_pyramid(None if which is None else [names[k] for k in which])
+            for k in (range(3) if which is None else which):
+                for p in range(B):
+                    for l in range(1, L):
+                        levels[l][p][k] = orc.rescale(frames[p][k], 1 / 1.5 ** l, anti_aliasing=True)
+        rebuild(None)
+        pin64 = ops.PinnedBuffer((B, H, W), np.float64)
+        pin8 = ops.PinnedBuffer((B, H, W), np.uint8)
+        for step in range(int(rng.integers(3, 9))):
+            op = rng.integers(0, 5)
+            if op == 0:                                           # a pair replaced from host arrays
+                p = int(rng.integers(0, B))
+                I0, D0, I1, _ = _random_scene(rng, H, W)
+                batch.upload(p, I0, D0, I1)
+                frames[p] = [I0, D0, I1]
+            elif op == 1:                                         # one array of a range of pairs from pinned float64
+                k = int(rng.integers(0, 3)); first = int(rng.integers(0, B)); n = int(rng.integers(1, B - first + 1))
+                new = rng.uniform(0.5, 3.0, (n, H, W))
+                pin64.array[:n] = new
+                batch.upload_async(names[k], first, n, pin64)
+                for i in range(n):
+                    frames[first + i][k] = new[i].copy()
+                ops.call("tdk_sync")                              # the pinned buffer is reused below
+            elif op == 2:                                         # 8-bit frames (I0 or I1), converted as img_as_float does
+                k = int(rng.choice([0, 2])); first = int(rng.integers(0, B)); n = int(rng.integers(1, B - first + 1))
+                new = rng.integers(0, 256, (n, H, W), dtype=np.uint8)
+                pin8.array[:n] = new
+                batch.upload_async(names[k], first, n, pin8)
+                for i in range(n):
+                    frames[first + i][k] = new[i] * (1.0 / 255.0)
+                ops.call("tdk_sync")
+            elif op == 3:
+                rebuild(sorted(set(int(v) for v in rng.integers(0, 3, int(rng.integers(1, 3))))))
+            else:
+                rebuild(None)
+            # look at a few (pair, level, array) cells
+            for _ in range(4):
+                p, l, k = int(rng.integers(0, B)), int(rng.integers(0, L)), int(rng.integers(0, 3))
+                want = frames[p][k] if l == 0 else levels[l][p][k]
+                assert _same(batch.download(p, l, names[k]), want), (case, step, int(op), p, l, names[k])
+        batch.close(); pin64.close(); pin8.close()
