@@ -904,3 +904,58 @@ def test_fuzz_batch_data_paths(ops, orc):
                 want = frames[p][k] if l == 0 else levels[l][p][k]
                 assert _same(batch.download(p, l, names[k]), want), (case, step, int(op), p, l, names[k])
         batch.close(); pin64.close(); pin8.close()
+
+
+# ---------------------------------------------------------------------------
+# sessions that outlive their ring of reference frames (saturating ages), several tracks
+# ---------------------------------------------------------------------------
+def test_fuzz_sd_session_ring(ops, orc):
+    rng = np.random.default_rng(17000 + SEED)
+    n_cases = max(1, N_CASES // 8)
+    defaults = (1.5, 10.0, 0.01)
+    for case in range(n_cases):
+        H, W = int(rng.integers(12, 90)), int(rng.integers(12, 120))
+        n_tracks = int(rng.choice([1, 3]))
+        R = int(rng.integers(1, 4))
+        n_steps = R + int(rng.integers(1, 4))
+        f = rng.uniform(0.6, 1.3) * max(H, W)
+        cam = np.array([f, f, W / 2, H / 2])
+        pa = (0.3, 12.0, rng.uniform(0.005, 0.05), rng.uniform(0.005, 0.05), rng.uniform(0.5, 1.5) / f, rng.uniform(0.0, 0.05))
+        pg, po = ops.make_params(*pa), orc.make_params(*pa)
+        sd = ops.SemiDenseSession(n_tracks, H, W, max_refframes=R)
+        sd.set_age_policy(True)
+        sd.set_params(pg, *defaults)
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+        state = []
+        for t in range(n_tracks):
+            a, b = rng.uniform(1.5, 6, 2)
+            frames, T = [], np.eye(4)
+            for s in range(n_steps + 1):
+                img = 0.5 + 0.3 * np.sin((xx + 0.7 * s) / a) * np.cos(yy / b) + 0.05 * rng.uniform(-1, 1, (H, W))
+                frames.append((cam, img, T.copy()))
+                T = T @ _T(Rotation.from_rotvec(rng.uniform(-0.01, 0.01, 3)).as_matrix(), rng.uniform(-0.05, 0.05, 3))
+            depth = rng.uniform(0.8, 5.0, (H, W)); var = rng.uniform(0.01, 0.3, (H, W))
+            age = np.zeros((H, W), dtype=np.uint64)
+            sd.push_frame(t, *frames[0])
+            sd.set_maps(t, depth, var, age)
+            state.append(dict(frames=frames, depth=depth, var=var, age=age))
+        for step in range(1, n_steps + 1):
+            T10s, Twfs = [], []
+            for t in range(n_tracks):
+                fr = state[t]["frames"]
+                sd.push_frame(t, fr[step][0], fr[step][1])
+                T10s.append(np.linalg.inv(fr[step][2]) @ fr[step - 1][2])
+                Twfs.append(fr[step][2])
+            sd.step(np.array(T10s), np.array(Twfs), commit=True)
+            n_ref = min(step, R)
+            for t in range(n_tracks):
+                st = state[t]
+                fr = st["frames"]
+                a1 = np.minimum(orc.increment_age(st["age"], cam, cam, T10s[t], st["depth"]), np.uint64(n_ref))
+                d1, v1 = orc.propagate(T10s[t], cam, cam, st["depth"], st["var"], *defaults)
+                d, v, f_ = orc.update_depth(fr[step], fr[step - n_ref:step], a1, d1, v1, po)
+                gd, gv, ga, gf = sd.get_maps(t, with_flag=True)
+                assert np.array_equal(ga, a1) and np.array_equal(gf, f_), (case, H, W, R, t, step)
+                assert _same(gd, d) and _same(gv, v), (case, H, W, R, t, step)
+                st.update(depth=d, var=v, age=a1)
+        sd.close()
