@@ -25,10 +25,17 @@ def photometric_error(warp, gray_image0, depth_map0, gray_image1):
     """mean((I0[u0] - I1<warp(u0)>)^2) over the pixels that land inside image 1.
     `warp` is a LocalWarp2D (it carries the two camera models and T10)."""
     h, w = depth_map0.shape
+    if hasattr(warp, "T10"):
+        T10 = warp.T10
+    elif hasattr(warp, "warp3d"):       # a Warp2D between two world poses: frame 0 -> world -> frame 1 as one transform
+        T10 = np.linalg.inv(warp.warp3d.T_w1) @ warp.warp3d.T_w0
+    else:
+        raise TypeError("photometric_error needs a LocalWarp2D or a Warp2D (the fused device pass takes the cameras "
+                        "and the relative pose, not a callable)")
     batch = ops.DvoBatch(1, h, w)
     try:
         batch.upload(0, gray_image0, depth_map0, gray_image1)
-        return _evaluate(batch, warp.camera_model0, warp.camera_model1, warp.T10)
+        return _evaluate(batch, warp.camera_model0, warp.camera_model1, T10)
     finally:
         batch.close()
 

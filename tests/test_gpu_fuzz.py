@@ -959,3 +959,57 @@ def test_fuzz_sd_session_ring(ops, orc):
                 assert _same(gd, d) and _same(gv, v), (case, H, W, R, t, step)
                 st.update(depth=d, var=v, age=a1)
         sd.close()
+
+
+# ---------------------------------------------------------------------------
+# the drop-in warp and metric classes (tadataka.warp, tadataka.metric)
+# ---------------------------------------------------------------------------
+def test_fuzz_dropin_warp_and_metric(orc):
+    import warnings
+    import tadataka_amd  # noqa: F401
+    from tadataka.camera import CameraModel, CameraParameters
+    from tadataka.metric import PhotometricError, photometric_error
+    from tadataka.pose import Pose
+    from tadataka.warp import LocalWarp2D, Warp2D
+    rng = np.random.default_rng(18000 + SEED)
+    for case in range(max(2, N_CASES // 2)):
+        H, W = (int(v) for v in rng.integers(4, 90, 2))
+        I0, D0, I1, cam0 = _random_scene(rng, H, W)
+        D0 = np.where(np.isfinite(D0) & (D0 > 1e-3) & (D0 < 1e3), D0, 2.0)      # the array-level warp is not about holes
+        cam1 = cam0 * rng.uniform(0.9, 1.1, 4) if rng.random() < 0.5 else cam0
+        cm0 = CameraModel(CameraParameters(cam0[0:2], cam0[2:4]), distortion_model=None)
+        cm1 = CameraModel(CameraParameters(cam1[0:2], cam1[2:4]), distortion_model=None)
+        R, t = _random_pose(rng)
+        if np.max(np.abs(t)) > 1.5:
+            t = t / 3
+        pose10 = Pose(Rotation.from_matrix(R), t)
+        T10 = np.array(pose10.T)            # (the Rotation object re-orthonormalises R: its matrix is what both sides get)
+        n = int(rng.integers(1, 400))
+        us = np.column_stack([rng.uniform(0, W - 1, n), rng.uniform(0, H - 1, n)])
+        ds = rng.uniform(0.5, 6.0, n)
+        # LocalWarp2D = unnormalize(warp_vecs(T10, normalize(us), d)): bit for bit through the granular operators
+        us1, d1 = LocalWarp2D(cm0, cm1, pose10)(us, ds)
+        xs1, od1 = orc.warp_vecs(T10, orc.normalize(us, cam0), ds)
+        assert _same(us1, orc.unnormalize(xs1, cam1)) and _same(d1, od1), (case, "LocalWarp2D")
+        # Warp2D between world poses: the same points through two transforms (rounding apart)
+        Rw, tw = _random_pose(rng)
+        pose_w0 = Pose(Rotation.from_matrix(Rw), tw)
+        pose_w1 = pose_w0 * pose10.inv() if hasattr(pose10, "inv") else None
+        if pose_w1 is not None:
+            us1w, d1w = Warp2D(cm0, cm1, pose_w0, pose_w1)(us, ds)
+            ok = np.isfinite(us1).all(axis=1) & (np.abs(d1) > 1e-6)
+            assert np.allclose(us1w[ok], us1[ok], rtol=1e-9, atol=1e-7 * max(H, W)) and np.allclose(d1w[ok], d1[ok], rtol=1e-9, atol=1e-9), (case, "Warp2D")
+        # photometric error: function and class
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            want = orc.photometric_error(I0, D0, I1, cam0, cam1, T10)
+        got_f = photometric_error(LocalWarp2D(cm0, cm1, pose10), I0, D0, I1)
+        got_c = PhotometricError(cm0, cm1, I0, D0, I1)(pose10)
+        for got in (got_f, got_c):
+            assert (np.isnan(got) and np.isnan(want)) or abs(got - want) <= 1e-9 * abs(want), (case, got, want)
+        # (not at the identity: through two world poses the relative transform is the identity up to 1e-17, and the
+        #  border pixels on the inclusive mask edge change sides -- in the reference's own Warp2D just as well)
+        if pose_w1 is not None and not np.array_equal(T10, np.eye(4)):
+            got_w = photometric_error(Warp2D(cm0, cm1, pose_w0, pose_w1), I0, D0, I1)
+            if np.isfinite(want):
+                assert abs(got_w - want) <= 1e-6 * abs(want) + 1e-12, (case, got_w, want)
