@@ -1013,3 +1013,54 @@ def test_fuzz_dropin_warp_and_metric(orc):
             got_w = photometric_error(Warp2D(cm0, cm1, pose_w0, pose_w1), I0, D0, I1)
             if np.isfinite(want):
                 assert abs(got_w - want) <= 1e-6 * abs(want) + 1e-12, (case, got_w, want)
+
+
+# ---------------------------------------------------------------------------
+# the array-level calc_pose_update of the drop-in tadataka.vo.dvo (points already in frame 1)
+# ---------------------------------------------------------------------------
+def test_fuzz_dropin_calc_pose_update(orc):
+    """vo/dvo/__init__.py:46-70 restated with the oracle's operators (mask, bilinear samples of the gradient maps,
+    jacobian.py:8-24, lstsq on sqrt(w) J) against the device reduction + 6 x 6 solve of the drop-in function."""
+    import warnings
+    import tadataka_amd  # noqa: F401
+    from tadataka.camera import CameraModel, CameraParameters
+    from tadataka.vo.dvo import calc_pose_update
+    rng = np.random.default_rng(19000 + SEED)
+    for case in range(max(2, N_CASES // 2)):
+        H, W = (int(v) for v in rng.integers(6, 80, 2))
+        f = rng.uniform(0.6, 1.5) * max(H, W)
+        cam = np.array([f, f * rng.uniform(0.95, 1.05), W / 2 + rng.uniform(-1, 1), H / 2 + rng.uniform(-1, 1)])
+        cm = CameraModel(CameraParameters(cam[0:2], cam[2:4]), distortion_model=None)
+        n = int(rng.integers(30, 3000))
+        z = rng.uniform(0.8, 5.0, n)
+        P1 = np.column_stack([rng.uniform(-0.7, 0.7, n) * z * W / f, rng.uniform(-0.7, 0.7, n) * z * H / f, z])
+        P1[rng.random(n) < 0.05, 2] *= -1.0                        # behind the camera
+        GX, GY = rng.normal(0, 0.1, (H, W)), rng.normal(0, 0.1, (H, W))
+        r = rng.normal(0, 0.05, n)
+        if rng.random() < 0.3:
+            r[rng.random(n) < 0.1] += 3.0
+        opt = [None, "huber", "student-t", "tukey", "map"][int(rng.integers(0, 5))]
+        wmap = rng.uniform(0.1, 2.0, n)
+        us1 = orc.unnormalize(orc.project_vecs(P1), cam)
+        mask = orc.is_in_image_range(us1, (H, W)) & (P1[:, 2] > 0)
+        got = calc_pose_update(cm, r, GX, GY, P1, wmap if opt == "map" else opt)
+        if not mask.any():
+            assert got is None, case
+            continue
+        gx, gy = orc.interpolation(GX, us1[mask]), orc.interpolation(GY, us1[mask])
+        x, y, zz = P1[mask, 0], P1[mask, 1], P1[mask, 2]
+        fgx, fgy = cam[0] * gx, cam[1] * gy
+        z2, xy = zz * zz, x * y
+        J = np.column_stack((fgx / zz, fgy / zz, -(fgx * x + fgy * y) / z2, -(fgx * xy + fgy * (z2 + y * y)) / z2,
+                             (fgx * (z2 + x * x) + fgy * xy) / z2, (-fgx * y + fgy * x) / zz))
+        rm = r[mask]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            w = None if opt is None else wmap[mask] if opt == "map" else _weights_numpy(rm, opt)
+        if w is not None and not np.all(np.isfinite(w)):
+            continue
+        want = orc.solve_lstsq(J, rm, w)
+        s = np.linalg.svd(J if w is None else J * np.sqrt(w)[:, None], compute_uv=False)
+        if s[-1] < 1e-5 * s[0] or mask.sum() < 12:
+            continue                                              # a rank-deficient draw: other rules apply (DESIGN 3)
+        assert got is not None and np.allclose(got, want, rtol=1e-7, atol=1e-9 * np.max(np.abs(want))), (case, opt, got, want)
