@@ -267,6 +267,9 @@ def test_fuzz_granular_bit_exact(ops, orc):
         a, b = ops.warp_vecs(T, xs, d)
         c, e = orc.warp_vecs(T, xs, d)
         assert _same(a, c) and _same(b, e), case
+        for i in range(min(n - 1, 40)):                           # src/triangulation.rs:8-39, one correspondence per call
+            g0, o0 = ops.calc_depth0(T, xs[i], xs[i + 1]), orc.calc_depth0(T, xs[i], xs[i + 1])
+            assert g0 == o0 or (g0 != g0 and o0 != o0), (case, i, g0, o0)
         H, W = (int(v) for v in rng.integers(2, 60, 2))
         img = rng.uniform(-1, 1, (H, W))
         m = rng.random(img.shape) < 0.05
@@ -685,7 +688,9 @@ def test_fuzz_dropin_pose_change_estimator(orc):
         # missing readings -- not at ratio 1.3: its prefilter (sigma 0.15, side weights 2e-10) turns a zero next to a
         # depth of 2 into a depth of 1e-9, a handful of Jacobian rows 1e9 times larger than the rest, cond(J) 3e8: lstsq
         # on J (the reference) still resolves the translation, normal equations in double cannot (limits)
-        if ratio > 1.4 and rng.random() < 0.25:
+        # ... nor with a single level: the identity-scale warp of level 0 turns a zero into a depth of ~1e-13, and at the
+        # identity prior that is z itself: cond(J) 2.8e12, where lstsq too is accurate to cond * eps = 6e-4 at best
+        if ratio > 1.4 and levels > 1 and rng.random() < 0.25:
             D0[rng.random((H, W)) < 0.05] = 0.0
         cm = CameraModel(CameraParameters(cam[0:2], cam[2:4]), distortion_model=None)
         with warnings.catch_warnings():
