@@ -1069,3 +1069,55 @@ def test_fuzz_dropin_calc_pose_update(orc):
         if s[-1] < 1e-5 * s[0] or mask.sum() < 12:
             continue                                              # a rank-deficient draw: other rules apply
         assert got is not None and np.allclose(got, want, rtol=1e-7, atol=1e-9 * np.max(np.abs(want))), (case, opt, got, want)
+
+
+# ---------------------------------------------------------------------------
+# the device loop's state machine: heterogeneous batches (pairs that stop at different evaluations, empty masks)
+# ---------------------------------------------------------------------------
+def test_fuzz_dvo_estimate_heterogeneous_batches(ops, orc):
+    """Pairs of one batch finish their levels at different evaluations, some never start (no valid depth), some diverge
+    at once (unrelated second frame): every pair's pose against the oracle's loop run on that pair alone."""
+    import warnings
+    from tadataka_amd import synthetic
+    rng = np.random.default_rng(20000 + SEED)
+    n = max(1, N_CASES // 12)
+    for case in range(n):
+        H, W = int(rng.integers(24, 70)), int(rng.integers(32, 90))
+        B = int(rng.choice([2, 5, 9, 20]))
+        levels = int(rng.integers(1, 4))
+        wname = [None, "huber", "student-t", "tukey"][int(rng.integers(0, 4))]
+        max_iter = int(rng.choice([20, 20, 3]))
+        batch = ops.DvoBatch(B, H, W, n_levels=levels)
+        pairs, cams, kinds = [], [], []
+        for p in range(B):
+            pair = synthetic.make_pair(H, W, seed=int(rng.integers(0, 1 << 30)))
+            kind = int(rng.choice([0, 0, 0, 1, 2, 3]))
+            I0, D0, I1 = pair["I0"], pair["D0"].copy(), pair["I1"]
+            if kind == 1:
+                D0[:] = np.nan                                    # nothing to warp: the reference warns and returns the prior
+            elif kind == 2:
+                I1 = rng.uniform(0, 1, (H, W))                    # unrelated frame: the first candidate is rejected
+            elif kind == 3:
+                I1 = I0.copy()                                    # identical frames
+            cam = pair["cam"] * rng.uniform(0.98, 1.02, 4) + np.array([0, 0, rng.uniform(-1, 1), rng.uniform(-1, 1)])
+            batch.upload(p, I0, D0, I1)
+            pairs.append((I0, D0, I1)); cams.append(cam); kinds.append(kind)
+        batch.build_pyramid()
+        cams = np.array(cams)
+        prior = np.tile(_pose12(np.eye(3), np.zeros(3)), (B, 1))
+        P, _ = batch.estimate(cams, cams, prior, ops.WEIGHT_MODES[wname], max_iter)
+        warned = batch.warnings()
+        for p in range(B):
+            I0, D0, I1 = pairs[p]
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                try:
+                    Rr, tr = orc.dvo_estimate(I0, D0, I1, cams[p], cams[p], wname, n_coarse_to_fine=levels,
+                                              max_iter=max_iter, anti_aliasing=True)[:2]
+                except np.linalg.LinAlgError:
+                    continue        # identical frames under Tukey / Student-t: 0 / 0 weights, the reference's lstsq raises
+            d = max(np.max(np.abs(P[p, :9].reshape(3, 3) - Rr.as_matrix())), np.max(np.abs(P[p, 9:] - tr)))
+            assert d < 1e-6, (case, p, kinds[p], H, W, B, levels, wname, max_iter, d)
+            if kinds[p] == 1:
+                assert warned[p], (case, p)
+        batch.close()
