@@ -770,20 +770,47 @@ def spawn_ranks(n, dry=False):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]                   # only a rendezvous key: nothing listens on it
-    procs = []
+    import tempfile
+    procs, logs = [], []
+    logdir = tempfile.mkdtemp(prefix="tdk_bench_ranks_")
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         if dry:
             env["TDK_BENCH_DRY"] = "1"
+        # every rank's stdout / stderr is kept (rank 0's stdout is the JSON line) so that a failed
+        # rank can be named with what it last said instead of an exit code only
+        o = open(os.path.join(logdir, "rank%d.out" % r), "w+")
+        e = open(os.path.join(logdir, "rank%d.err" % r), "w+")
+        logs.append((o, e))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out)
+                                      stdout=o, stderr=e, text=True))
+    rcs = [p.wait() for p in procs]
+
+    def tail(f, k):
+        f.flush()
+        f.seek(0)
+        return f.read().splitlines()[-k:]
+
+    sys.stdout.write("".join(line + "\n" for line in tail(logs[0][0], 10 ** 9)))
     sys.stdout.flush()
-    if any(rcs):
-        raise SystemExit("bench worker exit codes: %s" % rcs)
+    failed = any(rcs)
+    for r, (o, e) in enumerate(logs):
+        lines = tail(e, 10 ** 9 if (r == 0 and not failed) else 15)
+        if failed:
+            sys.stderr.write("---- rank %d: exit code %d, LOCAL_RANK=%d (HIP device LOCAL_RANK %% device count), "
+                             "last stderr lines:\n" % (r, rcs[r], r))
+            if r > 0:
+                lines += ["(stdout) " + s for s in tail(o, 5)]
+        for s in lines:
+            sys.stderr.write(("    " if failed else "") + s + "\n")
+        o.close()
+        e.close()
+    sys.stderr.flush()
+    if failed:
+        raise SystemExit("bench worker exit codes: %s (per-rank logs: %s)" % (rcs, logdir))
+    import shutil
+    shutil.rmtree(logdir, ignore_errors=True)
 
 
 def main():
