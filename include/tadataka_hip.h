@@ -554,7 +554,12 @@ tdk_status tdk_ba_solve(tdk_ba *h, double *poses, double *points, int max_iter, 
  * (SURVEY section 8(e)).  librccl.so is opened on the first call.  Rank 0 creates
  * a 128-byte unique id (ncclGetUniqueId) and hands it to the other ranks out of
  * band (tadataka_amd/sharding.py uses a file next to the rendezvous port);
- * tdk_comm_create is collective (ncclCommInitRank) on the current device. */
+ * tdk_comm_create is collective (ncclCommInitRank) on the current device.
+ * RANKS MUST BE SEPARATE PROCESSES: every entry of this library holds one
+ * process-wide lock for its whole duration, the blocking collectives included
+ * (tdk_comm_create, _all_gather, _all_reduce, _barrier,
+ * tdk_dvo_gather_poses_finish) -- two ranks hosted as threads of one process
+ * would deadlock (the first waits, lock held, for a peer that cannot enter). */
 typedef struct tdk_comm tdk_comm;
 tdk_status tdk_comm_available(void);   /* TDK_OK if librccl can be opened and has the symbols used here */
 tdk_status tdk_comm_unique_id(uint8_t *id128);

@@ -122,7 +122,10 @@ tdk_status tdk_comm_unique_id(uint8_t *id128) {
     return TDK_OK;
 }
 
-tdk_status tdk_comm_available(void) { return load_rccl(); }
+tdk_status tdk_comm_available(void) {
+    TDK_API_GUARD;                       // (load_rccl keeps static state)
+    return load_rccl();
+}
 
 tdk_status tdk_comm_destroy(tdk_comm *c) {
     TDK_API_GUARD;

@@ -183,7 +183,9 @@ __device__ __forceinline__ double robust_weight(double r, double w0, double ws) 
         g = __builtin_fma(g, e, g);
         h = __builtin_fma(h, e, h);
         g = __builtin_fma(__builtin_fma(-g, g, q), h, g);
-        return q > 0.0 ? g : q;      // r = +-Inf: q = 0, the weight is 0 (rsq(0) is Inf); NaN stays NaN
+        // r = +-Inf, or r * r * ws beyond the double range: t = Inf, rcp = 0 and the Newton steps make NaN of 0 * Inf;
+        // the reference's (nu + 1) / (nu + Inf) = 0 there, weight 0.  A NaN residual stays NaN.
+        return t == INFINITY ? 0.0 : (q > 0.0 ? g : q);
     }
     if (WMODE == TDK_W_TUKEY) {
         const double x = r * ws, q = x * (1.0 / kTukeyBeta), u = 1.0 - q * q;
@@ -2443,7 +2445,7 @@ struct tdk_dvo {
                                 // lv[0] IS the upload)
     unsigned level0_mask;       // bit k: array k (I0, D0, I1, W0) gets rescale(., 1.0) as its level 0
     bool clip;                  // clip=True: outputs clipped to the extremes of the filtered image
-    bool clip_clean;            // the last build left the clip slots reset (few slots: k_clip_small)
+    int clip_clean;             // how many clip slots the last build left reset (few slots: k_clip_small); 0: none
     void *d_clip;               // ClipSlot[n_pairs * 4 * n_levels]
     bool weights_dirty;         // the device copy of the kernels is stale (a plan changed)
     int n_cu, device;           // compute units and index of the batch's device
@@ -3056,7 +3058,7 @@ static tdk_status dvo_allocate(tdk_dvo *h, int n_pairs, int height, int width, i
     for (int k = 0; k < 4; k++) h->raw[k] = nullptr;
     h->level0_mask = 0u;
     h->clip = false;
-    h->clip_clean = false;
+    h->clip_clean = 0;
     h->d_clip = nullptr;
     h->weights_dirty = true;
     {
@@ -3331,8 +3333,12 @@ static tdk_status build_pyramid_of(tdk_dvo *h, unsigned arrays) {
         TDK_HIP(hipMalloc(&h->d_aa_weights, tdk::pyramid_weight_doubles(h->n_levels) * sizeof(double)));
         h->weights_dirty = true;
     }
-    if (h->clip && h->d_clip == nullptr)
-        TDK_HIP(hipMalloc(&h->d_clip, tdk::pyramid_clip_bytes((int64_t)h->n_pairs * 4, h->n_levels)));
+    if (h->clip && h->d_clip == nullptr) {
+        const size_t bytes = tdk::pyramid_clip_bytes((int64_t)h->n_pairs * 4, h->n_levels);
+        TDK_HIP(hipMalloc(&h->d_clip, bytes));
+        TDK_HIP(hipMemsetAsync(h->d_clip, 0, bytes, h->stream));   // (every build resets what it uses; never raw memory)
+        h->clip_clean = 0;
+    }
     const int use_stream = tdk::option(TDK_OPT_PYRAMID_STREAM);   // 0: never, 1 (default): large batches, 2: always
     // two groups of arrays: those with a level 0 of their own (sources: the uploads, levels 0 .. n - 1) and the rest
     // (sources: level 0 = the upload, levels 1 .. n - 1); the device kernels are stored per level: slot l of the
@@ -3345,7 +3351,7 @@ static tdk_status build_pyramid_of(tdk_dvo *h, unsigned arrays) {
             if (((arrays >> k) & 1u) && (((h->level0_mask >> k) & 1u) != 0) == (group == 0)) n++;
         if (n > 0 && h->n_levels - (group == 0 ? 0 : 1) > 0) n_groups_used++;
     }
-    if (n_groups_used != 1) h->clip_clean = false;
+    if (n_groups_used != 1) h->clip_clean = 0;
     for (int group = 0; group < 2; group++) {
         int sel[4], n_sel = 0;
         for (int k = 0; k < 4; k++) {
@@ -3630,6 +3636,7 @@ tdk_status tdk_dvo_set_level_plan(tdk_dvo *h, int level, const double *map, cons
     TDK_TRY(check_level(h, level));
     tdk_dvo::Plan &P = h->plan[level];
     h->weights_dirty = true;
+    h->clip_clean = 0;
     if (map == nullptr) {
         P.set = false;
         P.wr.clear(); P.wc.clear();
@@ -3673,6 +3680,7 @@ tdk_status tdk_dvo_set_rescale_options(tdk_dvo *h, unsigned int level0_arrays, i
     }
     h->level0_mask = level0_arrays;
     h->clip = clip != 0;
+    h->clip_clean = 0;                      // (the next build's slot layout may differ: it resets what it uses)
     return TDK_OK;
 }
 

@@ -631,12 +631,12 @@ __global__ __launch_bounds__(256) void k_rescale_aa_multi(AaMultiArgs m) {
 }
 
 // first output index o in [0, n_out] whose lower tap max(floor(pos(o)), 0) is >= s0 (pos is increasing)
-__device__ __forceinline__ int first_owned(int s0, const AxisMap &m, int n_out) {
+__host__ __device__ __forceinline__ int first_owned(int s0, const AxisMap &m, int n_out) {
     const double guess = m.ideal ? ((double)s0 + 0.5) / m.s - 0.5 : ((double)s0 - m.b) / m.a;
     int o = (int)ceil(guess);
-    o = max(0, min(o, n_out));
-    while (o > 0 && max((int)floor(axis_pos(m, o - 1)), 0) >= s0) o--;
-    while (o < n_out && max((int)floor(axis_pos(m, o)), 0) < s0) o++;
+    o = o < 0 ? 0 : (o > n_out ? n_out : o);
+    while (o > 0 && ((int)floor(axis_pos(m, o - 1)) > 0 ? (int)floor(axis_pos(m, o - 1)) : 0) >= s0) o--;
+    while (o < n_out && ((int)floor(axis_pos(m, o)) > 0 ? (int)floor(axis_pos(m, o)) : 0) < s0) o++;
     return o;
 }
 
@@ -671,12 +671,17 @@ struct StreamLevel {
     int lvl;
 };
 
+constexpr int kStreamMaxStrips = 16, kStreamMaxSegs = 16;
+struct StreamRange { int a0, a1, b0, b1; };      // first / end output index of the two levels
+
 struct StreamArgs {
     const double *src[4];
     int64_t src_stride;
     int H, W, n_arrays, batch, n_out;
     int n_strips, strip_w;                        // owned source columns per strip
     int pitch;                                    // ring row pitch: strip_w + 2 RM + 1 columns, rounded up (<= 256 threads)
+    int wave_cols;                                // columns a wave advances by: 64, or 62 when the identity-scale level rides
+                                                  // along (lanes 0 / 63 repeat the neighbour waves' border columns)
     int n_segs, seg_rows;                         // row segments: a block emits the outputs whose upper tap lies in its segment
     StreamLevel lv[2];
     // the identity-scale level (rescale(., 1.0)), written from the same pass: bit `arr` of l0_mask set = this array has one
@@ -686,6 +691,9 @@ struct StreamArgs {
     int l0_lvl;
     unsigned l0_mask;
     ClipSlot *slots;
+    // the output columns of a strip / output rows of a segment (first_owned of their bounds), tabulated by the host:
+    // the block reads its two entries instead of searching for them (eight searches: a tenth of a 15-chunk block's time)
+    StreamRange strip_tab[kStreamMaxStrips], seg_tab[kStreamMaxSegs];
 };
 
 // lane i <- lane i - 1 / lane i + 1 of the wave (DPP wave_shr:1 / wave_shl:1); the lane without a source gets 0
@@ -700,6 +708,42 @@ __device__ __forceinline__ double from_right_lane(double x) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0x130, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
+}
+
+// Vector memory operations the compiler does not count (k_pyramid_stream).  gfx950 has ONE counter for loads and stores
+// (vmcnt) and they retire in issue order, so "the rows prefetched at the top of the chunk have arrived" can only be
+// asked for as "at most N younger operations are in flight" -- and the compiler, which cannot know how many stores the
+// data-dependent emission loops issued behind the prefetch, asks with N = 0: every wave drained all its stores at the
+// end of every chunk (a quarter of its resident time in s_waitcnt, SQ_WAIT_INST_ANY, profiles/r06_pyramid.txt).  The
+// kernel counts for itself: the prefetch and the identity level's stores (the last stores of a chunk, a wave-uniform
+// number of them) go through these, and stream_rows_arrived() waits with that number.  Between stream_load() and
+// stream_rows_arrived() nothing may read or copy the destination registers: the wait names them all as operands, which
+// is the only use the compiler sees (checked in the ISA: tools/check_pyramid_isa.py).
+// (the scalar-base form `global_load_dwordx2 v, voff, s[..]` saves a 64-bit vector add per access and costs 44 more
+// spilled SGPRs: the same 1.24 ms on the same box)
+__device__ __forceinline__ double stream_load(const double *row, unsigned byte_off) {
+    double v;
+    const double *p = reinterpret_cast<const double *>(reinterpret_cast<const char *>(row) + byte_off);
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(v) : "v"(p));
+    return v;
+}
+__device__ __forceinline__ void stream_store(double *row, unsigned byte_off, double v) {
+    double *p = reinterpret_cast<double *>(reinterpret_cast<char *>(row) + byte_off);
+    asm volatile("global_store_dwordx2 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+}
+// `younger8`: wave-uniform, the last 8 vector memory operations issued are stores that may stay in flight.  ONE asm
+// statement for both cases: with two, the register allocator met them with a phi and copied the (not yet arrived)
+// registers in front of one of the waits.
+__device__ __forceinline__ void stream_rows_arrived(double (&r)[8], int younger8) {
+    asm volatile("s_cmp_lg_u32 %8, 0\n\t"
+                 "s_cbranch_scc0 1f\n\t"
+                 "s_waitcnt vmcnt(8)\n\t"
+                 "s_branch 2f\n"
+                 "1:\n\t"
+                 "s_waitcnt vmcnt(0)\n"
+                 "2:"
+                 : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                 : "s"(younger8) : "scc");
 }
 
 // ---------------------------------------------------------------------------
@@ -790,6 +834,71 @@ __global__ __launch_bounds__(256) void k_level0_stream(Level0Args a) {
     if (slot) tr.flush(slot);
 }
 
+// The identity-scale level of the streaming kernel for one chunk: K output rows y .. y + K - 1 of this thread's column.
+// The estimated map of rescale(., 1.0) is a o + b with a = 1 and |b| ~ 1e-13, so along an axis the sample position is
+// o + b while b survives the rounding (taps: the pixel and the NEXT one for b > 0), then o itself (one tap), then -- from
+// where a o rounds away from o -- the previous pixel and o: three runs per axis, and all but a few waves (columns) and
+// chunks (rows) lie inside one.  CM / RMode name the run, wave-uniform: 1 = the pixel and the next one (right / down),
+// 2 = the previous one and the pixel (left / up), 3 = the pixel itself, 0 = mixed (selected per lane / per row: the general
+// form).  Whatever the mode, the operations on the taps are those of k_level0_rows: h = wa * own + wn * nb per SOURCE row
+// (shared by the two output rows that tap it), v = (1 - dr) * top + dr * bot.
+template <int CM, int RMode, int RM, int K>
+__device__ __forceinline__ void stream_level0_chunk(const double (&w)[K + 2 * RM], const double wa, const double wn,
+                                                    const bool c_left, const bool c_right, const double my_dr,
+                                                    const unsigned up_bits, const unsigned down_bits, const int y,
+                                                    const int oy_end, const bool own, double *__restrict__ dst, const int W,
+                                                    const unsigned boff, ClipTrackExact &tr) {
+    auto hblend = [&](int i) {                                    // i: row y - 1 + i of the window
+        const double px = w[RM - 1 + i];
+        double nb;
+        if (CM == 1) nb = from_right_lane(px);
+        else if (CM == 2) nb = from_left_lane(px);
+        else if (CM == 3) nb = px;
+        else {
+            const double lv = from_left_lane(px), rv = from_right_lane(px);
+            nb = c_right ? rv : lv;
+            if (!(c_left || c_right)) nb = px;
+        }
+        return wa * px + wn * nb;
+    };
+    double h_prev = 0.0, h_cur = 0.0;
+    if (RMode == 0 || RMode == 2) h_prev = hblend(0);
+    if (RMode == 0 || RMode == 1) h_cur = hblend(1);
+#pragma unroll
+    for (int j = 0; j < K; j++) {                                 // (straight-line: rows beyond the segment are computed, not stored)
+        const int oy = y + j;
+        const double dr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_dr), j),
+                                           __builtin_amdgcn_readlane(__double2loint(my_dr), j));
+        double top, bot;
+        if (RMode == 1) {                                         // rows (y, y + 1)
+            const double h_next = hblend(j + 2);
+            top = h_cur; bot = h_next;
+            h_cur = h_next;
+        } else if (RMode == 2) {                                  // rows (y - 1, y)
+            const double h = hblend(j + 1);
+            top = h_prev; bot = h;
+            h_prev = h;
+        } else if (RMode == 3) {                                  // row y
+            top = bot = hblend(j + 1);
+        } else {
+            const double h_next = hblend(j + 2);
+            const bool up = (up_bits >> j) & 1u, down = (down_bits >> j) & 1u;   // uniform
+            top = up ? h_prev : h_cur;
+            bot = down ? h_next : h_cur;
+            h_prev = h_cur; h_cur = h_next;
+        }
+        const double v = (1.0 - dr) * top + dr * bot;
+        if (own && oy < oy_end) {
+            // (a store the compiler does not count, see stream_load: issued iff the wave has a lane with an output in
+            // this row -- the caller knows how many rows that is)
+            stream_store(dst + (int64_t)oy * W, boff, v);
+            tr.tap(w[RM + j]); tr.out(v);                         // (tracked whether or not there is a slot: 4 operations)
+        }
+        tr.nan_check(v, oy < oy_end);
+        __builtin_amdgcn_sched_barrier(0);                        // one row at a time
+    }
+}
+
 template <int R>
 __device__ __forceinline__ double stream_vtap(const double *w, int c, const double (&wk)[R + 1]) {
     double tmp = w[c] * wk[R];
@@ -865,7 +974,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     double *ringA = reinterpret_cast<double *>(aa_smem);                    // [Ring][SW]
     const int SW = a.pitch;
     double *ringB = ringA + (NL > 1 ? kStreamRing * SW : 0);
-    double *edge = ringB + kStreamRing * SW;   // [K + 2][4 waves][2]: the first / last lane's column, for the neighbour wave
 
     // 1-D grid, XCD-major like k_rescale_aa_multi: XCD k takes images k, k + 8, ...; the strips of an
     // image are neighbours in dispatch order (their halo columns meet in one L2)
@@ -881,9 +989,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int xa = strip * a.strip_w, xb = min(xa + a.strip_w, W);
     const int ya = seg * a.seg_rows, yb = min(ya + a.seg_rows, H);   // V rows ya .. min(yb, H - 1) are needed
-    // this thread's source column; threads beyond the strip's support (owned columns + RM on the left,
-    // RM + 1 on the right) repeat its last column
-    const unsigned xcol = (unsigned)mirror_idx(xa - RM + min((int)threadIdx.x, xb - xa + 2 * RM), W);
+    // this thread's source column, as an index into the strip's support (owned columns + RM on the left, RM + 1 on the
+    // right); threads beyond the support repeat its last column.  With the identity-scale level on board a wave advances
+    // by 62 columns only: its lanes 0 and 63 hold the neighbour waves' border columns, so that a lane's left / right
+    // neighbour column is always a lane of its own wave (DPP) -- no exchange through LDS, six columns of the vertical
+    // pass computed twice (they write the same doubles to the same ring cells).
+    const int ci = wave * a.wave_cols + lane;
+    const unsigned xcol = (unsigned)mirror_idx(xa - RM + min(ci, xb - xa + 2 * RM), W);
 
     // per level: the strip's output columns (those whose left tap lies in [xa, xb)), per 64-column
     // group the lane's left tap as a ring column and its blend weight
@@ -897,8 +1009,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         const StreamLevel &L = a.lv[0];
 #pragma unroll
         for (int k = 0; k <= RA; k++) { wkA[k] = L.wr[k]; wckA[k] = L.wc[k]; }
-        oxA0 = first_owned(xa, L.mx, L.Wo);
-        ncolsA = (xb >= W ? L.Wo : first_owned(xb, L.mx, L.Wo)) - oxA0;
+        oxA0 = a.strip_tab[strip].a0;
+        ncolsA = a.strip_tab[strip].a1 - oxA0;
         ngA = (ncolsA + 63) >> 6;
 #pragma unroll
         for (int g = 0; g < kStreamGroupsA; g++) {
@@ -912,8 +1024,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         const StreamLevel &L = a.lv[1];
 #pragma unroll
         for (int k = 0; k <= RB; k++) { wkB[k] = L.wr[k]; wckB[k] = L.wc[k]; }
-        oxB0 = first_owned(xa, L.mx, L.Wo);
-        ncolsB = (xb >= W ? L.Wo : first_owned(xb, L.mx, L.Wo)) - oxB0;
+        oxB0 = a.strip_tab[strip].b0;
+        ncolsB = a.strip_tab[strip].b1 - oxB0;
         ngB = (ncolsB + 63) >> 6;
 #pragma unroll
         for (int g = 0; g < kStreamGroupsB; g++) {
@@ -948,10 +1060,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     for (int i = 0; i < 2 * RM; i++) w[i] = s[(int64_t)mirror_idx(ya + i - RM, H) * W + xcol];
 #pragma unroll
     for (int i = 0; i < K; i++) w[2 * RM + i] = s[(int64_t)mirror_idx(ya + RM + i, H) * W + xcol];
-    const bool last_seg = yb >= H;
-    int nextA = first_owned(ya, a.lv[0].my, a.lv[0].Ho), nextB = NL > 1 ? first_owned(ya, a.lv[1].my, a.lv[1].Ho) : 0, unit = 0;
-    const int endA = last_seg ? a.lv[0].Ho : first_owned(yb, a.lv[0].my, a.lv[0].Ho);
-    const int endB = NL > 1 ? (last_seg ? a.lv[1].Ho : first_owned(yb, a.lv[1].my, a.lv[1].Ho)) : 0;
+    int nextA = a.seg_tab[seg].a0, nextB = NL > 1 ? a.seg_tab[seg].b0 : 0, unit = 0;
+    const int endA = a.seg_tab[seg].a1;
+    const int endB = NL > 1 ? a.seg_tab[seg].b1 : 0;
     const int y_last = min(yb, H - 1);                            // last V row this block needs
     const int n_chunks = (y_last - ya + K) / K;
     // Arguments used once per chunk (the levels' row maps, the identity level's maps) are read from the kernel-argument
@@ -960,6 +1071,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     // The pointer is laundered per chunk so that the loads stay inside the loop.
     typedef const __attribute__((address_space(4))) StreamArgs *KArgs;
     KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    // The window's first rows must have arrived before the loop is entered: left pending, the compiler guards their first
+    // use INSIDE the loop with s_waitcnt vmcnt(7 .. 0) behind the prefetch of the next chunk -- counts that are right for
+    // the first pass and in every later one wait for the loads that were issued a moment ago (the prefetch distance gone).
+    __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0)
     for (int c = 0; c < n_chunks; c++) {
         asm volatile("" : "+s"(ka));
         const int y = ya + c * K;                                 // first V row of this chunk
@@ -967,12 +1082,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             const int r0 = y + K + RM;
             if (r0 + K - 1 <= H - 1) {                            // inside the image: uniform row bases, the column is the offset
 #pragma unroll
-                for (int i = 0; i < K; i++) nxt[i] = (s + (int64_t)(r0 + i) * W)[xcol];
+                for (int i = 0; i < K; i++) nxt[i] = stream_load(s + (int64_t)(r0 + i) * W, xcol * 8u);
             } else {
 #pragma unroll
-                for (int i = 0; i < K; i++) nxt[i] = s[(int64_t)mirror_idx(r0 + i, H) * W + xcol];
+                for (int i = 0; i < K; i++) nxt[i] = stream_load(s + (int64_t)mirror_idx(r0 + i, H) * W, xcol * 8u);
             }
         }
+        int l0_stores_8 = 0;                                      // the chunk's last 8 vector memory operations are level-0 stores
         // vertical Gaussians of both levels at V rows y .. y + K - 1 (rows >= H: computed, never read)
 #pragma unroll
         for (int j = 0; j < K; j++) {
@@ -980,14 +1096,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             const double va = stream_vtap<RA>(w, j + RM, wkA);
             double vb = 0.0;
             if constexpr (NL > 1) vb = stream_vtap<RB>(w, j + RM, wkB);
-            if ((int)threadIdx.x < SW) {                          // threads beyond the pitch hold a repeated column
-                ringA[slot * SW + threadIdx.x] = va;
-                if constexpr (NL > 1) ringB[slot * SW + threadIdx.x] = vb;
+            if (ci < SW) {                                        // threads beyond the pitch hold a repeated column
+                ringA[slot * SW + ci] = va;
+                if constexpr (NL > 1) ringB[slot * SW + ci] = vb;
             }
-        }
-        if (do_l0 && (lane == 0 || lane == 63)) {                 // rows y - 1 .. y + K of the wave's border columns
-#pragma unroll
-            for (int i = 0; i < K + 2; i++) edge[(i * 4 + wave) * 2 + (lane == 63)] = w[RM - 1 + i];
         }
         __syncthreads();
         // outputs whose lower row tap y0 + 1 is now in the ring: y0 + 1 <= y + K - 1
@@ -1007,8 +1119,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         if (do_l0) {
             const int oy_end0 = min(yb, H);                       // this block's level-0 rows: those of its segment
             // the column terms, recomputed per chunk (six operations) rather than held in registers across it
-            const int l0_x = xa - RM + (int)threadIdx.x;          // halo threads hold the reflected columns
-            const bool l0_own = l0_x >= xa && l0_x < xb;
+            const int l0_x = xa - RM + ci;                        // lanes 0 / 63 and the halo threads hold neighbour / reflected columns
+            const bool l0_own = l0_x >= xa && l0_x < xb && lane >= 1 && lane <= 62;
             AxisMap l0mx, l0my;
             l0mx.a = ka->l0_mx.a; l0mx.b = ka->l0_mx.b; l0mx.s = ka->l0_mx.s; l0mx.ideal = ka->l0_mx.ideal;
             l0my.a = ka->l0_my.a; l0my.b = ka->l0_my.b; l0my.s = ka->l0_my.s; l0my.ideal = ka->l0_my.ideal;
@@ -1025,41 +1137,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             const unsigned down_bits = (unsigned)__ballot((int)ceil(my_r) > y + (lane & 7)) & 0xffu;
             // The horizontal blend of a SOURCE row, h(i) = (1 - dc) f0 + dc f1 with (f0, f1) = (neighbour, own) /
             // (own, neighbour) / (own, own), is the same double for both output rows that tap the row, so it is
-            // computed once per source row (K + 2 per chunk) and an output row is one vertical blend of two of them:
-            // 28 instead of 60 vector operations per output row.  The products commute, so one form serves all three
-            // cases: h = wa * own + wn * nb with the weights and nb picked per column.
+            // computed once per source row and an output row is one vertical blend of two of them.  The products
+            // commute, so one form serves all three cases: h = wa * own + wn * nb with the weights and nb picked per column.
             const double l0_wa = l0_left ? l0_dc : 1.0 - l0_dc, l0_wn = l0_left ? 1.0 - l0_dc : l0_dc;
-            const bool l0_edge = (lane == 0 && l0_left && wave > 0) || (lane == 63 && l0_right && wave < 3);
-            const int l0_nb = lane == 0 ? (wave - 1) * 2 + 1 : (wave + 1) * 2;   // the neighbour wave's border lane
-            auto hblend = [&](int i) {                            // i: row y - 1 + i of the window
-                const double own = w[RM - 1 + i];
-                const double lv = from_left_lane(own), rv = from_right_lane(own);
-                double nb = l0_right ? rv : lv;
-                if (l0_edge) nb = edge[(i * 4) * 2 + l0_nb];
-                if (!(l0_left || l0_right)) nb = own;             // the position is the pixel itself
-                return l0_wa * own + l0_wn * nb;
-            };
-            double h_prev = hblend(0), h_cur = hblend(1);
-#pragma unroll
-            for (int j = 0; j < K; j++) {                         // (straight-line: rows beyond the segment are computed, not stored)
-                const int oy = y + j;
-                const double h_next = hblend(j + 2);
-                const double dr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_dr), j),
-                                                   __builtin_amdgcn_readlane(__double2loint(my_dr), j));
-                const bool up = (up_bits >> j) & 1u, down = (down_bits >> j) & 1u;   // uniform: row taps (y - 1, y) / (y, y + 1) / y
-                const double top = up ? h_prev : h_cur;
-                const double bot = down ? h_next : h_cur;
-                const double v = (1.0 - dr) * top + dr * bot;
-                if (l0_own && oy < oy_end0) {
-                    dst0[(int64_t)oy * W + l0_x] = v;
-                    tr0.tap(w[RM + j]); tr0.out(v);               // (tracked whether or not there is a slot: 4 operations)
-                }
-                tr0.nan_check(v, oy < oy_end0);
-                h_prev = h_cur; h_cur = h_next;
-                __builtin_amdgcn_sched_barrier(0);                // one row at a time
+            // which run of the axis this wave's columns / this chunk's rows lie in (stream_level0_chunk): left and right
+            // exclude each other (floor(c) < x < ceil(c) has no integer x)
+            const unsigned long long own_m = __ballot(l0_own), right_m = __ballot(l0_right), left_m = __ballot(l0_left);
+            const int cm = (own_m & ~right_m) == 0ull ? 1 : (own_m & ~left_m) == 0ull ? 2 : (own_m & (left_m | right_m)) == 0ull ? 3 : 0;
+            const int rm = down_bits == 0xffu ? 1 : up_bits == 0xffu ? 2 : (up_bits | down_bits) == 0u ? 3 : 0;
+            const unsigned l0_boff = (unsigned)max(l0_x, 0) * 8u;
+            l0_stores_8 = own_m != 0ull && y + K <= oy_end0 ? 1 : 0;   // a store per row, each issued (some lane owns an output)
+#define TDK_L0_CASE(CM_, RM_)                                                                                              \
+    case CM_ * 4 + RM_:                                                                                                    \
+        stream_level0_chunk<CM_, RM_, RM, K>(w, l0_wa, l0_wn, l0_left, l0_right, my_dr, up_bits, down_bits, y, oy_end0,   \
+                                             l0_own, dst0, W, l0_boff, tr0);                                               \
+        break;
+            switch (cm && rm ? cm * 4 + rm : 0) {                 // wave-uniform
+                TDK_L0_CASE(1, 1) TDK_L0_CASE(1, 2) TDK_L0_CASE(1, 3)
+                TDK_L0_CASE(2, 1) TDK_L0_CASE(2, 2) TDK_L0_CASE(2, 3)
+                TDK_L0_CASE(3, 1) TDK_L0_CASE(3, 2) TDK_L0_CASE(3, 3)
+                default:
+                    stream_level0_chunk<0, 0, RM, K>(w, l0_wa, l0_wn, l0_left, l0_right, my_dr, up_bits, down_bits, y, oy_end0,
+                                                     l0_own, dst0, W, l0_boff, tr0);
             }
+#undef TDK_L0_CASE
         }
         if (kStreamRing < 2 * K + 1) __syncthreads();             // the next chunk's V rows overwrite rows read above
+        if (c + 1 < n_chunks) {                                   // the prefetched rows (stream_load)
+            stream_rows_arrived(nxt, __builtin_amdgcn_readfirstlane(l0_stores_8));
+        }
 #pragma unroll
         for (int i = 0; i < 2 * RM; i++) w[i] = w[K + i];
 #pragma unroll
@@ -1351,7 +1457,7 @@ int pyramid_max_radius() { return kMaxGaussRadius; }
 // clip=False.  stream_mode: 0 never the streaming kernel, 1 for batches that fill the chip, 2 always.
 tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride, int n_out,
                           const PyramidLevelDesc *levels, int batch, double *weights, bool upload_weights,
-                          void *clip_slots, int stream_mode, hipStream_t stream, bool *slots_clean) {
+                          void *clip_slots, int stream_mode, hipStream_t stream, int *slots_clean) {
     if (n_out <= 0) return TDK_OK;
     if (n_out > kMaxOut || n_arrays > 4) {
         set_error("pyramid too deep");
@@ -1384,13 +1490,15 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
     }
     ClipSlot *slots = static_cast<ClipSlot *>(clip_slots);
     const int64_t images = (int64_t)n_arrays * batch;
-    // (a build with few slots leaves them clean -- k_clip_small -- so the next one of the same owner needs no reset)
-    if (slots && !(slots_clean && *slots_clean)) {
+    // (a build with few slots leaves them clean -- k_clip_small -- so the next one of the same owner needs no reset,
+    // PROVIDED it uses the same number of slots: *slots_clean is that number.  A build of more arrays or levels than
+    // the last one would otherwise read slots nobody ever initialised)
+    if (slots && !(slots_clean && *slots_clean == (int)(images * n_out))) {
         const int n = (int)(images * n_out);
         k_clip_reset<<<(n + 255) / 256, 256, 0, stream>>>(slots, n);
         TDK_LAUNCH_CHECK();
     }
-    if (slots_clean) *slots_clean = false;
+    if (slots_clean) *slots_clean = 0;
     auto shrinks = [&](int l) {
         return taps_inside(dv[l].mx, W, dv[l].Wo) && taps_inside(dv[l].my, H, dv[l].Ho);
     };
@@ -1402,38 +1510,41 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
             if (!done[l] && dv[l].aa.Rr == 1 && dv[l].aa.Rc == 1 && shrinks(l)) lA = l;
         for (int l = 0; l < n_out && lA >= 0 && lB < 0; l++)
             if (!done[l] && dv[l].aa.Rr == 3 && dv[l].aa.Rc == 3 && shrinks(l)) lB = l;
-        const int n_strips = (W + 247) / 248, strip_w = (W + n_strips - 1) / n_strips;
+        // the identity-scale level rides along if its map stays within a pixel of the identity (every output's
+        // taps are its own column and one neighbour, rows y - 1 .. y + 1)
+        int l0 = -1;
+        for (int l = 0; l < n_out && l0 < 0; l++) {
+            if (done[l] || dv[l].Ho != H || dv[l].Wo != W || dv[l].aa.Rr || dv[l].aa.Rc) continue;
+            auto near_identity = [](const AxisMap &m, int n) {
+                return fabs(axis_pos(m, 0)) < 0.5 && fabs(axis_pos(m, n - 1) - (double)(n - 1)) < 0.5;
+            };
+            if (near_identity(dv[l].mx, W) && near_identity(dv[l].my, H)) l0 = l;
+        }
+        if (stream_mode == 3) l0 = -1;                            // (experiment: level 0 by k_level0_stream)
+        // a strip's support (owned columns + 2 RM + 1) must fit the columns the block's four waves hold
+        const int wave_cols = l0 >= 0 ? 62 : 64;
+        const int max_strip = 3 * wave_cols + 64 - 7 - 1;        // 248 / 242
+        const int n_strips = (W + max_strip - 1) / max_strip, strip_w = (W + n_strips - 1) / n_strips;
         if (stream_mode && lA >= 0 && (images * n_strips >= 256 || stream_mode == 2)) {
             const int nl = lB >= 0 ? 2 : 1;
             StreamArgs sa;
             for (int i = 0; i < 4; i++) sa.src[i] = i < n_arrays ? srcs[i] : nullptr;
             sa.src_stride = src_stride; sa.H = H; sa.W = W; sa.n_arrays = n_arrays; sa.batch = batch; sa.n_out = n_out;
-            sa.n_strips = n_strips; sa.strip_w = strip_w;
+            sa.n_strips = n_strips; sa.strip_w = strip_w; sa.wave_cols = wave_cols;
             sa.pitch = std::min(256, (strip_w + 2 * 3 + 1 + 7) & ~7);
             sa.slots = slots;
-            // the identity-scale level rides along if its map stays within a pixel of the identity (every output's
-            // taps are its own column and one neighbour, rows y - 1 .. y + 1)
             sa.l0_mask = 0u; sa.l0_lvl = 0; sa.l0_stride = 0;
             sa.l0_mx = sa.l0_my = ideal_axis(1, 1);
             for (int i = 0; i < 4; i++) sa.l0_dst[i] = nullptr;
-            int l0 = -1;
-            for (int l = 0; l < n_out && l0 < 0; l++) {
-                if (done[l] || dv[l].Ho != H || dv[l].Wo != W || dv[l].aa.Rr || dv[l].aa.Rc) continue;
-                auto near_identity = [](const AxisMap &m, int n) {
-                    return fabs(axis_pos(m, 0)) < 0.5 && fabs(axis_pos(m, n - 1) - (double)(n - 1)) < 0.5;
-                };
-                if (near_identity(dv[l].mx, W) && near_identity(dv[l].my, H)) l0 = l;
-            }
-            if (stream_mode == 3) l0 = -1;                        // (experiment: level 0 by k_level0_stream)
             if (l0 >= 0) {
                 for (int i = 0; i < 4; i++) sa.l0_dst[i] = dv[l0].dst[i];
                 sa.l0_stride = dv[l0].stride; sa.l0_mx = dv[l0].mx; sa.l0_my = dv[l0].my; sa.l0_lvl = l0;
                 sa.l0_mask = (1u << n_arrays) - 1u;
             }
             // row segments: enough blocks for several full rounds of the 1024 resident ones (a segment pays
-            // 2 RM warm-up rows)
+            // 2 RM warm-up rows and a prologue: 256 VGA pairs x 3 arrays, 2 / 3 / 4 / 8 segments: 1.21 / 1.21 / 1.23 / 1.27 ms)
             int n_segs = 1;
-            while (images * n_strips * n_segs < 8192 && H / (n_segs * 2) >= 48) n_segs *= 2;
+            while (images * n_strips * n_segs < 4096 && H / (n_segs * 2) >= 48 && n_segs * 2 <= kStreamMaxSegs) n_segs *= 2;
             sa.seg_rows = (H + n_segs - 1) / n_segs;
             sa.n_segs = (H + sa.seg_rows - 1) / sa.seg_rows;
             size_t lds = 0;
@@ -1445,8 +1556,6 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
                 sa.lv[k].wr = dv[l].aa.wr; sa.lv[k].wc = dv[l].aa.wc; sa.lv[k].lvl = l;
                 if (k < nl) lds += sizeof(double) * kStreamRing * sa.pitch;
             }
-            if (nl == 1) lds += sizeof(double) * kStreamRing * sa.pitch;      // (ringB's place: the border columns sit behind it)
-            lds += sizeof(double) * (kStreamK + 2) * 8;
             // outputs per strip must fit the 64-column groups the kernel holds terms for
             bool fits = true;
             for (int k = 0; k < nl; k++) {
@@ -1457,15 +1566,29 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
                 const double stepy = (axis_pos(my, sa.lv[k].Ho - 1) - axis_pos(my, 0)) / std::max(1, sa.lv[k].Ho - 1);
                 if (!(stepy > 0.0) || (double)kStreamK / stepy + 2.0 > 64.0) fits = false;
             }
+            if (n_strips > kStreamMaxStrips || sa.n_segs > kStreamMaxSegs) fits = false;
+            for (int t = 0; fits && t < n_strips; t++) {
+                const int xa = t * strip_w, xb = std::min(xa + strip_w, W);
+                StreamRange &r = sa.strip_tab[t];
+                r.a0 = first_owned(xa, sa.lv[0].mx, sa.lv[0].Wo);
+                r.a1 = xb >= W ? sa.lv[0].Wo : first_owned(xb, sa.lv[0].mx, sa.lv[0].Wo);
+                r.b0 = first_owned(xa, sa.lv[1].mx, sa.lv[1].Wo);
+                r.b1 = xb >= W ? sa.lv[1].Wo : first_owned(xb, sa.lv[1].mx, sa.lv[1].Wo);
+            }
+            for (int t = 0; fits && t < sa.n_segs; t++) {
+                const int ya = t * sa.seg_rows, yb = std::min(ya + sa.seg_rows, H);
+                StreamRange &r = sa.seg_tab[t];
+                r.a0 = first_owned(ya, sa.lv[0].my, sa.lv[0].Ho);
+                r.a1 = yb >= H ? sa.lv[0].Ho : first_owned(yb, sa.lv[0].my, sa.lv[0].Ho);
+                r.b0 = first_owned(ya, sa.lv[1].my, sa.lv[1].Ho);
+                r.b1 = yb >= H ? sa.lv[1].Ho : first_owned(yb, sa.lv[1].my, sa.lv[1].Ho);
+            }
             const int64_t blocks = 8 * ((images + 7) / 8) * n_strips * sa.n_segs;
             if (fits && blocks < (1ll << 31) && lds <= 160 * 1024) {
-                static bool attr_set = false;
-                if (!attr_set) {   // > 64 KiB of dynamic LDS has to be asked for
-                    TDK_HIP(hipFuncSetAttribute((const void *)k_pyramid_stream<1, 3>,
+                if (lds > 64 * 1024) {   // more than 64 KiB of dynamic LDS has to be asked for -- per device (the attribute
+                                         // belongs to the function ON the current device), so not remembered in a static
+                    TDK_HIP(hipFuncSetAttribute(nl == 2 ? (const void *)k_pyramid_stream<1, 3> : (const void *)k_pyramid_stream<1, 0>,
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    TDK_HIP(hipFuncSetAttribute((const void *)k_pyramid_stream<1, 0>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-                    attr_set = true;
                 }
                 if (nl == 2) k_pyramid_stream<1, 3><<<(unsigned)blocks, 256, lds, stream>>>(sa);
                 else k_pyramid_stream<1, 0><<<(unsigned)blocks, 256, lds, stream>>>(sa);
@@ -1607,7 +1730,7 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
         if (n <= 64) {
             k_clip_small<<<n, 256, lds, stream>>>(c);
             TDK_LAUNCH_CHECK();
-            if (slots_clean) *slots_clean = true;
+            if (slots_clean) *slots_clean = n;
         } else {
             k_clip_gate<<<(n + 255) / 256, 256, 0, stream>>>(slots, n);
             TDK_LAUNCH_CHECK();

@@ -61,7 +61,7 @@ size_t pyramid_clip_bytes(int64_t n_images, int n_out);
 // every level of `levels` for `n_arrays` arrays of `batch` images in a few launches (see pyramid.hip)
 tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W, int64_t src_stride, int n_out,
                           const PyramidLevelDesc *levels, int batch, double *weights, bool upload_weights,
-                          void *clip_slots, int stream_mode, hipStream_t stream, bool *slots_clean = nullptr);
+                          void *clip_slots, int stream_mode, hipStream_t stream, int *slots_clean = nullptr);
 
 // dvo.hip: the full-resolution input arrays of a DVO batch, for producers that fill it on the device (tdk_sd_export_dvo)
 struct DvoLevel0 {

@@ -17,6 +17,40 @@ def pytest_configure(config):
                                        "(skimage to the bit); every other GPU test gets the ideal-constants one")
 
 
+def fuzz_settings():
+    """(cases per family, seed) of tests/test_gpu_fuzz.py.  TDK_FUZZ_N / TDK_FUZZ_SEED win; by default the regular
+    `pytest -m gpu` run IS a soak of its own: 2 000 cases per family (about a minute on the GPU box) on a seed that
+    rotates with the code -- the first bytes of the SHA-256 of the built library (the snapshot on the GPU box has no
+    .git to take a commit hash from; the library changes whenever a kernel does).  Both are printed in the header
+    and in the last lines of the run, and every failure message carries the case number."""
+    n = int(os.environ.get("TDK_FUZZ_N", "2000"))
+    if "TDK_FUZZ_SEED" in os.environ:
+        return n, int(os.environ["TDK_FUZZ_SEED"])
+    import hashlib
+    lib = os.path.join(REPO, "tadataka_amd", "lib", "libtadataka_hip.so")
+    try:
+        with open(lib, "rb") as f:
+            digest = hashlib.sha256(f.read()).digest()
+        return n, 1000 + int.from_bytes(digest[:4], "big") % 9000
+    except OSError:
+        return n, 0
+
+
+def pytest_report_header(config):
+    n, seed = fuzz_settings()
+    return f"fuzz soak: TDK_FUZZ_N={n} cases per family, TDK_FUZZ_SEED={seed}"
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    ran = [r for r in terminalreporter.stats.get("passed", []) + terminalreporter.stats.get("failed", [])
+           if "test_gpu_fuzz.py" in r.nodeid]
+    if ran:
+        n, seed = fuzz_settings()
+        secs = sum(getattr(r, "duration", 0.0) for r in ran)
+        terminalreporter.write_line(f"fuzz soak: {len(ran)} families x TDK_FUZZ_N={n} cases, TDK_FUZZ_SEED={seed}, "
+                                    f"{secs:.0f} s in tests/test_gpu_fuzz.py")
+
+
 def _has_gpu():
     return os.path.exists("/dev/kfd") and os.path.isdir("/sys/class/kfd/kfd/topology/nodes")
 

@@ -105,3 +105,20 @@ def test_round5_entries_validate_their_arguments_without_a_gpu(lib):
     assert b"option" in h.tdk_last_error()
     n = C.c_int(5)
     assert h.tdk_debug_check_canaries(C.byref(n)) == 0 and n.value in (-1, 0)   # off (or on with nothing allocated)
+
+
+def test_streaming_pyramid_kernel_keeps_its_prefetch_registers_untouched():
+    """k_pyramid_stream issues its row prefetch and the identity level's stores behind the compiler's back and waits
+    for the prefetch with its own s_waitcnt (csrc/pyramid.hip: stream_load); nothing may touch the destination
+    registers in between.  The compiler cannot know, so the generated gfx950 assembly is checked (hipcc -S, no GPU)."""
+    import importlib.util
+    import shutil
+    if shutil.which("/opt/rocm/bin/hipcc") is None:
+        pytest.skip("no hipcc")
+    spec = importlib.util.spec_from_file_location(
+        "check_pyramid_isa", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools",
+                                          "check_pyramid_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kernels, problems = mod.check(mod.assembly())
+    assert kernels == 2 and not problems, problems

@@ -2,9 +2,10 @@
 shapes (down to 2 x 2), random poses (small, large, behind the camera), degenerate depths (0, negative,
 NaN, huge), ragged graphs -- the inputs nobody wrote a fixture for.
 
-TDK_FUZZ_N cases per family (default 12, seconds); the soaks of profiles/r05_fuzz.txt ran it with
-TDK_FUZZ_N=4000 - 6000 on two dozen seeds (~3.3 min per seed on the GPU box).  TDK_FUZZ_SEED moves the whole
-sequence, TDK_FUZZ_BIG=1 draws production-size frames and batches for the batch families.  Bars as everywhere: bit-exact for the
+TDK_FUZZ_N cases per family (default 2 000: about a minute of the regular `pytest -m gpu` run; the soaks of
+profiles/r05_fuzz.txt ran 4000 - 6000 on two dozen seeds, ~3.3 min per seed on the GPU box).  TDK_FUZZ_SEED moves the
+whole sequence (default: rotates with the built library, tests/conftest.py: fuzz_settings; printed in the header
+and the last lines of the run), TDK_FUZZ_BIG=1 draws production-size frames and batches for the batch families.  Bars as everywhere: bit-exact for the
 parity-granular operators, the pyramid and the semi-dense maps; 1e-9 per entry on the normal equations;
 1e-6 on poses."""
 import os
@@ -13,12 +14,11 @@ import numpy as np
 import pytest
 from scipy.spatial.transform import Rotation
 
-from conftest import b6_err, h21_err
+from conftest import b6_err, fuzz_settings, h21_err
 
 pytestmark = pytest.mark.gpu
 
-N_CASES = int(os.environ.get("TDK_FUZZ_N", "12"))
-SEED = int(os.environ.get("TDK_FUZZ_SEED", "0"))
+N_CASES, SEED = fuzz_settings()
 RTOL_SUMS = 1e-9
 
 
