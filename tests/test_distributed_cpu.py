@@ -149,3 +149,30 @@ def test_bench_pair_bookkeeping_world_8(tmp_path):
     assert last.shape == (24, 12)
     assert np.array_equal(last[:, 0], np.concatenate([np.arange(6 * r, 6 * r + 3) for r in range(8)]))
     assert all(np.array_equal(np.load(o), last) for o in outs)
+
+
+def test_rccl_comm_through_the_c_abi_signatures_world_8(tmp_path):
+    """Eight processes run the product's sharding.connect() -> RcclComm -> PoseGather (device-resident gather path)
+    against a stand-in whose entries are ctypes callbacks with the prototypes of include/tadataka_hip.h and gloo
+    behind them (tests/_dist_worker.py: GlooBackedAbi): rendezvous with the unique id, ncclCommInitRank's place,
+    bench.py's order of collectives, error by status, destroy.  Leaves csrc/comm.hip as the only code of the N > 1
+    path that has not run with real peers."""
+    import glob
+    world = 8
+    worker = os.path.join(REPO, "tests", "_dist_worker.py")
+    procs, outs = [], []
+    for rank in range(world):
+        out = str(tmp_path / f"abi{rank}.npy")
+        outs.append(out)
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT="29731", TMPDIR=str(tmp_path), OMP_NUM_THREADS="1", TDK_RENDEZVOUS_KEY="abi8")
+        procs.append(subprocess.Popen([sys.executable, worker, "--abi", out], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        stdout, _ = p.communicate(timeout=300)
+        assert p.returncode == 0, stdout[-3000:]
+    last = np.load(outs[0])
+    assert last.shape == (world * 3, 12)
+    assert np.array_equal(last[:, 0], np.concatenate([np.arange(6 * r, 6 * r + 3) for r in range(world)]) + 4000.0)
+    assert all(np.array_equal(np.load(o), last) for o in outs)
+    assert glob.glob(str(tmp_path / "tdk_rdv_*")) == []
