@@ -2,9 +2,17 @@ import numpy as np
 
 from tadataka_amd import ops
 
-# what scikit-image's rescale / resize default to, and all this stand-in implements.  The result is what
-# scikit-image 0.18.3 returns ON THIS INTERPRETER, to the bit (tadataka_amd/rescale_plan.py makes skimage's own NumPy
-# calls for the estimated affine map and the Gaussian kernels; tests/golden/skimage_rescale.npz pins the kernels).
+# what scikit-image's rescale / resize default to, and all this stand-in implements.  For FLOAT64 images the result is
+# what scikit-image 0.18.3 returns ON THIS INTERPRETER, to the bit (tadataka_amd/rescale_plan.py makes skimage's own
+# NumPy calls for the estimated affine map and the Gaussian kernels; tests/golden/skimage_rescale.npz pins the kernels).
+# Two input types the real package treats differently (measured on the real one: tests/golden/skimage_dtypes.npz,
+# generate_golden_skimage_dtypes.py):
+#   * integer / bool images: skimage runs the anti-aliasing prefilter IN the integer dtype (the filtered image is
+#     quantised: rescale(u8, 1 / 1.5) is up to 7.7e-3 away from rescale(img_as_float(u8), 1 / 1.5)) -- not reproduced,
+#     so a shrinking, filtered rescale of an integer image raises instead of silently returning the float pipeline's
+#     values; without a prefilter (scale >= 1 or anti_aliasing=False) the two agree exactly and the image is converted;
+#   * float32 images: skimage stays in single precision (float32 output); here they are widened to float64 first and
+#     the result is float64 (up to 1.7e-6 per pixel apart at scale 1 / 1.5).
 _DEFAULTS = {"order": 1, "mode": "reflect", "cval": 0, "preserve_range": False,
              "multichannel": False, "anti_aliasing_sigma": None}
 
@@ -35,10 +43,19 @@ def _as_float(image):
     return np.asarray(a, dtype=np.float64)
 
 
+def _refuse_filtered_integers(image, shrinks, anti_aliasing):
+    if anti_aliasing and shrinks and np.asarray(image).dtype.kind in "uib":
+        raise NotImplementedError(
+            f"rescale / resize of a {np.asarray(image).dtype} image with the anti-aliasing prefilter: scikit-image filters in "
+            "the integer dtype (quantised), which this stand-in does not reproduce -- convert with img_as_float first "
+            "(what the reference's examples do), or pass anti_aliasing=False")
+
+
 def rescale(image, scale, anti_aliasing=True, clip=True, **kwargs):
     """Bilinear (order=1) rescale of a 2-D image; anti_aliasing as in 0.15+ (Gaussian
     prefilter with sigma = (1/scale - 1) / 2 when shrinking).  Any other option raises."""
     _check_kwargs(kwargs)
+    _refuse_filtered_integers(image, np.ndim(scale) == 0 and scale < 1, anti_aliasing)
     image = _as_float(image)
     if image.ndim != 2:
         raise NotImplementedError("only 2-D images are rescaled on the hot path")
@@ -49,6 +66,9 @@ def rescale(image, scale, anti_aliasing=True, clip=True, **kwargs):
 
 def resize(image, output_shape, anti_aliasing=True, clip=True, **kwargs):
     _check_kwargs(kwargs)
+    shape = np.shape(image)
+    _refuse_filtered_integers(image, len(shape) >= 2 and (output_shape[0] < shape[0] or output_shape[1] < shape[1]),
+                              anti_aliasing)
     image = _as_float(image)
     if image.ndim != 2:
         raise NotImplementedError("only 2-D images are resized on the hot path")

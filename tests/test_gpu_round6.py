@@ -121,3 +121,36 @@ def test_streaming_level0_tap_runs_bit_for_bit(ops, orc, shape):
                     assert np.array_equal(got, want), (m.tolist(), i, name, l, float(np.max(np.abs(got - want))))
         batch.close()
     ops.set_option("pyramid_stream", 1)
+
+
+@pytest.mark.skimage_pyramid
+def test_dropin_on_float32_and_integer_frames_against_the_dtype_fixture(ops, golden):
+    """float32 frames are widened: the drop-in's pose is the reference's pose on the widened values to 1e-6 (and so
+    ~1e-5 from the reference's single-precision pose: the measured, documented gap of INTEGRATION.md).  Integer frames
+    are refused, in the estimator and in the scikit-image stand-in's filtered rescale."""
+    import tadataka_amd  # noqa: F401
+    import tadataka.vo.dvo as dvo
+    from skimage.transform import rescale
+    from tadataka.camera import CameraModel, CameraParameters
+    from tadataka_amd import rescale_plan, synthetic
+    g = golden("skimage_dtypes.npz")
+    pair = synthetic.make_pair(480, 640, seed=0)
+    cm = CameraModel(CameraParameters(pair["cam"][0:2], pair["cam"][2:4]), distortion_model=None)
+    f32 = {k: pair[k].astype(np.float32) for k in ("I0", "D0", "I1")}
+    u8 = np.clip(np.round(pair["I0"] * 255), 0, 255).astype(np.uint8)
+    dvo.PYRAMID_PLANS = lambda shape, n, ratio: rescale_plan.recorded_level_plans(g, (int(shape[0]), int(shape[1])), n, ratio)
+    try:
+        est = dvo.PoseChangeEstimator(cm, cm, n_coarse_to_fine=3, max_iter=20)
+        for name in ("None", "huber"):
+            pose = est(f32["I0"], f32["D0"], f32["I1"], None if name == "None" else name)
+            err = max(np.max(np.abs(pose.rotation.as_rotvec() - g[f"dvo_f32_widened_{name}_rotvec"])),
+                      np.max(np.abs(pose.t - g[f"dvo_f32_widened_{name}_t"])))
+            assert err < 1e-6, (name, err)
+            assert 1e-6 < np.max(np.abs(pose.t - g[f"dvo_f32_{name}_t"])) < 5e-5      # the single-precision reference
+        with pytest.raises(TypeError):
+            est(u8, pair["D0"], u8)
+    finally:
+        dvo.PYRAMID_PLANS = None
+    with pytest.raises(NotImplementedError):
+        rescale(u8, 1 / 1.5)
+    assert rescale(u8, 1.0).shape == u8.shape and rescale(u8, 1 / 1.5, anti_aliasing=False).shape == (320, 427)
