@@ -687,7 +687,7 @@ def test_fuzz_dropin_pose_change_estimator(orc):
         D0 = pair["D0"].copy()
         # missing readings -- not at ratio 1.3: its prefilter (sigma 0.15, side weights 2e-10) turns a zero next to a
         # depth of 2 into a depth of 1e-9, a handful of Jacobian rows 1e9 times larger than the rest, cond(J) 3e8: lstsq
-        # on J (the reference) still resolves the translation, normal equations in double cannot (limits)
+        # on J (the reference) still resolves the translation, normal equations in double cannot (docs/HISTORY.md 11b, limits)
         # ... nor with a single level: the identity-scale warp of level 0 turns a zero into a depth of ~1e-13, and at the
         # identity prior that is z itself: cond(J) 2.8e12, where lstsq too is accurate to cond * eps = 6e-4 at best
         if ratio > 1.4 and levels > 1 and rng.random() < 0.25:
