@@ -216,11 +216,11 @@ def measure_traffic_in_run(argv):
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     name = r["Kernel_Name"]
-                    if r["Counter_Name"] != ctr or not ("k_dvo_eval" in name or "k_dvo_probe" in name):
+                    if r["Counter_Name"] != ctr or "k_dvo_eval" not in name:
                         continue
                     per.setdefault(int(r["Grid_Size"]), []).append(float(r["Counter_Value"]))
             if not per:
-                return None, "no k_dvo_eval / k_dvo_probe rows in the %s pass" % ctr
+                return None, "no k_dvo_eval rows in the %s pass" % ctr
             top = max(per)               # the full-resolution launches
             raw[ctr] = (sum(per[top]) / len(per[top]), len(per[top]))
     finally:
@@ -230,8 +230,57 @@ def measure_traffic_in_run(argv):
     return ({"hbm_bytes_per_launch": (2.0 * fetch_kib + write_kib) * 1024.0, "FETCH_SIZE_KiB_raw": fetch_kib,
              "WRITE_SIZE_KiB_raw": write_kib, "launches_counted": [n_f, n_w], "seconds": time.perf_counter() - t0},
             "two child runs of this command (headline only, 6 steps) under rocprofv3 --pmc FETCH_SIZE / --pmc "
-            "WRITE_SIZE during this run; full-resolution k_dvo_eval + k_dvo_probe launches, launch-weighted; "
-            "read side doubled (gfx950 FETCH_SIZE correction)")
+            "WRITE_SIZE during this run; the full-resolution k_dvo_eval launches (the dominant kernel, full "
+            "evaluations); read side doubled (gfx950 FETCH_SIZE correction)")
+
+
+def measure_kernel_traffic(child, groups):
+    """HBM bytes per launch of the kernels named in `groups` ({label: (kernel-name substrings)}), summed per label
+    over its kernels (each launched once per step of `child`): two runs of `child` under rocprofv3 --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE, corrected as in measure_traffic_in_run.  Returns ({label: bytes}, note) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    if any(k in os.environ for k in ("ROCPROF_OUTPUT_PATH", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_SDK_TOOL_LIBRARIES")):
+        return None, "this run is itself under a profiler"
+    env = dict(os.environ, TMPDIR="/tmp")
+    tmp = tempfile.mkdtemp(prefix="tdk_pmc_", dir="/tmp")
+    raw = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            try:
+                subprocess.run([exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=150, check=True)
+            except (subprocess.SubprocessError, OSError) as e:
+                return None, "rocprofv3 --pmc %s failed: %r" % (ctr, e)
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == ctr:
+                        per.setdefault(r["Kernel_Name"], []).append(float(r["Counter_Value"]))
+            raw[ctr] = per
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for label, subs in groups.items():
+        total = 0.0
+        for sub in subs:
+            f = [v for k, vals in raw["FETCH_SIZE"].items() if sub in k for v in vals]
+            w = [v for k, vals in raw["WRITE_SIZE"].items() if sub in k for v in vals]
+            if not f or not w:
+                return None, "no %s rows in the counter passes" % sub
+            total += (2.0 * sum(f) / len(f) + sum(w) / len(w)) * 1024.0
+        out[label] = total
+    return out, ("two child runs (%s) under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE during this run; per-launch "
+                 "averages summed over the kernels of a step; read side doubled (gfx950 FETCH_SIZE correction)"
+                 % " ".join(os.path.basename(c) for c in child[1:2]))
 
 
 def roofline_fp64(prof_kind):
@@ -522,6 +571,14 @@ def workload_semi_dense(args, fixture):
                                             "k_sd_scatter + k_sd_fold for tracks whose displacement box is too large: "
                                             "%d of this run)" % fallbacks,
                                      bytes_per_px=BYTES_PER_PX_WARP, tracks=B)}
+    if not args.no_traffic_pass:
+        got, note = measure_kernel_traffic([sys.executable, os.path.join(REPO, "tools", "sd_child.py"), "4", str(B)],
+                                           {"warp": ("k_sd_targets", "k_sd_gather2"),
+                                            "update_depth": ("k_ud_classify", "k_ud_estimate")})
+        for key, label in (("roofline_warp", "warp"), ("roofline", "update_depth")):
+            out[key]["traffic"] = got[label] if got else None
+            out[key]["traffic_bytes_per_px"] = got[label] / (N * B) if got else None
+            out[key]["traffic_source"] = note
     if not args.no_cpu_baseline:
         from oracle import oracle as orc             # the checker, here as the thing that is timed
         po = orc.make_params(*SD_PARAMS)
@@ -1078,12 +1135,19 @@ def main():
         pmc = load_profile_json("pmc_dvo_eval.json") or {}
         traffic = pmc.get("hbm_bytes_per_launch")
         measured, measured_note = early.get("traffic", (None, "not attempted (--no-traffic-pass, or more than one rank)"))
-        rl = roofline(BYTES_PER_PX_EVAL * prof["pixels"] / max(prof["launches"], 1), kernel_ms,
-                      kernel=f"k_dvo_eval<{args.weights}> + k_dvo_probe, every full-resolution launch (by_mode: the two kernels on their own)",
+        # the dominant kernel: k_dvo_eval's full evaluations at full resolution (by_mode.full); the launch-weighted
+        # mix with the error-only probes -- what rounds 2-5 reported as `frac` -- stays as `mix`
+        dom = prof_kind["full"] if prof_kind["full"]["launches"] else prof
+        dom_ms = dom["total_ms"] / max(dom["launches"], 1)
+        rl = roofline(BYTES_PER_PX_EVAL * dom["pixels"] / max(dom["launches"], 1), dom_ms,
+                      kernel=f"k_dvo_eval<{args.weights}>, full evaluations at full resolution (by_mode.full); `mix`: every "
+                             "full-resolution launch incl. the error-only k_dvo_probe",
                       bytes_per_px=BYTES_PER_PX_EVAL,
-                      px_per_launch=prof["pixels"] / max(prof["launches"], 1), launches=prof["launches"],
-                      limiter="full evaluations: FP64 issue at the package power cap (DESIGN.md 5.1); "
-                              "probes (error only): HBM")
+                      px_per_launch=dom["pixels"] / max(dom["launches"], 1), launches=dom["launches"],
+                      limiter="FP64 issue at the package power cap (DESIGN.md 5.1); the probes (error only) are HBM-bound")
+        mix = roofline(BYTES_PER_PX_EVAL * prof["pixels"] / max(prof["launches"], 1), kernel_ms)
+        rl["mix"] = {k: mix[k] for k in ("achieved", "frac", "kernel_ms")}
+        rl["mix"]["launches"] = prof["launches"]
         if measured:
             rl["traffic"] = measured["hbm_bytes_per_launch"]
             rl["traffic_source"] = "measured in this run: " + measured_note

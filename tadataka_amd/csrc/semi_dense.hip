@@ -966,11 +966,16 @@ __global__ __launch_bounds__(kBlock) void k_ud_estimate(int H, int W, const Trac
                                                         const int *__restrict__ count,
                                                         double *__restrict__ out_depth,
                                                         double *__restrict__ out_var,
-                                                        int64_t *__restrict__ out_flag) {
-    const int track = blockIdx.y;
+                                                        int64_t *__restrict__ out_flag, int nb, int n_tracks) {
+    // XCD-major (xcd_major_track): all blocks of a track on ONE XCD, one after the other.  A live pixel gathers ~60
+    // texels of the track's key and reference frames; as a (blocks, tracks) grid every XCD worked on an eighth of
+    // every track and each of the eight L2s fetched both frames of all 64 tracks: 133 B/px of HBM-side traffic for
+    // 57.6 algorithmic (rocprofv3 FETCH_SIZE / WRITE_SIZE, profiles/r06_update_depth.txt).
+    int track, bx;
+    if (!xcd_major_track(nb, n_tracks, track, bx)) return;
     const int n_live = count[track * kCountStride];
-    if ((int)(blockIdx.x * kBlock) >= n_live) return;           // block-uniform
-    const int k = blockIdx.x * kBlock + (int)threadIdx.x;
+    if (bx * kBlock >= n_live) return;                           // block-uniform
+    const int k = bx * kBlock + (int)threadIdx.x;
     const int64_t base = (int64_t)track * stride;
     const TrackKey &key = keys[track];
     const Cam kc{key.cam[0], key.cam[1], key.cam[2], key.cam[3]};
@@ -1281,9 +1286,12 @@ tdk_status launch_update_depth(int n_tracks, int H, int W, const TrackKey *d_key
     k_ud_classify<<<cgrid, kBlock, 0, stream>>>(N, d_keys, age, prior_depth, prior_var, stride, pr.vmin, pr.vmax,
                                                 out_depth, out_var, out_flag, list, count, err);
     TDK_LAUNCH_CHECK();
-    dim3 egrid((N + kBlock - 1) / kBlock, n_tracks);
-    k_ud_estimate<<<egrid, kBlock, 0, stream>>>(H, W, d_keys, d_refs, refs_per_track, age, prior_depth, prior_var,
-                                                stride, pr, list, count, out_depth, out_var, out_flag);
+    const int nb = (N + kBlock - 1) / kBlock;
+    const int64_t eblocks = (int64_t)8 * ((n_tracks + 7) / 8) * nb;
+    if (eblocks >= (1ll << 31)) { tdk::set_error("update_depth: grid too large"); return TDK_ERR_INVALID_ARGUMENT; }
+    k_ud_estimate<<<(unsigned)eblocks, kBlock, 0, stream>>>(H, W, d_keys, d_refs, refs_per_track, age, prior_depth,
+                                                            prior_var, stride, pr, list, count, out_depth, out_var,
+                                                            out_flag, nb, n_tracks);
     TDK_LAUNCH_CHECK();
     return TDK_OK;
 }
