@@ -907,13 +907,59 @@ __device__ __forceinline__ double stream_vtap(const double *w, int c, const doub
     return tmp;
 }
 
-// the horizontal pass + blend of one level for the output rows [oy_lo, oy_hi) of this chunk
+// one output per lane: horizontal Gaussian at the four taps from two ring rows, blend.  aa_tile_fixed's arithmetic.
+template <int R>
+__device__ __forceinline__ double stream_unit(const double *p0, const double *p1, double wx, const double wy,
+                                              const double (&wck)[R + 1], double (&f)[2][2]) {
+#pragma unroll
+    for (int ry = 0; ry < 2; ry++) {
+        const double *pr = ry ? p1 : p0;
+        double u[2 * R + 2];                                      // one V row, columns x0 - R .. x0 + 1 + R
+#pragma unroll
+        for (int q = 0; q < 2 * R + 2; q++) u[q] = pr[q - R];
+#pragma unroll
+        for (int rx = 0; rx < 2; rx++) {
+            double tmp = u[R + rx] * wck[R];
+#pragma unroll
+            for (int j = -R; j < 0; j++) tmp += (u[R + rx + j] + u[R + rx - j]) * wck[R + j];
+            f[ry][rx] = tmp;
+        }
+        if (R >= 3) __builtin_amdgcn_sched_barrier(0);            // the two rows one after the other: 16 VGPRs less at R = 3
+    }
+    asm volatile("" : "+v"(wx));                                  // 1 - wx is computed here, not held per group across the chunk
+    const double top = (1.0 - wx) * f[0][0] + wx * f[0][1];
+    const double bot = (1.0 - wx) * f[1][0] + wx * f[1][1];
+    return (1.0 - wy) * top + wy * bot;
+}
+
+// How the last 64-column group of a strip is emitted.  It holds `tail` = ncols - 64 (n_groups - 1) columns -- 15 of 143 at
+// level 1, 31 of 95 at level 2 of a VGA strip -- so a unit of its own per output row runs 23 % / 48 % full.  With pack > 1 a
+// unit takes the tail columns of `pack` consecutive output rows instead: lane = (row in the pack, tail column), the row terms
+// per lane instead of per wave (~25 vector instructions more per unit, for 4 / 2 units less).
+struct StreamTail {
+    int pack, tail;     // rows per packed unit (1: not packed), columns of the tail group
+    int rs;             // this lane's row within a pack (rs >= pack: idle); its tail column is lane - rs * tail
+    __device__ __forceinline__ int ct(int lane) const { return lane - rs * tail; }
+};
+__device__ __forceinline__ StreamTail stream_tail(int ncols, int n_groups, int lane) {
+    StreamTail t;
+    t.tail = ncols - 64 * (n_groups - 1);
+    t.pack = (n_groups >= 1 && t.tail >= 1 && t.tail <= 32) ? min(64 / t.tail, 4) : 1;
+    const int tl = max(t.tail, 1);
+    t.rs = lane / tl;
+    return t;
+}
+
+// the horizontal pass + blend of one level for the output rows [oy_lo, oy_hi) of this chunk.  xoff / wxs: the lane's
+// left tap (ring column) and blend weight in the FULL groups g < n_groups - 1; xo_t / wx_t: in the last group (its tail
+// column when that group is packed) -- separate scalars, not a G-th array element: an element picked by the run-time
+// n_groups - 1 sends the arrays to scratch.
 template <int R, int G>
 __device__ __forceinline__ int stream_emit(const AxisMap Lmy, const int LWo, const double *__restrict__ ring, int SW, double *dst,
                                            int oy_lo, int oy_end, int ynew, int ya, int n_groups,
-                                           int ncols, int ox_first,
-                                           const int (&xoff)[G],
-                                           const double (&wxs)[G], const double (&wck)[R + 1],
+                                           int ox_first,
+                                           const int (&xoff)[G - 1], const double (&wxs)[G - 1], const int xo_t,
+                                           const double wx_t, const double (&wck)[R + 1], const StreamTail tl,
                                            int wave, int lane, int &unit, ClipTrack &tr, ClipSlot *slot) {
     // the row terms of the next rows: lane i computes those of row oy_lo + i, the rows read them by lane;
     // the rows to emit now are those whose lower tap y0 + 1 is in the ring (a prefix: y0 is monotone)
@@ -922,43 +968,58 @@ __device__ __forceinline__ int stream_emit(const AxisMap Lmy, const int LWo, con
     const double my_wy = my_cy - my_fy;
     const int my_y0 = (int)my_fy;
     const int n_rows = __builtin_popcountll(__ballot(oy_lo + lane < oy_end && my_y0 + 1 <= ynew));
+    const int gt = n_groups - 1;                                  // the last group: `tail` columns
+    // the ring slot of the upper tap, per lane with the row terms (one multiply-shift for 64 rows) instead of a scalar
+    // modulo per row (s_mul_hi + 5, twice per row: a sixth of the kernel's scalar instructions)
+    static_assert(kStreamRing == 10, "the multiply-shift below divides by 10");
+    const unsigned my_n0 = (unsigned)max(my_y0 - ya, 0) & 0xffffu;     // (rows that are emitted have 0 <= y0 - ya < 2^16)
+    const int my_s0 = (int)(my_n0 - ((my_n0 * 0xCCCDu) >> 19) * (unsigned)kStreamRing);
     for (int i = 0; i < n_rows; i++) {                            // wave-uniform
-        const int y0 = __builtin_amdgcn_readlane(my_y0, i);
         const double wy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_wy), i),
                                            __builtin_amdgcn_readlane(__double2loint(my_wy), i));
-        const int slot0 = (y0 - ya) % kStreamRing, slot1 = (y0 + 1 - ya) % kStreamRing;
+        const int slot0 = __builtin_amdgcn_readlane(my_s0, i);
+        const int slot1 = slot0 + 1 == kStreamRing ? 0 : slot0 + 1;
         double *dst_row = dst + (int64_t)(oy_lo + i) * LWo + ox_first;   // uniform base, the lane is the offset
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            if (g >= n_groups) break;
+        for (int g = 0; g < G - 1; g++) {                         // full groups
+            if (g >= gt) break;
             const bool mine = ((unit++) & 3) == wave;             // units dealt round-robin to the waves
             if (!mine) continue;
-            if (g * 64 + lane >= ncols) continue;
-            const double *p0 = ring + slot0 * SW + xoff[g];
-            const double *p1 = ring + slot1 * SW + xoff[g];
             double f[2][2];
-#pragma unroll
-            for (int ry = 0; ry < 2; ry++) {
-                const double *pr = ry ? p1 : p0;
-                double u[2 * R + 2];                              // one V row, columns x0 - R .. x0 + 1 + R
-#pragma unroll
-                for (int q = 0; q < 2 * R + 2; q++) u[q] = pr[q - R];
-#pragma unroll
-                for (int rx = 0; rx < 2; rx++) {
-                    double tmp = u[R + rx] * wck[R];
-#pragma unroll
-                    for (int j = -R; j < 0; j++) tmp += (u[R + rx + j] + u[R + rx - j]) * wck[R + j];
-                    f[ry][rx] = tmp;
-                }
-                if (R >= 3) __builtin_amdgcn_sched_barrier(0);    // the two rows one after the other: 16 VGPRs less at R = 3
-            }
-            double wx = wxs[g];
-            asm volatile("" : "+v"(wx));                          // 1 - wx is computed here, not held per group across the chunk
-            const double top = (1.0 - wx) * f[0][0] + wx * f[0][1];
-            const double bot = (1.0 - wx) * f[1][0] + wx * f[1][1];
-            const double v = (1.0 - wy) * top + wy * bot;
+            const double v = stream_unit<R>(ring + slot0 * SW + xoff[g], ring + slot1 * SW + xoff[g], wxs[g], wy, wck, f);
             (dst_row + g * 64)[lane] = v;
             if (slot) tr.add(slot, v, f[0][0], f[0][1], f[1][0], f[1][1]);
+        }
+        if (tl.pack == 1 && gt >= 0) {                            // the last group, a unit per row
+            const bool mine = ((unit++) & 3) == wave;
+            if (mine && lane < tl.tail) {
+                double f[2][2];
+                const double v = stream_unit<R>(ring + slot0 * SW + xo_t, ring + slot1 * SW + xo_t, wx_t, wy, wck, f);
+                (dst_row + gt * 64)[lane] = v;
+                if (slot) tr.add(slot, v, f[0][0], f[0][1], f[1][0], f[1][1]);
+            }
+        }
+    }
+    if (tl.pack > 1) {                                            // the last group, `pack` rows per unit
+        for (int i0 = 0; i0 < n_rows; i0 += tl.pack) {            // wave-uniform
+            const bool mine = ((unit++) & 3) == wave;
+            if (!mine) continue;
+            const int r = i0 + tl.rs;
+            const bool active = tl.rs < tl.pack && r < n_rows;
+            const int rc = min(r, n_rows - 1);                    // (idle lanes compute a valid row and do not store)
+            // the row's terms per lane: the same operations on the same operands as my_cy above
+            const double cy = axis_pos(Lmy, oy_lo + rc);
+            const double fy = floor(cy);
+            const double wy = cy - fy;
+            const unsigned n0 = (unsigned)((int)fy - ya);         // < 2^16 (a segment's rows): n0 / 10 by multiplication
+            const unsigned s0 = n0 - ((n0 * 0xCCCDu) >> 19) * (unsigned)kStreamRing;
+            const unsigned s1 = s0 + 1u == (unsigned)kStreamRing ? 0u : s0 + 1u;
+            double f[2][2];
+            const double v = stream_unit<R>(ring + s0 * (unsigned)SW + xo_t, ring + s1 * (unsigned)SW + xo_t, wx_t, wy, wck, f);
+            if (active) {
+                dst[(int64_t)(oy_lo + rc) * LWo + ox_first + gt * 64 + tl.ct(lane)] = v;
+                if (slot) tr.add(slot, v, f[0][0], f[0][1], f[1][0], f[1][1]);
+            }
         }
     }
     return oy_lo + n_rows;
@@ -1001,10 +1062,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     // group the lane's left tap as a ring column and its blend weight
     double wkA[RA + 1], wckA[RA + 1];
     double wkB[RB + 1], wckB[RB + 1];
-    int oxA0, ncolsA, ngA, xoffA[kStreamGroupsA];
-    double wxA[kStreamGroupsA];
-    int oxB0 = 0, ncolsB = 0, ngB = 0, xoffB[kStreamGroupsB];
-    double wxB[kStreamGroupsB];
+    int oxA0, ncolsA, ngA, xoffA[kStreamGroupsA - 1], xoA_t;
+    double wxA[kStreamGroupsA - 1], wxA_t;
+    int oxB0 = 0, ncolsB = 0, ngB = 0, xoffB[kStreamGroupsB - 1], xoB_t = 0;
+    double wxB[kStreamGroupsB - 1], wxB_t = 0.0;
+    StreamTail tlA = stream_tail(64, 1, lane), tlB = stream_tail(64, 1, lane);
     {
         const StreamLevel &L = a.lv[0];
 #pragma unroll
@@ -1012,12 +1074,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         oxA0 = a.strip_tab[strip].a0;
         ncolsA = a.strip_tab[strip].a1 - oxA0;
         ngA = (ncolsA + 63) >> 6;
+        tlA = stream_tail(ncolsA, ngA, lane);
 #pragma unroll
-        for (int g = 0; g < kStreamGroupsA; g++) {
+        for (int g = 0; g < kStreamGroupsA - 1; g++) {
             const double cx = axis_pos(L.mx, oxA0 + g * 64 + lane);
             const double fx0 = floor(cx);
             wxA[g] = cx - fx0;
             xoffA[g] = min(max((int)fx0 - (xa - RM), RA), SW - RA - 2);   // clamp: lanes beyond ncols
+        }
+        {
+            const double cx = axis_pos(L.mx, oxA0 + max(ngA - 1, 0) * 64 + (tlA.pack > 1 ? tlA.ct(lane) : lane));
+            const double fx0 = floor(cx);
+            wxA_t = cx - fx0;
+            xoA_t = min(max((int)fx0 - (xa - RM), RA), SW - RA - 2);
         }
     }
     if constexpr (NL > 1) {
@@ -1027,12 +1096,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         oxB0 = a.strip_tab[strip].b0;
         ncolsB = a.strip_tab[strip].b1 - oxB0;
         ngB = (ncolsB + 63) >> 6;
+        tlB = stream_tail(ncolsB, ngB, lane);
 #pragma unroll
-        for (int g = 0; g < kStreamGroupsB; g++) {
+        for (int g = 0; g < kStreamGroupsB - 1; g++) {
             const double cx = axis_pos(L.mx, oxB0 + g * 64 + lane);
             const double fx0 = floor(cx);
             wxB[g] = cx - fx0;
             xoffB[g] = min(max((int)fx0 - (xa - RM), RB), SW - RB - 2);
+        }
+        {
+            const double cx = axis_pos(L.mx, oxB0 + max(ngB - 1, 0) * 64 + (tlB.pack > 1 ? tlB.ct(lane) : lane));
+            const double fx0 = floor(cx);
+            wxB_t = cx - fx0;
+            xoB_t = min(max((int)fx0 - (xa - RM), RB), SW - RB - 2);
         }
     }
     double *dstA = a.lv[0].dst[arr] + (int64_t)pair * a.lv[0].dst_stride;
@@ -1075,6 +1151,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
     // use INSIDE the loop with s_waitcnt vmcnt(7 .. 0) behind the prefetch of the next chunk -- counts that are right for
     // the first pass and in every later one wait for the loads that were issued a moment ago (the prefetch distance gone).
     __builtin_amdgcn_s_waitcnt(0x0F70);                          // vmcnt(0)
+    int slot_c = 0;                                               // (c K) % ring, carried instead of divided
+    static_assert(kStreamK < kStreamRing, "");
     for (int c = 0; c < n_chunks; c++) {
         asm volatile("" : "+s"(ka));
         const int y = ya + c * K;                                 // first V row of this chunk
@@ -1092,7 +1170,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         // vertical Gaussians of both levels at V rows y .. y + K - 1 (rows >= H: computed, never read)
 #pragma unroll
         for (int j = 0; j < K; j++) {
-            const int slot = (c * K + j) % kStreamRing;
+            const int slot = slot_c + j >= kStreamRing ? slot_c + j - kStreamRing : slot_c + j;   // (c K + j) % ring
             const double va = stream_vtap<RA>(w, j + RM, wkA);
             double vb = 0.0;
             if constexpr (NL > 1) vb = stream_vtap<RB>(w, j + RM, wkB);
@@ -1107,14 +1185,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         {
             AxisMap my;
             my.a = ka->lv[0].my.a; my.b = ka->lv[0].my.b; my.s = ka->lv[0].my.s; my.ideal = ka->lv[0].my.ideal;
-            nextA = stream_emit<RA, kStreamGroupsA>(my, ka->lv[0].Wo, ringA, SW, dstA, nextA, endA, ynew, ya, ngA, ncolsA, oxA0,
-                                                    xoffA, wxA, wckA, wave, lane, unit, trA, slotA);
+            nextA = stream_emit<RA, kStreamGroupsA>(my, ka->lv[0].Wo, ringA, SW, dstA, nextA, endA, ynew, ya, ngA, oxA0,
+                                                    xoffA, wxA, xoA_t, wxA_t, wckA, tlA, wave, lane, unit, trA, slotA);
         }
         if constexpr (NL > 1) {
             AxisMap my;
             my.a = ka->lv[1].my.a; my.b = ka->lv[1].my.b; my.s = ka->lv[1].my.s; my.ideal = ka->lv[1].my.ideal;
-            nextB = stream_emit<RB, kStreamGroupsB>(my, ka->lv[1].Wo, ringB, SW, dstB, nextB, endB, ynew, ya, ngB, ncolsB, oxB0,
-                                                    xoffB, wxB, wckB, wave, lane, unit, trB, slotB);
+            nextB = stream_emit<RB, kStreamGroupsB>(my, ka->lv[1].Wo, ringB, SW, dstB, nextB, endB, ynew, ya, ngB, oxB0,
+                                                    xoffB, wxB, xoB_t, wxB_t, wckB, tlB, wave, lane, unit, trB, slotB);
         }
         if (do_l0) {
             const int oy_end0 = min(yb, H);                       // this block's level-0 rows: those of its segment
@@ -1163,6 +1241,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
 #undef TDK_L0_CASE
         }
         if (kStreamRing < 2 * K + 1) __syncthreads();             // the next chunk's V rows overwrite rows read above
+        slot_c = slot_c + K >= kStreamRing ? slot_c + K - kStreamRing : slot_c + K;
         if (c + 1 < n_chunks) {                                   // the prefetched rows (stream_load)
             stream_rows_arrived(nxt, __builtin_amdgcn_readfirstlane(l0_stores_8));
         }
