@@ -496,7 +496,7 @@ __global__ __launch_bounds__(kBlock) void k_sd_gather2(int H, int W, const Track
         __syncthreads();
         const int x = tx0 + lx;
         int kk[kG2Rows], me[kG2Rows], s[kG2Rows][kSlots], last[kG2Rows];
-        double2 w0[kG2Rows];
+        double2 w0[kG2Rows], w1[kG2Rows];
         uint64_t a0[kG2Rows];
 #pragma unroll
         for (int e = 0; e < kG2Rows; e++) {
@@ -515,7 +515,13 @@ __global__ __launch_bounds__(kBlock) void k_sd_gather2(int H, int W, const Track
             const bool fast = me[e] >= 0 && k > 0 && k <= kSlots;
             last[e] = fast ? (k > 3 ? s[e][3] : k > 2 ? s[e][2] : k > 1 ? s[e][1] : s[e][0]) : -1;
             const int f = fast ? s[e][0] : max(me[e], 0);
-            if (PROP) w0[e] = warped[base + f];
+            if (PROP) {
+                w0[e] = warped[base + f];
+                // the second source's hypothesis with the first's, unconditionally (a target without one re-reads the
+                // first): most waves hold some target with two sources, and loading it inside the fold was a fourth
+                // dependent memory phase per tile
+                w1[e] = warped[base + ((fast && k > 1) ? s[e][1] : f)];
+            }
             if (AGE) a0[e] = age0[base + (fast ? last[e] : max(me[e], 0))];
         }
 #pragma unroll
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(kBlock) void k_sd_gather2(int H, int W, const Track
             if (k > 0 && k <= kSlots) {
                 if (PROP) {
                     fold(w0[e]);
-                    if (k > 1) fold(warped[base + s[e][1]]);
+                    if (k > 1) fold(w1[e]);
                     if (k > 2) fold(warped[base + s[e][2]]);
                     if (k > 3) fold(warped[base + s[e][3]]);
                 }
