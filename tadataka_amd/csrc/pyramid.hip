@@ -1130,6 +1130,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         slot0 = a.slots ? a.slots + ((int64_t)pair * a.n_arrays + arr) * a.n_out + a.l0_lvl : nullptr;
     }
 
+    // level 0's column terms (held across the chunks: five registers).  The horizontal blend of a SOURCE row is
+    // h = wa * own + wn * nb with (wa, wn, nb) = (1 - dc, dc, right) / (dc, 1 - dc, left) / (1 - dc, dc, own) for taps (x, x + 1) /
+    // (x - 1, x) / x alone; cm: which of the three runs ALL of this wave's own columns lie in (0: mixed), see stream_level0_chunk;
+    // left and right exclude each other (floor(c) < x < ceil(c) has no integer x)
+    double l0_wa = 0.0, l0_wn = 0.0;
+    int l0_flags = 0, cm = 0;                                     // bit 0 left, 1 right, 2 this lane owns an output column
+    unsigned l0_boff = 0u;
+    bool l0_any_own = false;
+    if (do_l0) {
+        const int l0_x = xa - RM + ci;                            // lanes 0 / 63 and the halo threads hold neighbour / reflected columns
+        const bool own = l0_x >= xa && l0_x < xb && lane >= 1 && lane <= 62;
+        const double l0_c = axis_pos(a.l0_mx, l0_x);
+        const double l0_fc = floor(l0_c);
+        const double l0_dc = l0_c - l0_fc;
+        const bool left = (int)l0_fc < l0_x;                      // taps (x - 1, x)
+        const bool right = (int)ceil(l0_c) > l0_x;                // taps (x, x + 1); neither: the position is the pixel itself
+        l0_wa = left ? l0_dc : 1.0 - l0_dc;
+        l0_wn = left ? 1.0 - l0_dc : l0_dc;
+        l0_flags = (left ? 1 : 0) | (right ? 2 : 0) | (own ? 4 : 0);
+        const unsigned long long own_m = __ballot(own), right_m = __ballot(right), left_m = __ballot(left);
+        cm = (own_m & ~right_m) == 0ull ? 1 : (own_m & ~left_m) == 0ull ? 2 : (own_m & (left_m | right_m)) == 0ull ? 3 : 0;
+        l0_any_own = own_m != 0ull;
+        l0_boff = (unsigned)max(l0_x, 0) * 8u;
+    }
+
     // the column's window: w[i] = source row (y - RM + i) for the chunk that starts at V row y
     double w[K + 2 * RM], nxt[K];
 #pragma unroll
@@ -1196,17 +1221,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
         }
         if (do_l0) {
             const int oy_end0 = min(yb, H);                       // this block's level-0 rows: those of its segment
-            // the column terms, recomputed per chunk (six operations) rather than held in registers across it
-            const int l0_x = xa - RM + ci;                        // lanes 0 / 63 and the halo threads hold neighbour / reflected columns
-            const bool l0_own = l0_x >= xa && l0_x < xb && lane >= 1 && lane <= 62;
-            AxisMap l0mx, l0my;
-            l0mx.a = ka->l0_mx.a; l0mx.b = ka->l0_mx.b; l0mx.s = ka->l0_mx.s; l0mx.ideal = ka->l0_mx.ideal;
+            AxisMap l0my;
             l0my.a = ka->l0_my.a; l0my.b = ka->l0_my.b; l0my.s = ka->l0_my.s; l0my.ideal = ka->l0_my.ideal;
-            const double l0_c = axis_pos(l0mx, l0_x);
-            const double l0_fc = floor(l0_c);
-            const double l0_dc = l0_c - l0_fc;
-            const bool l0_left = (int)l0_fc < l0_x;               // taps (x - 1, x)
-            const bool l0_right = (int)ceil(l0_c) > l0_x;         // taps (x, x + 1); neither: the position is the pixel itself
             // the row terms: lane j computes those of row y + j, the rows read them by lane (-0.04 ms of 1.73)
             const double my_r = axis_pos(l0my, y + (lane & 7));
             const double my_fr = floor(my_r);
@@ -1217,14 +1233,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void k
             // (own, neighbour) / (own, own), is the same double for both output rows that tap the row, so it is
             // computed once per source row and an output row is one vertical blend of two of them.  The products
             // commute, so one form serves all three cases: h = wa * own + wn * nb with the weights and nb picked per column.
-            const double l0_wa = l0_left ? l0_dc : 1.0 - l0_dc, l0_wn = l0_left ? 1.0 - l0_dc : l0_dc;
-            // which run of the axis this wave's columns / this chunk's rows lie in (stream_level0_chunk): left and right
-            // exclude each other (floor(c) < x < ceil(c) has no integer x)
-            const unsigned long long own_m = __ballot(l0_own), right_m = __ballot(l0_right), left_m = __ballot(l0_left);
-            const int cm = (own_m & ~right_m) == 0ull ? 1 : (own_m & ~left_m) == 0ull ? 2 : (own_m & (left_m | right_m)) == 0ull ? 3 : 0;
+            const bool l0_left = (l0_flags & 1) != 0, l0_right = (l0_flags & 2) != 0, l0_own = (l0_flags & 4) != 0;
             const int rm = down_bits == 0xffu ? 1 : up_bits == 0xffu ? 2 : (up_bits | down_bits) == 0u ? 3 : 0;
-            const unsigned l0_boff = (unsigned)max(l0_x, 0) * 8u;
-            l0_stores_8 = own_m != 0ull && y + K <= oy_end0 ? 1 : 0;   // a store per row, each issued (some lane owns an output)
+            l0_stores_8 = l0_any_own && y + K <= oy_end0 ? 1 : 0;   // a store per row, each issued (some lane owns an output)
 #define TDK_L0_CASE(CM_, RM_)                                                                                              \
     case CM_ * 4 + RM_:                                                                                                    \
         stream_level0_chunk<CM_, RM_, RM, K>(w, l0_wa, l0_wn, l0_left, l0_right, my_dr, up_bits, down_bits, y, oy_end0,   \
