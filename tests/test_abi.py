@@ -122,3 +122,30 @@ def test_streaming_pyramid_kernel_keeps_its_prefetch_registers_untouched():
     spec.loader.exec_module(mod)
     kernels, problems = mod.check(mod.assembly())
     assert kernels == 2 and not problems, problems
+
+
+def test_the_isa_check_itself_sees_a_touched_prefetch_register(tmp_path):
+    """tools/check_pyramid_isa.py on hand-made assembly: a copy out of a prefetch register before the kernel's wait is
+    reported (this is what the register allocator did once, with two wait statements and a phi between them), the
+    same instruction after the wait is not."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_pyramid_isa", os.path.join(REPO, "tools", "check_pyramid_isa.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    head = "_ZN1_16k_pyramid_streamILi1ELi3EEEv: ; @x\n"
+    load = "\t;;#ASMSTART\n\tglobal_load_dwordx2 v[76:77], v[0:1], off\n\t;;#ASMEND\n"
+    wait = ("\t;;#ASMSTART\n\ts_cmp_lg_u32 s0, 0\n\ts_cbranch_scc0 1f\n\ts_waitcnt vmcnt(8)\n\ts_branch 2f\n1:\n"
+            "\ts_waitcnt vmcnt(0)\n2:\n\t;;#ASMEND\n")
+    copy = "\tv_mov_b64_e32 v[2:3], v[76:77]\n"
+    other = "\tv_add_f64 v[4:5], v[6:7], v[8:9]\n"
+    good = tmp_path / "good.s"
+    good.write_text(head + load + other + wait + copy + "\ts_endpgm\n")
+    bad = tmp_path / "bad.s"
+    bad.write_text(head + load + copy + wait + "\ts_endpgm\n")
+    kernels, problems = mod.check(str(good))
+    assert kernels == 1 and not problems, problems
+    kernels, problems = mod.check(str(bad))
+    assert kernels == 1 and len(problems) == 1 and "v_mov_b64_e32" in problems[0], problems
+    stale = tmp_path / "stale.s"
+    stale.write_text(head + other + "\ts_endpgm\n")
+    assert mod.check(str(stale))[1], "a kernel without the prefetch / wait pattern must be reported (stale check)"
