@@ -1657,6 +1657,7 @@ tdk_status launch_pyramid(const double *const *srcs, int n_arrays, int H, int W,
                 if (!(stepy > 0.0) || (double)kStreamK / stepy + 2.0 > 64.0) fits = false;
             }
             if (n_strips > kStreamMaxStrips || sa.n_segs > kStreamMaxSegs) fits = false;
+            if (sa.seg_rows + 2 * kStreamK >= 60000) fits = false;    // (ring slots by a 16-bit multiply-shift: stream_emit)
             for (int t = 0; fits && t < n_strips; t++) {
                 const int xa = t * strip_w, xb = std::min(xa + strip_w, W);
                 StreamRange &r = sa.strip_tab[t];
