@@ -176,3 +176,20 @@ def test_rccl_comm_through_the_c_abi_signatures_world_8(tmp_path):
     assert np.array_equal(last[:, 0], np.concatenate([np.arange(6 * r, 6 * r + 3) for r in range(world)]) + 4000.0)
     assert all(np.array_equal(np.load(o), last) for o in outs)
     assert glob.glob(str(tmp_path / "tdk_rdv_*")) == []
+
+
+def test_bench_spawner_names_every_failed_rank(tmp_path):
+    """`python bench.py --dry-ranks 2` on a box WITHOUT a GPU: both workers fail (there is no CPU fallback) and the
+    spawner says, per rank, exit code, device rule and the last lines of that rank's stderr -- not exit codes only."""
+    from conftest import _has_gpu
+    import pytest
+    if _has_gpu():
+        pytest.skip("needs a box without a GPU: the workers must fail")
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--dry-ranks", "2", "--steps", "1", "--warmup", "0"],
+                       env=dict(os.environ, TMPDIR=str(tmp_path)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=300)
+    assert p.returncode != 0 and p.stdout.strip() == ""
+    for r in (0, 1):
+        assert f"---- rank {r}: exit code 1, LOCAL_RANK={r}" in p.stderr
+    assert p.stderr.count("no MI355X / HIP device visible") >= 2
+    assert "bench worker exit codes: [1, 1]" in p.stderr
